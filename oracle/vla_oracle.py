@@ -1,0 +1,420 @@
+"""CPU restatement (oracle) of the VLA-Adapter fine-tune hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is the *checker* for the HIP kernels in ``vla_adapter_amd/csrc``: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.  The product path
+(``vla_adapter_amd``) never imports anything from ``oracle/`` and fails loudly when the HIP extension is
+missing.
+
+Every function restates, as explicit tensor arithmetic on CPU (torch is used here as a numpy-like array
+library + reverse-mode differentiation of the restated math), one row of SURVEY.md §8(a).  Citations are
+``path:line`` relative to the reference checkout (``/root/reference``).
+
+Pinning: the reference ships no tests/golden vectors.  ``tools/make_golden.py`` imports the
+reference's own leaf modules (``prismatic/models/action_heads.py``, ``prismatic/models/projectors.py``,
+``prismatic/training/train_utils.py``, ``prismatic/vla/constants.py``) and the installed ``transformers``
+Qwen2 (the reference's pinned fork is absent) and writes ``tests/golden/*.npz``; ``tests/test_oracle_golden.py``
+checks this file against them.  Rows a1, a7, a8, a9, a10 are therefore pinned by reference code run here;
+a5 is pinned by installed-transformers Qwen2 (third-party, version differs from the reference's pin);
+a2, a3, a4, a6, a11 (ViT from timm, VLM glue, LoRA from peft: not importable) are **parity unpinned** -
+restated from the reference text and checked only for self-consistency.
+
+Precision: ``emu=False`` is straight fp32.  ``emu=True`` rounds to bf16 at the points where the reference's
+bf16 autocast / bf16 modules round (after every Linear, activation, residual add, norm output), with fp32
+accumulation inside each op - the same rounding points the HIP kernels use.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F  # only: erf-GELU / softmax primitives used as array math
+
+IGNORE_INDEX = -100                 # prismatic/vla/constants.py:11
+ACTION_TOKEN_BEGIN_IDX = 151386     # prismatic/vla/constants.py:13
+NUM_TOKENS = 64                     # prismatic/vla/constants.py:15
+ACTION_DIM = 7                      # prismatic/vla/constants.py:28-33 (LIBERO)
+NUM_ACTIONS_CHUNK = 8
+PROPRIO_DIM = 8
+
+
+def rnd(x: torch.Tensor, emu: bool) -> torch.Tensor:
+    """bf16 rounding point (identity in fp32 mode)."""
+    return x.to(torch.bfloat16).to(torch.float32) if emu else x
+
+
+def linear(x, w, b=None, emu=False):
+    """nn.Linear: y = x W^T + b, one rounding after bias (fp32 accumulate)."""
+    y = x @ w.t()
+    if b is not None:
+        y = y + b
+    return rnd(y, emu)
+
+
+def gelu(x, emu=False, tanh=False):
+    return rnd(F.gelu(x, approximate="tanh" if tanh else "none"), emu)
+
+
+def layer_norm(x, w, b, eps, emu=False):
+    """nn.LayerNorm over the last dim, fp32 statistics (biased variance)."""
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return rnd((x - mu) * torch.rsqrt(var + eps) * w + b, emu)
+
+
+# ----------------------------------------------------------------------------------------------
+# a1  action masks  (prismatic/training/train_utils.py:8-23, 26-41; modeling_prismatic.py:456-461)
+# ----------------------------------------------------------------------------------------------
+def current_action_mask(token_ids: torch.Tensor) -> torch.Tensor:
+    cumsum = torch.cumsum((token_ids != IGNORE_INDEX).to(torch.int64), dim=1)
+    return ((1 <= cumsum) & (cumsum <= ACTION_DIM)) & (token_ids > ACTION_TOKEN_BEGIN_IDX)
+
+
+def next_actions_mask(token_ids: torch.Tensor) -> torch.Tensor:
+    cumsum = torch.cumsum((token_ids != IGNORE_INDEX).to(torch.int64), dim=1)
+    return (cumsum > ACTION_DIM) & (token_ids > ACTION_TOKEN_BEGIN_IDX)
+
+
+def all_actions_mask(labels: torch.Tensor) -> torch.Tensor:
+    return current_action_mask(labels) | next_actions_mask(labels)
+
+
+# ----------------------------------------------------------------------------------------------
+# a2  embedding + action-query splice (modeling_prismatic.py:601, 418-454, 486-510)
+# ----------------------------------------------------------------------------------------------
+def embed_splice(input_ids, labels, attention_mask, embed_table, action_queries, patches):
+    """-> (multimodal_embeddings [B, L+Np, D], multimodal_mask [B, L+Np] bool).
+
+    k-th True position of the (current|next) mask on ``labels`` receives ``action_queries[k]``;
+    sequence = [tok0 | patches | tok1..]; mask = attention_mask with ones for the patches.
+    """
+    B, L = input_ids.shape
+    emb = embed_table[input_ids]                                  # :601
+    mask = all_actions_mask(labels)                               # :605
+    out = emb.clone()
+    for b in range(B):                                            # :439-447 (k-th True <- k-th query)
+        idx = torch.where(mask[b])[0]
+        assert idx.numel() == action_queries.shape[0], "mask must select NUM_TOKENS positions per row"
+        out[b, idx] = action_queries
+    mm = torch.cat([out[:, :1], patches, out[:, 1:]], dim=1)      # :499-501
+    ones = torch.ones(B, patches.shape[1], dtype=torch.bool)
+    mm_mask = torch.cat([attention_mask[:, :1].bool(), ones, attention_mask[:, 1:].bool()], dim=1)  # :505-508
+    return mm, mm_mask
+
+
+# ----------------------------------------------------------------------------------------------
+# a3  ViT featurizer (timm VisionTransformer semantics; evidence film_vit_wrapper.py:69-75,114-168;
+#     modeling_prismatic.py:120-144, 196-237).  PARITY UNPINNED (timm absent).
+# ----------------------------------------------------------------------------------------------
+def vit_forward(pixels, p: Dict[str, torch.Tensor], cfg: Dict, emu=False) -> torch.Tensor:
+    """pixels [B,3,H,W] -> patch features [B, Np, d] = output of block ``depth-2``, prefix tokens dropped,
+    no final norm (get_intermediate_layers(n={depth-2}), norm=False).
+
+    cfg: dict(d, depth, heads, mlp, patch, n_prefix (0 SigLIP / 5 DINOv2 cls+4reg), layerscale, eps, gelu_tanh)
+    params: timm names (patch_embed.proj.weight [d,3,P,P], pos_embed [1,Np,d], cls_token, reg_token,
+            blocks.N.{norm1,attn.qkv,attn.proj,ls1.scale_factor,norm2,mlp.fc1,mlp.fc2,ls2.scale_factor}).
+    """
+    d, heads, P = cfg["d"], cfg["heads"], cfg["patch"]
+    B, C, H, W = pixels.shape
+    gh, gw = H // P, W // P
+    # patch embed = conv PxP stride P == GEMM over im2col'd patches (c, py, px ordering of conv weight)
+    cols = pixels.reshape(B, C, gh, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * P * P)
+    x = linear(rnd(cols, emu), p["patch_embed.proj.weight"].reshape(d, -1), p["patch_embed.proj.bias"], emu)
+    x = rnd(x + p["pos_embed"], emu)                               # _pos_embed (no_embed_class / no cls)
+    if cfg.get("n_prefix", 0):
+        pref = [p["cls_token"].expand(B, -1, -1)]
+        if "reg_token" in p:
+            pref.append(p["reg_token"].expand(B, -1, -1))
+        x = torch.cat(pref + [x], dim=1)
+    dh = d // heads
+    last = cfg["depth"] - 2                                        # modeling_prismatic.py:141-142
+    for i in range(last + 1):                                      # blocks after `last` are dead work
+        pre = f"blocks.{i}."
+        h = layer_norm(x, p[pre + "norm1.weight"], p[pre + "norm1.bias"], cfg["eps"], emu)
+        qkv = linear(h, p[pre + "attn.qkv.weight"], p[pre + "attn.qkv.bias"], emu)
+        T = x.shape[1]
+        q, k, v = qkv.reshape(B, T, 3, heads, dh).permute(2, 0, 3, 1, 4)
+        s = (q @ k.transpose(-1, -2)) * dh ** -0.5
+        a = rnd(torch.softmax(s, dim=-1), emu) @ v
+        a = rnd(a, emu).transpose(1, 2).reshape(B, T, d)
+        a = linear(a, p[pre + "attn.proj.weight"], p[pre + "attn.proj.bias"], emu)
+        if cfg.get("layerscale"):
+            a = rnd(a * p[pre + "ls1.scale_factor"], emu)          # modeling_prismatic.py:58-66
+        x = rnd(x + a, emu)
+        h = layer_norm(x, p[pre + "norm2.weight"], p[pre + "norm2.bias"], cfg["eps"], emu)
+        h = gelu(linear(h, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"], emu), emu, cfg.get("gelu_tanh", False))
+        h = linear(h, p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"], emu)
+        if cfg.get("layerscale"):
+            h = rnd(h * p[pre + "ls2.scale_factor"], emu)
+        x = rnd(x + h, emu)
+    return x[:, cfg.get("n_prefix", 0):]
+
+
+# ----------------------------------------------------------------------------------------------
+# a4  projector (modeling_prismatic.py:242-273).  PARITY UNPINNED (glue not importable: top-level timm).
+# ----------------------------------------------------------------------------------------------
+def projector(x, p: Dict[str, torch.Tensor], fused: bool, emu=False):
+    h = gelu(linear(x, p["fc1.weight"], p["fc1.bias"], emu), emu)
+    h = linear(h, p["fc2.weight"], p["fc2.bias"], emu)
+    if fused:
+        h = linear(gelu(h, emu), p["fc3.weight"], p["fc3.bias"], emu)
+    return h
+
+
+# ----------------------------------------------------------------------------------------------
+# a5  Qwen2 decoder stack (transformers Qwen2ForCausalLM; call site modeling_prismatic.py:644-655)
+# ----------------------------------------------------------------------------------------------
+def rms_norm(x, w, eps, emu=False):
+    """Qwen2RMSNorm: w * bf16(x * rsqrt(mean(x^2)+eps))  (two rounding points in bf16)."""
+    n = rnd(x * torch.rsqrt((x * x).mean(-1, keepdim=True) + eps), emu)
+    return rnd(w * n, emu)
+
+
+def rope_half_tables(S: int, dh: int, theta: float, emu=False):
+    inv = 1.0 / (theta ** (torch.arange(0, dh, 2, dtype=torch.float32) / dh))
+    f = torch.arange(S, dtype=torch.float32)[:, None] * inv[None, :]
+    e = torch.cat([f, f], dim=-1)
+    return rnd(e.cos(), emu), rnd(e.sin(), emu)
+
+
+def rope_half(x, cos, sin, emu=False):
+    """HF rotate_half convention: pairs (i, i+dh/2). x [B,H,S,dh], cos/sin [S,dh]."""
+    h = x.shape[-1] // 2
+    rot = torch.cat([-x[..., h:], x[..., :h]], dim=-1)
+    return rnd(rnd(x * cos, emu) + rnd(rot * sin, emu), emu)
+
+
+def qwen2_forward(x, mask, p: Dict[str, torch.Tensor], cfg: Dict, emu=False) -> List[torch.Tensor]:
+    """x [B,S,D] inputs_embeds, mask [B,S] bool key-padding mask -> hidden_states (n_layers+1 tensors):
+    [0]=inputs_embeds, [i]=output of layer i (i<n), [n]=final-norm output (HF convention).
+
+    cfg: dict(n_layers, heads, kv_heads, dh, eps, theta).  Params use HF names under ``layers.N.``.
+    Attention: causal AND key-padding, softmax fp32, P rounded to bf16 before P@V (eager path).
+    """
+    B, S, D = x.shape
+    H, KV, dh = cfg["heads"], cfg["kv_heads"], cfg["dh"]
+    cos, sin = rope_half_tables(S, dh, cfg["theta"], emu)
+    causal = torch.tril(torch.ones(S, S, dtype=torch.bool))
+    allow = causal[None, None] & mask[:, None, None, :].bool()
+    hs = [x]
+    for i in range(cfg["n_layers"]):
+        pre = f"layers.{i}."
+        h = rms_norm(x, p[pre + "input_layernorm.weight"], cfg["eps"], emu)
+        q = linear(h, p[pre + "self_attn.q_proj.weight"], p[pre + "self_attn.q_proj.bias"], emu)
+        k = linear(h, p[pre + "self_attn.k_proj.weight"], p[pre + "self_attn.k_proj.bias"], emu)
+        v = linear(h, p[pre + "self_attn.v_proj.weight"], p[pre + "self_attn.v_proj.bias"], emu)
+        q = rope_half(q.reshape(B, S, H, dh).transpose(1, 2), cos, sin, emu)
+        k = rope_half(k.reshape(B, S, KV, dh).transpose(1, 2), cos, sin, emu)
+        v = v.reshape(B, S, KV, dh).transpose(1, 2)
+        k = k.repeat_interleave(H // KV, dim=1)
+        v = v.repeat_interleave(H // KV, dim=1)
+        s = (q @ k.transpose(-1, -2)) * dh ** -0.5
+        s = s.masked_fill(~allow, float("-inf"))
+        a = rnd(torch.softmax(s, dim=-1), emu) @ v
+        a = rnd(a, emu).transpose(1, 2).reshape(B, S, H * dh)
+        x = rnd(x + linear(a, p[pre + "self_attn.o_proj.weight"], None, emu), emu)
+        h = rms_norm(x, p[pre + "post_attention_layernorm.weight"], cfg["eps"], emu)
+        g = linear(h, p[pre + "mlp.gate_proj.weight"], None, emu)
+        u = linear(h, p[pre + "mlp.up_proj.weight"], None, emu)
+        m = rnd(rnd(g * torch.sigmoid(g), emu) * u, emu)
+        x = rnd(x + linear(m, p[pre + "mlp.down_proj.weight"], None, emu), emu)
+        hs.append(x)
+    hs[-1] = rms_norm(x, p["norm.weight"], cfg["eps"], emu)
+    return hs
+
+
+# ----------------------------------------------------------------------------------------------
+# a6  hidden-state regroup (vla-scripts/finetune.py:396-409)
+# ----------------------------------------------------------------------------------------------
+def regroup_hidden_states(hidden_states: List[torch.Tensor], labels, num_patches: int) -> torch.Tensor:
+    """-> [B, n_states, num_patches + 64, D].  task = item[:, :num_patches] (tok0 + first num_patches-1
+    patches: reference off-by-one kept); actions = item[:, num_patches:-1][mask(labels[:,1:])]."""
+    gt = labels[:, 1:]
+    m = current_action_mask(gt) | next_actions_mask(gt)            # finetune.py:351-353
+    outs = []
+    for item in hidden_states:
+        B = item.shape[0]
+        text = item[:, num_patches:-1]
+        act = text[m].reshape(B, 1, NUM_TOKENS, -1)
+        task = item[:, :num_patches].reshape(B, 1, num_patches, -1)
+        outs.append(torch.cat([task, act], dim=2))
+    return torch.cat(outs, dim=1)
+
+
+# ----------------------------------------------------------------------------------------------
+# a7  proprio projector (prismatic/models/projectors.py:19-24)
+# ----------------------------------------------------------------------------------------------
+def proprio_projector(proprio, p: Dict[str, torch.Tensor], emu=False):
+    return linear(gelu(linear(rnd(proprio, emu), p["fc1.weight"], p["fc1.bias"], emu), emu),
+                  p["fc2.weight"], p["fc2.bias"], emu)
+
+
+# ----------------------------------------------------------------------------------------------
+# a8/a9  action head (prismatic/models/action_heads.py)
+# ----------------------------------------------------------------------------------------------
+def head_rope_tables(T: int, dh: int, emu=False, base: float = 10000.0):
+    """RotaryPositionEmbedding.forward (action_heads.py:150-164): cos/sin of cat([f, f])."""
+    inv = 1.0 / (base ** (torch.arange(0, dh, 2).float() / dh))
+    f = torch.arange(T, dtype=torch.float32)[:, None] * inv[None, :]
+    e = torch.cat([f, f], dim=-1)
+    return rnd(e.cos(), emu), rnd(e.sin(), emu)
+
+
+def head_rope(x, cos, sin, emu=False):
+    """apply_rope (action_heads.py:125-146): rotation pairs (2i, 2i+1) but cos/sin laid out as cat([f,f])
+    (the reference's mixed convention, kept).  x [B,H,T,dh]."""
+    x1, x2 = x[..., ::2], x[..., 1::2]
+    rot = torch.stack((-x2, x1), dim=-1).reshape_as(x)
+    return rnd(rnd(x * cos, emu) + rnd(rot * sin, emu), emu)
+
+
+def _heads(t, B, L, H):
+    return t.reshape(B, L, H, -1).transpose(1, 2)
+
+
+def head_block_pro(x, h_t, h_a, pp, p: Dict[str, torch.Tensor], pre: str, emu=False, H: int = 8):
+    """MLPResNetBlock_Pro.forward (action_heads.py:337-410)."""
+    B, T, C = x.shape
+    dh = C // H
+    ratio_g = torch.tanh(p[pre + "gating_factor"])                 # :343-344
+    h_ad = torch.cat([h_a, pp], dim=1)                             # :347
+    Ka, Kt = h_ad.shape[1], h_t.shape[1]
+    L = lambda n, t: linear(t, p[pre + n + ".weight"], p[pre + n + ".bias"], emu)
+    q = _heads(L("q_proj", x), B, T, H)
+    ks, vs = _heads(L("k_self", x), B, T, H), _heads(L("v_self", x), B, T, H)
+    ka, va = _heads(L("k_adapter", h_ad), B, Ka, H), _heads(L("v_adapter", h_ad), B, Ka, H)
+    kt, vt = _heads(L("k_task", h_t), B, Kt, H), _heads(L("v_task", h_t), B, Kt, H)
+    cm, sm = head_rope_tables(T, dh, emu)                          # :383-388 positions restart per segment
+    q, ks = head_rope(q, cm, sm, emu), head_rope(ks, cm, sm, emu)
+    ca, sa = head_rope_tables(Ka, dh, emu)
+    ka = head_rope(ka, ca, sa, emu)
+    ct, st = head_rope_tables(Kt, dh, emu)
+    kt = head_rope(kt, ct, st, emu)
+    s = torch.cat([rnd(q @ ks.transpose(-1, -2), emu),
+                   rnd(q @ ka.transpose(-1, -2), emu),
+                   rnd(rnd(q @ kt.transpose(-1, -2), emu) * rnd(ratio_g, emu), emu)], dim=-1)   # :391-394
+    s = rnd(s / math.sqrt(dh), emu)
+    w = rnd(torch.softmax(s, dim=-1), emu)                         # :395
+    o = rnd(w @ torch.cat([vs, va, vt], dim=2), emu)               # :398-401
+    o = L("o_proj", o.transpose(1, 2).reshape(B, T, C))
+    y = rnd(o + x, emu)                                            # :409 (no outer residual)
+    y = layer_norm(y, p[pre + "ffn.0.weight"], p[pre + "ffn.0.bias"], 1e-5, emu)
+    return rnd(torch.relu(L("ffn.1", y)), emu)
+
+
+def head_block_orig(x, h_t, h_a, pp, p: Dict[str, torch.Tensor], pre: str, emu=False, H: int = 8):
+    """MLPResNetBlock.forward (action_heads.py:218-283): shared k/v proj, no RoPE, tanh gate on the h_t segment,
+    order [self, (h_a,p), h_t]."""
+    B, T, C = x.shape
+    dh = C // H
+    ratio_g = torch.tanh(p[pre + "gating_factor"])
+    h = torch.cat([h_a, pp], dim=1)
+    L = lambda n, t: linear(t, p[pre + n + ".weight"], p[pre + n + ".bias"], emu)
+    q = _heads(L("q_proj", x), B, T, H)
+    kx, vx = _heads(L("k_proj", x), B, T, H), _heads(L("v_proj", x), B, T, H)
+    kh, vh = _heads(L("k_proj", h), B, h.shape[1], H), _heads(L("v_proj", h), B, h.shape[1], H)
+    kt, vt = _heads(L("k_proj", h_t), B, h_t.shape[1], H), _heads(L("v_proj", h_t), B, h_t.shape[1], H)
+    s = torch.cat([rnd(q @ kx.transpose(-1, -2), emu),
+                   rnd(q @ kh.transpose(-1, -2), emu),
+                   rnd(rnd(q @ kt.transpose(-1, -2), emu) * rnd(ratio_g, emu), emu)], dim=-1)
+    s = rnd(s / math.sqrt(dh), emu)
+    w = rnd(torch.softmax(s, dim=-1), emu)
+    o = rnd(w @ torch.cat([vx, vh, vt], dim=2), emu)
+    o = L("o_proj", o.transpose(1, 2).reshape(B, T, C))
+    y = layer_norm(rnd(o + x, emu), p[pre + "ffn.0.weight"], p[pre + "ffn.0.bias"], 1e-5, emu)
+    return rnd(torch.relu(L("ffn.1", y)), emu)
+
+
+def head_predict_action(mlhs, proprio, head_p: Dict[str, torch.Tensor], proprio_p: Dict[str, torch.Tensor],
+                        num_task_tokens: int, pro: bool = True, noise: Optional[torch.Tensor] = None,
+                        emu=False, num_blocks: int = 24) -> torch.Tensor:
+    """L1RegressionActionHead.predict_action + MLPResNet.forward (action_heads.py:43-81, 111-121).
+
+    mlhs [B, n_states, num_task_tokens+64, D]; ``noise`` [8, 7*D] is the Training-phase perturbation
+    (action_heads.py:14-17, 69-72) injected explicitly; None == phase "Inference" (zeros input).
+    head_p keys are the reference state-dict keys under ``model.``.
+    """
+    B, D = mlhs.shape[0], mlhs.shape[-1]
+    pf = proprio_projector(proprio.reshape(B, -1), proprio_p, emu)[:, None, :]           # :53-55
+    h_t_all, h_a_all = mlhs[:, :, :num_task_tokens], mlhs[:, :, num_task_tokens:]        # :57-58
+    x = torch.zeros(B, NUM_ACTIONS_CHUNK, ACTION_DIM * D)                                 # :60-66
+    if noise is not None:
+        x = rnd(x + noise, emu)
+    x = layer_norm(x, head_p["model.layer_norm1.weight"], head_p["model.layer_norm1.bias"], 1e-5, emu)
+    x = rnd(torch.relu(linear(x, head_p["model.fc1.weight"], head_p["model.fc1.bias"], emu)), emu)
+    blk = head_block_pro if pro else head_block_orig
+    for i in range(num_blocks):                                                           # :117-118
+        x = blk(x, h_t_all[:, i + 1], h_a_all[:, i + 1], pf, head_p, f"model.mlp_resnet_blocks.{i}.", emu)
+    x = layer_norm(x, head_p["model.layer_norm2.weight"], head_p["model.layer_norm2.bias"], 1e-5, emu)
+    return linear(x, head_p["model.fc2.weight"], head_p["model.fc2.bias"], emu)
+
+
+# ----------------------------------------------------------------------------------------------
+# a10  loss + metrics (finetune.py:418-444)
+# ----------------------------------------------------------------------------------------------
+def l1_loss(pred, target, emu=False):
+    return (pred - rnd(target, emu)).abs().mean()
+
+
+def l1_metrics(pred, target):
+    return dict(loss_value=(pred - target).abs().mean(),
+                curr_action_l1_loss=(pred[:, 0] - target[:, 0]).abs().mean(),
+                next_actions_l1_loss=(pred[:, 1:] - target[:, 1:]).abs().mean())
+
+
+# ----------------------------------------------------------------------------------------------
+# a11  LoRA linear (peft LoraConfig r, alpha=2r; finetune.py:832-844).  PARITY UNPINNED (peft absent).
+# ----------------------------------------------------------------------------------------------
+def lora_linear(x, w, b, A, Bm, scale: float, emu=False):
+    return rnd(linear(x, w, b, emu) + rnd(linear(linear(x, A, None, emu), Bm, None, emu) * scale, emu), emu)
+
+
+# ----------------------------------------------------------------------------------------------
+# a12  AdamW (torch.optim.AdamW defaults as used at finetune.py:910) + LR schedule (:917, 1061-1065)
+# ----------------------------------------------------------------------------------------------
+def adamw_step(p, g, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, wd=0.01, emu=False):
+    """One AdamW update; returns (p, m, v).  With ``emu`` every elementwise op rounds to bf16, which is what
+    torch's (foreach) AdamW does on bf16 params/states: lerp_, mul_/addcmul_, sqrt/div/add, addcdiv_."""
+    def fma(a, b, c):  # fp32 fused multiply-add (a*b exact in f64), as the vectorised ATen kernels contract it
+        return (a.double() * b.double() + c.double()).float()
+    f32 = lambda s: torch.tensor(s, dtype=torch.float32)
+    p = rnd(p * f32(1.0 - lr * wd), emu)
+    m = rnd(fma(f32(1.0 - beta1), g - m, m), emu)                  # exp_avg.lerp_(grad, 1-beta1)
+    v = rnd(fma(f32(1.0 - beta2) * g, g, rnd(v * f32(beta2), emu)), emu)   # mul_(beta2).addcmul_(g, g, 1-beta2)
+    bc1 = 1.0 - beta1 ** step
+    bc2_sqrt = math.sqrt(1.0 - beta2 ** step)
+    denom = rnd(rnd(rnd(v.sqrt(), emu) / f32(bc2_sqrt), emu) + f32(eps), emu)
+    p = rnd(fma(f32(-(lr / bc1)), m / denom, p), emu)              # addcdiv_(exp_avg, denom, -step_size)
+    return p, m, v
+
+
+def lr_at(step: int, base_lr: float, warmup_steps: float = 0.1, decay_at: int = 100000, gamma: float = 0.1):
+    """finetune.py:1061-1065 warm-up (10%->100% over warmup_steps) then MultiStepLR(:917)."""
+    lr = base_lr * (gamma if step >= decay_at else 1.0)
+    return lr * (0.1 + 0.9 * min((step + 1) / warmup_steps, 1.0))
+
+
+# ----------------------------------------------------------------------------------------------
+# Composite: the whole fine-tune forward of run_forward_pass (finetune.py:288-447) on the oracle pieces.
+# ----------------------------------------------------------------------------------------------
+def vla_forward(batch: Dict[str, torch.Tensor], W: Dict[str, Dict[str, torch.Tensor]], cfg: Dict, emu=False,
+                noise: Optional[torch.Tensor] = None):
+    """-> dict(pred [B,8,7], loss, hidden_states, mlhs).  ``W`` = dict(vit=[..one dict per backbone..],
+    proj, llm, embed, action_queries, head, proprio); cfg = dict(vit=[...], fused, llm, n_img, pro)."""
+    px = batch["pixel_values"]
+    n_img, nb = cfg["n_img"], len(cfg["vit"])
+    feats = []
+    for im in range(n_img):                                        # modeling_prismatic.py:206-237
+        chans = px[:, im * 3 * nb:(im + 1) * 3 * nb]
+        f = [vit_forward(chans[:, 3 * j:3 * j + 3], W["vit"][j], cfg["vit"][j], emu) for j in range(nb)]
+        feats.append(torch.cat(f, dim=2))
+    patches = projector(torch.cat(feats, dim=1), W["proj"], cfg["fused"], emu)
+    mm, mm_mask = embed_splice(batch["input_ids"], batch["labels"], batch["attention_mask"],
+                               W["embed"], W["action_queries"], patches)
+    hs = qwen2_forward(mm, mm_mask, W["llm"], cfg["llm"], emu)
+    npatch = patches.shape[1]
+    mlhs = regroup_hidden_states(hs, batch["labels"], npatch)
+    pred = head_predict_action(mlhs, batch["proprio"], W["head"], W["proprio"], npatch, cfg.get("pro", True),
+                               noise, emu)
+    loss = l1_loss(pred, batch["actions"], emu)
+    return dict(pred=pred, loss=loss, hidden_states=hs, mlhs=mlhs, patches=patches)
