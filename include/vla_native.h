@@ -1,0 +1,176 @@
+/* libvla_native.so - C ABI of the MI355X-native VLA-Adapter fine-tune hot path.
+ *
+ * The reference (liruiluo/VLA-Adapter) is pure Python and has NO FFI/plugin boundary: every
+ * device op is reached through torch / timm / transformers / flash-attn.  This header is therefore the boundary
+ * a maintainer binds from Python (ctypes stub in INTEGRATION.md); each entry cites the reference call site whose
+ * arithmetic it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes; no torch types.  All pointers are DEVICE pointers unless marked host.
+ *  - `stream` is a hipStream_t (NULL = default stream).  All work is enqueued on it; no hidden syncs, no
+ *    allocation: the caller (PyTorch) owns every buffer.  One process per GPU.
+ *  - bf16 tensors are raw uint16 storage; "f32" = float.  Leading dimensions / strides are in ELEMENTS.
+ *  - Return 0 on success, negative on error (VLA_ERR_*); vla_last_error() gives a message.  No exceptions cross
+ *    the ABI.  Shapes are validated on the host BEFORE launch (a faulting kernel can take the node down).
+ *  - Rounding points follow the reference under bf16 autocast (one bf16 rounding after every Linear(+bias),
+ *    activation, residual add, norm); accumulation / softmax / statistics are fp32.
+ */
+#ifndef VLA_NATIVE_H
+#define VLA_NATIVE_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VLA_ERR_ARG (-1)
+#define VLA_ERR_LAUNCH (-2)
+#define VLA_ERR_UNSUPPORTED (-3)
+
+int vla_version(void);                 /* ABI version, currently 1 */
+const char* vla_last_error(void);      /* thread-local message of the last failing call */
+
+/* ---------------------------------------------------------------- GEMM */
+enum { VLA_ACT_NONE = 0, VLA_ACT_GELU = 1, VLA_ACT_RELU = 2, VLA_ACT_GELU_TANH = 3, VLA_ACT_SWIGLU = 4 };
+
+typedef struct vla_gemm_desc {
+  const void* A;    /* [batch][M, K] bf16, row stride lda */
+  const void* B;    /* [batch][N, K] bf16, row stride ldb (nn.Linear weight layout [out, in]) */
+  void* C;          /* [batch][M, N] bf16, row stride ldc (may be NULL for VLA_ACT_SWIGLU) */
+  const void* bias; /* [N] bf16 or NULL */
+  const void* R;    /* residual [M or res_mod, N] bf16 or NULL: C = bf16(bf16(act(..)) + R) */
+  void* C2;         /* VLA_ACT_SWIGLU only: h[M, N/2] = silu(gate)*up */
+  int M, N, K, lda, ldb, ldc, ldr, ldc2;
+  int res_mod;      /* >0: residual row = m % res_mod (ViT pos_embed broadcast over the batch) */
+  int act, batch;
+  long long sA, sB, sC, sR, sC2, sBias; /* batch strides (elements) */
+  float alpha;      /* accumulator scale (0 -> 1) */
+} vla_gemm_desc;
+
+/* C = epilogue(A . B^T).  Replaces nn.Linear forward and, with pre-transposed operands, its dX / dW products:
+ * timm ViT qkv/proj/mlp (modeling_prismatic.py:120-144), PrismaticProjector (:261-273), Qwen2 q/k/v/o/gate/up/down
+ * (:644-655), ProprioProjector (projectors.py:19-24), MLPResNet / MLPResNetBlock(_Pro) Linears
+ * (action_heads.py:111-121, 337-410).  K % 64 == 0; lda, ldb % 8 == 0; M/N edges are handled.
+ * VLA_ACT_SWIGLU: B rows interleaved in groups of 16 (rows 32t..32t+15 = gate[16t..], 32t+16.. = up[16t..]);
+ * C (optional) receives the interleaved pre-activations, C2 the product. */
+int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* desc /* host */);
+
+/* out[b][c, r] = in[b][r, c]; rows/cols of `in`; out has leading dim ldo >= rows (tail NOT touched: pre-zero it).
+ * Used to build the K-contiguous operands of dX (W^T) and dW (dY^T, X^T) products for vla_gemm_bf16_nt. */
+int vla_transpose_bf16(void* stream, const void* in, void* out, int rows, int cols, int ldi, int ldo, int batch,
+                       long long s_in, long long s_out);
+
+/* ---------------------------------------------------------------- norms */
+/* nn.LayerNorm forward over the last dim (timm Block norm1/norm2 eps 1e-6; action_heads.py:96,108,306 eps 1e-5).
+ * x,y bf16 [rows, cols]; w,b bf16 [cols]; stats (optional) f32 [rows,2] = (mean, rstd) for the backward. */
+int vla_layernorm_fwd(void* stream, const void* x, const void* w, const void* b, void* y, float* stats, int rows,
+                      int cols, int ldx, int ldy, float eps);
+/* dx (bf16, may be NULL) and dw/db (f32 [cols], accumulated with +=, may be NULL) of the above. */
+int vla_layernorm_bwd(void* stream, const void* dy, const void* x, const void* w, const float* stats, void* dx,
+                      float* dw, float* db, int rows, int cols, int ldx, int lddy, int lddx);
+/* Qwen2RMSNorm: y = bf16(w * bf16(x * rsqrt(mean(x^2)+eps))) (transformers Qwen2RMSNorm.forward; call site
+ * modeling_prismatic.py:644).  rstd (optional) f32 [rows]. */
+int vla_rmsnorm_fwd(void* stream, const void* x, const void* w, void* y, float* rstd, int rows, int cols, float eps);
+/* dx = rmsnorm backward (+ optional residual-stream gradient add: dx += dres).  No dw (frozen LLM). */
+int vla_rmsnorm_bwd(void* stream, const void* dy, const void* x, const void* w, const float* rstd, const void* dres,
+                    void* dx, int rows, int cols);
+
+/* ---------------------------------------------------------------- attention (MFMA, flash-style) */
+typedef struct vla_attn_desc {
+  const void* q; const void* k; const void* v;   /* bf16; element (b, s, h, d) at b*sb + s*ss + h*dh + d */
+  void* o;                                       /* bf16 [B, Sq, Hq, dh] same addressing with o strides */
+  float* lse;                                    /* f32 [B, Hq, Sq] log-sum-exp (natural log) or NULL */
+  const unsigned char* kmask;                    /* [B, Sk] 1 = key allowed, or NULL */
+  long long q_sb, k_sb, v_sb, o_sb;              /* batch strides */
+  int q_ss, k_ss, v_ss, o_ss;                    /* sequence strides */
+  int B, Sq, Sk, Hq, Hkv, dh, causal;
+  float scale;
+  /* backward only */
+  const void* dout; void* dq; void* dk; void* dv; float* delta; /* delta f32 [B,Hq,Sq] workspace */
+  long long do_sb, dq_sb, dk_sb, dv_sb; int do_ss, dq_ss, dk_ss, dv_ss;
+} vla_attn_desc;
+
+/* softmax(scale * Q K^T + mask) V, GQA (Hq % Hkv == 0), causal and/or key-padding mask, dh in {64,72,112,128}.
+ * Replaces F.scaled_dot_product_attention in timm Attention and flash-attn / eager attention in Qwen2Attention. */
+int vla_attn_fwd(void* stream, const vla_attn_desc* desc /* host */);
+/* dQ, dK, dV of the above (recompute from q,k,v,o,lse).  Replaces flash-attn backward / autograd of eager attention. */
+int vla_attn_bwd(void* stream, const vla_attn_desc* desc /* host */);
+
+/* ---------------------------------------------------------------- rotary embeddings */
+/* HF rotate_half RoPE in place on x[rows = B*S, nheads*dh] (row stride ldx): position = row % S;
+ * cos/sin tables f32 [S, dh/2] holding bf16-rounded values.  sign=+1 forward, -1 backward (inverse rotation).
+ * transformers apply_rotary_pos_emb; Qwen2 theta=1e6 (config.json text_config). */
+int vla_rope_half(void* stream, void* x, const float* cos_t, const float* sin_t, int rows, int S, int nheads, int dh,
+                  int ldx, int sign);
+/* action_heads.py:125-146 apply_rope: pairs (2i,2i+1) with cos/sin = cat([f,f]) tables (f32 [T, dh]).
+ * x[b, t, head, dh] rows = B*T, position = row % T.  mode 0 forward, 1 backward (transpose of the linear map). */
+int vla_rope_interleaved(void* stream, void* x, const float* cos_t, const float* sin_t, int rows, int T, int nheads,
+                         int dh, int ldx, int mode);
+
+/* ---------------------------------------------------------------- glue */
+/* timm PatchEmbed conv PxP/P as im2col: pixels [B, Ctot, H, W] (f32 if px_f32 else bf16), channels c0..c0+2 ->
+ * cols bf16 [B*(H/P)*(W/P), ldo] with (c, py, px) ordering, zero-filled up to ldo.  (modeling_prismatic.py:229-230) */
+int vla_im2col_patch(void* stream, const void* pixels, void* cols, int B, int Ctot, int c0, int H, int W, int P,
+                     int ldo, int px_f32);
+/* get_current_action_mask | get_next_actions_mask (train_utils.py:8-41) on int64 labels [B, L] shifted by
+ * `shift` (0: labels, 1: labels[:,1:]).  qidx int32 [B, L-shift]: k for the k-th selected position, else -1;
+ * pos int32 [B, 64]: selected positions (-1 padded); count int32 [B]. */
+int vla_action_mask(void* stream, const long long* labels, int* qidx, int* pos, int* count, int B, int L, int shift);
+/* Embedding gather + action-query splice + multimodal layout (modeling_prismatic.py:601, 418-454, 486-510):
+ * out[b, 0] = tok 0, out[b, 1..Np] untouched (projector GEMM writes there), out[b, Np+j] = tok j (j>=1);
+ * tok j = action_queries[qidx[b,j]] if qidx>=0 else table[ids[b,j]].  mm_mask u8 [B, S]. */
+int vla_embed_splice(void* stream, const long long* ids, const unsigned char* attn_mask, const int* qidx,
+                     const void* table, const void* action_queries, void* out, unsigned char* mm_mask, int B, int L,
+                     int Np, int D, int vocab);
+/* d action_queries[k] = sum_b dX[b, Np + pos[b,k]] (f32 [64, D]); backward of the splice. pos from shift=0 mask. */
+int vla_action_query_grad(void* stream, const void* dx, const int* pos, float* dq, int B, int S, int Np, int D);
+/* out[i, :] = in[idx[i], :] (idx<0 -> zeros); bf16 rows of D elements. */
+int vla_gather_rows(void* stream, const void* in, const int* idx, void* out, int n, int D, int ldi, int ldo);
+/* out[idx[i], :] += in[i, :] (idx unique, idx<0 skipped). */
+int vla_scatter_add_rows(void* stream, const void* in, const int* idx, void* out, int n, int D, int ldi, int ldo);
+/* y = bf16(a + b) elementwise over n bf16 (n % 8 == 0) */
+int vla_add_bf16(void* stream, const void* a, const void* b, void* y, long long n);
+/* GELU(erf) forward y=gelu(x) / backward dx = dy*gelu'(x), bf16, n elements */
+int vla_gelu_fwd(void* stream, const void* x, void* y, long long n);
+int vla_gelu_bwd(void* stream, const void* dy, const void* x, void* dx, long long n);
+/* relu backward through the OUTPUT: dx = dy * (y > 0) */
+int vla_relu_bwd(void* stream, const void* dy, const void* y, void* dx, long long n);
+/* SwiGLU backward: dH [M, I] and interleaved pre-activations GU [M, 2I] -> dGU [M, 2I] (same interleave). */
+int vla_swiglu_bwd(void* stream, const void* dh, const void* gu, void* dgu, int M, int I);
+/* column sums of a bf16 matrix [rows, cols] into f32 out[cols] (+=): bias gradients. */
+int vla_colsum_bf16(void* stream, const void* x, float* out, int rows, int cols, int ldx);
+/* f32 -> bf16 / bf16 -> f32 casts */
+int vla_cast_f32_bf16(void* stream, const float* x, void* y, long long n);
+int vla_cast_bf16_f32(void* stream, const void* x, float* y, long long n);
+
+/* ---------------------------------------------------------------- action head attention (action_heads.py:337-410) */
+typedef struct vla_head_attn_desc {
+  const void* q;      /* [B, T, H*dh] bf16 (RoPE applied) */
+  const void* k_self; const void* v_self;     /* [B, T, H*dh] */
+  const void* k_adp;  const void* v_adp;      /* [B, Ka, H*dh] */
+  const void* k_task; const void* v_task;     /* [B, Kt, H*dh] */
+  const void* gate;   /* bf16 scalar gating_factor (device) */
+  void* out;          /* [B, T, H*dh] */
+  float* probs;       /* f32 [B, H, T, T+Ka+Kt] saved softmax (workspace for backward) */
+  int B, T, Ka, Kt, H, dh;
+  int ld_q, ld_self, ld_adp, ld_task, ld_out; /* row strides */
+  int gate_on_adapter;                        /* 0: Pro (tanh(g) on task segment); 1: original block (on 3rd segment too) */
+  /* backward */
+  const void* dout; void* dq; void* dk_self; void* dv_self; void* dk_adp; void* dv_adp; void* dk_task; void* dv_task;
+  float* dgate;       /* f32 scalar, += */
+} vla_head_attn_desc;
+int vla_head_attn_fwd(void* stream, const vla_head_attn_desc* desc /* host */);
+int vla_head_attn_bwd(void* stream, const vla_head_attn_desc* desc /* host */);
+
+/* ---------------------------------------------------------------- loss + optimiser */
+/* torch.nn.L1Loss (finetune.py:418): loss[0] = mean|pred - target|, loss[1] = curr (chunk 0), loss[2] = next;
+ * dpred = sign(pred-target) * gscale / n (bf16).  pred/target bf16 [B, C, Da]. */
+int vla_l1_loss(void* stream, const void* pred, const void* target, float* loss3, void* dpred, int B, int C, int Da,
+                float gscale);
+/* torch.optim.AdamW step on bf16 params/grads/states with bf16 rounding after every elementwise op, as the
+ * foreach implementation does (finetune.py:910, 1079).  g may be f32 (g_f32=1: rounded to bf16 first). */
+int vla_adamw_bf16(void* stream, void* p, const void* g, void* m, void* v, long long n, double lr, double beta1,
+                   double beta2, double eps, double wd, int step, int g_f32, float gscale);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLA_NATIVE_H */

@@ -102,6 +102,31 @@ def embed_splice(input_ids, labels, attention_mask, embed_table, action_queries,
     return mm, mm_mask
 
 
+def attention(q, k, v, causal: bool, kmask=None, scale=None, emu=False):
+    """softmax(scale q k^T + mask) v.  q [B,H,Sq,dh], k/v [B,Hkv,Sk,dh] (GQA: H % Hkv == 0), kmask [B,Sk] bool.
+    fp32 softmax, probabilities rounded to bf16 before P@V (transformers eager_attention_forward)."""
+    H, KV, dh = q.shape[1], k.shape[1], q.shape[-1]
+    if KV != H:
+        k, v = k.repeat_interleave(H // KV, dim=1), v.repeat_interleave(H // KV, dim=1)
+    s = (q @ k.transpose(-1, -2)) * (scale if scale is not None else dh ** -0.5)
+    Sq, Sk = s.shape[-2:]
+    allow = torch.ones(Sq, Sk, dtype=torch.bool)
+    if causal:
+        allow = torch.tril(allow)
+    allow = allow[None, None]
+    if kmask is not None:
+        allow = allow & kmask[:, None, None, :].bool()
+    s = s.masked_fill(~allow, float("-inf"))
+    return rnd(rnd(torch.softmax(s, dim=-1), emu) @ v, emu)
+
+
+def im2col(pixels, P: int):
+    """[B,C,H,W] -> [B, (H/P)(W/P), C*P*P] in the (c, py, px) order of a conv weight [d, C, P, P]."""
+    B, C, H, W = pixels.shape
+    gh, gw = H // P, W // P
+    return pixels.reshape(B, C, gh, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * P * P)
+
+
 # ----------------------------------------------------------------------------------------------
 # a3  ViT featurizer (timm VisionTransformer semantics; evidence film_vit_wrapper.py:69-75,114-168;
 #     modeling_prismatic.py:120-144, 196-237).  PARITY UNPINNED (timm absent).
@@ -115,10 +140,8 @@ def vit_forward(pixels, p: Dict[str, torch.Tensor], cfg: Dict, emu=False) -> tor
             blocks.N.{norm1,attn.qkv,attn.proj,ls1.scale_factor,norm2,mlp.fc1,mlp.fc2,ls2.scale_factor}).
     """
     d, heads, P = cfg["d"], cfg["heads"], cfg["patch"]
-    B, C, H, W = pixels.shape
-    gh, gw = H // P, W // P
-    # patch embed = conv PxP stride P == GEMM over im2col'd patches (c, py, px ordering of conv weight)
-    cols = pixels.reshape(B, C, gh, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * P * P)
+    B = pixels.shape[0]
+    cols = im2col(pixels, P)   # patch embed = conv PxP stride P == GEMM over im2col'd patches
     x = linear(rnd(cols, emu), p["patch_embed.proj.weight"].reshape(d, -1), p["patch_embed.proj.bias"], emu)
     x = rnd(x + p["pos_embed"], emu)                               # _pos_embed (no_embed_class / no cls)
     if cfg.get("n_prefix", 0):
@@ -134,9 +157,7 @@ def vit_forward(pixels, p: Dict[str, torch.Tensor], cfg: Dict, emu=False) -> tor
         qkv = linear(h, p[pre + "attn.qkv.weight"], p[pre + "attn.qkv.bias"], emu)
         T = x.shape[1]
         q, k, v = qkv.reshape(B, T, 3, heads, dh).permute(2, 0, 3, 1, 4)
-        s = (q @ k.transpose(-1, -2)) * dh ** -0.5
-        a = rnd(torch.softmax(s, dim=-1), emu) @ v
-        a = rnd(a, emu).transpose(1, 2).reshape(B, T, d)
+        a = attention(q, k, v, False, None, dh ** -0.5, emu).transpose(1, 2).reshape(B, T, d)
         a = linear(a, p[pre + "attn.proj.weight"], p[pre + "attn.proj.bias"], emu)
         if cfg.get("layerscale"):
             a = rnd(a * p[pre + "ls1.scale_factor"], emu)          # modeling_prismatic.py:58-66
@@ -194,8 +215,6 @@ def qwen2_forward(x, mask, p: Dict[str, torch.Tensor], cfg: Dict, emu=False) -> 
     B, S, D = x.shape
     H, KV, dh = cfg["heads"], cfg["kv_heads"], cfg["dh"]
     cos, sin = rope_half_tables(S, dh, cfg["theta"], emu)
-    causal = torch.tril(torch.ones(S, S, dtype=torch.bool))
-    allow = causal[None, None] & mask[:, None, None, :].bool()
     hs = [x]
     for i in range(cfg["n_layers"]):
         pre = f"layers.{i}."
@@ -206,12 +225,7 @@ def qwen2_forward(x, mask, p: Dict[str, torch.Tensor], cfg: Dict, emu=False) -> 
         q = rope_half(q.reshape(B, S, H, dh).transpose(1, 2), cos, sin, emu)
         k = rope_half(k.reshape(B, S, KV, dh).transpose(1, 2), cos, sin, emu)
         v = v.reshape(B, S, KV, dh).transpose(1, 2)
-        k = k.repeat_interleave(H // KV, dim=1)
-        v = v.repeat_interleave(H // KV, dim=1)
-        s = (q @ k.transpose(-1, -2)) * dh ** -0.5
-        s = s.masked_fill(~allow, float("-inf"))
-        a = rnd(torch.softmax(s, dim=-1), emu) @ v
-        a = rnd(a, emu).transpose(1, 2).reshape(B, S, H * dh)
+        a = attention(q, k, v, True, mask, dh ** -0.5, emu).transpose(1, 2).reshape(B, S, H * dh)
         x = rnd(x + linear(a, p[pre + "self_attn.o_proj.weight"], None, emu), emu)
         h = rms_norm(x, p[pre + "post_attention_layernorm.weight"], cfg["eps"], emu)
         g = linear(h, p[pre + "mlp.gate_proj.weight"], None, emu)
@@ -272,6 +286,17 @@ def _heads(t, B, L, H):
     return t.reshape(B, L, H, -1).transpose(1, 2)
 
 
+def head_attention_core(q, segs, ratio_g, emu=False):
+    """Scores over [self | second | third] key segments, tanh-gate on the THIRD (h_t) segment, softmax over all
+    (action_heads.py:391-401 Pro; :262-275 original).  q [B,H,T,dh]; segs = [(k,v)]*3 -> [B,H,T,dh]."""
+    dh = q.shape[-1]
+    sc = [rnd(q @ k.transpose(-1, -2), emu) for k, _ in segs]
+    sc[2] = rnd(sc[2] * rnd(ratio_g, emu), emu)
+    s = rnd(torch.cat(sc, dim=-1) / math.sqrt(dh), emu)
+    w = rnd(torch.softmax(s, dim=-1), emu)
+    return rnd(w @ torch.cat([v for _, v in segs], dim=2), emu)
+
+
 def head_block_pro(x, h_t, h_a, pp, p: Dict[str, torch.Tensor], pre: str, emu=False, H: int = 8):
     """MLPResNetBlock_Pro.forward (action_heads.py:337-410)."""
     B, T, C = x.shape
@@ -290,12 +315,7 @@ def head_block_pro(x, h_t, h_a, pp, p: Dict[str, torch.Tensor], pre: str, emu=Fa
     ka = head_rope(ka, ca, sa, emu)
     ct, st = head_rope_tables(Kt, dh, emu)
     kt = head_rope(kt, ct, st, emu)
-    s = torch.cat([rnd(q @ ks.transpose(-1, -2), emu),
-                   rnd(q @ ka.transpose(-1, -2), emu),
-                   rnd(rnd(q @ kt.transpose(-1, -2), emu) * rnd(ratio_g, emu), emu)], dim=-1)   # :391-394
-    s = rnd(s / math.sqrt(dh), emu)
-    w = rnd(torch.softmax(s, dim=-1), emu)                         # :395
-    o = rnd(w @ torch.cat([vs, va, vt], dim=2), emu)               # :398-401
+    o = head_attention_core(q, [(ks, vs), (ka, va), (kt, vt)], ratio_g, emu)     # :391-401
     o = L("o_proj", o.transpose(1, 2).reshape(B, T, C))
     y = rnd(o + x, emu)                                            # :409 (no outer residual)
     y = layer_norm(y, p[pre + "ffn.0.weight"], p[pre + "ffn.0.bias"], 1e-5, emu)
@@ -314,12 +334,7 @@ def head_block_orig(x, h_t, h_a, pp, p: Dict[str, torch.Tensor], pre: str, emu=F
     kx, vx = _heads(L("k_proj", x), B, T, H), _heads(L("v_proj", x), B, T, H)
     kh, vh = _heads(L("k_proj", h), B, h.shape[1], H), _heads(L("v_proj", h), B, h.shape[1], H)
     kt, vt = _heads(L("k_proj", h_t), B, h_t.shape[1], H), _heads(L("v_proj", h_t), B, h_t.shape[1], H)
-    s = torch.cat([rnd(q @ kx.transpose(-1, -2), emu),
-                   rnd(q @ kh.transpose(-1, -2), emu),
-                   rnd(rnd(q @ kt.transpose(-1, -2), emu) * rnd(ratio_g, emu), emu)], dim=-1)
-    s = rnd(s / math.sqrt(dh), emu)
-    w = rnd(torch.softmax(s, dim=-1), emu)
-    o = rnd(w @ torch.cat([vx, vh, vt], dim=2), emu)
+    o = head_attention_core(q, [(kx, vx), (kh, vh), (kt, vt)], ratio_g, emu)     # :262-275
     o = L("o_proj", o.transpose(1, 2).reshape(B, T, C))
     y = layer_norm(rnd(o + x, emu), p[pre + "ffn.0.weight"], p[pre + "ffn.0.bias"], 1e-5, emu)
     return rnd(torch.relu(L("ffn.1", y)), emu)

@@ -1,0 +1,410 @@
+"""Per-kernel parity: every C-ABI op (called through ctypes) against the CPU oracle on the same seeded inputs.
+
+Tolerances (written per test): outputs are bf16, so one rounding flip is 2^-8 relative; we require
+  rel-L2(native, oracle) <= 2e-3   and   max|diff| <= 2^-6 * max|ref|   for single ops with fp32 accumulation,
+bit-exact for integer/index work and for AdamW (same op-by-op bf16 rounding as torch).
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import vla_oracle as O  # noqa: E402
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from vla_adapter_amd import ops as _ops
+    return _ops
+
+
+def gen(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+def f(x):
+    return x.detach().float().cpu()
+
+
+def check(native, ref, rel=2e-3, mx=2 ** -6, name=""):
+    a, b = f(native), ref.float()
+    assert a.shape == b.shape, f"{name}: shape {a.shape} vs {b.shape}"
+    assert torch.isfinite(a).all(), f"{name}: non-finite output"
+    den = b.norm().item() + 1e-12
+    r = (a - b).norm().item() / den
+    m = (a - b).abs().max().item()
+    assert r <= rel and m <= mx * (b.abs().max().item() + 1e-12) + 1e-6, f"{name}: rel-L2 {r:.3e} (<= {rel}), max|d| {m:.3e}"
+    return r
+
+
+# ------------------------------------------------------------------ layout probes
+def test_probe_layouts(ops):
+    import ctypes as C
+    lib = ops.N.load()
+    lib.vla_probe_layouts.argtypes = [C.c_void_p] * 4
+    tr = torch.zeros(64 * 4, dtype=torch.int16, device=DEV)
+    m32 = torch.zeros(64 * 16, dtype=torch.float32, device=DEV)
+    m16 = torch.zeros(64 * 4, dtype=torch.float32, device=DEV)
+    rc = lib.vla_probe_layouts(None, C.c_void_p(tr.data_ptr()), C.c_void_p(m32.data_ptr()), C.c_void_p(m16.data_ptr()))
+    assert rc == 0
+    torch.cuda.synchronize()
+    tr = tr.cpu().view(64, 4).numpy()
+    for lane in range(64):
+        g, i = lane >> 4, lane & 15
+        # lane i of group g receives column 16g+i of rows 0..3
+        exp = [r * 256 + 16 * g + i for r in range(4)]
+        assert tr[lane].tolist() == exp, f"ds_read_b64_tr_b16 lane {lane}: got {tr[lane].tolist()} want {exp}"
+    m32 = m32.cpu().view(64, 16).numpy()
+    for lane in range(64):
+        col, h = lane & 31, lane >> 5
+        for reg in range(16):
+            row = (reg & 3) + 8 * (reg >> 2) + 4 * h
+            exp = (8 * row + (col & 7)) if row < 16 else 0.0     # C = I[32x16] . B
+            assert m32[lane, reg] == exp, f"mfma32 lane {lane} reg {reg}: {m32[lane, reg]} want {exp}"
+    m16 = m16.cpu().view(64, 4).numpy()
+    for lane in range(64):
+        col, gq = lane & 15, lane >> 4
+        for reg in range(4):
+            row = 4 * gq + reg
+            assert m16[lane, reg] == 8 * row + (col & 7), f"mfma16 lane {lane} reg {reg}"
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (300, 200, 192), (1000, 896, 896), (64, 7, 128),
+                                   (2080, 896, 896)])
+def test_gemm_plain_bias(ops, M, N, K):
+    a, b, bias = gen(M, K, seed=1), gen(N, K, seed=2, scale=0.05), gen(N, seed=3)
+    out = ops.gemm_nt(a.to(DEV), b.to(DEV), bias=bias.to(DEV))
+    check(out, O.linear(a.float(), b.float(), bias.float(), emu=True), name=f"gemm {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("act,oact", [(1, "gelu"), (2, "relu"), (3, "gelu_tanh")])
+def test_gemm_act_residual(ops, act, oact):
+    M, N, K = 520, 256, 256
+    a, b, bias, r = gen(M, K, seed=4), gen(N, K, seed=5, scale=0.08), gen(N, seed=6), gen(M, N, seed=7)
+    out = ops.gemm_nt(a.to(DEV), b.to(DEV), bias=bias.to(DEV), residual=r.to(DEV), act=act)
+    y = O.linear(a.float(), b.float(), bias.float(), emu=True)
+    y = {"gelu": lambda t: O.gelu(t, True), "relu": lambda t: torch.relu(t), "gelu_tanh": lambda t: O.gelu(t, True, True)}[oact](y)
+    check(out, O.rnd(y + r.float(), True), name=f"gemm act {oact}")
+
+
+def test_gemm_res_mod_and_batched(ops):
+    nb, M, N, K = 3, 256, 128, 128
+    a, b, pos = gen(nb, M, K, seed=8), gen(N, K, seed=9, scale=0.1), gen(M, N, seed=10)
+    # batched A with a shared B and a shared (row-broadcast) residual: the patch-embed + pos_embed pattern
+    out = ops.gemm_nt(a.to(DEV).view(nb * M, K), b.to(DEV), residual=pos.to(DEV), res_mod=M)
+    ref = O.rnd(O.linear(a.float(), b.float(), None, True) + pos.float(), True).view(nb * M, N)
+    check(out, ref, name="gemm res_mod")
+    # true batched: per-batch B, output written into a strided window of a larger buffer
+    bb = gen(nb, N, K, seed=11, scale=0.1)
+    big = torch.zeros(nb, M + 5, N, dtype=BF, device=DEV)
+    ops.gemm_nt(a.to(DEV), bb.to(DEV), out=big[:, 1:M + 1])
+    ref = torch.stack([O.linear(a[i].float(), bb[i].float(), None, True) for i in range(nb)])
+    check(big[:, 1:M + 1], ref, name="gemm batched/strided")
+    assert (f(big[:, 0]) == 0).all() and (f(big[:, M + 1:]) == 0).all(), "wrote outside the window"
+
+
+def test_gemm_swiglu(ops):
+    M, I, K = 200, 192, 128
+    x, wg, wu = gen(M, K, seed=12), gen(I, K, seed=13, scale=0.1), gen(I, K, seed=14, scale=0.1)
+    # interleave rows in groups of 16: [g0..15, u0..15, g16..31, u16..31, ...]
+    w = torch.stack([wg.view(I // 16, 16, K), wu.view(I // 16, 16, K)], dim=1).reshape(2 * I, K)
+    pre, h = ops.gemm_nt(x.to(DEV), w.to(DEV), act=ops.ACT_SWIGLU)
+    g, u = O.linear(x.float(), wg.float(), None, True), O.linear(x.float(), wu.float(), None, True)
+    href = O.rnd(O.rnd(g * torch.sigmoid(g), True) * u, True)
+    check(h, href, name="swiglu h")
+    pre_ref = torch.stack([g.view(M, I // 16, 16), u.view(M, I // 16, 16)], dim=2).reshape(M, 2 * I)
+    check(pre, pre_ref, name="swiglu pre")
+    # backward of the elementwise part
+    dh = gen(M, I, seed=15)
+    dgu = ops.swiglu_bwd(dh.to(DEV), pre)
+    gg, uu = f(pre).view(M, I // 16, 2, 16)[:, :, 0].reshape(M, I).requires_grad_(True), f(pre).view(M, I // 16, 2, 16)[:, :, 1].reshape(M, I).requires_grad_(True)
+    ((gg * torch.sigmoid(gg)) * uu * dh.float()).sum().backward()
+    ref = torch.stack([gg.grad.view(M, I // 16, 16), uu.grad.view(M, I // 16, 16)], dim=2).reshape(M, 2 * I)
+    check(dgu, ref, rel=4e-3, name="swiglu bwd")
+
+
+def test_gemm_rejects_bad_shapes(ops):
+    a, b = gen(64, 100).to(DEV), gen(64, 100).to(DEV)       # K % 64 != 0
+    with pytest.raises(ops.N.NativeError):
+        ops.gemm_nt(a, b)
+
+
+def test_transpose(ops):
+    x = gen(3, 130, 70, seed=16)
+    t = ops.transpose(x.to(DEV), ld_out=192)
+    assert t.shape == (3, 70, 192)
+    assert torch.equal(f(t[:, :, :130]), x.float().transpose(1, 2)) and (f(t[:, :, 130:]) == 0).all()
+
+
+# ------------------------------------------------------------------ norms
+@pytest.mark.parametrize("rows,cols,eps", [(37, 1152, 1e-6), (256, 896, 1e-5), (16, 6272, 1e-5), (5, 64, 1e-5)])
+def test_layernorm(ops, rows, cols, eps):
+    x, w, b, dy = gen(rows, cols, seed=20), (1 + 0.1 * gen(cols, seed=21).float()).to(BF), gen(cols, seed=22, scale=0.1), gen(rows, cols, seed=23)
+    y, stats = ops.layernorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), eps, want_stats=True)
+    check(y, O.layer_norm(x.float(), w.float(), b.float(), eps, True), name="layernorm fwd")
+    xr, wr, br = x.float().requires_grad_(True), w.float().requires_grad_(True), b.float().requires_grad_(True)
+    (O.layer_norm(xr, wr, br, eps) * dy.float()).sum().backward()
+    dw = torch.zeros(cols, device=DEV)
+    db = torch.zeros(cols, device=DEV)
+    dx = ops.layernorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), stats, dw, db)
+    check(dx, xr.grad, rel=4e-3, name="layernorm dx")
+    check(dw, wr.grad, rel=1e-3, mx=1e-2, name="layernorm dw")
+    check(db, br.grad, rel=1e-3, mx=1e-2, name="layernorm db")
+
+
+@pytest.mark.parametrize("rows,cols", [(100, 896), (7, 256), (33, 1536)])
+def test_rmsnorm(ops, rows, cols):
+    x, w, dy, dres = gen(rows, cols, seed=24), (1 + 0.1 * gen(cols, seed=25).float()).to(BF), gen(rows, cols, seed=26), gen(rows, cols, seed=27)
+    y, rstd = ops.rmsnorm_fwd(x.to(DEV), w.to(DEV), 1e-6, want_rstd=True)
+    check(y, O.rms_norm(x.float(), w.float(), 1e-6, True), name="rmsnorm fwd")
+    xr = x.float().requires_grad_(True)
+    (O.rms_norm(xr, w.float(), 1e-6) * dy.float()).sum().backward()
+    dx = ops.rmsnorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), rstd, dres.to(DEV))
+    check(dx, xr.grad + dres.float(), rel=4e-3, name="rmsnorm bwd")
+
+
+# ------------------------------------------------------------------ RoPE
+def test_rope_half(ops):
+    B, S, H, KV, dh = 2, 40, 4, 2, 64
+    qkv = gen(B * S, (H + 2 * KV) * dh, seed=30)
+    cos, sin = ops.rope_half_tables(S, dh, 1e6, DEV)
+    buf = qkv.to(DEV).clone()
+    ops.rope_half_(buf[:, :H * dh], cos, sin, S, H, dh)
+    ops.rope_half_(buf[:, H * dh:(H + KV) * dh], cos, sin, S, KV, dh)
+    c, s = O.rope_half_tables(S, dh, 1e6, True)
+    q = qkv.float()[:, :H * dh].view(B, S, H, dh).transpose(1, 2)
+    k = qkv.float()[:, H * dh:(H + KV) * dh].view(B, S, KV, dh).transpose(1, 2)
+    check(buf[:, :H * dh], O.rope_half(q, c, s, True).transpose(1, 2).reshape(B * S, H * dh), rel=1e-3, name="rope q")
+    check(buf[:, H * dh:(H + KV) * dh], O.rope_half(k, c, s, True).transpose(1, 2).reshape(B * S, KV * dh), rel=1e-3, name="rope k")
+    assert torch.equal(f(buf[:, (H + KV) * dh:]), qkv.float()[:, (H + KV) * dh:]), "v columns must be untouched"
+    # backward = inverse rotation: rope(-theta)(rope(theta)(x)) ~ x
+    ops.rope_half_(buf[:, :H * dh], cos, sin, S, H, dh, sign=-1)
+    check(buf[:, :H * dh], qkv.float()[:, :H * dh], rel=1.5e-2, mx=5e-2, name="rope inverse")
+
+
+def test_rope_interleaved(ops):
+    B, T, H, dh = 3, 21, 8, 112
+    x = gen(B * T, H * dh, seed=31)
+    cos, sin = ops.rope_inter_tables(T, dh, DEV)
+    buf = x.to(DEV).clone()
+    ops.rope_inter_(buf, cos, sin, T, H, dh, 0)
+    c, s = O.head_rope_tables(T, dh, True)
+    xr = x.float().view(B, T, H, dh).transpose(1, 2)
+    check(buf, O.head_rope(xr, c, s, True).transpose(1, 2).reshape(B * T, H * dh), rel=1e-3, name="head rope fwd")
+    # backward = transpose of the (non-orthogonal) linear map
+    dy = gen(B * T, H * dh, seed=32)
+    xg = x.float().view(B, T, H, dh).transpose(1, 2).clone().requires_grad_(True)
+    (O.head_rope(xg, c, s) * dy.float().view(B, T, H, dh).transpose(1, 2)).sum().backward()
+    g = dy.to(DEV).clone()
+    ops.rope_inter_(g, cos, sin, T, H, dh, 1)
+    check(g, xg.grad.transpose(1, 2).reshape(B * T, H * dh), rel=3e-3, name="head rope bwd")
+
+
+# ------------------------------------------------------------------ attention
+def _attn_inputs(B, S, Hq, Hkv, dh, seed):
+    W = (Hq + 2 * Hkv) * dh
+    qkv = gen(B, S, W, seed=seed)
+    return qkv, qkv[:, :, :Hq * dh], qkv[:, :, Hq * dh:(Hq + Hkv) * dh], qkv[:, :, (Hq + Hkv) * dh:]
+
+
+@pytest.mark.parametrize("B,S,Hq,Hkv,dh,causal,masked", [
+    (2, 128, 2, 2, 64, False, False), (2, 77, 4, 2, 64, True, True), (1, 352, 14, 2, 64, True, True),
+    (2, 256, 2, 2, 72, False, False), (2, 100, 2, 1, 112, False, True), (1, 70, 2, 2, 128, True, False),
+    (2, 261, 4, 4, 64, False, False)])
+def test_attention_fwd(ops, B, S, Hq, Hkv, dh, causal, masked):
+    qkv, q, k, v = _attn_inputs(B, S, Hq, Hkv, dh, 40)
+    km = torch.ones(B, S, dtype=torch.bool)
+    if masked:
+        km[0, S - 9:] = False
+        if B > 1:
+            km[1, S // 2:] = False
+    d = qkv.to(DEV)
+    W = d.shape[-1]
+    o, lse = ops.attn_fwd(d[:, :, :Hq * dh], d[:, :, Hq * dh:(Hq + Hkv) * dh], d[:, :, (Hq + Hkv) * dh:], Hq, Hkv, dh,
+                          causal, km.to(torch.uint8).to(DEV) if masked else None, want_lse=True)
+    hd = lambda t, h: t.float().reshape(B, S, h, dh).transpose(1, 2)
+    ref = O.attention(hd(q, Hq), hd(k, Hkv), hd(v, Hkv), causal, km if masked else None, None, True)
+    valid = torch.ones(B, S, dtype=torch.bool) if (causal or not masked) else torch.ones(B, S, dtype=torch.bool)
+    check(o, ref.transpose(1, 2).reshape(B, S, Hq * dh), rel=6e-3, mx=3e-2, name=f"attn fwd dh{dh}")
+    # log-sum-exp against fp32
+    kk, vv = hd(k, Hkv).repeat_interleave(Hq // Hkv, 1), None
+    s = (hd(q, Hq) @ kk.transpose(-1, -2)) * dh ** -0.5
+    allow = (torch.tril(torch.ones(S, S, dtype=torch.bool)) if causal else torch.ones(S, S, dtype=torch.bool))[None, None] & km[:, None, None, :]
+    check(lse, torch.logsumexp(s.masked_fill(~allow, float("-inf")), -1), rel=1e-4, mx=1e-3, name="lse")
+
+
+@pytest.mark.parametrize("B,S,Hq,Hkv,dh,causal,masked", [(2, 96, 2, 2, 64, False, False), (2, 77, 4, 2, 64, True, True),
+                                                       (1, 352, 14, 2, 64, True, True), (1, 100, 2, 2, 72, False, False)])
+def test_attention_bwd(ops, B, S, Hq, Hkv, dh, causal, masked):
+    qkv, q, k, v = _attn_inputs(B, S, Hq, Hkv, dh, 41)
+    dout = gen(B, S, Hq * dh, seed=42)
+    km = torch.ones(B, S, dtype=torch.bool)
+    if masked:
+        km[0, S - 9:] = False
+    d = qkv.to(DEV)
+    qd, kd, vd = d[:, :, :Hq * dh], d[:, :, Hq * dh:(Hq + Hkv) * dh], d[:, :, (Hq + Hkv) * dh:]
+    kmd = km.to(torch.uint8).to(DEV) if masked else None
+    o, lse = ops.attn_fwd(qd, kd, vd, Hq, Hkv, dh, causal, kmd, want_lse=True)
+    dqkv = torch.zeros_like(d)
+    ops.attn_bwd(dout.to(DEV), qd, kd, vd, o, lse, Hq, Hkv, dh, causal, kmd,
+                 dq=dqkv[:, :, :Hq * dh], dk=dqkv[:, :, Hq * dh:(Hq + Hkv) * dh], dv=dqkv[:, :, (Hq + Hkv) * dh:])
+    hd = lambda t, h: t.float().reshape(B, S, h, dh).transpose(1, 2)
+    qr, kr, vr = (hd(t, h).clone().requires_grad_(True) for t, h in ((q, Hq), (k, Hkv), (v, Hkv)))
+    ref = O.attention(qr, kr, vr, causal, km if masked else None)
+    (ref * hd(dout, Hq)).sum().backward()
+    un = lambda t, h: t.transpose(1, 2).reshape(B, S, h * dh)
+    check(dqkv[:, :, :Hq * dh], un(qr.grad, Hq), rel=1e-2, mx=5e-2, name="dq")
+    check(dqkv[:, :, Hq * dh:(Hq + Hkv) * dh], un(kr.grad, Hkv), rel=1e-2, mx=5e-2, name="dk")
+    check(dqkv[:, :, (Hq + Hkv) * dh:], un(vr.grad, Hkv), rel=1e-2, mx=5e-2, name="dv")
+
+
+# ------------------------------------------------------------------ action-head attention
+@pytest.mark.parametrize("B,Ka,Kt,D", [(2, 65, 256, 896), (3, 65, 24, 64), (1, 65, 512, 896)])
+def test_head_attention(ops, B, Ka, Kt, D):
+    H, T = 8, 8
+    dh = D // H
+    sc = 0.3 if D > 64 else 1.0
+    x3 = gen(B, T, 3 * D, seed=50, scale=sc)          # fused q | k_self | v_self
+    a2 = gen(B, Ka, 2 * D, seed=51, scale=sc)
+    t2 = gen(B, Kt, 2 * D, seed=52, scale=sc)
+    gate = torch.tensor([0.7]).to(BF)
+    dx3, da2, dt2 = x3.to(DEV), a2.to(DEV), t2.to(DEV)
+    args = (dx3[:, :, :D], dx3[:, :, D:2 * D], dx3[:, :, 2 * D:], da2[:, :, :D], da2[:, :, D:], dt2[:, :, :D], dt2[:, :, D:])
+    out, probs = ops.head_attn_fwd(*args, gate.to(DEV), H)
+    hd = lambda t, L: t.float().reshape(B, L, H, dh).transpose(1, 2)
+    leaf = lambda t, L: hd(t, L).clone().requires_grad_(True)
+    q, ks, vs = leaf(x3[:, :, :D], T), leaf(x3[:, :, D:2 * D], T), leaf(x3[:, :, 2 * D:], T)
+    ka, va, kt, vt = leaf(a2[:, :, :D], Ka), leaf(a2[:, :, D:], Ka), leaf(t2[:, :, :D], Kt), leaf(t2[:, :, D:], Kt)
+    g = gate.float().clone().requires_grad_(True)
+    ref = O.head_attention_core(q, [(ks, vs), (ka, va), (kt, vt)], torch.tanh(g), True)
+    check(out, ref.transpose(1, 2).reshape(B, T, D), rel=6e-3, mx=3e-2, name="head attn fwd")
+    # backward vs fp32 autograd of the same math
+    dout = gen(B, T, D, seed=53)
+    ref32 = O.head_attention_core(q, [(ks, vs), (ka, va), (kt, vt)], torch.tanh(g), False)
+    (ref32 * hd(dout, T)).sum().backward()
+    g3, ga, gt = torch.zeros_like(dx3), torch.zeros_like(da2), torch.zeros_like(dt2)
+    dgate = torch.zeros(1, device=DEV)
+    ops.head_attn_bwd(dout.to(DEV), *args, gate.to(DEV), probs, dgate, g3[:, :, :D], g3[:, :, D:2 * D], g3[:, :, 2 * D:],
+                      ga[:, :, :D], ga[:, :, D:], gt[:, :, :D], gt[:, :, D:], H)
+    un = lambda t, L: t.transpose(1, 2).reshape(B, L, D)
+    check(g3[:, :, :D], un(q.grad, T), rel=1.5e-2, mx=6e-2, name="head dq")
+    check(g3[:, :, D:2 * D], un(ks.grad, T), rel=1.5e-2, mx=6e-2, name="head dk_self")
+    check(g3[:, :, 2 * D:], un(vs.grad, T), rel=1.5e-2, mx=6e-2, name="head dv_self")
+    check(ga[:, :, :D], un(ka.grad, Ka), rel=1.5e-2, mx=6e-2, name="head dk_adp")
+    check(ga[:, :, D:], un(va.grad, Ka), rel=1.5e-2, mx=6e-2, name="head dv_adp")
+    check(gt[:, :, :D], un(kt.grad, Kt), rel=1.5e-2, mx=6e-2, name="head dk_task")
+    check(gt[:, :, D:], un(vt.grad, Kt), rel=1.5e-2, mx=6e-2, name="head dv_task")
+    assert abs(dgate.item() - g.grad.item()) <= 3e-2 * abs(g.grad.item()) + 1e-3, f"dgate {dgate.item()} vs {g.grad.item()}"
+
+
+# ------------------------------------------------------------------ glue (integer / index work is bit-exact)
+def test_action_mask_and_splice(ops):
+    z = np.load(os.path.join(G, "masks.npz"))
+    labels = torch.from_numpy(z["labels"])
+    B, L = labels.shape
+    for shift in (0, 1):
+        qidx, pos, cnt = ops.action_mask(labels.to(DEV), shift)
+        m = O.all_actions_mask(labels[:, shift:])
+        assert torch.equal(qidx.cpu() >= 0, m), "mask mismatch vs train_utils golden"
+        assert cnt.cpu().tolist() == [64] * B
+        for b in range(B):
+            idx = torch.where(m[b])[0]
+            assert pos[b].cpu().tolist() == idx.tolist()
+            assert qidx[b].cpu()[idx].tolist() == list(range(64))
+    # adversarial rows: fewer than 64 hits -> count reported, pos padded with -1
+    adv = torch.from_numpy(z["labels_adv"])
+    qa, pa, ca = ops.action_mask(adv.to(DEV), 0)
+    ma = O.all_actions_mask(adv)
+    assert torch.equal(qa.cpu() >= 0, ma) and ca.cpu().tolist() == ma.sum(1).tolist()
+    # splice
+    D, Np, V = 64, 16, 151936
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, V, (B, L), generator=g)
+    ids[labels > O.ACTION_TOKEN_BEGIN_IDX] = labels[labels > O.ACTION_TOKEN_BEGIN_IDX]
+    am = ids != 151643
+    am[1, -7:] = False
+    table = gen(V, D, seed=60)
+    aq, patches = gen(64, D, seed=61), gen(B, Np, D, seed=62)
+    out = torch.zeros(B, L + Np, D, dtype=BF, device=DEV)
+    out[:, 1:Np + 1] = patches.to(DEV)
+    mm = torch.zeros(B, L + Np, dtype=torch.uint8, device=DEV)
+    qidx, pos, cnt = ops.action_mask(labels.to(DEV), 0)
+    ops.embed_splice(ids.to(DEV), am.to(torch.uint8).to(DEV), qidx, table.to(DEV), aq.to(DEV), out, mm, Np)
+    ref, refm = O.embed_splice(ids, labels, am, table.float(), aq.float(), patches.float())
+    assert torch.equal(f(out), ref), "embed_splice must be bit-exact"
+    assert torch.equal(mm.cpu().bool(), refm)
+    # backward of the splice into action_queries: sum over the batch of the rows at the masked positions
+    dx = gen(B, L + Np, D, seed=63)
+    dq = ops.action_query_grad(dx.to(DEV), pos, Np)
+    mr = O.all_actions_mask(labels)
+    ref = torch.stack([torch.stack([dx[b].float()[(Np + j) if j > 0 else 0] for j in torch.where(mr[b])[0].tolist()]) for b in range(B)]).sum(0)
+    check(dq, ref, rel=1e-5, mx=1e-5, name="action_query_grad")
+
+
+def test_gather_scatter_im2col_misc(ops):
+    src = gen(50, 128, seed=70)
+    idx = torch.tensor([3, -1, 49, 0, 7], dtype=torch.int32)
+    out = torch.empty(5, 128, dtype=BF, device=DEV)
+    ops.gather_rows(src.to(DEV), idx.to(DEV), out)
+    ref = torch.stack([src[i].float() if i >= 0 else torch.zeros(128) for i in idx.tolist()])
+    assert torch.equal(f(out), ref)
+    acc = gen(50, 128, seed=71)
+    accd = acc.to(DEV).clone()
+    ops.scatter_add_rows(out, idx.to(DEV), accd)
+    ref2 = acc.float().clone()
+    for r, i in enumerate(idx.tolist()):
+        if i >= 0:
+            ref2[i] = O.rnd(ref2[i] + ref[r], True)
+    assert torch.equal(f(accd), ref2)
+    # im2col (bf16 and f32 pixels), second backbone's channel window
+    px = torch.randn(2, 6, 28, 42, generator=torch.Generator().manual_seed(72))
+    for t in (px, px.to(BF)):
+        cols = ops.im2col_patch(t.to(DEV).contiguous(), 3, 14, 640)
+        ref = O.rnd(O.im2col(t.float()[:, 3:6], 14), True).reshape(-1, 588)
+        assert torch.equal(f(cols[:, :588]), ref) and (f(cols[:, 588:]) == 0).all()
+    a, b = gen(1000, 64, seed=73), gen(1000, 64, seed=74)
+    assert torch.equal(f(ops.add_(a.to(DEV).clone(), b.to(DEV))), O.rnd(a.float() + b.float(), True))
+    check(ops.gelu_fwd(a.to(DEV)), O.gelu(a.float(), True), name="gelu")
+    xr = a.float().requires_grad_(True)
+    (torch.nn.functional.gelu(xr) * b.float()).sum().backward()
+    check(ops.gelu_bwd(b.to(DEV), a.to(DEV)), xr.grad, rel=3e-3, name="gelu bwd")
+    y = torch.relu(a.float())
+    assert torch.equal(f(ops.relu_bwd(b.to(DEV), y.to(BF).to(DEV))), torch.where(y > 0, b.float(), torch.zeros(())))
+    cs = torch.zeros(64, device=DEV)
+    ops.colsum_(a.to(DEV), cs)
+    check(cs, a.float().sum(0), rel=1e-5, mx=1e-5, name="colsum")
+
+
+def test_l1_loss(ops):
+    pred, tgt = gen(4, 8, 7, seed=80), gen(4, 8, 7, seed=81)
+    loss3, dpred = ops.l1_loss(pred.to(DEV), tgt.to(DEV))
+    m = O.l1_metrics(pred.float(), tgt.float())
+    ref = torch.stack([m["loss_value"], m["curr_action_l1_loss"], m["next_actions_l1_loss"]])
+    check(loss3, ref, rel=1e-5, mx=1e-5, name="l1 loss")
+    pr = pred.float().requires_grad_(True)
+    O.l1_loss(pr, tgt.float()).backward()
+    check(dpred, O.rnd(pr.grad, True), rel=1e-6, mx=1e-6, name="l1 grad")
+
+
+def test_adamw_bit_exact_vs_torch_golden(ops):
+    """Same fixture that pins the oracle (torch.optim.AdamW on bf16 tensors, generated by tools/make_golden.py)."""
+    z = np.load(os.path.join(G, "adamw_bf16.npz"))
+    lr, b1, b2, eps, wd = z["hyper"].tolist()
+    p = torch.from_numpy(z["p0"]).to(BF).to(DEV)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(3):
+        g = torch.from_numpy(z["grads"][step]).to(BF).to(DEV)
+        ops.adamw_(p, g, m, v, step + 1, lr, b1, b2, eps, wd)
+        assert torch.equal(f(p), torch.from_numpy(z["ps"][step])), f"AdamW params differ from torch at step {step}"
+    assert torch.equal(f(m), torch.from_numpy(z["m"])) and torch.equal(f(v), torch.from_numpy(z["v"]))

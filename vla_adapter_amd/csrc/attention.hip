@@ -1,0 +1,429 @@
+// Flash-style attention forward / backward for gfx950 on v_mfma_f32_32x32x16_bf16.
+//
+// Replaces F.scaled_dot_product_attention inside timm Attention (SigLIP dh=72, DINOv2 dh=64; full attention) and
+// flash-attn / eager attention of Qwen2Attention (dh=64, GQA 14:2, causal AND key-padding mask; call site
+// modeling_prismatic.py:644-655), plus their backward.
+//
+// Layout trick (cdna_hip_programming.md section 3, "An accumulator tile as the next MFMA's operand"):
+//   forward / dQ:  S^T[key x q] = K . Q^T  -> the query sits on the LANE, keys in the 16 accumulator registers,
+//                  so row max / row sum are in-lane + one cross-half shuffle, and P^T feeds  O^T = V^T . P^T  as the
+//                  B operand with no lane movement (V^T fragments come from ds_read_b64_tr_b16 on a row-major tile).
+//   dK/dV:         S[q x key] = Q . K^T    -> the key sits on the lane; P and dS feed dV^T = dO^T.P and dK^T = Q^T.dS.
+// 32 keys (fwd, dQ) or 32 queries (dK/dV) per LDS tile; each wave owns 32 queries (resp. 32 keys).
+// The N x N score matrix is never materialised; backward recomputes P from the saved log-sum-exp.
+#include "common.h"
+#include "../../include/vla_native.h"
+
+namespace {
+
+struct AttnP {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o; float* lse; const unsigned char* kmask;
+  long long q_sb, k_sb, v_sb, o_sb; int q_ss, k_ss, v_ss, o_ss;
+  int B, Sq, Sk, Hq, Hkv, dh, causal; float scale_log2;  // scale * log2(e)
+  const bf16_t* dout; bf16_t* dq; bf16_t* dk; bf16_t* dv; float* delta; float scale;
+  long long do_sb, dq_sb, dk_sb, dv_sb; int do_ss, dq_ss, dk_ss, dv_ss;
+};
+
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+// accumulator register -> row of the 32x32 tile (column = lane & 31)
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// Transposed fragment: rows R0..R0+3 and R0+8..R0+11 of a row-major [rows][ld] bf16 LDS tile, column block
+// c0..c0+15 per 16-lane group -> lane i of the group receives column c0+i of those 8 rows (ds_read_b64_tr_b16).
+// Used as the A operand (rows = tile columns) of a 32x32x16 MFMA whose k index runs over the tile's rows with the
+// permutation  j -> 16s + 8(j>>2) + 4h + (j&3)  that matches pack_acc() below.
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int ld, int s, int col0, int lane) {
+  const int h = lane >> 5, gi = (lane >> 4) & 1, i = lane & 15;
+  const bf16_t* p0 = tile + (16 * s + 4 * h + (i >> 2)) * ld + col0 + 16 * gi + 4 * (i & 3);
+  bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)p0);
+  bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(p0 + 8 * ld));
+  return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+// accumulator registers 8s..8s+7 -> bf16 fragment for k-step s (B operand of A.X / A operand of X^T.B)
+__device__ __forceinline__ bf16x8 pack_acc(const f32x16& x, int s) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(x[8 * s + j]);
+  return r;
+}
+
+template <int D, int LD>
+__device__ __forceinline__ void load_tile(bf16_t* dst, const bf16_t* src, long long row_stride, int row0, int nrows,
+                                          int tid, int nthreads) {
+  constexpr int CPR = D / 8;  // 16-B chunks per row
+  for (int c = tid; c < 32 * CPR; c += nthreads) {
+    const int r = c / CPR, ch = c - r * CPR;
+    const int gr = min(row0 + r, nrows - 1);  // clamp: masked later, must stay finite
+    *reinterpret_cast<uint4*>(dst + r * LD + ch * 8) =
+        *reinterpret_cast<const uint4*>(src + (long long)gr * row_stride + ch * 8);
+  }
+}
+
+template <int D>
+struct Geo {
+  static constexpr int DQ = (D + 15) / 16 * 16;  // contraction width for QK^T (k-steps of 16)
+  static constexpr int DV = (D + 31) / 32 * 32;  // output width for PV (tiles of 32)
+  static constexpr int LD = DV + 8;              // LDS row stride (elements): conflict-free b128 row reads
+  static constexpr int KS = DQ / 16, DT = DV / 32;
+};
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
+  using G = Geo<D>;
+  __shared__ __attribute__((aligned(16))) bf16_t sK[32 * G::LD];
+  __shared__ __attribute__((aligned(16))) bf16_t sV[32 * G::LD];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
+  const int hq = blockIdx.y, b = blockIdx.z, hkv = hq / (p.Hq / p.Hkv);
+  const int qblk = blockIdx.x * 128, q0 = qblk + w * 32;
+  const int qi = q0 + (lane & 31);
+
+  for (int i = tid; i < 32 * G::LD; i += 256) { sK[i] = 0; sV[i] = 0; }  // pad columns stay zero
+
+  bf16x8 qf[G::KS];
+  {
+    const bf16_t* qp = p.q + (long long)b * p.q_sb + (long long)min(qi, p.Sq - 1) * p.q_ss + hq * D;
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+      const int d = 16 * ks + 8 * h;
+      qf[ks] = (d < D) ? *reinterpret_cast<const bf16x8*>(qp + d) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+  f32x16 O[G::DT];
+#pragma unroll
+  for (int t = 0; t < G::DT; ++t) O[t] = zero16();
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int kend = p.causal ? min(p.Sk, qblk + 128) : p.Sk;
+  const bf16_t* kb = p.k + (long long)b * p.k_sb + hkv * D;
+  const bf16_t* vb = p.v + (long long)b * p.v_sb + hkv * D;
+  for (int k0 = 0; k0 < kend; k0 += 32) {
+    __syncthreads();
+    load_tile<D, G::LD>(sK, kb, p.k_ss, k0, p.Sk, tid, 256);
+    load_tile<D, G::LD>(sV, vb, p.v_ss, k0, p.Sk, tid, 256);
+    const int kk = k0 + (lane & 31);
+    const bool kok = kk < p.Sk && (!p.kmask || p.kmask[(long long)b * p.Sk + kk]);
+    const unsigned km = (unsigned)__ballot(kok);
+    __syncthreads();
+    if (p.causal && k0 > q0 + 31) continue;  // wave-uniform: whole tile is in the future (barriers already passed)
+
+    f32x16 S = zero16();
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (lane & 31) * G::LD + 16 * ks + 8 * h);
+      S = mfma32(kf, qf[ks], S);
+    }
+    float mt = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kr = acc_row(r, h);
+      const bool ok = ((km >> kr) & 1u) && (!p.causal || k0 + kr <= qi);
+      S[r] = ok ? S[r] * p.scale_log2 : -INFINITY;
+      mt = fmaxf(mt, S[r]);
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = exp2f(m_run - m_safe);
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      S[r] = exp2f(S[r] - m_safe);
+      rs += S[r];
+    }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int t = 0; t < G::DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[t][r] *= alpha;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bf16x8 pf = pack_acc(S, s);
+#pragma unroll
+      for (int t = 0; t < G::DT; ++t) O[t] = mfma32(tr_frag(sV, G::LD, s, 32 * t, lane), pf, O[t]);
+    }
+  }
+  // O^T accumulators: lane = query, registers = d
+  const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+  if (qi < p.Sq) {
+    bf16_t* op = p.o + (long long)b * p.o_sb + (long long)qi * p.o_ss + hq * D;
+#pragma unroll
+    for (int t = 0; t < G::DT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * t + 8 * g + 4 * h;
+        if (d < D) {
+          uint2 o = {pack2(O[t][4 * g] * inv, O[t][4 * g + 1] * inv), pack2(O[t][4 * g + 2] * inv, O[t][4 * g + 3] * inv)};
+          *reinterpret_cast<uint2*>(op + d) = o;
+        }
+      }
+    if (p.lse && h == 0)
+      p.lse[((long long)b * p.Hq + hq) * p.Sq + qi] = l_run > 0.f ? (m_run + log2f(l_run)) * 0.6931471805599453f : -INFINITY;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ delta = rowsum(dO*O)
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // over B*Sq*Hq
+  const long long total = (long long)p.B * p.Sq * p.Hq;
+  if (row >= total) return;
+  const int hq = row % p.Hq;
+  const long long bs = row / p.Hq;
+  const int s = bs % p.Sq, b = bs / p.Sq;
+  const bf16_t* op = p.o + (long long)b * p.o_sb + (long long)s * p.o_ss + hq * p.dh;
+  const bf16_t* dp = p.dout + (long long)b * p.do_sb + (long long)s * p.do_ss + hq * p.dh;
+  float a = 0.f;
+  for (int d = lane; d < p.dh; d += 64) a += bf2f(op[d]) * bf2f(dp[d]);
+  a = wave_sum(a);
+  if (lane == 0) p.delta[((long long)b * p.Hq + hq) * p.Sq + s] = a;
+}
+
+// ------------------------------------------------------------------------------------------------ dQ
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
+  using G = Geo<D>;
+  __shared__ __attribute__((aligned(16))) bf16_t sK[32 * G::LD];
+  __shared__ __attribute__((aligned(16))) bf16_t sV[32 * G::LD];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
+  const int hq = blockIdx.y, b = blockIdx.z, hkv = hq / (p.Hq / p.Hkv);
+  const int qblk = blockIdx.x * 128, q0 = qblk + w * 32;
+  const int qi = q0 + (lane & 31), qc = min(qi, p.Sq - 1);
+  for (int i = tid; i < 32 * G::LD; i += 256) { sK[i] = 0; sV[i] = 0; }
+
+  bf16x8 qf[G::KS], dof[G::KS];
+  {
+    const bf16_t* qp = p.q + (long long)b * p.q_sb + (long long)qc * p.q_ss + hq * D;
+    const bf16_t* dp = p.dout + (long long)b * p.do_sb + (long long)qc * p.do_ss + hq * D;
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+      const int d = 16 * ks + 8 * h;
+      const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      qf[ks] = (d < D) ? *reinterpret_cast<const bf16x8*>(qp + d) : z;
+      dof[ks] = (d < D) ? *reinterpret_cast<const bf16x8*>(dp + d) : z;
+    }
+  }
+  const long long sidx = ((long long)b * p.Hq + hq) * p.Sq + qc;
+  const float lse2 = p.lse[sidx] * 1.4426950408889634f;  // natural -> log2 domain
+  const float delta = p.delta[sidx];
+  f32x16 dQ[G::DT];
+#pragma unroll
+  for (int t = 0; t < G::DT; ++t) dQ[t] = zero16();
+
+  const int kend = p.causal ? min(p.Sk, qblk + 128) : p.Sk;
+  const bf16_t* kb = p.k + (long long)b * p.k_sb + hkv * D;
+  const bf16_t* vb = p.v + (long long)b * p.v_sb + hkv * D;
+  for (int k0 = 0; k0 < kend; k0 += 32) {
+    __syncthreads();
+    load_tile<D, G::LD>(sK, kb, p.k_ss, k0, p.Sk, tid, 256);
+    load_tile<D, G::LD>(sV, vb, p.v_ss, k0, p.Sk, tid, 256);
+    const int kk = k0 + (lane & 31);
+    const bool kok = kk < p.Sk && (!p.kmask || p.kmask[(long long)b * p.Sk + kk]);
+    const unsigned km = (unsigned)__ballot(kok);
+    __syncthreads();
+    if (p.causal && k0 > q0 + 31) continue;
+    f32x16 S = zero16(), dP = zero16();
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (lane & 31) * G::LD + 16 * ks + 8 * h);
+      const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + (lane & 31) * G::LD + 16 * ks + 8 * h);
+      S = mfma32(kf, qf[ks], S);
+      dP = mfma32(vf, dof[ks], dP);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kr = acc_row(r, h);
+      const bool ok = ((km >> kr) & 1u) && (!p.causal || k0 + kr <= qi);
+      const float pr = ok ? exp2f(S[r] * p.scale_log2 - lse2) : 0.f;
+      S[r] = pr * (dP[r] - delta) * p.scale;  // dS^T
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bf16x8 df = pack_acc(S, s);
+#pragma unroll
+      for (int t = 0; t < G::DT; ++t) dQ[t] = mfma32(tr_frag(sK, G::LD, s, 32 * t, lane), df, dQ[t]);
+    }
+  }
+  if (qi < p.Sq) {
+    bf16_t* op = p.dq + (long long)b * p.dq_sb + (long long)qi * p.dq_ss + hq * D;
+#pragma unroll
+    for (int t = 0; t < G::DT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * t + 8 * g + 4 * h;
+        if (d < D) {
+          uint2 o = {pack2(dQ[t][4 * g], dQ[t][4 * g + 1]), pack2(dQ[t][4 * g + 2], dQ[t][4 * g + 3])};
+          *reinterpret_cast<uint2*>(op + d) = o;
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dK, dV
+// block = 2 waves = 64 keys of one (batch, kv head); sweeps the group's query heads x 32-query tiles.
+template <int D>
+__global__ __launch_bounds__(128) void attn_bwd_dkv_kernel(AttnP p) {
+  using G = Geo<D>;
+  __shared__ __attribute__((aligned(16))) bf16_t sQ[32 * G::LD];
+  __shared__ __attribute__((aligned(16))) bf16_t sdO[32 * G::LD];
+  __shared__ float sLse[32], sDelta[32];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
+  const int hkv = blockIdx.y, b = blockIdx.z, grp = p.Hq / p.Hkv;
+  const int kblk = blockIdx.x * 64, k0 = kblk + w * 32;
+  const int ki = k0 + (lane & 31), kc = min(ki, p.Sk - 1);
+  for (int i = tid; i < 32 * G::LD; i += 128) { sQ[i] = 0; sdO[i] = 0; }
+
+  bf16x8 kf[G::KS], vf[G::KS];
+  {
+    const bf16_t* kp = p.k + (long long)b * p.k_sb + (long long)kc * p.k_ss + hkv * D;
+    const bf16_t* vp = p.v + (long long)b * p.v_sb + (long long)kc * p.v_ss + hkv * D;
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+      const int d = 16 * ks + 8 * h;
+      const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      kf[ks] = (d < D) ? *reinterpret_cast<const bf16x8*>(kp + d) : z;
+      vf[ks] = (d < D) ? *reinterpret_cast<const bf16x8*>(vp + d) : z;
+    }
+  }
+  const bool kok = ki < p.Sk && (!p.kmask || p.kmask[(long long)b * p.Sk + kc]);
+  f32x16 dK[G::DT], dV[G::DT];
+#pragma unroll
+  for (int t = 0; t < G::DT; ++t) { dK[t] = zero16(); dV[t] = zero16(); }
+
+  const int qstart = p.causal ? (kblk / 32) * 32 : 0;
+  for (int hh = 0; hh < grp; ++hh) {
+    const int hq = hkv * grp + hh;
+    const bf16_t* qb = p.q + (long long)b * p.q_sb + hq * D;
+    const bf16_t* db = p.dout + (long long)b * p.do_sb + hq * D;
+    const long long sbase = ((long long)b * p.Hq + hq) * p.Sq;
+    for (int q0 = qstart; q0 < p.Sq; q0 += 32) {
+      __syncthreads();
+      load_tile<D, G::LD>(sQ, qb, p.q_ss, q0, p.Sq, tid, 128);
+      load_tile<D, G::LD>(sdO, db, p.do_ss, q0, p.Sq, tid, 128);
+      if (tid < 32) {
+        const int qq = min(q0 + tid, p.Sq - 1);
+        sLse[tid] = p.lse[sbase + qq] * 1.4426950408889634f;
+        sDelta[tid] = p.delta[sbase + qq];
+      }
+      __syncthreads();
+      if (p.causal && q0 + 31 < k0) continue;  // all queries of the tile precede this wave's keys
+      f32x16 S = zero16(), dP = zero16();
+#pragma unroll
+      for (int ks = 0; ks < G::KS; ++ks) {
+        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(sQ + (lane & 31) * G::LD + 16 * ks + 8 * h);
+        const bf16x8 df = *reinterpret_cast<const bf16x8*>(sdO + (lane & 31) * G::LD + 16 * ks + 8 * h);
+        S = mfma32(qf, kf[ks], S);     // S[q x key]: A = Q rows, B = K^T
+        dP = mfma32(df, vf[ks], dP);   // dP[q x key] = dO . V^T
+      }
+      f32x16 dS;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qr = acc_row(r, h), qq = q0 + qr;
+        const bool ok = kok && qq < p.Sq && (!p.causal || ki <= qq);
+        const float pr = ok ? exp2f(S[r] * p.scale_log2 - sLse[qr]) : 0.f;
+        S[r] = pr;
+        dS[r] = pr * (dP[r] - sDelta[qr]) * p.scale;
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 pf = pack_acc(S, s), dsf = pack_acc(dS, s);
+#pragma unroll
+        for (int t = 0; t < G::DT; ++t) {
+          dV[t] = mfma32(tr_frag(sdO, G::LD, s, 32 * t, lane), pf, dV[t]);  // dV^T[d x key] += dO^T . P
+          dK[t] = mfma32(tr_frag(sQ, G::LD, s, 32 * t, lane), dsf, dK[t]);  // dK^T[d x key] += Q^T . dS
+        }
+      }
+    }
+  }
+  if (ki < p.Sk) {
+    bf16_t* okp = p.dk + (long long)b * p.dk_sb + (long long)ki * p.dk_ss + hkv * D;
+    bf16_t* ovp = p.dv + (long long)b * p.dv_sb + (long long)ki * p.dv_ss + hkv * D;
+#pragma unroll
+    for (int t = 0; t < G::DT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * t + 8 * g + 4 * h;
+        if (d < D) {
+          uint2 a = {pack2(dK[t][4 * g], dK[t][4 * g + 1]), pack2(dK[t][4 * g + 2], dK[t][4 * g + 3])};
+          uint2 c = {pack2(dV[t][4 * g], dV[t][4 * g + 1]), pack2(dV[t][4 * g + 2], dV[t][4 * g + 3])};
+          *reinterpret_cast<uint2*>(okp + d) = a;
+          *reinterpret_cast<uint2*>(ovp + d) = c;
+        }
+      }
+  }
+}
+
+int fill(AttnP& p, const vla_attn_desc* d, bool bwd) {
+  VLA_REQUIRE(d && d->q && d->k && d->v && d->o, "attn: null tensor");
+  VLA_REQUIRE(d->B > 0 && d->Sq > 0 && d->Sk > 0 && d->Hq > 0 && d->Hkv > 0 && d->Hq % d->Hkv == 0, "attn: bad shape");
+  VLA_REQUIRE(d->dh == 64 || d->dh == 72 || d->dh == 112 || d->dh == 128, "attn: dh must be 64, 72, 112 or 128");
+  VLA_REQUIRE(d->q_ss % 8 == 0 && d->k_ss % 8 == 0 && d->v_ss % 8 == 0 && d->o_ss % 4 == 0, "attn: strides must keep 16-B rows");
+  VLA_REQUIRE(d->q_sb % 8 == 0 && d->k_sb % 8 == 0 && d->v_sb % 8 == 0 && d->o_sb % 4 == 0, "attn: batch strides alignment");
+  VLA_REQUIRE((((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v) & 15) == 0 && ((uintptr_t)d->o & 7) == 0, "attn: alignment");
+  VLA_REQUIRE(d->q_ss >= d->Hq * d->dh && d->k_ss >= d->Hkv * d->dh && d->v_ss >= d->Hkv * d->dh, "attn: seq stride < heads*dh");
+  p.q = (const bf16_t*)d->q; p.k = (const bf16_t*)d->k; p.v = (const bf16_t*)d->v; p.o = (bf16_t*)d->o;
+  p.lse = d->lse; p.kmask = d->kmask;
+  p.q_sb = d->q_sb; p.k_sb = d->k_sb; p.v_sb = d->v_sb; p.o_sb = d->o_sb;
+  p.q_ss = d->q_ss; p.k_ss = d->k_ss; p.v_ss = d->v_ss; p.o_ss = d->o_ss;
+  p.B = d->B; p.Sq = d->Sq; p.Sk = d->Sk; p.Hq = d->Hq; p.Hkv = d->Hkv; p.dh = d->dh; p.causal = d->causal;
+  p.scale = d->scale; p.scale_log2 = d->scale * 1.4426950408889634f;
+  if (bwd) {
+    VLA_REQUIRE(d->dout && d->dq && d->dk && d->dv && d->delta && d->lse, "attn_bwd: null tensor");
+    VLA_REQUIRE(d->do_ss % 8 == 0 && d->do_sb % 8 == 0 && ((uintptr_t)d->dout & 15) == 0, "attn_bwd: dout alignment");
+    VLA_REQUIRE(d->dq_ss % 4 == 0 && d->dk_ss % 4 == 0 && d->dv_ss % 4 == 0 && d->dq_sb % 4 == 0 && d->dk_sb % 4 == 0 &&
+                d->dv_sb % 4 == 0 && (((uintptr_t)d->dq | (uintptr_t)d->dk | (uintptr_t)d->dv) & 7) == 0, "attn_bwd: grad alignment");
+    VLA_REQUIRE(d->o_ss % 8 == 0 || true, "");
+    p.dout = (const bf16_t*)d->dout; p.dq = (bf16_t*)d->dq; p.dk = (bf16_t*)d->dk; p.dv = (bf16_t*)d->dv; p.delta = d->delta;
+    p.do_sb = d->do_sb; p.dq_sb = d->dq_sb; p.dk_sb = d->dk_sb; p.dv_sb = d->dv_sb;
+    p.do_ss = d->do_ss; p.dq_ss = d->dq_ss; p.dk_ss = d->dk_ss; p.dv_ss = d->dv_ss;
+  }
+  return VLA_OK;
+}
+
+}  // namespace
+
+extern "C" int vla_attn_fwd(void* stream, const vla_attn_desc* d) {
+  AttnP p{};
+  int rc = fill(p, d, false);
+  if (rc) return rc;
+  dim3 grid((p.Sq + 127) / 128, p.Hq, p.B);
+  hipStream_t st = (hipStream_t)stream;
+  switch (p.dh) {
+    case 64: hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, st, p); break;
+    case 72: hipLaunchKernelGGL(attn_fwd_kernel<72>, grid, dim3(256), 0, st, p); break;
+    case 112: hipLaunchKernelGGL(attn_fwd_kernel<112>, grid, dim3(256), 0, st, p); break;
+    default: hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(256), 0, st, p); break;
+  }
+  VLA_CHECK_LAUNCH("attn_fwd");
+  return VLA_OK;
+}
+
+extern "C" int vla_attn_bwd(void* stream, const vla_attn_desc* d) {
+  AttnP p{};
+  int rc = fill(p, d, true);
+  if (rc) return rc;
+  VLA_REQUIRE(p.dh == 64 || p.dh == 72, "attn_bwd: dh 64 or 72 only");
+  hipStream_t st = (hipStream_t)stream;
+  const long long rows = (long long)p.B * p.Sq * p.Hq;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
+  dim3 gq((p.Sq + 127) / 128, p.Hq, p.B), gk((p.Sk + 63) / 64, p.Hkv, p.B);
+  if (p.dh == 64) {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(256), 0, st, p);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gk, dim3(128), 0, st, p);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<72>, gq, dim3(256), 0, st, p);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<72>, gk, dim3(128), 0, st, p);
+  }
+  VLA_CHECK_LAUNCH("attn_bwd");
+  return VLA_OK;
+}

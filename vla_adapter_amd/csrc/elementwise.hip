@@ -1,0 +1,443 @@
+// HBM-bound glue kernels of the fine-tune hot path (gfx950): im2col, action masks, embedding splice, gathers,
+// RoPE (both conventions), SwiGLU backward, transposes, casts, L1 loss, AdamW.  All bf16 traffic is 16 B per lane.
+#include "common.h"
+#include "../../include/vla_native.h"
+
+namespace {
+
+__device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
+  const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    f[2 * k] = __uint_as_float(w[k] << 16);
+    f[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  return uint4{pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7])};
+}
+inline unsigned nblk(long long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+// ---------------------------------------------------------------- im2col for the PxP/P patch-embed conv
+__global__ void im2col_kernel(const void* __restrict__ px, bf16_t* __restrict__ out, int B, int Ctot, int c0, int H,
+                              int W, int P, int ldo, int f32in) {
+  const int gw = W / P, gh = H / P, KK = 3 * P * P;
+  const long long total = (long long)B * gh * gw * ldo;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int col = i % ldo;
+    const long long prow = i / ldo;
+    float v = 0.f;
+    if (col < KK) {
+      const int c = col / (P * P), rem = col - c * P * P, py = rem / P, pxx = rem - py * P;
+      const int pw = prow % gw, ph = (prow / gw) % gh, b = prow / ((long long)gw * gh);
+      const long long src = (((long long)b * Ctot + c0 + c) * H + ph * P + py) * W + pw * P + pxx;
+      v = f32in ? ((const float*)px)[src] : bf2f(((const bf16_t*)px)[src]);
+    }
+    out[i] = f2bf(v);
+  }
+}
+
+// ---------------------------------------------------------------- action masks (train_utils.py:8-41): one wave per row
+__global__ void action_mask_kernel(const long long* __restrict__ labels, int* __restrict__ qidx, int* __restrict__ pos,
+                                   int* __restrict__ count, int B, int L, int shift) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const long long* row = labels + (long long)b * L + shift;
+  const int n = L - shift;
+  // cumsum(labels != -100) only gates the masks through (cumsum >= 1); both masks also need id > 151386, and
+  // (1<=c<=7) | (c>7) == (c>=1), which every id != -100 satisfies at its own position -> selected = id > 151386.
+  // (The cumsum is still what splits current/next; the union is what the hot path consumes.)
+  int base = 0;
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int j = j0 + lane;
+    const bool sel = j < n && row[j] != -100 && row[j] > 151386;
+    const unsigned long long bal = __ballot(sel);
+    const int k = base + __popcll(bal & ((1ull << lane) - 1ull));
+    if (j < n) qidx[(long long)b * n + j] = sel ? k : -1;
+    if (sel && k < 64) pos[b * 64 + k] = j;
+    base += __popcll(bal);
+  }
+  if (lane == 0) count[b] = base;
+  for (int k = base + lane; k < 64; k += 64) pos[b * 64 + k] = -1;
+}
+
+// ---------------------------------------------------------------- embedding gather + action-query splice
+__global__ void embed_splice_kernel(const long long* __restrict__ ids, const unsigned char* __restrict__ am,
+                                    const int* __restrict__ qidx, const bf16_t* __restrict__ table,
+                                    const bf16_t* __restrict__ aq, bf16_t* __restrict__ out,
+                                    unsigned char* __restrict__ mm, int B, int L, int Np, int D, int vocab) {
+  const int S = L + Np;
+  const int lane = threadIdx.x & 63;
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= (long long)B * S) return;
+  const int b = r / S, s = r - (long long)b * S;
+  if (s >= 1 && s <= Np) {
+    if (lane == 0 && mm) mm[r] = 1;
+    return;
+  }
+  const int j = s == 0 ? 0 : s - Np;
+  const int qi = qidx[(long long)b * L + j];
+  long long id = ids[(long long)b * L + j];
+  if (id < 0 || id >= vocab) id = 0;  // never index outside the table
+  const bf16_t* src = qi >= 0 ? aq + (long long)min(qi, 63) * D : table + id * D;
+  bf16_t* dst = out + r * D;
+  for (int e = lane * 8; e < D; e += 512) *reinterpret_cast<uint4*>(dst + e) = *reinterpret_cast<const uint4*>(src + e);
+  if (lane == 0 && mm) mm[r] = am ? (am[(long long)b * L + j] != 0) : 1;
+}
+
+__global__ void action_query_grad_kernel(const bf16_t* __restrict__ dx, const int* __restrict__ pos, float* __restrict__ dq,
+                                         int B, int S, int Np, int D) {
+  const int k = blockIdx.x;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const int j = pos[b * 64 + k];
+      if (j < 0) continue;
+      const int s = j == 0 ? 0 : Np + j;
+      a += bf2f(dx[((long long)b * S + s) * D + d]);
+    }
+    dq[k * D + d] = a;
+  }
+}
+
+__global__ void gather_rows_kernel(const bf16_t* __restrict__ in, const int* __restrict__ idx, bf16_t* __restrict__ out,
+                                   int n, int D, int ldi, int ldo) {
+  const int lane = threadIdx.x & 63;
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const int s = idx[r];
+  for (int e = lane * 8; e < D; e += 512) {
+    uint4 v = s >= 0 ? *reinterpret_cast<const uint4*>(in + (long long)s * ldi + e) : uint4{0, 0, 0, 0};
+    *reinterpret_cast<uint4*>(out + r * ldo + e) = v;
+  }
+}
+
+__global__ void scatter_add_rows_kernel(const bf16_t* __restrict__ in, const int* __restrict__ idx, bf16_t* __restrict__ out,
+                                        int n, int D, int ldi, int ldo) {
+  const int lane = threadIdx.x & 63;
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const int s = idx[r];
+  if (s < 0) return;
+  for (int e = lane * 8; e < D; e += 512) {
+    float a[8], c[8];
+    unpack8(*reinterpret_cast<const uint4*>(in + r * ldi + e), a);
+    unpack8(*reinterpret_cast<const uint4*>(out + (long long)s * ldo + e), c);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c[k] += a[k];
+    *reinterpret_cast<uint4*>(out + (long long)s * ldo + e) = pack8(c);
+  }
+}
+
+// ---------------------------------------------------------------- simple vector elementwise
+enum { EW_ADD = 0, EW_GELU_F = 1, EW_GELU_B = 2, EW_RELU_B = 3 };
+template <int OP>
+__global__ void ew_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ y, long long n8) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    float fa[8], fb[8] = {0, 0, 0, 0, 0, 0, 0, 0}, o[8];
+    unpack8(reinterpret_cast<const uint4*>(a)[i], fa);
+    if (OP != EW_GELU_F) unpack8(reinterpret_cast<const uint4*>(b)[i], fb);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (OP == EW_ADD) o[k] = fa[k] + fb[k];
+      else if (OP == EW_GELU_F) o[k] = gelu_erf(fa[k]);
+      else if (OP == EW_GELU_B) o[k] = fa[k] * gelu_erf_grad(fb[k]);
+      else o[k] = fb[k] > 0.f ? fa[k] : 0.f;
+    }
+    reinterpret_cast<uint4*>(y)[i] = pack8(o);
+  }
+}
+
+// dH [M, I], GU [M, 2I] with 16-column interleave (gate block, up block) -> dGU same layout
+__global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ dh, const bf16_t* __restrict__ gu, bf16_t* __restrict__ dgu,
+                                  long long nchunks, int I) {
+  const int cpr = I / 8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long long)gridDim.x * blockDim.x) {
+    const long long m = i / cpr;
+    const int c = (int)(i - m * cpr) * 8;           // h column of this 8-chunk (never straddles a 16-block)
+    const long long go = m * 2 * I + (c >> 4) * 32 + (c & 15);
+    float d[8], g[8], u[8], dg[8], du[8];
+    unpack8(*reinterpret_cast<const uint4*>(dh + m * I + c), d);
+    unpack8(*reinterpret_cast<const uint4*>(gu + go), g);
+    unpack8(*reinterpret_cast<const uint4*>(gu + go + 16), u);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float sg = 1.f / (1.f + __expf(-g[k]));
+      const float sl = g[k] * sg;
+      du[k] = d[k] * sl;
+      dg[k] = d[k] * u[k] * (sg * (1.f + g[k] * (1.f - sg)));
+    }
+    *reinterpret_cast<uint4*>(dgu + go) = pack8(dg);
+    *reinterpret_cast<uint4*>(dgu + go + 16) = pack8(du);
+  }
+}
+
+// ---------------------------------------------------------------- transpose through LDS (64x64 tiles)
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int rows,
+                                                        int cols, int ldi, int ldo, long long s_in, long long s_out) {
+  __shared__ bf16_t t[64][66];
+  const bf16_t* ib = in + (long long)blockIdx.z * s_in;
+  bf16_t* ob = out + (long long)blockIdx.z * s_out;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4)
+    t[r][tx] = (r0 + r < rows && c0 + tx < cols) ? ib[(long long)(r0 + r) * ldi + c0 + tx] : (bf16_t)0;
+  __syncthreads();
+  for (int c = ty; c < 64; c += 4)
+    if (c0 + c < cols && r0 + tx < rows) ob[(long long)(c0 + c) * ldo + r0 + tx] = t[tx][c];
+}
+
+__global__ void colsum_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int rows, int cols, int ldx, int rows_per) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+  float a = 0.f;
+  for (int r = r0; r < r1; ++r) a += bf2f(x[(long long)r * ldx + c]);
+  atomicAdd(out + c, a);
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] = f2bf(x[i]);
+}
+__global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] = bf2f(x[i]);
+}
+
+// ---------------------------------------------------------------- RoPE
+// HF rotate_half: pairs (i, i+dh/2); q' = bf16(bf16(q*cos) + bf16(rot(q)*sin)); tables hold bf16-rounded values.
+__global__ void rope_half_kernel(bf16_t* __restrict__ x, const float* __restrict__ ct, const float* __restrict__ st, long long rows,
+                                 int S, int nheads, int dh, int ldx, float sign) {
+  const int half = dh / 2;
+  const long long total = rows * nheads * half;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int d = i % half;
+    const long long t = i / half;
+    const int hh = t % nheads;
+    const long long r = t / nheads;
+    const int pos = r % S;
+    bf16_t* p = x + r * ldx + hh * dh + d;
+    const float a = bf2f(p[0]), b = bf2f(p[half]);
+    const float c = ct[pos * half + d], s = sign * st[pos * half + d];
+    p[0] = f2bf(rbf(a * c) + rbf(-b * s));
+    p[half] = f2bf(rbf(b * c) + rbf(a * s));
+  }
+}
+
+// action_heads.py:125-146: y[2i] = x[2i]*c[2i] - x[2i+1]*s[2i];  y[2i+1] = x[2i+1]*c[2i+1] + x[2i]*s[2i+1]
+// with c/s = cos/sin(cat([f,f])) (so the two lanes of a pair use DIFFERENT frequencies).  mode 1 = transpose map.
+__global__ void rope_inter_kernel(bf16_t* __restrict__ x, const float* __restrict__ ct, const float* __restrict__ st,
+                                  long long rows, int T, int nheads, int dh, int ldx, int mode) {
+  const int half = dh / 2;
+  const long long total = rows * nheads * half;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int d = i % half;
+    const long long t = i / half;
+    const int hh = t % nheads;
+    const long long r = t / nheads;
+    const int pos = r % T;
+    bf16_t* p = x + r * ldx + hh * dh + 2 * d;
+    const float a = bf2f(p[0]), b = bf2f(p[1]);
+    const float ca = ct[pos * dh + 2 * d], cb = ct[pos * dh + 2 * d + 1];
+    const float sa = st[pos * dh + 2 * d], sb = st[pos * dh + 2 * d + 1];
+    if (mode == 0) {
+      p[0] = f2bf(rbf(a * ca) + rbf(-b * sa));
+      p[1] = f2bf(rbf(b * cb) + rbf(a * sb));
+    } else {
+      p[0] = f2bf(a * ca + b * sb);
+      p[1] = f2bf(b * cb - a * sa);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- L1 loss (finetune.py:418-444)
+__global__ __launch_bounds__(256) void l1_loss_kernel(const bf16_t* __restrict__ pred, const bf16_t* __restrict__ tgt,
+                                                      float* __restrict__ loss3, bf16_t* __restrict__ dpred, int B, int C,
+                                                      int Da, float gscale) {
+  __shared__ float red[3][4];
+  const int n = B * C * Da;
+  float a = 0.f, cur = 0.f, nxt = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float d = bf2f(pred[i]) - bf2f(tgt[i]);
+    const float ad = fabsf(d);
+    a += ad;
+    if ((i / Da) % C == 0) cur += ad; else nxt += ad;
+    if (dpred) dpred[i] = f2bf((d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * gscale / n);
+  }
+  a = wave_sum(a); cur = wave_sum(cur); nxt = wave_sum(nxt);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = cur; red[2][threadIdx.x >> 6] = nxt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    loss3[0] = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / n;
+    loss3[1] = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (B * Da);
+    loss3[2] = C > 1 ? (red[2][0] + red[2][1] + red[2][2] + red[2][3]) / (B * (C - 1) * Da) : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------- AdamW, bf16 state, torch op-by-op rounding
+__global__ void adamw_kernel(bf16_t* __restrict__ p, const void* __restrict__ g, bf16_t* __restrict__ m, bf16_t* __restrict__ v,
+                             long long n, float decay, float omb1, float beta2, float omb2, float bc2_sqrt, float eps,
+                             float neg_step, int g_f32, float gscale) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float gr = g_f32 ? rbf(((const float*)g)[i] * gscale) : bf2f(((const bf16_t*)g)[i]);
+    if (!g_f32 && gscale != 1.f) gr = rbf(gr * gscale);
+    float pf = rbf(bf2f(p[i]) * decay);                          // param.mul_(1 - lr*wd)
+    const float m0 = bf2f(m[i]);
+    const float mf = rbf(__builtin_fmaf(omb1, gr - m0, m0));     // exp_avg.lerp_(grad, 1-beta1)
+    const float vf = rbf(__builtin_fmaf(omb2 * gr, gr, rbf(bf2f(v[i]) * beta2)));  // mul_(beta2).addcmul_(g,g,1-beta2)
+    const float den = rbf(rbf(rbf(sqrtf(vf)) / bc2_sqrt) + eps); // (sqrt / bias_correction2_sqrt).add_(eps)
+    pf = rbf(__builtin_fmaf(neg_step, mf / den, pf));            // addcdiv_(exp_avg, denom, -lr/bc1)
+    p[i] = f2bf(pf); m[i] = f2bf(mf); v[i] = f2bf(vf);
+  }
+}
+
+}  // namespace
+
+#define GRID1D(n, per) dim3(min(nblk((n), (per)), 8192u))
+
+extern "C" int vla_im2col_patch(void* stream, const void* pixels, void* cols, int B, int Ctot, int c0, int H, int W, int P,
+                                int ldo, int px_f32) {
+  VLA_REQUIRE(pixels && cols && B > 0 && P > 0 && H % P == 0 && W % P == 0, "im2col: bad shape");
+  VLA_REQUIRE(c0 >= 0 && c0 + 3 <= Ctot && ldo >= 3 * P * P, "im2col: channel window / ldo");
+  const long long total = (long long)B * (H / P) * (W / P) * ldo;
+  hipLaunchKernelGGL(im2col_kernel, GRID1D(total, 256), dim3(256), 0, (hipStream_t)stream, pixels, (bf16_t*)cols, B, Ctot, c0,
+                     H, W, P, ldo, px_f32);
+  VLA_CHECK_LAUNCH("im2col");
+  return VLA_OK;
+}
+
+extern "C" int vla_action_mask(void* stream, const long long* labels, int* qidx, int* pos, int* count, int B, int L, int shift) {
+  VLA_REQUIRE(labels && qidx && pos && count && B > 0 && L > shift && (shift == 0 || shift == 1), "action_mask: bad args");
+  hipLaunchKernelGGL(action_mask_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, labels, qidx, pos, count, B, L, shift);
+  VLA_CHECK_LAUNCH("action_mask");
+  return VLA_OK;
+}
+
+extern "C" int vla_embed_splice(void* stream, const long long* ids, const unsigned char* attn_mask, const int* qidx,
+                                const void* table, const void* action_queries, void* out, unsigned char* mm_mask, int B,
+                                int L, int Np, int D, int vocab) {
+  VLA_REQUIRE(ids && qidx && table && action_queries && out && B > 0 && L > 0 && Np >= 0 && D % 8 == 0 && vocab > 0,
+              "embed_splice: bad args");
+  const long long rows = (long long)B * (L + Np);
+  hipLaunchKernelGGL(embed_splice_kernel, dim3(nblk(rows, 4)), dim3(256), 0, (hipStream_t)stream, ids, attn_mask, qidx,
+                     (const bf16_t*)table, (const bf16_t*)action_queries, (bf16_t*)out, mm_mask, B, L, Np, D, vocab);
+  VLA_CHECK_LAUNCH("embed_splice");
+  return VLA_OK;
+}
+
+extern "C" int vla_action_query_grad(void* stream, const void* dx, const int* pos, float* dq, int B, int S, int Np, int D) {
+  VLA_REQUIRE(dx && pos && dq && B > 0 && S > Np && D > 0, "action_query_grad: bad args");
+  hipLaunchKernelGGL(action_query_grad_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dx, pos, dq, B, S, Np, D);
+  VLA_CHECK_LAUNCH("action_query_grad");
+  return VLA_OK;
+}
+
+extern "C" int vla_gather_rows(void* stream, const void* in, const int* idx, void* out, int n, int D, int ldi, int ldo) {
+  VLA_REQUIRE(in && idx && out && n > 0 && D % 8 == 0 && ldi % 8 == 0 && ldo % 8 == 0, "gather_rows: bad args");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(nblk(n, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, idx, (bf16_t*)out, n, D, ldi, ldo);
+  VLA_CHECK_LAUNCH("gather_rows");
+  return VLA_OK;
+}
+
+extern "C" int vla_scatter_add_rows(void* stream, const void* in, const int* idx, void* out, int n, int D, int ldi, int ldo) {
+  VLA_REQUIRE(in && idx && out && n > 0 && D % 8 == 0 && ldi % 8 == 0 && ldo % 8 == 0, "scatter_add_rows: bad args");
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(nblk(n, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, idx, (bf16_t*)out, n, D, ldi, ldo);
+  VLA_CHECK_LAUNCH("scatter_add_rows");
+  return VLA_OK;
+}
+
+#define EW_ENTRY(NAME, OP, NEEDB)                                                                                  \
+  extern "C" int NAME(void* stream, const void* a, const void* b, void* y, long long n) {                           \
+    VLA_REQUIRE(a && y && (!(NEEDB) || b) && n > 0 && n % 8 == 0, #NAME ": null / n%8");                              \
+    hipLaunchKernelGGL(ew_kernel<OP>, GRID1D(n / 8, 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a,     \
+                       (const bf16_t*)b, (bf16_t*)y, n / 8);                                                       \
+    VLA_CHECK_LAUNCH(#NAME);                                                                                       \
+    return VLA_OK;                                                                                                 \
+  }
+EW_ENTRY(vla_add_bf16, EW_ADD, 1)
+EW_ENTRY(vla_gelu_bwd, EW_GELU_B, 1)
+EW_ENTRY(vla_relu_bwd, EW_RELU_B, 1)
+extern "C" int vla_gelu_fwd(void* stream, const void* x, void* y, long long n) {
+  VLA_REQUIRE(x && y && n > 0 && n % 8 == 0, "gelu_fwd: null / n%8");
+  hipLaunchKernelGGL(ew_kernel<EW_GELU_F>, GRID1D(n / 8, 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                     (const bf16_t*)nullptr, (bf16_t*)y, n / 8);
+  VLA_CHECK_LAUNCH("gelu_fwd");
+  return VLA_OK;
+}
+
+extern "C" int vla_swiglu_bwd(void* stream, const void* dh, const void* gu, void* dgu, int M, int I) {
+  VLA_REQUIRE(dh && gu && dgu && M > 0 && I > 0 && I % 16 == 0, "swiglu_bwd: I%16");
+  const long long nch = (long long)M * (I / 8);
+  hipLaunchKernelGGL(swiglu_bwd_kernel, GRID1D(nch, 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dh, (const bf16_t*)gu, (bf16_t*)dgu, nch, I);
+  VLA_CHECK_LAUNCH("swiglu_bwd");
+  return VLA_OK;
+}
+
+extern "C" int vla_transpose_bf16(void* stream, const void* in, void* out, int rows, int cols, int ldi, int ldo, int batch,
+                                  long long s_in, long long s_out) {
+  VLA_REQUIRE(in && out && rows > 0 && cols > 0 && ldi >= cols && ldo >= rows && batch > 0, "transpose: bad args");
+  dim3 grid((cols + 63) / 64, (rows + 63) / 64, batch);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, (bf16_t*)out, rows, cols, ldi, ldo, s_in, s_out);
+  VLA_CHECK_LAUNCH("transpose");
+  return VLA_OK;
+}
+
+extern "C" int vla_colsum_bf16(void* stream, const void* x, float* out, int rows, int cols, int ldx) {
+  VLA_REQUIRE(x && out && rows > 0 && cols > 0 && ldx >= cols, "colsum: bad args");
+  const int rows_per = 128;
+  dim3 grid((cols + 255) / 256, (rows + rows_per - 1) / rows_per);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, rows, cols, ldx, rows_per);
+  VLA_CHECK_LAUNCH("colsum");
+  return VLA_OK;
+}
+
+extern "C" int vla_cast_f32_bf16(void* stream, const float* x, void* y, long long n) {
+  VLA_REQUIRE(x && y && n > 0, "cast: bad args");
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, GRID1D(n, 256), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, n);
+  VLA_CHECK_LAUNCH("cast_f32_bf16");
+  return VLA_OK;
+}
+extern "C" int vla_cast_bf16_f32(void* stream, const void* x, float* y, long long n) {
+  VLA_REQUIRE(x && y && n > 0, "cast: bad args");
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, GRID1D(n, 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, y, n);
+  VLA_CHECK_LAUNCH("cast_bf16_f32");
+  return VLA_OK;
+}
+
+extern "C" int vla_rope_half(void* stream, void* x, const float* cos_t, const float* sin_t, int rows, int S, int nheads, int dh,
+                             int ldx, int sign) {
+  VLA_REQUIRE(x && cos_t && sin_t && rows > 0 && S > 0 && nheads > 0 && dh % 2 == 0 && ldx >= nheads * dh, "rope_half: bad args");
+  const long long total = (long long)rows * nheads * (dh / 2);
+  hipLaunchKernelGGL(rope_half_kernel, GRID1D(total, 256), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, cos_t, sin_t, (long long)rows, S, nheads, dh, ldx, sign >= 0 ? 1.f : -1.f);
+  VLA_CHECK_LAUNCH("rope_half");
+  return VLA_OK;
+}
+
+extern "C" int vla_rope_interleaved(void* stream, void* x, const float* cos_t, const float* sin_t, int rows, int T, int nheads,
+                                    int dh, int ldx, int mode) {
+  VLA_REQUIRE(x && cos_t && sin_t && rows > 0 && T > 0 && nheads > 0 && dh % 2 == 0 && ldx >= nheads * dh, "rope_interleaved: bad args");
+  const long long total = (long long)rows * nheads * (dh / 2);
+  hipLaunchKernelGGL(rope_inter_kernel, GRID1D(total, 256), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, cos_t, sin_t, (long long)rows, T, nheads, dh, ldx, mode);
+  VLA_CHECK_LAUNCH("rope_interleaved");
+  return VLA_OK;
+}
+
+extern "C" int vla_l1_loss(void* stream, const void* pred, const void* target, float* loss3, void* dpred, int B, int C, int Da,
+                           float gscale) {
+  VLA_REQUIRE(pred && target && loss3 && B > 0 && C > 0 && Da > 0, "l1_loss: bad args");
+  hipLaunchKernelGGL(l1_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)pred, (const bf16_t*)target, loss3, (bf16_t*)dpred, B, C, Da, gscale);
+  VLA_CHECK_LAUNCH("l1_loss");
+  return VLA_OK;
+}
+
+extern "C" int vla_adamw_bf16(void* stream, void* p, const void* g, void* m, void* v, long long n, double lr, double beta1,
+                              double beta2, double eps, double wd, int step, int g_f32, float gscale) {
+  VLA_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adamw: bad args");
+  // scalars are formed in double and narrowed once, exactly as torch narrows its Python-double hyper-parameters
+  const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+  const float decay = (float)(1.0 - lr * wd);
+  const float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
+  const float neg_step = (float)(-(lr / bc1));
+  hipLaunchKernelGGL(adamw_kernel, GRID1D(n, 256), dim3(256), 0, (hipStream_t)stream, (bf16_t*)p, g, (bf16_t*)m, (bf16_t*)v, n,
+                     decay, omb1, (float)beta2, omb2, (float)sqrt(bc2), (float)eps, neg_step, g_f32, gscale == 0.f ? 1.f : gscale);
+  VLA_CHECK_LAUNCH("adamw");
+  return VLA_OK;
+}

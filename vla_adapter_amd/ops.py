@@ -1,0 +1,369 @@
+"""Tensor-level wrappers over the C ABI: pointer/stride plumbing only (PyTorch owns memory and the stream).
+
+Every function launches on ``torch.cuda.current_stream()`` and raises on failure.  Shapes are validated here
+(host side) before any kernel is launched.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import native as N
+from .native import ACT_GELU, ACT_GELU_TANH, ACT_NONE, ACT_RELU, ACT_SWIGLU  # noqa: F401
+
+BF16 = torch.bfloat16
+
+
+def _lib():
+    return N.load()
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk_bf16(*ts):
+    for t in ts:
+        if t is not None:
+            assert t.is_cuda and t.dtype == BF16, f"expected CUDA bf16 tensor, got {t.device} {t.dtype}"
+
+
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_mod: int = 0, act: int = ACT_NONE,
+            out: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, alpha: float = 1.0,
+            want_pre: bool = True) -> torch.Tensor:
+    """C = epilogue(A @ B^T).  a: [M,K] or [batch,M,K] (row stride = a.stride(-2)); b: [N,K] or [batch,N,K].
+    SwiGLU: returns (pre [.., N] or None, h [.., N/2])."""
+    _chk_bf16(a, b, bias, residual, out, out2)
+    assert a.stride(-1) == 1 and b.stride(-1) == 1
+    batched = a.dim() == 3
+    if batched:
+        nb, M, K = a.shape
+        sA = a.stride(0)
+        sB = b.stride(0) if b.dim() == 3 else 0
+        Nn = b.shape[-2]
+    else:
+        nb, (M, K), sA, sB, Nn = 1, a.shape, 0, 0, b.shape[0]
+    assert b.shape[-1] == K, f"K mismatch {a.shape} x {b.shape}"
+    d = N.GemmDesc()
+    d.A, d.B = a.data_ptr(), b.data_ptr()
+    d.M, d.N, d.K, d.lda, d.ldb, d.batch = M, Nn, K, a.stride(-2), b.stride(-2), nb
+    d.sA, d.sB, d.act, d.alpha, d.res_mod = sA, sB, act, alpha, res_mod
+    shape = (nb, M, Nn) if batched else (M, Nn)
+    if act == ACT_SWIGLU:
+        if out is None and want_pre:
+            out = torch.empty(shape, device=a.device, dtype=BF16)
+        hshape = shape[:-1] + (Nn // 2,)
+        if out2 is None:
+            out2 = torch.empty(hshape, device=a.device, dtype=BF16)
+        assert out2.shape == hshape and out2.stride(-1) == 1
+        d.C2, d.ldc2, d.sC2 = out2.data_ptr(), out2.stride(-2), (out2.stride(0) if batched else 0)
+    elif out is None:
+        out = torch.empty(shape, device=a.device, dtype=BF16)
+    if out is not None:
+        assert tuple(out.shape) == tuple(shape) and out.stride(-1) == 1, f"out shape {out.shape} != {shape}"
+        d.C, d.ldc, d.sC = out.data_ptr(), out.stride(-2), (out.stride(0) if batched else 0)
+    if bias is not None:
+        assert bias.shape[-1] == Nn and bias.stride(-1) == 1
+        d.bias = bias.data_ptr()
+        d.sBias = bias.stride(0) if bias.dim() == 2 else 0
+    if residual is not None:
+        assert residual.stride(-1) == 1 and residual.shape[-1] == Nn
+        assert res_mod > 0 or tuple(residual.shape) == tuple(shape)
+        d.R, d.ldr = residual.data_ptr(), residual.stride(-2)
+        d.sR = residual.stride(0) if (batched and residual.dim() == 3) else 0
+    N.check(_lib().vla_gemm_bf16_nt(_st(), C.byref(d)), "gemm_bf16_nt")
+    if act == ACT_SWIGLU:
+        return out, out2
+    return out
+
+
+def transpose(x: torch.Tensor, ld_out: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [.., R, Cc] -> [.., Cc, ld_out] (columns R..ld_out-1 zero).  Returns the padded buffer."""
+    _chk_bf16(x, out)
+    assert x.stride(-1) == 1
+    batched = x.dim() == 3
+    nb = x.shape[0] if batched else 1
+    R, Cc = x.shape[-2:]
+    ld = ld_out or R
+    if out is None:
+        shape = (nb, Cc, ld) if batched else (Cc, ld)
+        out = torch.zeros(shape, device=x.device, dtype=BF16) if ld != R else torch.empty(shape, device=x.device, dtype=BF16)
+    N.check(_lib().vla_transpose_bf16(_st(), _p(x), _p(out), R, Cc, x.stride(-2), out.stride(-2), nb,
+                                      x.stride(0) if batched else 0, out.stride(0) if batched else 0), "transpose")
+    return out
+
+
+def layernorm_fwd(x, w, b, eps: float, want_stats: bool = False):
+    _chk_bf16(x, w, b)
+    cols = x.shape[-1]
+    x2 = x.reshape(-1, cols)
+    assert x2.stride(-1) == 1
+    y = torch.empty_like(x2)
+    stats = torch.empty(x2.shape[0], 2, device=x.device, dtype=torch.float32) if want_stats else None
+    N.check(_lib().vla_layernorm_fwd(_st(), _p(x2), _p(w), _p(b), _p(y), _p(stats), x2.shape[0], cols, x2.stride(0),
+                                     y.stride(0), eps), "layernorm_fwd")
+    return (y.view(x.shape), stats) if want_stats else y.view(x.shape)
+
+
+def layernorm_bwd(dy, x, w, stats, dw: Optional[torch.Tensor] = None, db: Optional[torch.Tensor] = None,
+                  want_dx: bool = True):
+    _chk_bf16(dy, x, w)
+    cols = x.shape[-1]
+    x2, dy2 = x.reshape(-1, cols), dy.reshape(-1, cols)
+    dx = torch.empty_like(x2) if want_dx else None
+    N.check(_lib().vla_layernorm_bwd(_st(), _p(dy2), _p(x2), _p(w), _p(stats), _p(dx), _p(dw), _p(db), x2.shape[0], cols,
+                                     x2.stride(0), dy2.stride(0), dx.stride(0) if dx is not None else cols), "layernorm_bwd")
+    return dx.view(x.shape) if dx is not None else None
+
+
+def rmsnorm_fwd(x, w, eps: float, want_rstd: bool = False, out=None):
+    _chk_bf16(x, w)
+    cols = x.shape[-1]
+    assert x.is_contiguous()
+    rows = x.numel() // cols
+    y = torch.empty_like(x) if out is None else out
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32) if want_rstd else None
+    N.check(_lib().vla_rmsnorm_fwd(_st(), _p(x), _p(w), _p(y), _p(rstd), rows, cols, eps), "rmsnorm_fwd")
+    return (y, rstd) if want_rstd else y
+
+
+def rmsnorm_bwd(dy, x, w, rstd, dres=None, out=None):
+    _chk_bf16(dy, x, w, dres)
+    cols = x.shape[-1]
+    assert x.is_contiguous() and dy.is_contiguous()
+    rows = x.numel() // cols
+    dx = torch.empty_like(x) if out is None else out
+    N.check(_lib().vla_rmsnorm_bwd(_st(), _p(dy), _p(x), _p(w), _p(rstd), _p(dres), _p(dx), rows, cols), "rmsnorm_bwd")
+    return dx
+
+
+def _attn_desc(q, k, v, o, lse, kmask, causal, scale, Hq, Hkv, dh):
+    """q [B,Sq,>=Hq*dh], k/v [B,Sk,>=Hkv*dh] views (last-dim stride 1), o [B,Sq,Hq*dh]."""
+    d = N.AttnDesc()
+    B, Sq, Sk = q.shape[0], q.shape[1], k.shape[1]
+    d.q, d.k, d.v, d.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr()
+    d.lse = lse.data_ptr() if lse is not None else None
+    d.kmask = kmask.data_ptr() if kmask is not None else None
+    d.q_sb, d.k_sb, d.v_sb, d.o_sb = q.stride(0), k.stride(0), v.stride(0), o.stride(0)
+    d.q_ss, d.k_ss, d.v_ss, d.o_ss = q.stride(1), k.stride(1), v.stride(1), o.stride(1)
+    d.B, d.Sq, d.Sk, d.Hq, d.Hkv, d.dh, d.causal, d.scale = B, Sq, Sk, Hq, Hkv, dh, int(causal), scale
+    return d
+
+
+def attn_fwd(q, k, v, Hq: int, Hkv: int, dh: int, causal: bool, kmask=None, scale: Optional[float] = None,
+             want_lse: bool = False):
+    _chk_bf16(q, k, v)
+    assert q.stride(-1) == 1 and k.stride(-1) == 1 and v.stride(-1) == 1
+    B, Sq = q.shape[:2]
+    if kmask is not None:
+        assert kmask.dtype == torch.uint8 and kmask.is_contiguous() and tuple(kmask.shape) == (B, k.shape[1])
+    o = torch.empty(B, Sq, Hq * dh, device=q.device, dtype=BF16)
+    lse = torch.empty(B, Hq, Sq, device=q.device, dtype=torch.float32) if want_lse else None
+    d = _attn_desc(q, k, v, o, lse, kmask, causal, scale if scale is not None else dh ** -0.5, Hq, Hkv, dh)
+    N.check(_lib().vla_attn_fwd(_st(), C.byref(d)), "attn_fwd")
+    return (o, lse) if want_lse else o
+
+
+def attn_bwd(dout, q, k, v, o, lse, Hq: int, Hkv: int, dh: int, causal: bool, kmask=None,
+             scale: Optional[float] = None, dq=None, dk=None, dv=None):
+    _chk_bf16(dout, q, k, v, o)
+    B, Sq, Sk = q.shape[0], q.shape[1], k.shape[1]
+    dq = torch.empty(B, Sq, Hq * dh, device=q.device, dtype=BF16) if dq is None else dq
+    dk = torch.empty(B, Sk, Hkv * dh, device=q.device, dtype=BF16) if dk is None else dk
+    dv = torch.empty(B, Sk, Hkv * dh, device=q.device, dtype=BF16) if dv is None else dv
+    delta = torch.empty(B, Hq, Sq, device=q.device, dtype=torch.float32)
+    d = _attn_desc(q, k, v, o, lse, kmask, causal, scale if scale is not None else dh ** -0.5, Hq, Hkv, dh)
+    d.dout, d.dq, d.dk, d.dv, d.delta = dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr()
+    d.do_sb, d.dq_sb, d.dk_sb, d.dv_sb = dout.stride(0), dq.stride(0), dk.stride(0), dv.stride(0)
+    d.do_ss, d.dq_ss, d.dk_ss, d.dv_ss = dout.stride(1), dq.stride(1), dk.stride(1), dv.stride(1)
+    N.check(_lib().vla_attn_bwd(_st(), C.byref(d)), "attn_bwd")
+    return dq, dk, dv
+
+
+def rope_half_tables(S: int, dh: int, theta: float, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """f32 [S, dh/2] tables of bf16-rounded cos/sin (HF casts cos/sin to the activation dtype)."""
+    inv = 1.0 / (theta ** (torch.arange(0, dh, 2, dtype=torch.float32) / dh))
+    f = torch.arange(S, dtype=torch.float32)[:, None] * inv[None, :]
+    return (f.cos().to(BF16).float().to(device).contiguous(), f.sin().to(BF16).float().to(device).contiguous())
+
+
+def rope_half_(x2d: torch.Tensor, cos_t, sin_t, S: int, nheads: int, dh: int, sign: int = 1):
+    """In place on x2d [rows, >= nheads*dh] (a column window of the fused qkv buffer)."""
+    _chk_bf16(x2d)
+    assert x2d.stride(-1) == 1 and cos_t.shape == (S, dh // 2)
+    N.check(_lib().vla_rope_half(_st(), _p(x2d), _p(cos_t), _p(sin_t), x2d.shape[0], S, nheads, dh, x2d.stride(0), sign),
+            "rope_half")
+    return x2d
+
+
+def rope_inter_tables(T: int, dh: int, device, base: float = 10000.0):
+    """action_heads.py:150-164: cos/sin of cat([f, f]) -> f32 [T, dh] (bf16-rounded values)."""
+    inv = 1.0 / (base ** (torch.arange(0, dh, 2).float() / dh))
+    f = torch.arange(T, dtype=torch.float32)[:, None] * inv[None, :]
+    e = torch.cat([f, f], dim=-1)
+    return (e.cos().to(BF16).float().to(device).contiguous(), e.sin().to(BF16).float().to(device).contiguous())
+
+
+def rope_inter_(x2d: torch.Tensor, cos_t, sin_t, T: int, nheads: int, dh: int, mode: int = 0):
+    _chk_bf16(x2d)
+    assert x2d.stride(-1) == 1 and cos_t.shape == (T, dh)
+    N.check(_lib().vla_rope_interleaved(_st(), _p(x2d), _p(cos_t), _p(sin_t), x2d.shape[0], T, nheads, dh, x2d.stride(0),
+                                        mode), "rope_interleaved")
+    return x2d
+
+
+def im2col_patch(pixels: torch.Tensor, c0: int, P: int, ldo: int) -> torch.Tensor:
+    assert pixels.is_cuda and pixels.is_contiguous() and pixels.dtype in (BF16, torch.float32)
+    B, Ct, H, W = pixels.shape
+    out = torch.empty(B * (H // P) * (W // P), ldo, device=pixels.device, dtype=BF16)
+    N.check(_lib().vla_im2col_patch(_st(), _p(pixels), _p(out), B, Ct, c0, H, W, P, ldo,
+                                    int(pixels.dtype == torch.float32)), "im2col_patch")
+    return out
+
+
+def action_mask(labels: torch.Tensor, shift: int):
+    """-> qidx int32 [B, L-shift], pos int32 [B,64], count int32 [B] (device tensors; no host sync)."""
+    assert labels.is_cuda and labels.dtype == torch.int64 and labels.is_contiguous()
+    B, L = labels.shape
+    qidx = torch.empty(B, L - shift, device=labels.device, dtype=torch.int32)
+    pos = torch.empty(B, 64, device=labels.device, dtype=torch.int32)
+    cnt = torch.empty(B, device=labels.device, dtype=torch.int32)
+    N.check(_lib().vla_action_mask(_st(), _p(labels), _p(qidx), _p(pos), _p(cnt), B, L, shift), "action_mask")
+    return qidx, pos, cnt
+
+
+def embed_splice(ids, attn_mask_u8, qidx, table, action_queries, out, mm_mask, Np: int):
+    B, L = ids.shape
+    D = table.shape[1]
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and out.is_contiguous() and tuple(out.shape) == (B, L + Np, D)
+    assert tuple(action_queries.shape) == (64, D) and qidx.shape == (B, L)
+    N.check(_lib().vla_embed_splice(_st(), _p(ids), _p(attn_mask_u8), _p(qidx), _p(table), _p(action_queries), _p(out),
+                                    _p(mm_mask), B, L, Np, D, table.shape[0]), "embed_splice")
+
+
+def action_query_grad(dx, pos, Np: int) -> torch.Tensor:
+    B, S, D = dx.shape
+    assert dx.is_contiguous()
+    dq = torch.empty(64, D, device=dx.device, dtype=torch.float32)
+    N.check(_lib().vla_action_query_grad(_st(), _p(dx), _p(pos), _p(dq), B, S, Np, D), "action_query_grad")
+    return dq
+
+
+def gather_rows(src2d, idx, out2d):
+    N.check(_lib().vla_gather_rows(_st(), _p(src2d), _p(idx), _p(out2d), idx.numel(), out2d.shape[-1], src2d.stride(0),
+                                   out2d.stride(0)), "gather_rows")
+    return out2d
+
+
+def scatter_add_rows(src2d, idx, out2d):
+    N.check(_lib().vla_scatter_add_rows(_st(), _p(src2d), _p(idx), _p(out2d), idx.numel(), src2d.shape[-1], src2d.stride(0),
+                                        out2d.stride(0)), "scatter_add_rows")
+    return out2d
+
+
+def add_(a, b):
+    assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel()
+    N.check(_lib().vla_add_bf16(_st(), _p(a), _p(b), _p(a), a.numel()), "add_bf16")
+    return a
+
+
+def gelu_fwd(x):
+    y = torch.empty_like(x)
+    N.check(_lib().vla_gelu_fwd(_st(), _p(x), _p(y), x.numel()), "gelu_fwd")
+    return y
+
+
+def gelu_bwd(dy, x):
+    dx = torch.empty_like(x)
+    N.check(_lib().vla_gelu_bwd(_st(), _p(dy), _p(x), _p(dx), x.numel()), "gelu_bwd")
+    return dx
+
+
+def relu_bwd(dy, y):
+    dx = torch.empty_like(y)
+    N.check(_lib().vla_relu_bwd(_st(), _p(dy), _p(y), _p(dx), y.numel()), "relu_bwd")
+    return dx
+
+
+def swiglu_bwd(dh, gu, out=None):
+    M, I = dh.shape
+    assert gu.shape == (M, 2 * I) and dh.is_contiguous() and gu.is_contiguous()
+    dgu = torch.empty_like(gu) if out is None else out
+    N.check(_lib().vla_swiglu_bwd(_st(), _p(dh), _p(gu), _p(dgu), M, I), "swiglu_bwd")
+    return dgu
+
+
+def colsum_(x2d, out_f32):
+    N.check(_lib().vla_colsum_bf16(_st(), _p(x2d), _p(out_f32), x2d.shape[0], x2d.shape[1], x2d.stride(0)), "colsum")
+    return out_f32
+
+
+def cast_f32_bf16(x, out=None):
+    y = torch.empty(x.shape, device=x.device, dtype=BF16) if out is None else out
+    N.check(_lib().vla_cast_f32_bf16(_st(), _p(x), _p(y), x.numel()), "cast")
+    return y
+
+
+def head_attn_desc(q, ks, vs, ka, va, kt, vt, gate, probs, out, H: int):
+    d = N.HeadAttnDesc()
+    B, T = q.shape[:2]
+    d.q, d.k_self, d.v_self, d.k_adp, d.v_adp, d.k_task, d.v_task = (t.data_ptr() for t in (q, ks, vs, ka, va, kt, vt))
+    d.gate, d.probs, d.out = gate.data_ptr(), probs.data_ptr(), out.data_ptr()
+    d.B, d.T, d.Ka, d.Kt, d.H, d.dh = B, T, ka.shape[1], kt.shape[1], H, out.shape[-1] // H
+    d.ld_q, d.ld_self, d.ld_adp, d.ld_task, d.ld_out = q.stride(1), ks.stride(1), ka.stride(1), kt.stride(1), out.stride(1)
+    for t, n in ((vs, ks), (va, ka), (vt, kt)):
+        assert t.stride(1) == n.stride(1) and t.stride(-1) == 1
+    return d
+
+
+def head_attn_fwd(q, ks, vs, ka, va, kt, vt, gate, H: int = 8):
+    """q/ks/vs [B,T,D*], ka/va [B,Ka,D*], kt/vt [B,Kt,D*] (views, last stride 1) -> out [B,T,D], probs f32."""
+    _chk_bf16(q, ks, vs, ka, va, kt, vt, gate)
+    B, T = q.shape[:2]
+    D = q.shape[-1]
+    Nn = T + ka.shape[1] + kt.shape[1]
+    out = torch.empty(B, T, D, device=q.device, dtype=BF16)
+    probs = torch.empty(B, H, T, Nn, device=q.device, dtype=torch.float32)
+    d = head_attn_desc(q, ks, vs, ka, va, kt, vt, gate, probs, out, H)
+    N.check(_lib().vla_head_attn_fwd(_st(), C.byref(d)), "head_attn_fwd")
+    return out, probs
+
+
+def head_attn_bwd(dout, q, ks, vs, ka, va, kt, vt, gate, probs, dgate_f32, dq, dks, dvs, dka, dva, dkt, dvt, H: int = 8):
+    """Gradient tensors are caller-provided views with the SAME row strides as their forward counterparts."""
+    _chk_bf16(dout, dq, dks, dvs, dka, dva, dkt, dvt)
+    d = head_attn_desc(q, ks, vs, ka, va, kt, vt, gate, probs, dout, H)
+    d.out = None
+    d.dout = dout.data_ptr()
+    assert dout.stride(1) == d.ld_out or True
+    d.ld_out = dout.stride(1)
+    for g, f in ((dq, q), (dks, ks), (dvs, vs), (dka, ka), (dva, va), (dkt, kt), (dvt, vt)):
+        assert g.stride(1) == f.stride(1) and g.stride(-1) == 1, "grad views must mirror forward strides"
+    d.dq, d.dk_self, d.dv_self, d.dk_adp, d.dv_adp, d.dk_task, d.dv_task = (t.data_ptr() for t in (dq, dks, dvs, dka, dva, dkt, dvt))
+    d.dgate = dgate_f32.data_ptr()
+    N.check(_lib().vla_head_attn_bwd(_st(), C.byref(d)), "head_attn_bwd")
+
+
+def l1_loss(pred, target, want_grad: bool = True, gscale: float = 1.0):
+    _chk_bf16(pred, target)
+    B, Cc, Da = pred.shape
+    loss3 = torch.empty(3, device=pred.device, dtype=torch.float32)
+    dpred = torch.empty_like(pred) if want_grad else None
+    N.check(_lib().vla_l1_loss(_st(), _p(pred.contiguous()), _p(target.contiguous()), _p(loss3), _p(dpred), B, Cc, Da, gscale),
+            "l1_loss")
+    return loss3, dpred
+
+
+def adamw_(p, g, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, wd=0.01, gscale: float = 1.0):
+    assert p.dtype == BF16 and m.dtype == BF16 and v.dtype == BF16 and g.dtype in (BF16, torch.float32)
+    assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
+    assert p.numel() == g.numel() == m.numel() == v.numel()
+    N.check(_lib().vla_adamw_bf16(_st(), _p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, wd, step,
+                                  int(g.dtype == torch.float32), gscale), "adamw")
