@@ -43,6 +43,10 @@ typedef struct vla_gemm_desc {
   int act, batch;
   long long sA, sB, sC, sR, sC2, sBias; /* batch strides (elements) */
   float alpha;      /* accumulator scale (0 -> 1) */
+  /* optional row-group addressing (0 = plain): row r of A lives at (r / a_group) * a_group_stride + (r % a_group) * lda
+   * (likewise C): lets a GEMM read/write the [B, first Np of S, D] window of a [B, S, D] tensor as one [B*Np, D] matrix */
+  int a_group, c_group;
+  long long a_group_stride, c_group_stride;
 } vla_gemm_desc;
 
 /* C = epilogue(A . B^T).  Replaces nn.Linear forward and, with pre-transposed operands, its dX / dW products:

@@ -430,6 +430,6 @@ def vla_forward(batch: Dict[str, torch.Tensor], W: Dict[str, Dict[str, torch.Ten
     npatch = patches.shape[1]
     mlhs = regroup_hidden_states(hs, batch["labels"], npatch)
     pred = head_predict_action(mlhs, batch["proprio"], W["head"], W["proprio"], npatch, cfg.get("pro", True),
-                               noise, emu)
+                               noise, emu, cfg.get("num_blocks", 24))
     loss = l1_loss(pred, batch["actions"], emu)
     return dict(pred=pred, loss=loss, hidden_states=hs, mlhs=mlhs, patches=patches)

@@ -32,6 +32,7 @@ struct GemmP {
   long long sA, sB, sC, sR, sC2, sBias;
   int tiles_n, ntiles;
   float alpha;
+  int gA, gC; long long sgA, sgC;  // row-group addressing: row r -> (r / g) * sg + (r % g) * ld
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
   for (int i = 0; i < 4; ++i) {
     const int row = (wid * 4 + i) * 8 + (lane >> 3);
     const int ra = min(m0 + row, p.M - 1), rb = min(n0 + row, p.N - 1);
-    pa[i] = Ab + (long long)ra * p.lda + kc;
+    pa[i] = Ab + (p.gA > 0 ? (long long)(ra / p.gA) * p.sgA + (long long)(ra % p.gA) * p.lda : (long long)ra * p.lda) + kc;
     pb[i] = Bb + (long long)rb * p.ldb + kc;
   }
   auto stage = [&](int buf, int k0) {
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
     uint4 v = *reinterpret_cast<const uint4*>(reg + row * EPI_STRIDE + ch * 16);
     if (m >= p.M || n >= p.N) continue;
     const int rrow = p.res_mod > 0 ? (m % p.res_mod) : m;
+    const long long crow = p.gC > 0 ? (long long)(m / p.gC) * p.sgC + (long long)(m % p.gC) * p.ldc : (long long)m * p.ldc;
     if (vec_ok && n + 8 <= p.N) {
       if (Rb) {
         const uint4 rv = *reinterpret_cast<const uint4*>(Rb + (long long)rrow * p.ldr + n);
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
                        bf2f((bf16_t)(a[k] >> 16)) + bf2f((bf16_t)(b[k] >> 16)));
         v = uint4{o[0], o[1], o[2], o[3]};
       }
-      *reinterpret_cast<uint4*>(Cb + (long long)m * p.ldc + n) = v;
+      *reinterpret_cast<uint4*>(Cb + crow + n) = v;
     } else {
       const unsigned wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
         if (n + k < p.N) {
           float f = bf2f((bf16_t)((k & 1) ? (wv[k >> 1] >> 16) : (wv[k >> 1] & 0xffffu)));
           if (Rb) f += bf2f(Rb[(long long)rrow * p.ldr + n + k]);
-          Cb[(long long)m * p.ldc + n + k] = f2bf(f);
+          Cb[crow + n + k] = f2bf(f);
         }
       }
     }
@@ -246,6 +248,9 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   p.tiles_n = (d->N + BN - 1) / BN;
   p.ntiles = tm * p.tiles_n;
   p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
+  p.gA = d->a_group; p.sgA = d->a_group_stride; p.gC = d->c_group; p.sgC = d->c_group_stride;
+  VLA_REQUIRE(d->a_group >= 0 && d->c_group >= 0 && d->a_group_stride % 8 == 0 && (d->c_group == 0 || d->ldc % 8 != 0 || d->c_group_stride % 8 == 0),
+              "gemm: row-group strides must keep 16-B alignment");
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

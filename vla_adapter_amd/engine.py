@@ -1,0 +1,725 @@
+"""Native execution engine of the VLA-Adapter fine-tune hot path on MI355X.
+
+Orchestrates the HIP kernels of ``libvla_native.so`` (through ``ops``) for the whole training step of
+``vla-scripts/finetune.py:run_forward_pass`` + backward + AdamW (reference citations per method).  PyTorch is used
+for device memory, streams and (in ``ddp.py``) RCCL only; every FLOP and every byte moved on the hot path is a
+hand-written gfx950 kernel.  No autograd: backward is explicit, activations live in buffers allocated once and
+reused every step (static shapes -> the step is hipGraph-capturable).
+
+Layout decisions (MI355X-first, 288 GB HBM):
+  * frozen weights are stored twice: [out,in] for the forward NT GEMM and pre-transposed [in,out] for dX, so every
+    product is the K-contiguous NT form the MFMA kernel wants;
+  * q/k/v and gate/up projections are fused ([1152,896] and a 16-row interleaved [9728,896]) so the SwiGLU product
+    is formed in the GEMM epilogue;
+  * ViT MLP width 4304 is zero-padded to 4352 (=34*128) so every GEMM dim is tile-aligned;
+  * LLM hidden states for all layers live in one [n+2, B, S, D] buffer that the action head reads in place
+    (no [B,25,576,896] regroup copy, finetune.py:396-409); the lm_head (modeling_prismatic.py:680-686, discarded by
+    the reference) and the last ViT block (output unused) are never computed;
+  * trainable parameters (action head, proprio projector, action queries) are views into ONE flat bf16 buffer
+    grouped by kind across the 24 blocks -> batched GEMMs over layers, one AdamW launch, one gradient bucket.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from .ops import ACT_GELU, ACT_GELU_TANH, ACT_NONE, ACT_RELU, ACT_SWIGLU, BF16
+
+NUM_TOKENS = 64          # prismatic/vla/constants.py:15
+IGNORE_INDEX = -100
+
+
+def rup(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+# ------------------------------------------------------------------------------------------------ configs
+@dataclass
+class ViTCfg:
+    d: int = 1152
+    depth: int = 27
+    heads: int = 16
+    mlp: int = 4304
+    patch: int = 14
+    img: int = 224
+    n_prefix: int = 0          # 0 SigLIP; 5 DINOv2 (cls + 4 reg)
+    layerscale: bool = False
+    eps: float = 1e-6
+    gelu_tanh: bool = False
+
+    @property
+    def n_patches(self):
+        return (self.img // self.patch) ** 2
+
+    def as_oracle(self):
+        return dict(d=self.d, depth=self.depth, heads=self.heads, mlp=self.mlp, patch=self.patch, n_prefix=self.n_prefix,
+                    layerscale=self.layerscale, eps=self.eps, gelu_tanh=self.gelu_tanh)
+
+
+SIGLIP_SO400M = ViTCfg(1152, 27, 16, 4304, 14, 224, 0, False)
+DINOV2_L_REG4 = ViTCfg(1024, 24, 16, 4096, 14, 224, 5, True)
+
+
+@dataclass
+class LLMCfg:
+    d: int = 896
+    n_layers: int = 24
+    heads: int = 14
+    kv_heads: int = 2
+    dh: int = 64
+    inter: int = 4864
+    eps: float = 1e-6
+    theta: float = 1e6
+    vocab: int = 151936
+
+    def as_oracle(self):
+        return dict(n_layers=self.n_layers, heads=self.heads, kv_heads=self.kv_heads, dh=self.dh, eps=self.eps, theta=self.theta)
+
+
+@dataclass
+class VLACfg:
+    vit: List[ViTCfg] = field(default_factory=lambda: [SIGLIP_SO400M])
+    llm: LLMCfg = field(default_factory=LLMCfg)
+    n_img: int = 1
+    num_blocks: int = 24       # MLPResNet(num_blocks=24), action_heads.py:35
+    action_dim: int = 7
+    chunk: int = 8
+    proprio_dim: int = 8
+    pro: bool = True
+
+    @property
+    def fused(self):
+        return len(self.vit) == 2
+
+    @property
+    def n_patches(self):
+        return self.vit[0].n_patches * self.n_img
+
+    @property
+    def vis_dim(self):
+        return sum(v.d for v in self.vit)
+
+
+def config2() -> VLACfg:
+    """BASELINE.json configs[1]: SigLIP-224 + Qwen2.5-0.5B, adapter-only, 1 image."""
+    return VLACfg()
+
+
+def tiny_config() -> VLACfg:
+    """BASELINE.json configs[0] 'prismatic-tiny': 2 useful ViT-T blocks + 2-layer 256-d LLM + adapter.
+    The head reads hidden_states[i+1] for every block i (action_heads.py:117-118), so it can have at most
+    n_layers blocks: 2 here (the reference hard-codes 24 and therefore needs >= 24 LLM layers)."""
+    return VLACfg(vit=[ViTCfg(192, 3, 3, 768, 14, 56, 0, False)],
+                  llm=LLMCfg(256, 2, 4, 2, 64, 512, 1e-6, 1e6, 1024), num_blocks=2)
+
+
+# ------------------------------------------------------------------------------------------------ frozen ViT
+class ViT:
+    """timm VisionTransformer forward up to block depth-2, no final norm (modeling_prismatic.py:120-144,196-237;
+    block structure film_vit_wrapper.py:69-75).  Frozen: forward only."""
+
+    def __init__(self, cfg: ViTCfg, sd: Dict[str, torch.Tensor], device):
+        self.cfg = cfg
+        d, P = cfg.d, cfg.patch
+        g = lambda k: sd[k].to(device=device, dtype=BF16).contiguous()
+        self.kpe = rup(3 * P * P, 64)
+        wpe = torch.zeros(d, self.kpe, device=device, dtype=BF16)
+        wpe[:, :3 * P * P] = g("patch_embed.proj.weight").reshape(d, -1)
+        self.wpe, self.bpe = wpe, g("patch_embed.proj.bias")
+        self.pos = g("pos_embed").reshape(-1, d)
+        assert self.pos.shape[0] == cfg.n_patches, "pos_embed covers patches only (no_embed_class / no cls token)"
+        self.prefix = None
+        if cfg.n_prefix:
+            toks = [g("cls_token").reshape(1, d)] + ([g("reg_token").reshape(-1, d)] if "reg_token" in sd else [])
+            self.prefix = torch.cat(toks, 0)
+            assert self.prefix.shape[0] == cfg.n_prefix
+        self.mlp_pad = rup(cfg.mlp, 128)
+        self.blocks = []
+        for i in range(cfg.depth - 1):          # the last block's output is never used
+            p = f"blocks.{i}."
+            w1 = torch.zeros(self.mlp_pad, d, device=device, dtype=BF16)
+            w1[:cfg.mlp] = g(p + "mlp.fc1.weight")
+            b1 = torch.zeros(self.mlp_pad, device=device, dtype=BF16)
+            b1[:cfg.mlp] = g(p + "mlp.fc1.bias")
+            w2 = torch.zeros(d, self.mlp_pad, device=device, dtype=BF16)
+            w2[:, :cfg.mlp] = g(p + "mlp.fc2.weight")
+            wproj, bproj, b2 = g(p + "attn.proj.weight"), g(p + "attn.proj.bias"), g(p + "mlp.fc2.bias")
+            if cfg.layerscale:                  # fold LayerScale (modeling_prismatic.py:58-66) into the projections
+                ls1, ls2 = g(p + "ls1.scale_factor").float(), g(p + "ls2.scale_factor").float()
+                wproj = (wproj.float() * ls1[:, None]).to(BF16)
+                bproj = (bproj.float() * ls1).to(BF16)
+                w2 = (w2.float() * ls2[:, None]).to(BF16)
+                b2 = (b2.float() * ls2).to(BF16)
+            self.blocks.append(dict(n1w=g(p + "norm1.weight"), n1b=g(p + "norm1.bias"), wqkv=g(p + "attn.qkv.weight"),
+                                    bqkv=g(p + "attn.qkv.bias"), wproj=wproj, bproj=bproj, n2w=g(p + "norm2.weight"),
+                                    n2b=g(p + "norm2.bias"), w1=w1, b1=b1, w2=w2, b2=b2))
+
+    def forward(self, pixels: torch.Tensor, c0: int, out: torch.Tensor, c_group=None):
+        """pixels [B, C, H, W] (channels c0..c0+2 used) -> writes patch features into ``out`` (a [B*Np, d] window,
+        possibly a column slice of the fused feature buffer)."""
+        cfg = self.cfg
+        B, Np, d, T = pixels.shape[0], cfg.n_patches, cfg.d, cfg.n_patches + cfg.n_prefix
+        cols = ops.im2col_patch(pixels, c0, cfg.patch, self.kpe)
+        if cfg.n_prefix:
+            x = torch.empty(B, T, d, device=pixels.device, dtype=BF16)
+            tmp = ops.gemm_nt(cols, self.wpe, bias=self.bpe, residual=self.pos, res_mod=Np)
+            x[:, cfg.n_prefix:] = tmp.view(B, Np, d)
+            x[:, :cfg.n_prefix] = self.prefix
+            x = x.view(B * T, d)
+        else:
+            x = ops.gemm_nt(cols, self.wpe, bias=self.bpe, residual=self.pos, res_mod=Np)
+        act = ACT_GELU_TANH if cfg.gelu_tanh else ACT_GELU
+        dh = d // cfg.heads
+        nb = len(self.blocks)
+        for i, b in enumerate(self.blocks):
+            h = ops.layernorm_fwd(x, b["n1w"], b["n1b"], cfg.eps)
+            qkv = ops.gemm_nt(h, b["wqkv"], bias=b["bqkv"]).view(B, T, 3 * d)
+            a = ops.attn_fwd(qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], cfg.heads, cfg.heads, dh, False)
+            ops.gemm_nt(a.view(B * T, d), b["wproj"], bias=b["bproj"], residual=x, out=x)
+            h = ops.layernorm_fwd(x, b["n2w"], b["n2b"], cfg.eps)
+            m = ops.gemm_nt(h, b["w1"], bias=b["b1"], act=act)
+            if i == nb - 1 and cfg.n_prefix == 0:
+                ops.gemm_nt(m, b["w2"], bias=b["b2"], residual=x, out=out, c_group=c_group)
+            else:
+                ops.gemm_nt(m, b["w2"], bias=b["b2"], residual=x, out=x)
+        if cfg.n_prefix:
+            assert c_group is None
+            out.view(B, Np, -1).copy_(x.view(B, T, d)[:, cfg.n_prefix:])
+        return out
+
+
+# ------------------------------------------------------------------------------------------------ frozen LLM
+class LLM:
+    """Qwen2 decoder stack (transformers Qwen2ForCausalLM; reference call site modeling_prismatic.py:644-655),
+    forward with hidden-state taps and explicit dX backward (weights frozen: adapter-only fine-tune)."""
+
+    def __init__(self, cfg: LLMCfg, sd: Dict[str, torch.Tensor], device):
+        self.cfg, self.device = cfg, device
+        D, H, KV, dh, I = cfg.d, cfg.heads, cfg.kv_heads, cfg.dh, cfg.inter
+        assert D % 64 == 0 and I % 64 == 0 and (H + 2 * KV) * dh % 64 == 0 and I % 16 == 0
+        g = lambda k: sd[k].to(device=device, dtype=BF16).contiguous()
+        self.layers = []
+        for i in range(cfg.n_layers):
+            p = f"layers.{i}."
+            wqkv = torch.cat([g(p + "self_attn.q_proj.weight"), g(p + "self_attn.k_proj.weight"), g(p + "self_attn.v_proj.weight")], 0)
+            bqkv = torch.cat([g(p + "self_attn.q_proj.bias"), g(p + "self_attn.k_proj.bias"), g(p + "self_attn.v_proj.bias")], 0)
+            wg, wu = g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight")
+            wgu = torch.stack([wg.view(I // 16, 16, D), wu.view(I // 16, 16, D)], 1).reshape(2 * I, D).contiguous()
+            wo, wd = g(p + "self_attn.o_proj.weight"), g(p + "mlp.down_proj.weight")
+            self.layers.append(dict(n1=g(p + "input_layernorm.weight"), n2=g(p + "post_attention_layernorm.weight"),
+                                    wqkv=wqkv.contiguous(), bqkv=bqkv.contiguous(), wo=wo, wgu=wgu, wd=wd,
+                                    wqkvT=wqkv.t().contiguous(), woT=wo.t().contiguous(), wguT=wgu.t().contiguous(),
+                                    wdT=wd.t().contiguous()))
+        self.norm = g("norm.weight")
+        self.embed = g("embed_tokens.weight")
+        self._buf_key = None
+
+    def _alloc(self, B: int, S: int):
+        if self._buf_key == (B, S):
+            return
+        c, dev = self.cfg, self.device
+        n, M, D = c.n_layers, B * S, c.d
+        W = (c.heads + 2 * c.kv_heads) * c.dh
+        e = lambda *s, dt=BF16: torch.empty(*s, device=dev, dtype=dt)
+        # slots 0..n-1: residual stream entering layer i (slot 0 = inputs_embeds); slot n = FINAL-NORM output
+        # (= hidden_states[n] of the HF convention); slot n+1 = raw output of the last layer.
+        self.HS = e(n + 2, B, S, D)
+        self.X1, self.QKV, self.AO = e(n, M, D), e(n, M, W), e(n, M, c.heads * c.dh)
+        self.GU = e(n, M, 2 * c.inter)
+        self.LSE = e(n, B, c.heads, S, dt=torch.float32)
+        self.R1, self.R2, self.RF = e(n, M, dt=torch.float32), e(n, M, dt=torch.float32), e(M, dt=torch.float32)
+        self.nbuf, self.hbuf = e(M, D), e(M, c.inter)
+        self.d_a, self.d_b, self.d_h, self.d_gu, self.d_qkv, self.d_n = e(M, D), e(M, D), e(M, c.inter), e(M, 2 * c.inter), e(M, W), e(M, D)
+        self.cos, self.sin = ops.rope_half_tables(S, c.dh, c.theta, dev)
+        self._buf_key = (B, S)
+
+    def out_slot(self, i: int) -> int:
+        """HS slot holding the output of layer i (0-based)."""
+        n = self.cfg.n_layers
+        return i + 1 if i < n - 1 else n + 1
+
+    def forward(self, B: int, S: int, kmask_u8: torch.Tensor):
+        """HS[0] must already hold inputs_embeds [B,S,D].  Fills HS[1..n] (HF hidden_states semantics)."""
+        c = self.cfg
+        n, M, D, H, KV, dh = c.n_layers, B * S, c.d, c.heads, c.kv_heads, c.dh
+        self.kmask = kmask_u8
+        for i, L in enumerate(self.layers):
+            x = self.HS[i].view(M, D)
+            self._rms(x, L["n1"], self.nbuf, self.R1[i])
+            qkv = self.QKV[i]
+            ops.gemm_nt(self.nbuf, L["wqkv"], bias=L["bqkv"], out=qkv)
+            ops.rope_half_(qkv[:, :H * dh], self.cos, self.sin, S, H, dh)
+            ops.rope_half_(qkv[:, H * dh:(H + KV) * dh], self.cos, self.sin, S, KV, dh)
+            q3 = qkv.view(B, S, -1)
+            self._attn_fwd(q3, i, B, S)
+            x1 = self.X1[i]
+            ops.gemm_nt(self.AO[i], L["wo"], residual=x, out=x1)
+            self._rms(x1, L["n2"], self.nbuf, self.R2[i])
+            ops.gemm_nt(self.nbuf, L["wgu"], act=ACT_SWIGLU, out=self.GU[i], out2=self.hbuf)
+            ops.gemm_nt(self.hbuf, L["wd"], residual=x1, out=self.HS[self.out_slot(i)].view(M, D))
+        self._rms(self.HS[n + 1].view(M, D), self.norm, self.HS[n].view(M, D), self.RF)
+
+    def _rms(self, x, w, out, rstd):
+        ops.N.check(ops._lib().vla_rmsnorm_fwd(ops._st(), ops._p(x), ops._p(w), ops._p(out), ops._p(rstd), x.shape[0],
+                                               x.shape[1], self.cfg.eps), "rmsnorm_fwd")
+
+    def _attn_views(self, t3):
+        c = self.cfg
+        a, b = c.heads * c.dh, (c.heads + c.kv_heads) * c.dh
+        return t3[:, :, :a], t3[:, :, a:b], t3[:, :, b:]
+
+    def _attn_fwd(self, q3, i, B, S):
+        import ctypes as C
+        c = self.cfg
+        q, k, v = self._attn_views(q3)
+        o = self.AO[i].view(B, S, -1)
+        d = ops._attn_desc(q, k, v, o, self.LSE[i], self.kmask, True, c.dh ** -0.5, c.heads, c.kv_heads, c.dh)
+        ops.N.check(ops._lib().vla_attn_fwd(ops._st(), C.byref(d)), "attn_fwd")
+
+    def backward(self, dHS: torch.Tensor, B: int, S: int) -> torch.Tensor:
+        """dHS [n+1, B, S, D]: gradient w.r.t. hidden_states[i] (i = 0..n, HF convention; [0] unused).
+        Returns the gradient w.r.t. inputs_embeds [B,S,D] (frozen weights: no dW)."""
+        c = self.cfg
+        n, M, D, H, KV, dh = c.n_layers, B * S, c.d, c.heads, c.kv_heads, c.dh
+        d = ops.rmsnorm_bwd(dHS[n].view(M, D), self.HS[n + 1].view(M, D), self.norm, self.RF, out=self.d_a)
+        other = self.d_b
+        for i in range(n - 1, -1, -1):
+            L = self.layers[i]
+            if i < n - 1:                                   # head contribution to the output of layer i
+                ops.add_(d, dHS[i + 1].view(M, D))
+            ops.gemm_nt(d, L["wdT"], out=self.d_h)
+            ops.swiglu_bwd(self.d_h, self.GU[i], out=self.d_gu)
+            ops.gemm_nt(self.d_gu, L["wguT"], out=self.d_n)
+            d1 = ops.rmsnorm_bwd(self.d_n, self.X1[i], L["n2"], self.R2[i], dres=d, out=other)
+            dao = ops.gemm_nt(d1, L["woT"], out=self.d_n)
+            q3 = self.QKV[i].view(B, S, -1)
+            q, k, v = self._attn_views(q3)
+            dq, dk, dv = self._attn_views(self.d_qkv.view(B, S, -1))
+            ops.attn_bwd(dao.view(B, S, -1), q, k, v, self.AO[i].view(B, S, -1), self.LSE[i], H, KV, dh, True, self.kmask,
+                         dq=dq, dk=dk, dv=dv)
+            ops.rope_half_(self.d_qkv[:, :H * dh], self.cos, self.sin, S, H, dh, sign=-1)
+            ops.rope_half_(self.d_qkv[:, H * dh:(H + KV) * dh], self.cos, self.sin, S, KV, dh, sign=-1)
+            ops.gemm_nt(self.d_qkv, L["wqkvT"], out=self.d_n)
+            d_new = ops.rmsnorm_bwd(self.d_n, self.HS[i].view(M, D), L["n1"], self.R1[i], dres=d1, out=d)
+            d, other = d_new, d1
+        return d.view(B, S, D)
+
+
+# ------------------------------------------------------------------------------------------------ trainable params
+class FlatParams:
+    """Named bf16 views into one flat buffer (+ matching flat grad / AdamW state buffers)."""
+
+    def __init__(self, spec: List[Tuple[str, Tuple[int, ...]]], device):
+        self.offsets, off = {}, 0
+        for name, shape in spec:
+            n = math.prod(shape)
+            self.offsets[name] = (off, shape)
+            off += rup(n, 8)                      # every region 16-B aligned
+        self.numel = off
+        self.data = torch.zeros(off, device=device, dtype=BF16)
+        self.grad = torch.zeros(off, device=device, dtype=BF16)
+        self.m = torch.zeros(off, device=device, dtype=BF16)
+        self.v = torch.zeros(off, device=device, dtype=BF16)
+
+    def view(self, name, buf=None):
+        off, shape = self.offsets[name]
+        return (self.data if buf is None else buf)[off:off + math.prod(shape)].view(shape)
+
+    def g(self, name):
+        return self.view(name, self.grad)
+
+
+class Head:
+    """L1RegressionActionHead (Pro blocks) + ProprioProjector + action_queries: the trainable set of the
+    adapter-only fine-tune (action_heads.py:21-121, 287-410; projectors.py:6-24; modeling_prismatic.py:375-376)."""
+
+    H = 8
+
+    def __init__(self, cfg: VLACfg, device):
+        assert cfg.pro, "only MLPResNetBlock_Pro (use_pro_version=True, the reference default) is implemented natively"
+        self.cfg, self.device = cfg, device
+        D, nb, Da, Pd = cfg.llm.d, cfg.num_blocks, cfg.action_dim, cfg.proprio_dim
+        assert D % 64 == 0 and (D // self.H) % 8 == 0
+        self.D, self.nb, self.Din = D, nb, Da * D
+        assert self.Din % 64 == 0
+        spec = [("w_x", (nb, 3 * D, D)), ("b_x", (nb, 3 * D)),        # q_proj | k_self | v_self
+                ("w_adp", (nb, 2 * D, D)), ("b_adp", (nb, 2 * D)),    # k_adapter | v_adapter
+                ("w_task", (nb, 2 * D, D)), ("b_task", (nb, 2 * D)),  # k_task | v_task
+                ("w_o", (nb, D, D)), ("b_o", (nb, D)), ("w_ffn", (nb, D, D)), ("b_ffn", (nb, D)),
+                ("ln_w", (nb, D)), ("ln_b", (nb, D)), ("gate", (nb, 8)),
+                ("ln1_w", (self.Din,)), ("ln1_b", (self.Din,)), ("fc1_w", (D, self.Din)), ("fc1_b", (D,)),
+                ("ln2_w", (D,)), ("ln2_b", (D,)), ("fc2_w", (Da, D)), ("fc2_b", (Da,)),
+                ("p_fc1_w", (D, Pd)), ("p_fc1_b", (D,)), ("p_fc2_w", (D, D)), ("p_fc2_b", (D,)),
+                ("action_queries", (NUM_TOKENS, D))]
+        self.P = FlatParams(spec, device)
+        self.film = {}            # film_gen.0.{weight,bias}: in the state dict, never used, never updated (:327-329)
+        # transposed copies for the dX products (rebuilt after every optimiser step)
+        z = lambda *s: torch.zeros(*s, device=device, dtype=BF16)
+        self.T = dict(w_x=z(nb, D, 3 * D), w_adp=z(nb, D, 2 * D), w_task=z(nb, D, 2 * D), w_o=z(nb, D, D), w_ffn=z(nb, D, D),
+                      p_fc2_w=z(D, D))
+        self.fc2T = z(D, 64)                       # fc2^T zero-padded to K=64
+        self.pfc1_pad = z(D, 64)                   # proprio fc1 weight zero-padded to K=64
+        self.dirty = True
+        self._key = None
+        dh = D // self.H
+        self.rope_x = ops.rope_inter_tables(cfg.chunk, dh, device)
+        self.rope_a = ops.rope_inter_tables(NUM_TOKENS + 1, dh, device)
+        self.rope_t = {}
+
+    # ---- reference state-dict interop (file names / keys: finetune.py:527-572) -------------------------
+    _BLK = [("q_proj", "w_x", "b_x", 0), ("k_self", "w_x", "b_x", 1), ("v_self", "w_x", "b_x", 2),
+            ("k_adapter", "w_adp", "b_adp", 0), ("v_adapter", "w_adp", "b_adp", 1),
+            ("k_task", "w_task", "b_task", 0), ("v_task", "w_task", "b_task", 1),
+            ("o_proj", "w_o", "b_o", 0), ("ffn.1", "w_ffn", "b_ffn", 0)]
+
+    def named_views(self, buf=None) -> Dict[str, torch.Tensor]:
+        """Reference-named views ('model.mlp_resnet_blocks.N.q_proj.weight', ...) into the flat buffer."""
+        P, D, out = self.P, self.D, {}
+        v = lambda n: P.view(n, buf)
+        for i in range(self.nb):
+            pre = f"model.mlp_resnet_blocks.{i}."
+            for name, w, b, k in self._BLK:
+                out[pre + name + ".weight"] = v(w)[i, k * D:(k + 1) * D]
+                out[pre + name + ".bias"] = v(b)[i, k * D:(k + 1) * D]
+            out[pre + "ffn.0.weight"], out[pre + "ffn.0.bias"] = v("ln_w")[i], v("ln_b")[i]
+            out[pre + "gating_factor"] = v("gate")[i, :1]
+        for a, b in (("model.layer_norm1.weight", "ln1_w"), ("model.layer_norm1.bias", "ln1_b"), ("model.fc1.weight", "fc1_w"),
+                     ("model.fc1.bias", "fc1_b"), ("model.layer_norm2.weight", "ln2_w"), ("model.layer_norm2.bias", "ln2_b"),
+                     ("model.fc2.weight", "fc2_w"), ("model.fc2.bias", "fc2_b")):
+            out[a] = v(b)
+        return out
+
+    def proprio_views(self, buf=None):
+        v = lambda n: self.P.view(n, buf)
+        return {"fc1.weight": v("p_fc1_w"), "fc1.bias": v("p_fc1_b"), "fc2.weight": v("p_fc2_w"), "fc2.bias": v("p_fc2_b")}
+
+    def load_state_dicts(self, head_sd: Dict[str, torch.Tensor], proprio_sd: Dict[str, torch.Tensor],
+                         action_queries: Optional[torch.Tensor] = None):
+        nv = self.named_views()
+        for k, t in nv.items():
+            t.copy_(head_sd[k].to(self.device, BF16).reshape(t.shape))
+        for k, t in head_sd.items():
+            if "film_gen" in k:
+                self.film[k] = t.to(self.device, BF16)
+        for k, t in self.proprio_views().items():
+            t.copy_(proprio_sd[k].to(self.device, BF16))
+        if action_queries is not None:
+            self.P.view("action_queries").copy_(action_queries.to(self.device, BF16))
+        self.dirty = True
+
+    def head_state_dict(self):
+        sd = {k: v.clone() for k, v in self.named_views().items()}
+        sd.update(self.film)
+        return sd
+
+    def refresh_transposes(self):
+        if not self.dirty:
+            return
+        P = self.P
+        for k in ("w_x", "w_adp", "w_task", "w_o", "w_ffn"):
+            ops.transpose(P.view(k), out=self.T[k])
+        ops.transpose(P.view("p_fc2_w"), out=self.T["p_fc2_w"])
+        self.fc2T[:, :self.cfg.action_dim] = P.view("fc2_w").t()
+        self.pfc1_pad[:, :self.cfg.proprio_dim] = P.view("p_fc1_w")
+        self.dirty = False
+
+    def _alloc(self, B: int, Kt: int):
+        if self._key == (B, Kt):
+            return
+        D, nb, T, dev = self.D, self.nb, self.cfg.chunk, self.device
+        Ka = NUM_TOKENS + 1
+        e = lambda *s, dt=BF16: torch.empty(*s, device=dev, dtype=dt)
+        z = lambda *s, dt=BF16: torch.zeros(*s, device=dev, dtype=dt)
+        R = B * T
+        self.Ka, self.Kt, self.R = Ka, Kt, R
+        self.h_adp = e(nb, B, Ka, D)
+        self.KV_adp, self.KV_task = e(nb, B * Ka, 2 * D), e(nb, B * Kt, 2 * D)
+        self.dKV_adp, self.dKV_task = e(nb, B * Ka, 2 * D), e(nb, B * Kt, 2 * D)
+        self.X = e(nb + 1, R, D)                       # block inputs; X[nb] = output of the last block
+        self.QKVx, self.dQKVx = e(nb, R, 3 * D), e(nb, R, 3 * D)
+        self.AOx, self.O2, self.LNo = e(nb, R, D), e(nb, R, D), e(nb, R, D)
+        self.dO2, self.dFF = e(nb, R, D), e(nb, R, D)
+        self.probs = e(nb, B, self.H, T, T + Ka + Kt, dt=torch.float32)
+        self.stats = e(nb, R, 2, dt=torch.float32)
+        self.dgate = z(nb, dt=torch.float32)
+        self.ln_dw, self.ln_db = z(nb, D, dt=torch.float32), z(nb, D, dt=torch.float32)
+        self.b_f32 = {k: z(*self.P.offsets[k][1], dt=torch.float32) for k in ("b_x", "b_adp", "b_task", "b_o", "b_ffn", "fc1_b", "fc2_b", "p_fc1_b", "p_fc2_b")}
+        self.ln1_dw, self.ln1_db = z(self.Din, dt=torch.float32), z(self.Din, dt=torch.float32)
+        self.ln2_dw, self.ln2_db = z(D, dt=torch.float32), z(D, dt=torch.float32)
+        self.x_in = z(R, self.Din)
+        self.pr_in = z(B, 64)
+        # transposed operands for the batched dW products (K-dim = rows, zero-padded to a multiple of 64)
+        self.RK, self.AK, self.TK = rup(R, 64), rup(B * Ka, 64), rup(B * Kt, 64)
+        self.XT, self.dQKVxT = z(nb, D, self.RK), z(nb, 3 * D, self.RK)
+        self.AOxT, self.dO2T, self.LNoT, self.dFFT = z(nb, D, self.RK), z(nb, D, self.RK), z(nb, D, self.RK), z(nb, D, self.RK)
+        self.h_adpT, self.dKV_adpT = z(nb, D, self.AK), z(nb, 2 * D, self.AK)
+        self.h_taskT, self.dKV_taskT = z(nb, D, self.TK), z(nb, 2 * D, self.TK)
+        self.dh_adp = e(nb, B * Ka, D)
+        if Kt not in self.rope_t:
+            self.rope_t[Kt] = ops.rope_inter_tables(Kt, D // self.H, dev)
+        self._key = (B, Kt)
+
+    # ---- forward (action_heads.py:43-81, 111-121, 337-410) -------------------------------------------------
+    def forward(self, HS: torch.Tensor, pos1: torch.Tensor, proprio: torch.Tensor, Np: int,
+                noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """HS [>=nb+1, B, S, D] hidden states (HF indexing: block i reads HS[i+1]); pos1 int32 [B,64] = positions of
+        the action-query hidden states in text coordinates (mask on labels[:,1:], finetune.py:351-353, 399-405);
+        proprio [B, Pd]; noise [chunk, 7*D] or None (phase Inference).  Returns predicted actions [B, chunk, 7]."""
+        cfg, P, D, nb, H = self.cfg, self.P, self.D, self.nb, self.H
+        B, S = HS.shape[1], HS.shape[2]
+        T, Ka, Kt = cfg.chunk, NUM_TOKENS + 1, Np
+        self._alloc(B, Kt)
+        self.refresh_transposes()
+        self.HSref, self.Np, self.S, self.B = HS, Np, S, B
+        R, dh = B * T, D // H
+        # proprio projector (projectors.py:19-24); proprio rounded to bf16 first (action_heads.py:53)
+        self.pr_in[:, :cfg.proprio_dim] = proprio.to(BF16)
+        self.pp_pre = ops.gemm_nt(self.pr_in, self.pfc1_pad, bias=P.view("p_fc1_b"))
+        self.pp_act = ops.gelu_fwd(self.pp_pre)
+        pf = ops.gemm_nt(self.pp_act, P.view("p_fc2_w"), bias=P.view("p_fc2_b"))            # [B, D]
+        # adapter tokens: 64 action-query hidden states per layer + the proprio token (action_heads.py:347)
+        self.row_idx = (torch.arange(B, device=HS.device, dtype=torch.int32)[:, None] * S + Np + pos1).to(torch.int32)  # [B,64]
+        assert HS[1:nb + 1].is_contiguous()
+        hs_rows = HS[1:nb + 1].view(nb * B * S, D)
+        gidx = (torch.arange(nb, device=HS.device, dtype=torch.int32)[:, None, None] * (B * S) + self.row_idx[None]).reshape(-1)
+        tmp = torch.empty(nb * B * NUM_TOKENS, D, device=HS.device, dtype=BF16)
+        ops.gather_rows(hs_rows, gidx.contiguous(), tmp)
+        self.h_adp[:, :, :NUM_TOKENS] = tmp.view(nb, B, NUM_TOKENS, D)
+        self.h_adp[:, :, NUM_TOKENS] = pf
+        # K/V of the adapter and task segments for all blocks at once (batched over the 24 layers)
+        ops.gemm_nt(self.h_adp.view(nb, B * Ka, D), P.view("w_adp"), bias=P.view("b_adp"), out=self.KV_adp)
+        ops.rope_inter_(self.KV_adp.view(nb * B * Ka, 2 * D)[:, :D], *self.rope_a, Ka, H, dh, 0)
+        for i in range(nb):   # task tokens = HS[i+1][:, :Np] read in place (row-group addressing)
+            ops.gemm_nt(HS[i + 1].view(B * S, D)[:B * Kt], P.view("w_task")[i], bias=P.view("b_task")[i], out=self.KV_task[i],
+                        a_group=(Kt, S * D))
+        ops.rope_inter_(self.KV_task.view(nb * B * Kt, 2 * D)[:, :D], *self.rope_t[Kt], Kt, H, dh, 0)
+        # input: zeros (+ noise in the Training phase) -> LN -> fc1 -> ReLU   (action_heads.py:60-72, 113-115)
+        if noise is not None:
+            self.x_in.view(B, T, self.Din).copy_(noise.to(BF16)[None].expand(B, T, self.Din))
+        else:
+            self.x_in.zero_()
+        self.x_ln, self.st1 = ops.layernorm_fwd(self.x_in, P.view("ln1_w"), P.view("ln1_b"), 1e-5, want_stats=True)
+        ops.gemm_nt(self.x_ln, P.view("fc1_w"), bias=P.view("fc1_b"), act=ACT_RELU, out=self.X[0])
+        for i in range(nb):
+            x = self.X[i]
+            qkv = self.QKVx[i]
+            ops.gemm_nt(x, P.view("w_x")[i], bias=P.view("b_x")[i], out=qkv)
+            ops.rope_inter_(qkv[:, :2 * D], *self.rope_x, T, 2 * H, dh, 0)       # q and k_self share positions 0..T-1
+            self._attn(i, fwd=True)
+            ops.gemm_nt(self.AOx[i], P.view("w_o")[i], bias=P.view("b_o")[i], residual=x, out=self.O2[i])
+            self._ln(self.O2[i], P.view("ln_w")[i], P.view("ln_b")[i], self.LNo[i], self.stats[i])
+            ops.gemm_nt(self.LNo[i], P.view("w_ffn")[i], bias=P.view("b_ffn")[i], act=ACT_RELU, out=self.X[i + 1])
+        self.xf_ln, self.st2 = ops.layernorm_fwd(self.X[nb], P.view("ln2_w"), P.view("ln2_b"), 1e-5, want_stats=True)
+        self.pred = ops.gemm_nt(self.xf_ln, P.view("fc2_w"), bias=P.view("fc2_b"))
+        return self.pred.view(B, T, cfg.action_dim)
+
+    def _ln(self, x, w, b, y, stats):
+        ops.N.check(ops._lib().vla_layernorm_fwd(ops._st(), ops._p(x), ops._p(w), ops._p(b), ops._p(y), ops._p(stats),
+                                                 x.shape[0], x.shape[1], x.stride(0), y.stride(0), 1e-5), "layernorm_fwd")
+
+    def _attn(self, i: int, fwd: bool, dout=None):
+        import ctypes as C
+        B, T, D, Ka, Kt, H = self.B, self.cfg.chunk, self.D, self.Ka, self.Kt, self.H
+        qkv = self.QKVx[i].view(B, T, 3 * D)
+        ka = self.KV_adp[i].view(B, Ka, 2 * D)
+        kt = self.KV_task[i].view(B, Kt, 2 * D)
+        args = (qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], ka[:, :, :D], ka[:, :, D:], kt[:, :, :D], kt[:, :, D:])
+        gate = self.P.view("gate")[i]
+        out = self.AOx[i].view(B, T, D)
+        if fwd:
+            d = ops.head_attn_desc(*args, gate, self.probs[i], out, H)
+            ops.N.check(ops._lib().vla_head_attn_fwd(ops._st(), C.byref(d)), "head_attn_fwd")
+        else:
+            g = self.dQKVx[i].view(B, T, 3 * D)
+            ga = self.dKV_adp[i].view(B, Ka, 2 * D)
+            gt = self.dKV_task[i].view(B, Kt, 2 * D)
+            ops.head_attn_bwd(dout.view(B, T, D), *args, gate, self.probs[i], self.dgate[i:i + 1], g[:, :, :D], g[:, :, D:2 * D],
+                              g[:, :, 2 * D:], ga[:, :, :D], ga[:, :, D:], gt[:, :, :D], gt[:, :, D:], H)
+
+    # ---- backward ---------------------------------------------------------------------------------------------
+    def backward(self, dpred: torch.Tensor, dHS: torch.Tensor):
+        """dpred [B, chunk, 7] bf16.  Writes parameter gradients into the flat grad buffer and the hidden-state
+        gradients into dHS [nb+1, B, S, D] (HF indexing; rows not touched by the head must be pre-zeroed)."""
+        cfg, P, D, nb, H = self.cfg, self.P, self.D, self.nb, self.H
+        B, S, Np, T, Ka, Kt, R = self.B, self.S, self.Np, cfg.chunk, self.Ka, self.Kt, self.R
+        dh, Da = D // H, cfg.action_dim
+        G = P.g
+        for t in (self.dgate, self.ln_dw, self.ln_db, self.ln1_dw, self.ln1_db, self.ln2_dw, self.ln2_db, *self.b_f32.values()):
+            t.zero_()
+        dp = dpred.reshape(R, Da)
+        # fc2 / layer_norm2
+        dpad = torch.zeros(R, 64, device=dp.device, dtype=BF16)
+        dpad[:, :Da] = dp
+        ops.colsum_(dp, self.b_f32["fc2_b"])
+        G("fc2_w").copy_(self._dw(dp, self.xf_ln))
+        d_ln2 = ops.gemm_nt(dpad, self.fc2T)                                   # [R, D]
+        dx = ops.layernorm_bwd(d_ln2, self.X[nb], P.view("ln2_w"), self.st2, self.ln2_dw, self.ln2_db)
+        for i in range(nb - 1, -1, -1):
+            dff = self.dFF[i]
+            ops.N.check(ops._lib().vla_relu_bwd(ops._st(), ops._p(dx), ops._p(self.X[i + 1]), ops._p(dff), dx.numel()), "relu_bwd")
+            d_ln = ops.gemm_nt(dff, self.T["w_ffn"][i])
+            do2 = self.dO2[i]
+            self._ln_bwd(d_ln, self.O2[i], P.view("ln_w")[i], self.stats[i], do2, self.ln_dw[i], self.ln_db[i])
+            d_ao = ops.gemm_nt(do2, self.T["w_o"][i])
+            self._attn(i, fwd=False, dout=d_ao)
+            ops.rope_inter_(self.dQKVx[i][:, :2 * D], *self.rope_x, T, 2 * H, dh, 1)
+            dx = ops.gemm_nt(self.dQKVx[i], self.T["w_x"][i], residual=do2)
+        # input stage: relu -> fc1 -> layer_norm1 (input is noise/zeros: only parameter gradients)
+        dy1 = ops.relu_bwd(dx, self.X[0])
+        ops.colsum_(dy1, self.b_f32["fc1_b"])
+        G("fc1_w").copy_(self._dw(dy1, self.x_ln))
+        d_xln = ops.gemm_nt(dy1, self._t(P.view("fc1_w")))
+        ops.layernorm_bwd(d_xln, self.x_in, P.view("ln1_w"), self.st1, self.ln1_dw, self.ln1_db, want_dx=False)
+        # RoPE backward on the K halves, then everything that is batched over the 24 blocks
+        ops.rope_inter_(self.dKV_adp.view(nb * B * Ka, 2 * D)[:, :D], *self.rope_a, Ka, H, dh, 1)
+        ops.rope_inter_(self.dKV_task.view(nb * B * Kt, 2 * D)[:, :D], *self.rope_t[Kt], Kt, H, dh, 1)
+        # d h_adapter -> scatter into dHS (action positions) + proprio token gradient
+        ops.gemm_nt(self.dKV_adp, self.T["w_adp"], out=self.dh_adp)
+        dha = self.dh_adp.view(nb, B, Ka, D)
+        gidx = (torch.arange(nb, device=dHS.device, dtype=torch.int32)[:, None, None] * (B * S) + self.row_idx[None]).reshape(-1).contiguous()
+        ops.scatter_add_rows(dha[:, :, :NUM_TOKENS].reshape(nb * B * NUM_TOKENS, D), gidx, dHS[1:nb + 1].view(nb * B * S, D))
+        d_pf = dha[:, :, NUM_TOKENS].float().sum(0).to(BF16)                   # [B, D] (sum over blocks)
+        # d h_task -> written in place into dHS[i+1][:, :Np]
+        for i in range(nb):
+            ops.gemm_nt(self.dKV_task[i], self.T["w_task"][i], out=dHS[i + 1].view(B * S, D)[:B * Kt], c_group=(Kt, S * D))
+        # proprio projector backward
+        ops.colsum_(d_pf, self.b_f32["p_fc2_b"])
+        G("p_fc2_w").copy_(self._dw(d_pf, self.pp_act))
+        d_act = ops.gemm_nt(d_pf, self.T["p_fc2_w"])
+        d_pre = ops.gelu_bwd(d_act, self.pp_pre)
+        ops.colsum_(d_pre, self.b_f32["p_fc1_b"])
+        G("p_fc1_w").copy_(self._dw(d_pre, self.pr_in)[:, :cfg.proprio_dim])
+        # batched dW products: dW = dY^T . X  as NT GEMMs on transposed operands
+        bt = lambda src, dst: ops.transpose(src, out=dst)
+        bt(self.X[:nb], self.XT); bt(self.dQKVx, self.dQKVxT); bt(self.AOx, self.AOxT); bt(self.dO2, self.dO2T)
+        bt(self.LNo, self.LNoT); bt(self.dFF, self.dFFT); bt(self.h_adp.view(nb, B * Ka, D), self.h_adpT); bt(self.dKV_adp, self.dKV_adpT)
+        bt(self.dKV_task, self.dKV_taskT)
+        for i in range(nb):
+            self._transpose_task(i)
+        ops.gemm_nt(self.dQKVxT, self.XT, out=G("w_x"))
+        ops.gemm_nt(self.dO2T, self.AOxT, out=G("w_o"))
+        ops.gemm_nt(self.dFFT, self.LNoT, out=G("w_ffn"))
+        ops.gemm_nt(self.dKV_adpT, self.h_adpT, out=G("w_adp"))
+        ops.gemm_nt(self.dKV_taskT, self.h_taskT, out=G("w_task"))
+        for i in range(nb):
+            ops.colsum_(self.dQKVx[i], self.b_f32["b_x"][i]); ops.colsum_(self.dO2[i], self.b_f32["b_o"][i])
+            ops.colsum_(self.dFF[i], self.b_f32["b_ffn"][i])
+            ops.colsum_(self.dKV_adp[i], self.b_f32["b_adp"][i]); ops.colsum_(self.dKV_task[i], self.b_f32["b_task"][i])
+        for k, t in self.b_f32.items():
+            ops.cast_f32_bf16(t, out=G(k))
+        ops.cast_f32_bf16(self.ln_dw, out=G("ln_w")); ops.cast_f32_bf16(self.ln_db, out=G("ln_b"))
+        ops.cast_f32_bf16(self.ln1_dw, out=G("ln1_w")); ops.cast_f32_bf16(self.ln1_db, out=G("ln1_b"))
+        ops.cast_f32_bf16(self.ln2_dw, out=G("ln2_w")); ops.cast_f32_bf16(self.ln2_db, out=G("ln2_b"))
+        G("gate")[:, 0] = self.dgate.to(BF16)
+
+    def _t(self, w2d):
+        return ops.transpose(w2d.contiguous())
+
+    def _dw(self, dy, x):
+        """dW[N, K] = dY[R, N]^T . X[R, K] for the small one-off layers (R zero-padded to a multiple of 64)."""
+        Rp = rup(dy.shape[0], 64)
+        return ops.gemm_nt(ops.transpose(dy.contiguous(), ld_out=Rp), ops.transpose(x.contiguous(), ld_out=Rp))
+
+    def _ln_bwd(self, dy, x, w, stats, dx, dw, db):
+        ops.N.check(ops._lib().vla_layernorm_bwd(ops._st(), ops._p(dy), ops._p(x), ops._p(w), ops._p(stats), ops._p(dx), ops._p(dw),
+                                                 ops._p(db), x.shape[0], x.shape[1], x.stride(0), dy.stride(0), dx.stride(0)), "layernorm_bwd")
+
+    def _transpose_task(self, i: int):
+        """h_taskT[i][:, b*Kt:(b+1)*Kt] = HS[i+1][b, :Kt]^T  (one batched transpose over the batch)."""
+        B, S, D, Kt = self.B, self.S, self.D, self.Kt
+        src = self.HSref[i + 1]
+        ops.N.check(ops._lib().vla_transpose_bf16(ops._st(), ops._p(src), ops._p(self.h_taskT[i]), Kt, D, D, self.TK, B, S * D, Kt),
+                    "transpose")
+
+
+# ------------------------------------------------------------------------------------------------ whole model
+class VLAEngine:
+    """Adapter-only fine-tune step of VLA-Adapter (finetune.py:288-447 + 1039-1082) on one GPU."""
+
+    def __init__(self, cfg: VLACfg, weights: Dict, device="cuda"):
+        """weights = dict(vit=[sd...], proj=sd, llm=sd (HF names without 'model.' prefix incl. embed_tokens/norm),
+        head=sd, proprio=sd, action_queries=tensor)."""
+        self.cfg, self.device = cfg, device
+        self.vits = [ViT(c, sd, device) for c, sd in zip(cfg.vit, weights["vit"])]
+        self.llm = LLM(cfg.llm, weights["llm"], device)
+        self.head = Head(cfg, device)
+        self.head.load_state_dicts(weights["head"], weights["proprio"], weights.get("action_queries"))
+        g = lambda k: weights["proj"][k].to(device=device, dtype=BF16).contiguous()
+        self.proj = {k: g(k) for k in weights["proj"]}
+        self.step_count = 0
+        self._dHS = None
+
+    # modeling_prismatic.py:596-655 (multimodal forward) + finetune.py:396-418
+    def forward(self, batch: Dict[str, torch.Tensor], noise: Optional[torch.Tensor] = None):
+        cfg, llm = self.cfg, self.llm
+        ids, labels, am = batch["input_ids"], batch["labels"], batch["attention_mask"]
+        B, L = ids.shape
+        Np, D = cfg.n_patches, cfg.llm.d
+        S = L + Np
+        llm._alloc(B, S)
+        X0 = llm.HS[0]
+        # vision: per image, per backbone (modeling_prismatic.py:196-237) -> fused feature buffer
+        px = batch["pixel_values"]
+        nbk, npi = len(cfg.vit), cfg.vit[0].n_patches
+        feats = torch.empty(B, Np, cfg.vis_dim, device=self.device, dtype=BF16)
+        single = nbk == 1 and cfg.n_img == 1
+        col = 0
+        for j, vit in enumerate(self.vits):
+            for im in range(cfg.n_img):
+                c0 = im * 3 * nbk + 3 * j
+                if single:
+                    vit.forward(px, c0, feats.view(B * Np, -1))
+                else:
+                    tmp = torch.empty(B * npi, vit.cfg.d, device=self.device, dtype=BF16)
+                    vit.forward(px, c0, tmp)
+                    feats[:, im * npi:(im + 1) * npi, col:col + vit.cfg.d] = tmp.view(B, npi, -1)
+            col += vit.cfg.d
+        # projector (modeling_prismatic.py:261-273); the last Linear writes straight into the multimodal sequence
+        f2 = feats.view(B * Np, -1)
+        h = ops.gemm_nt(f2, self.proj["fc1.weight"], bias=self.proj["fc1.bias"], act=ACT_GELU)
+        dst = X0.view(B * S, D)[1:]
+        if cfg.fused:
+            h = ops.gemm_nt(h, self.proj["fc2.weight"], bias=self.proj["fc2.bias"], act=ACT_GELU)
+            ops.gemm_nt(h, self.proj["fc3.weight"], bias=self.proj["fc3.bias"], out=dst[:B * Np], c_group=(Np, S * D))
+        else:
+            ops.gemm_nt(h, self.proj["fc2.weight"], bias=self.proj["fc2.bias"], out=dst[:B * Np], c_group=(Np, S * D))
+        # masks + embedding splice (train_utils.py:8-41; modeling_prismatic.py:601-636)
+        self.qidx0, self.pos0, self.cnt0 = ops.action_mask(labels, 0)
+        _, self.pos1, self.cnt1 = ops.action_mask(labels, 1)
+        mm = torch.empty(B, S, device=self.device, dtype=torch.uint8)
+        ops.embed_splice(ids, am.to(torch.uint8).contiguous(), self.qidx0, llm.embed, self.head.P.view("action_queries"), X0, mm, Np)
+        llm.forward(B, S, mm)
+        pred = self.head.forward(llm.HS, self.pos1, batch["proprio"], Np, noise)
+        self.B, self.S, self.Np = B, S, Np
+        return pred
+
+    def loss_and_backward(self, pred, actions, gscale: float = 1.0):
+        """L1 loss (finetune.py:418) + full backward into the flat grad buffer."""
+        llm, head = self.llm, self.head
+        B, S, Np, D, n = self.B, self.S, self.Np, self.cfg.llm.d, self.cfg.llm.n_layers
+        loss3, dpred = ops.l1_loss(pred, actions.to(BF16), True, gscale)
+        if self._dHS is None or self._dHS.shape[1:3] != (B, S):
+            self._dHS = torch.empty(n + 1, B, S, D, device=self.device, dtype=BF16)
+        self._dHS.zero_()
+        head.backward(dpred, self._dHS)
+        dX0 = llm.backward(self._dHS, B, S)
+        dq = ops.action_query_grad(dX0.contiguous(), self.pos0, Np)
+        ops.cast_f32_bf16(dq, out=head.P.g("action_queries"))
+        return loss3
+
+    def optimizer_step(self, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, wd=0.01):
+        """torch.optim.AdamW semantics on the flat trainable buffer (finetune.py:910, 1078-1082)."""
+        self.step_count += 1
+        P = self.head.P
+        ops.adamw_(P.data, P.grad, P.m, P.v, self.step_count, lr, beta1, beta2, eps, wd)
+        self.head.dirty = True
+
+    def train_step(self, batch, lr: float, noise=None):
+        pred = self.forward(batch, noise)
+        loss3 = self.loss_and_backward(pred, batch["actions"])
+        self.optimizer_step(lr)
+        return loss3

@@ -24,7 +24,8 @@ class GemmDesc(C.Structure):
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int),
                 ("ldr", C.c_int), ("ldc2", C.c_int), ("res_mod", C.c_int), ("act", C.c_int), ("batch", C.c_int),
                 ("sA", C.c_longlong), ("sB", C.c_longlong), ("sC", C.c_longlong), ("sR", C.c_longlong),
-                ("sC2", C.c_longlong), ("sBias", C.c_longlong), ("alpha", C.c_float)]
+                ("sC2", C.c_longlong), ("sBias", C.c_longlong), ("alpha", C.c_float),
+                ("a_group", C.c_int), ("c_group", C.c_int), ("a_group_stride", C.c_longlong), ("c_group_stride", C.c_longlong)]
 
 
 class AttnDesc(C.Structure):

@@ -37,7 +37,7 @@ def _chk_bf16(*ts):
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_mod: int = 0, act: int = ACT_NONE,
             out: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, alpha: float = 1.0,
-            want_pre: bool = True) -> torch.Tensor:
+            want_pre: bool = True, a_group=None, c_group=None) -> torch.Tensor:
     """C = epilogue(A @ B^T).  a: [M,K] or [batch,M,K] (row stride = a.stride(-2)); b: [N,K] or [batch,N,K].
     SwiGLU: returns (pre [.., N] or None, h [.., N/2])."""
     _chk_bf16(a, b, bias, residual, out, out2)
@@ -78,6 +78,10 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_m
         assert res_mod > 0 or tuple(residual.shape) == tuple(shape)
         d.R, d.ldr = residual.data_ptr(), residual.stride(-2)
         d.sR = residual.stride(0) if (batched and residual.dim() == 3) else 0
+    if a_group is not None:      # (rows per group, stride between groups): a = first row-group view [g, K]
+        d.a_group, d.a_group_stride = a_group
+    if c_group is not None:
+        d.c_group, d.c_group_stride = c_group
     N.check(_lib().vla_gemm_bf16_nt(_st(), C.byref(d)), "gemm_bf16_nt")
     if act == ACT_SWIGLU:
         return out, out2
