@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Headline benchmark: adapter-only fine-tune throughput (samples/s) of SigLIP-224 + Qwen2.5-0.5B + Pro action head,
+bf16, per-GPU batch 32 (BASELINE.json configs[1]; configs[2] with --gpus 8), forward + backward + AdamW, synthetic
+224x224 image + 32-token prompt batches, random-init weights (no network).
+
+    python bench.py --gpus N --steps K --warmup W
+    N>1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `value` = whole-job samples/s (all ranks), inputs resident in HBM when the timed
+region starts.  `roofline` prices the dominant kernel (the bf16 MFMA GEMM) with HIP events on the launch stream;
+`cpu_baseline` times the CPU oracle (fp32, torch CPU threads) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+
+
+def gemm_flops_of_call(a, b, batched):
+    M, K = a.shape[-2:]
+    N = b.shape[-2]
+    nb = a.shape[0] if batched else 1
+    return 2.0 * nb * M * N * K
+
+
+def measure_gemm_roofline(eng, batch, noise, lr):
+    """One extra instrumented step: every GEMM launch is bracketed by HIP events on the stream it is launched on
+    (torch's current stream == the stream the C ABI receives)."""
+    from vla_adapter_amd import ops
+    recs = []
+    orig = ops.gemm_nt
+
+    def timed(a, b, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig(a, b, **kw)
+        e1.record()
+        recs.append((e0, e1, gemm_flops_of_call(a, b, a.dim() == 3)))
+        return r
+
+    ops.gemm_nt = timed
+    try:
+        eng.train_step(batch, lr, noise)
+        torch.cuda.synchronize()
+    finally:
+        ops.gemm_nt = orig
+    t = sum(e0.elapsed_time(e1) for e0, e1, _ in recs) * 1e-3
+    fl = sum(f for _, _, f in recs)
+    return dict(launches=len(recs), seconds=t, flops=fl, tflops=fl / t / 1e12)
+
+
+def cpu_baseline(cfg, W, batch, noise, nsample, seconds_cap=60.0):
+    """The CPU oracle (fp32 restatement, torch CPU threads) on `nsample` samples of the same batch: forward + backward
+    + AdamW on the trainable set.  kind="port" (the reference's own Python cannot travel to the GPU box)."""
+    from oracle import vla_oracle as O
+    f = lambda sd: {k: v.float().cpu() for k, v in sd.items()}
+    llm = f(W["llm"])
+    leaf = lambda d: {k: v.requires_grad_(True) for k, v in d.items()}
+    OW = dict(vit=[f(s) for s in W["vit"]], proj=f(W["proj"]), llm=llm, embed=llm["embed_tokens.weight"],
+              action_queries=W["action_queries"].float().cpu().requires_grad_(True), head=leaf(f(W["head"])), proprio=leaf(f(W["proprio"])))
+    cb = {k: v[:nsample].cpu() for k, v in batch.items()}
+    cb["pixel_values"], cb["proprio"] = cb["pixel_values"].float(), cb["proprio"].bfloat16().float()
+    ocfg = dict(vit=[v.as_oracle() for v in cfg.vit], fused=cfg.fused, llm=cfg.llm.as_oracle(), n_img=cfg.n_img, pro=True,
+                num_blocks=cfg.num_blocks)
+    nz = noise.float().cpu() if noise is not None else None
+    params = [OW["action_queries"]] + [p for k, p in OW["head"].items() if "film_gen" not in k] + list(OW["proprio"].values())
+    steps, t0 = 0, time.time()
+    while True:
+        out = O.vla_forward(cb, OW, ocfg, emu=False, noise=nz)
+        out["loss"].backward()
+        with torch.no_grad():
+            for p in params:
+                if p.grad is not None:
+                    pn, _, _ = O.adamw_step(p, p.grad, torch.zeros_like(p), torch.zeros_like(p), 1, 5e-4)
+                    p.copy_(pn)
+                    p.grad = None
+        steps += 1
+        el = time.time() - t0
+        if el > 10.0 or steps >= 3 or el * (steps + 1) / steps > seconds_cap:
+            break
+    return dict(value=steps * nsample / el, unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{steps} step(s) x {nsample} sample(s) of the same synthetic batch, fp32 torch-CPU oracle fwd+bwd+AdamW, {el:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE config: 32)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-samples", type=int, default=1)
+    args = ap.parse_args()
+
+    from vla_adapter_amd import ddp, engine as E, flops, synthetic as S
+    rank, local, world = ddp.init_process_group_from_env()
+    assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    cfg = E.config2()
+    B, P = args.batch, 32
+    W = S.make_weights(cfg, dev, seed=0)                    # identical on every rank (== DDP's initial broadcast)
+    eng = E.VLAEngine(cfg, W, dev)
+    batch = S.make_batch(cfg, B, dev, seed=1000 + rank, P=P)  # every rank draws its own samples (finetune.py:988-994)
+    batch["pixel_values"] = batch["pixel_values"].to(torch.bfloat16)   # finetune.py:339
+    noise = (torch.randn(cfg.chunk, cfg.action_dim * cfg.llm.d, device=dev) * 0.02).to(torch.bfloat16)  # phase="Training"
+    if world > 1:
+        eng.reducer = ddp.FlatGradReducer()
+    lr = 5e-4
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.train_step(batch, lr, noise)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss3 = eng.train_step(batch, lr, noise)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    ms = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+    fl = flops.step_flops_per_sample(cfg, L=P + 64)
+    if rank == 0:
+        roof = measure_gemm_roofline(eng, batch, noise, lr)
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(cfg, W, batch, noise, args.cpu_samples)
+        line = {
+            "metric": "fine-tune samples/sec (224px img + 32-tok prompt), adapter-only, fwd+bwd+AdamW",
+            "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: Prismatic SigLIP-224 + Qwen2.5-0.5B + Pro action head, adapter-only fine-tune, "
+                                   "1 image (256 patches) + 32-token prompt + 64 action queries (S=352)",
+                       "global_batch": world * B, "per_gpu_batch": B, "seq_len": cfg.n_patches + P + 64,
+                       "parallelism": f"dp{world}", "weights": "random-init", "final_loss": round(float(loss3[0]), 5)},
+            "samples_per_s_per_gpu": round(value / world, 2),
+            "step_algorithmic_tflops_per_gpu": round(fl["step"] * B / (ms * 1e-3) / 1e12, 1),
+            "step_frac_of_bf16_mfma_peak": round(fl["step"] * B / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 MFMA NT GEMM, all launches of one step)",
+                         "achieved": round(roof["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(roof["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": roof["launches"], "gemm_ms_per_step": round(roof["seconds"] * 1e3, 3),
+                         "gemm_flops_per_step": roof["flops"]},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

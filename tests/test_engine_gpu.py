@@ -98,7 +98,12 @@ def test_backward_and_step_parity(setup):
     loss3 = eng.loss_and_backward(pred, batch["actions"])
     torch.cuda.synchronize()
     out, OW = _oracle_run(cfg, W, batch, None, True, cfg.num_blocks)
-    out["loss"].backward()
+    # L1's gradient is sign(pred - target)/n: a bf16-level difference in pred flips signs and changes the whole
+    # backward signal discretely (oracle bf16-vs-fp32 grads differ by ~5% for that reason alone), so the oracle's
+    # backward is driven by the SAME upstream gradient the engine used.
+    from vla_adapter_amd import ops
+    _, dpred = ops.l1_loss(pred, batch["actions"].to(BF), True)
+    out["pred"].backward(dpred.float().cpu())
     assert abs(loss3[0].item() - out["loss"].item()) <= 1e-2 * abs(out["loss"].item())
     g_head = eng.head.named_views(eng.head.P.grad)
     bad = []
@@ -107,14 +112,14 @@ def test_backward_and_step_parity(setup):
         if ref is None:
             continue
         r = rel(v, ref.reshape(v.shape))
-        if r > 5e-2 and ref.abs().max() > 1e-6:
+        if r > 3e-2 and ref.abs().max() > 1e-6:
             bad.append((k, r))
     assert not bad, f"head grads off: {bad[:8]}"
     for k, v in eng.head.proprio_views(eng.head.P.grad).items():
         r = rel(v, OW["proprio"][k].grad)
-        assert r < 5e-2, f"proprio grad {k}: {r:.3e}"
+        assert r < 3e-2, f"proprio grad {k}: {r:.3e}"
     r = rel(eng.head.P.g("action_queries"), OW["action_queries"].grad)
-    assert r < 5e-2, f"action_queries grad (through the whole frozen LLM): {r:.3e}"
+    assert r < 3e-2, f"action_queries grad (through the whole frozen LLM): {r:.3e}"
     # optimiser step: bit-exact AdamW on the engine's own gradients
     P = eng.head.P
     p0, g0 = P.data.float().cpu().clone(), P.grad.float().cpu().clone()

@@ -652,6 +652,7 @@ class VLAEngine:
         self.proj = {k: g(k) for k in weights["proj"]}
         self.step_count = 0
         self._dHS = None
+        self.reducer = None        # ddp.FlatGradReducer when world_size > 1
 
     # modeling_prismatic.py:596-655 (multimodal forward) + finetune.py:396-418
     def forward(self, batch: Dict[str, torch.Tensor], noise: Optional[torch.Tensor] = None):
@@ -706,16 +707,25 @@ class VLAEngine:
             self._dHS = torch.empty(n + 1, B, S, D, device=self.device, dtype=BF16)
         self._dHS.zero_()
         head.backward(dpred, self._dHS)
+        aq_off = head.P.offsets["action_queries"][0]
+        if self.reducer is not None:       # head/proprio grads are final: exchange them under the LLM backward
+            self.reducer.reduce_async(head.P.grad, 0, aq_off)
         dX0 = llm.backward(self._dHS, B, S)
         dq = ops.action_query_grad(dX0.contiguous(), self.pos0, Np)
         ops.cast_f32_bf16(dq, out=head.P.g("action_queries"))
+        if self.reducer is not None:
+            self.reducer.reduce_async(head.P.grad, aq_off, None)
         return loss3
 
     def optimizer_step(self, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, wd=0.01):
         """torch.optim.AdamW semantics on the flat trainable buffer (finetune.py:910, 1078-1082)."""
         self.step_count += 1
         P = self.head.P
-        ops.adamw_(P.data, P.grad, P.m, P.v, self.step_count, lr, beta1, beta2, eps, wd)
+        gscale = 1.0
+        if self.reducer is not None:
+            self.reducer.wait()
+            gscale = self.reducer.grad_scale       # DDP averages: sum-all-reduce then 1/N, folded into AdamW
+        ops.adamw_(P.data, P.grad, P.m, P.v, self.step_count, lr, beta1, beta2, eps, wd, gscale=gscale)
         self.head.dirty = True
 
     def train_step(self, batch, lr: float, noise=None):

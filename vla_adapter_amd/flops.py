@@ -1,0 +1,53 @@
+"""Algorithmic FLOP model of the fine-tune hot path: the single source for roofline.achieved.
+
+2 FLOPs per MAC.  Excluded (never computed by this build, dead work in the reference): the last ViT block, the
+lm_head, film_gen, hidden_states[0].  Backward convention: dX GEMMs for every op downstream of a trainable tensor
+(action_queries sits at the LLM input -> the whole LLM needs dX), dW GEMMs only for trainable weights, attention
+backward = 2x attention forward.
+"""
+from __future__ import annotations
+
+from .engine import NUM_TOKENS, VLACfg
+
+
+def vit_fwd(c) -> float:
+    T, Lu = c.n_patches + c.n_prefix, c.depth - 1
+    return Lu * (2 * T * (4 * c.d ** 2 + 2 * c.d * c.mlp) + 4 * T * T * c.d) + 2 * c.n_patches * (3 * c.patch ** 2) * c.d
+
+
+def proj_fwd(cfg: VLACfg) -> float:
+    D, vd, Np = cfg.llm.d, cfg.vis_dim, cfg.n_patches
+    per_tok = (vd * 4 * vd + 4 * vd * D + D * D) if cfg.fused else (vd * D + D * D)
+    return 2 * Np * per_tok
+
+
+def llm_linear_fwd(cfg: VLACfg, S: int) -> float:
+    c = cfg.llm
+    p_layer = c.d * (c.heads + 2 * c.kv_heads) * c.dh + c.heads * c.dh * c.d + 3 * c.d * c.inter
+    return c.n_layers * 2 * S * p_layer
+
+
+def llm_attn_fwd(cfg: VLACfg, S: int) -> float:
+    c = cfg.llm
+    return c.n_layers * 2 * S * S * c.heads * c.dh          # causal-useful half of 4 S^2 d
+
+
+def head_fwd(cfg: VLACfg) -> float:
+    D, T, A, Kt = cfg.llm.d, cfg.chunk, NUM_TOKENS, cfg.n_patches
+    return cfg.num_blocks * (2 * D * D * (5 * T + 2 * (A + 1) + 2 * Kt) + 4 * T * (T + A + 1 + Kt) * D) + 2 * T * cfg.action_dim * D * D
+
+
+def step_flops_per_sample(cfg: VLACfg, L: int = 96) -> dict:
+    """Adapter-only fine-tune (BASELINE configs 2/3): frozen ViT + projector forward only; LLM forward + dX; head x3."""
+    S = cfg.n_patches + L
+    vit = sum(vit_fwd(c) for c in cfg.vit) * cfg.n_img
+    proj, lin, att, head = proj_fwd(cfg), llm_linear_fwd(cfg, S), llm_attn_fwd(cfg, S), head_fwd(cfg)
+    total = vit + proj + 2 * lin + 3 * att + 3 * head
+    return dict(vit_fwd=vit, proj_fwd=proj, llm_linear_fwd=lin, llm_attn_fwd=att, head_fwd=head, forward=vit + proj + lin + att + head,
+                step=total)
+
+
+if __name__ == "__main__":
+    from .engine import config2
+    for k, v in step_flops_per_sample(config2()).items():
+        print(f"{k:16s} {v / 1e9:10.1f} GF/sample")
