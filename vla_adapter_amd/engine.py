@@ -733,3 +733,51 @@ class VLAEngine:
         loss3 = self.loss_and_backward(pred, batch["actions"])
         self.optimizer_step(lr)
         return loss3
+
+    # ---- hipGraph path: the step is ~2000 launches of 15-350 us kernels, i.e. launch-bound from Python.  With static
+    # shapes and preallocated buffers the whole forward+backward is captured once and replayed (two graphs, cut where
+    # the data-parallel exchange of the head gradients is launched); AdamW stays outside (its bias corrections are
+    # host scalars that change every step).
+    def capture(self, batch: Dict[str, torch.Tensor], noise: Optional[torch.Tensor] = None, warmup: int = 2):
+        """``batch``/``noise`` become the static input buffers: copy new data INTO them before each replay."""
+        self._static_batch, self._static_noise = batch, noise
+        for _ in range(warmup):                      # allocate every buffer / set kernel attributes outside capture
+            self.head.dirty = True
+            self._fwd_head_bwd(batch, noise)
+            self._llm_bwd()
+        torch.cuda.synchronize()
+        self.head.dirty = True
+        self._g1, self._g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g1):
+            self._loss3 = self._fwd_head_bwd(batch, noise)
+        with torch.cuda.graph(self._g2, pool=self._g1.pool()):
+            self._llm_bwd()
+        torch.cuda.synchronize()
+
+    def _fwd_head_bwd(self, batch, noise):
+        llm, head = self.llm, self.head
+        pred = self.forward(batch, noise)
+        B, S, D, n = self.B, self.S, self.cfg.llm.d, self.cfg.llm.n_layers
+        loss3, dpred = ops.l1_loss(pred, batch["actions"].to(BF16), True, 1.0)
+        if self._dHS is None or self._dHS.shape[1:3] != (B, S):
+            self._dHS = torch.empty(n + 1, B, S, D, device=self.device, dtype=BF16)
+        self._dHS.zero_()
+        head.backward(dpred, self._dHS)
+        return loss3
+
+    def _llm_bwd(self):
+        dX0 = self.llm.backward(self._dHS, self.B, self.S)
+        dq = ops.action_query_grad(dX0.contiguous(), self.pos0, self.Np)
+        ops.cast_f32_bf16(dq, out=self.head.P.g("action_queries"))
+
+    def train_step_graphed(self, lr: float):
+        """Replay of the captured step on the static buffers (+ RCCL exchange + AdamW)."""
+        aq_off = self.head.P.offsets["action_queries"][0]
+        self._g1.replay()
+        if self.reducer is not None:
+            self.reducer.reduce_async(self.head.P.grad, 0, aq_off)
+        self._g2.replay()
+        if self.reducer is not None:
+            self.reducer.reduce_async(self.head.P.grad, aq_off, None)
+        self.optimizer_step(lr)
+        return self._loss3
