@@ -139,8 +139,9 @@ int vla_gelu_bwd(void* stream, const void* dy, const void* x, void* dx, long lon
 int vla_relu_bwd(void* stream, const void* dy, const void* y, void* dx, long long n);
 /* SwiGLU backward: dH [M, I] and interleaved pre-activations GU [M, 2I] -> dGU [M, 2I] (same interleave). */
 int vla_swiglu_bwd(void* stream, const void* dh, const void* gu, void* dgu, int M, int I);
-/* column sums of a bf16 matrix [rows, cols] into f32 out[cols] (+=): bias gradients. */
-int vla_colsum_bf16(void* stream, const void* x, float* out, int rows, int cols, int ldx);
+/* column sums of bf16 matrices [batch][rows, cols] into f32 out[batch][cols] (+=): bias gradients. */
+int vla_colsum_bf16(void* stream, const void* x, float* out, int rows, int cols, int ldx, int batch, long long s_x,
+                    long long s_out);
 /* f32 -> bf16 / bf16 -> f32 casts */
 int vla_cast_f32_bf16(void* stream, const float* x, void* y, long long n);
 int vla_cast_bf16_f32(void* stream, const void* x, float* y, long long n);

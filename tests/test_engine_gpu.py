@@ -171,8 +171,9 @@ def test_graph_replay_matches_eager(setup):
 
 def test_head_only_parity_identical_inputs(setup):
     """Head forward/backward on IDENTICAL hidden states (no upstream forward noise): tighter bounds."""
-    cfg, W, batch, eng = setup
-    from vla_adapter_amd import ops
+    cfg, W, batch, _ = setup
+    from vla_adapter_amd import ops, engine as E
+    eng = E.VLAEngine(cfg, W, DEV)        # fresh parameters (the shared engine has taken an optimiser step)
     B, L = batch["input_ids"].shape
     Np, D, nb = cfg.n_patches, cfg.llm.d, cfg.num_blocks
     S = L + Np

@@ -384,6 +384,14 @@ def test_gather_scatter_im2col_misc(ops):
     cs = torch.zeros(64, device=DEV)
     ops.colsum_(a.to(DEV), cs)
     check(cs, a.float().sum(0), rel=1e-5, mx=1e-5, name="colsum")
+    x3 = gen(3, 700, 520, seed=75)
+    cs3 = torch.zeros(3, 520, device=DEV)
+    ops.colsum_(x3.to(DEV), cs3)
+    check(cs3, x3.float().sum(1), rel=1e-5, mx=1e-5, name="colsum batched/vectorised")
+    x7 = gen(100, 7, seed=76)
+    cs7 = torch.zeros(7, device=DEV)
+    ops.colsum_(x7.to(DEV), cs7)
+    check(cs7, x7.float().sum(0), rel=1e-5, mx=1e-5, name="colsum odd cols")
 
 
 def test_l1_loss(ops):

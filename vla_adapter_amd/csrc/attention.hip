@@ -55,15 +55,36 @@ __device__ __forceinline__ bf16x8 pack_acc(const f32x16& x, int s) {
   return r;
 }
 
-template <int D, int LD>
-__device__ __forceinline__ void load_tile(bf16_t* dst, const bf16_t* src, long long row_stride, int row0, int nrows,
-                                          int tid, int nthreads) {
-  constexpr int CPR = D / 8;  // 16-B chunks per row
-  for (int c = tid; c < 32 * CPR; c += nthreads) {
+// Tile staging split in two (cdna_hip_programming.md T14): the global loads of tile t+1 are issued into registers
+// BEFORE the MFMAs of tile t and written to LDS after the next barrier, so HBM/L2 latency hides under compute.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in VGPRs (HIP's uint4 struct did not)
+template <int D, int NT>
+struct TileGeo {
+  static constexpr int CPR = D / 8;                       // 16-B chunks per row
+  static constexpr int NCH = (32 * CPR + NT - 1) / NT;    // chunks per thread
+};
+template <int D, int NT>
+__device__ __forceinline__ void tile_prefetch(u32x4* __restrict__ v, const bf16_t* src, long long row_stride,
+                                              int row0, int nrows, int tid) {
+  constexpr int CPR = TileGeo<D, NT>::CPR, NCH = TileGeo<D, NT>::NCH;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = min(tid + i * NT, 32 * CPR - 1);        // surplus threads re-load the last chunk (never stored)
     const int r = c / CPR, ch = c - r * CPR;
-    const int gr = min(row0 + r, nrows - 1);  // clamp: masked later, must stay finite
-    *reinterpret_cast<uint4*>(dst + r * LD + ch * 8) =
-        *reinterpret_cast<const uint4*>(src + (long long)gr * row_stride + ch * 8);
+    const int gr = min(row0 + r, nrows - 1);              // clamp: masked later, must stay finite
+    v[i] = *reinterpret_cast<const u32x4*>(src + (long long)gr * row_stride + ch * 8);
+  }
+}
+template <int D, int NT, int LD>
+__device__ __forceinline__ void tile_store(const u32x4* __restrict__ v, bf16_t* dst, int tid) {
+  constexpr int CPR = TileGeo<D, NT>::CPR, NCH = TileGeo<D, NT>::NCH;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = tid + i * NT;
+    if (c < 32 * CPR) {
+      const int r = c / CPR, ch = c - r * CPR;
+      *reinterpret_cast<u32x4*>(dst + r * LD + ch * 8) = v[i];
+    }
   }
 }
 
@@ -105,14 +126,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
   const int kend = p.causal ? min(p.Sk, qblk + 128) : p.Sk;
   const bf16_t* kb = p.k + (long long)b * p.k_sb + hkv * D;
   const bf16_t* vb = p.v + (long long)b * p.v_sb + hkv * D;
+  u32x4 rk[TileGeo<D, 256>::NCH], rv[TileGeo<D, 256>::NCH];
+  tile_prefetch<D, 256>(rk, kb, p.k_ss, 0, p.Sk, tid);
+  tile_prefetch<D, 256>(rv, vb, p.v_ss, 0, p.Sk, tid);
   for (int k0 = 0; k0 < kend; k0 += 32) {
     __syncthreads();
-    load_tile<D, G::LD>(sK, kb, p.k_ss, k0, p.Sk, tid, 256);
-    load_tile<D, G::LD>(sV, vb, p.v_ss, k0, p.Sk, tid, 256);
+    tile_store<D, 256, G::LD>(rk, sK, tid);
+    tile_store<D, 256, G::LD>(rv, sV, tid);
     const int kk = k0 + (lane & 31);
     const bool kok = kk < p.Sk && (!p.kmask || p.kmask[(long long)b * p.Sk + kk]);
     const unsigned km = (unsigned)__ballot(kok);
     __syncthreads();
+    if (k0 + 32 < kend) {
+      tile_prefetch<D, 256>(rk, kb, p.k_ss, k0 + 32, p.Sk, tid);
+      tile_prefetch<D, 256>(rv, vb, p.v_ss, k0 + 32, p.Sk, tid);
+    }
     if (p.causal && k0 > q0 + 31) continue;  // wave-uniform: whole tile is in the future (barriers already passed)
 
     f32x16 S = zero16();
@@ -172,23 +200,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------ delta = rowsum(dO*O)
-__global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p) {
-  const int lane = threadIdx.x & 63;
-  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // over B*Sq*Hq
-  const long long total = (long long)p.B * p.Sq * p.Hq;
-  if (row >= total) return;
-  const int hq = row % p.Hq;
-  const long long bs = row / p.Hq;
-  const int s = bs % p.Sq, b = bs / p.Sq;
-  const bf16_t* op = p.o + (long long)b * p.o_sb + (long long)s * p.o_ss + hq * p.dh;
-  const bf16_t* dp = p.dout + (long long)b * p.do_sb + (long long)s * p.do_ss + hq * p.dh;
-  float a = 0.f;
-  for (int d = lane; d < p.dh; d += 64) a += bf2f(op[d]) * bf2f(dp[d]);
-  a = wave_sum(a);
-  if (lane == 0) p.delta[((long long)b * p.Hq + hq) * p.Sq + s] = a;
-}
-
 // ------------------------------------------------------------------------------------------------ dQ
 template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
@@ -215,7 +226,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
   }
   const long long sidx = ((long long)b * p.Hq + hq) * p.Sq + qc;
   const float lse2 = p.lse[sidx] * 1.4426950408889634f;  // natural -> log2 domain
-  const float delta = p.delta[sidx];
+  // delta = rowsum(dO * O): each half-wave owns the d-chunks 16ks+8h.. of its query row; published for the dK/dV pass
+  float delta = 0.f;
+  {
+    const bf16_t* op = p.o + (long long)b * p.o_sb + (long long)qc * p.o_ss + hq * D;
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+      const int d = 16 * ks + 8 * h;
+      if (d < D) {
+        const bf16x8 ov = *reinterpret_cast<const bf16x8*>(op + d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) delta += bf2f((bf16_t)ov[j]) * bf2f((bf16_t)dof[ks][j]);
+      }
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    if (h == 0 && qi < p.Sq) p.delta[sidx] = delta;
+  }
   f32x16 dQ[G::DT];
 #pragma unroll
   for (int t = 0; t < G::DT; ++t) dQ[t] = zero16();
@@ -223,14 +249,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
   const int kend = p.causal ? min(p.Sk, qblk + 128) : p.Sk;
   const bf16_t* kb = p.k + (long long)b * p.k_sb + hkv * D;
   const bf16_t* vb = p.v + (long long)b * p.v_sb + hkv * D;
+  u32x4 rk[TileGeo<D, 256>::NCH], rv[TileGeo<D, 256>::NCH];
+  tile_prefetch<D, 256>(rk, kb, p.k_ss, 0, p.Sk, tid);
+  tile_prefetch<D, 256>(rv, vb, p.v_ss, 0, p.Sk, tid);
   for (int k0 = 0; k0 < kend; k0 += 32) {
     __syncthreads();
-    load_tile<D, G::LD>(sK, kb, p.k_ss, k0, p.Sk, tid, 256);
-    load_tile<D, G::LD>(sV, vb, p.v_ss, k0, p.Sk, tid, 256);
+    tile_store<D, 256, G::LD>(rk, sK, tid);
+    tile_store<D, 256, G::LD>(rv, sV, tid);
     const int kk = k0 + (lane & 31);
     const bool kok = kk < p.Sk && (!p.kmask || p.kmask[(long long)b * p.Sk + kk]);
     const unsigned km = (unsigned)__ballot(kok);
     __syncthreads();
+    if (k0 + 32 < kend) {
+      tile_prefetch<D, 256>(rk, kb, p.k_ss, k0 + 32, p.Sk, tid);
+      tile_prefetch<D, 256>(rv, vb, p.v_ss, k0 + 32, p.Sk, tid);
+    }
     if (p.causal && k0 > q0 + 31) continue;
     f32x16 S = zero16(), dP = zero16();
 #pragma unroll
@@ -301,47 +334,56 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_kernel(AttnP p) {
   for (int t = 0; t < G::DT; ++t) { dK[t] = zero16(); dV[t] = zero16(); }
 
   const int qstart = p.causal ? (kblk / 32) * 32 : 0;
-  for (int hh = 0; hh < grp; ++hh) {
+  const int ntq = (p.Sq - qstart + 31) / 32, nit = grp * ntq;     // flattened (head, q-tile) iteration space
+  u32x4 rq[TileGeo<D, 128>::NCH], rdo[TileGeo<D, 128>::NCH];
+  {
+    const int hq0 = hkv * grp;
+    tile_prefetch<D, 128>(rq, p.q + (long long)b * p.q_sb + hq0 * D, p.q_ss, qstart, p.Sq, tid);
+    tile_prefetch<D, 128>(rdo, p.dout + (long long)b * p.do_sb + hq0 * D, p.do_ss, qstart, p.Sq, tid);
+  }
+  for (int it = 0; it < nit; ++it) {
+    const int hh = it / ntq, q0 = qstart + (it - hh * ntq) * 32;
     const int hq = hkv * grp + hh;
-    const bf16_t* qb = p.q + (long long)b * p.q_sb + hq * D;
-    const bf16_t* db = p.dout + (long long)b * p.do_sb + hq * D;
     const long long sbase = ((long long)b * p.Hq + hq) * p.Sq;
-    for (int q0 = qstart; q0 < p.Sq; q0 += 32) {
-      __syncthreads();
-      load_tile<D, G::LD>(sQ, qb, p.q_ss, q0, p.Sq, tid, 128);
-      load_tile<D, G::LD>(sdO, db, p.do_ss, q0, p.Sq, tid, 128);
-      if (tid < 32) {
-        const int qq = min(q0 + tid, p.Sq - 1);
-        sLse[tid] = p.lse[sbase + qq] * 1.4426950408889634f;
-        sDelta[tid] = p.delta[sbase + qq];
-      }
-      __syncthreads();
-      if (p.causal && q0 + 31 < k0) continue;  // all queries of the tile precede this wave's keys
-      f32x16 S = zero16(), dP = zero16();
+    __syncthreads();
+    tile_store<D, 128, G::LD>(rq, sQ, tid);
+    tile_store<D, 128, G::LD>(rdo, sdO, tid);
+    if (tid < 32) {
+      const int qq = min(q0 + tid, p.Sq - 1);
+      sLse[tid] = p.lse[sbase + qq] * 1.4426950408889634f;
+      sDelta[tid] = p.delta[sbase + qq];
+    }
+    __syncthreads();
+    if (it + 1 < nit) {
+      const int hn = (it + 1) / ntq, qn = qstart + ((it + 1) - hn * ntq) * 32;
+      tile_prefetch<D, 128>(rq, p.q + (long long)b * p.q_sb + (hkv * grp + hn) * D, p.q_ss, qn, p.Sq, tid);
+      tile_prefetch<D, 128>(rdo, p.dout + (long long)b * p.do_sb + (hkv * grp + hn) * D, p.do_ss, qn, p.Sq, tid);
+    }
+    if (p.causal && q0 + 31 < k0) continue;  // all queries of the tile precede this wave's keys
+    f32x16 S = zero16(), dP = zero16();
 #pragma unroll
-      for (int ks = 0; ks < G::KS; ++ks) {
-        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(sQ + (lane & 31) * G::LD + 16 * ks + 8 * h);
-        const bf16x8 df = *reinterpret_cast<const bf16x8*>(sdO + (lane & 31) * G::LD + 16 * ks + 8 * h);
-        S = mfma32(qf, kf[ks], S);     // S[q x key]: A = Q rows, B = K^T
-        dP = mfma32(df, vf[ks], dP);   // dP[q x key] = dO . V^T
-      }
-      f32x16 dS;
+    for (int ks = 0; ks < G::KS; ++ks) {
+      const bf16x8 qf = *reinterpret_cast<const bf16x8*>(sQ + (lane & 31) * G::LD + 16 * ks + 8 * h);
+      const bf16x8 df = *reinterpret_cast<const bf16x8*>(sdO + (lane & 31) * G::LD + 16 * ks + 8 * h);
+      S = mfma32(qf, kf[ks], S);     // S[q x key]: A = Q rows, B = K^T
+      dP = mfma32(df, vf[ks], dP);   // dP[q x key] = dO . V^T
+    }
+    f32x16 dS;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int qr = acc_row(r, h), qq = q0 + qr;
-        const bool ok = kok && qq < p.Sq && (!p.causal || ki <= qq);
-        const float pr = ok ? exp2f(S[r] * p.scale_log2 - sLse[qr]) : 0.f;
-        S[r] = pr;
-        dS[r] = pr * (dP[r] - sDelta[qr]) * p.scale;
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int qr = acc_row(r, h), qq = q0 + qr;
+      const bool ok = kok && qq < p.Sq && (!p.causal || ki <= qq);
+      const float pr = ok ? exp2f(S[r] * p.scale_log2 - sLse[qr]) : 0.f;
+      S[r] = pr;
+      dS[r] = pr * (dP[r] - sDelta[qr]) * p.scale;
+    }
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const bf16x8 pf = pack_acc(S, s), dsf = pack_acc(dS, s);
+    for (int s = 0; s < 2; ++s) {
+      const bf16x8 pf = pack_acc(S, s), dsf = pack_acc(dS, s);
 #pragma unroll
-        for (int t = 0; t < G::DT; ++t) {
-          dV[t] = mfma32(tr_frag(sdO, G::LD, s, 32 * t, lane), pf, dV[t]);  // dV^T[d x key] += dO^T . P
-          dK[t] = mfma32(tr_frag(sQ, G::LD, s, 32 * t, lane), dsf, dK[t]);  // dK^T[d x key] += Q^T . dS
-        }
+      for (int t = 0; t < G::DT; ++t) {
+        dV[t] = mfma32(tr_frag(sdO, G::LD, s, 32 * t, lane), pf, dV[t]);  // dV^T[d x key] += dO^T . P
+        dK[t] = mfma32(tr_frag(sQ, G::LD, s, 32 * t, lane), dsf, dK[t]);  // dK^T[d x key] += Q^T . dS
       }
     }
   }
@@ -382,7 +424,7 @@ int fill(AttnP& p, const vla_attn_desc* d, bool bwd) {
     VLA_REQUIRE(d->do_ss % 8 == 0 && d->do_sb % 8 == 0 && ((uintptr_t)d->dout & 15) == 0, "attn_bwd: dout alignment");
     VLA_REQUIRE(d->dq_ss % 4 == 0 && d->dk_ss % 4 == 0 && d->dv_ss % 4 == 0 && d->dq_sb % 4 == 0 && d->dk_sb % 4 == 0 &&
                 d->dv_sb % 4 == 0 && (((uintptr_t)d->dq | (uintptr_t)d->dk | (uintptr_t)d->dv) & 7) == 0, "attn_bwd: grad alignment");
-    VLA_REQUIRE(d->o_ss % 8 == 0 || true, "");
+    VLA_REQUIRE(d->o_ss % 8 == 0 && d->o_sb % 8 == 0 && ((uintptr_t)d->o & 15) == 0, "attn_bwd: o must allow 16-B row loads");
     p.dout = (const bf16_t*)d->dout; p.dq = (bf16_t*)d->dq; p.dk = (bf16_t*)d->dk; p.dv = (bf16_t*)d->dv; p.delta = d->delta;
     p.do_sb = d->do_sb; p.dq_sb = d->dq_sb; p.dk_sb = d->dk_sb; p.dv_sb = d->dv_sb;
     p.do_ss = d->do_ss; p.dq_ss = d->dq_ss; p.dk_ss = d->dk_ss; p.dv_ss = d->dv_ss;
@@ -414,8 +456,6 @@ extern "C" int vla_attn_bwd(void* stream, const vla_attn_desc* d) {
   if (rc) return rc;
   VLA_REQUIRE(p.dh == 64 || p.dh == 72, "attn_bwd: dh 64 or 72 only");
   hipStream_t st = (hipStream_t)stream;
-  const long long rows = (long long)p.B * p.Sq * p.Hq;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
   dim3 gq((p.Sq + 127) / 128, p.Hq, p.B), gk((p.Sk + 63) / 64, p.Hkv, p.B);
   if (p.dh == 64) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(256), 0, st, p);

@@ -186,13 +186,43 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
     if (c0 + c < cols && r0 + tx < rows) ob[(long long)(c0 + c) * ldo + r0 + tx] = t[tx][c];
 }
 
-__global__ void colsum_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int rows, int cols, int ldx, int rows_per) {
+__global__ void colsum_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int rows, int cols, int ldx, int rows_per,
+                              long long s_x, long long s_out) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= cols) return;
+  x += (long long)blockIdx.z * s_x;
+  out += (long long)blockIdx.z * s_out;
   const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
   float a = 0.f;
   for (int r = r0; r < r1; ++r) a += bf2f(x[(long long)r * ldx + c]);
   atomicAdd(out + c, a);
+}
+
+// vectorised variant (cols % 8 == 0): each lane owns 8 columns (16-B loads), the 4 waves of a block split the rows
+// of the chunk, partial sums meet in LDS, one f32 atomic per column per block.
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int rows, int cols,
+                                                         int ldx, int rows_per, long long s_x, long long s_out) {
+  __shared__ float sm[4][512];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 512 + lane * 8;
+  x += (long long)blockIdx.z * s_x;
+  out += (long long)blockIdx.z * s_out;
+  const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c < cols)
+    for (int r = r0 + w; r < r1; r += 4) {
+      float f[8];
+      unpack8(*reinterpret_cast<const uint4*>(x + (long long)r * ldx + c), f);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a[k] += f[k];
+    }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sm[w][lane * 8 + k] = a[k];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 512; i += 256) {
+    const int cc = blockIdx.x * 512 + i;
+    if (cc < cols) atomicAdd(out + cc, sm[0][i] + sm[1][i] + sm[2][i] + sm[3][i]);
+  }
 }
 
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long long n) {
@@ -380,11 +410,19 @@ extern "C" int vla_transpose_bf16(void* stream, const void* in, void* out, int r
   return VLA_OK;
 }
 
-extern "C" int vla_colsum_bf16(void* stream, const void* x, float* out, int rows, int cols, int ldx) {
-  VLA_REQUIRE(x && out && rows > 0 && cols > 0 && ldx >= cols, "colsum: bad args");
+extern "C" int vla_colsum_bf16(void* stream, const void* x, float* out, int rows, int cols, int ldx, int batch, long long s_x,
+                               long long s_out) {
+  VLA_REQUIRE(x && out && rows > 0 && cols > 0 && ldx >= cols && batch > 0, "colsum: bad args");
+  if (cols % 8 == 0 && ldx % 8 == 0 && s_x % 8 == 0 && ((uintptr_t)x & 15) == 0) {
+    const int rows_per = 256;
+    dim3 grid((cols + 511) / 512, (rows + rows_per - 1) / rows_per, batch);
+    hipLaunchKernelGGL(colsum_vec_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, rows, cols, ldx, rows_per, s_x, s_out);
+    VLA_CHECK_LAUNCH("colsum");
+    return VLA_OK;
+  }
   const int rows_per = 128;
-  dim3 grid((cols + 255) / 256, (rows + rows_per - 1) / rows_per);
-  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, rows, cols, ldx, rows_per);
+  dim3 grid((cols + 255) / 256, (rows + rows_per - 1) / rows_per, batch);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, rows, cols, ldx, rows_per, s_x, s_out);
   VLA_CHECK_LAUNCH("colsum");
   return VLA_OK;
 }

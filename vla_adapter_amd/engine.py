@@ -605,10 +605,8 @@ class Head:
         ops.gemm_nt(self.dFFT, self.LNoT, out=G("w_ffn"))
         ops.gemm_nt(self.dKV_adpT, self.h_adpT, out=G("w_adp"))
         ops.gemm_nt(self.dKV_taskT, self.h_taskT, out=G("w_task"))
-        for i in range(nb):
-            ops.colsum_(self.dQKVx[i], self.b_f32["b_x"][i]); ops.colsum_(self.dO2[i], self.b_f32["b_o"][i])
-            ops.colsum_(self.dFF[i], self.b_f32["b_ffn"][i])
-            ops.colsum_(self.dKV_adp[i], self.b_f32["b_adp"][i]); ops.colsum_(self.dKV_task[i], self.b_f32["b_task"][i])
+        ops.colsum_(self.dQKVx, self.b_f32["b_x"]); ops.colsum_(self.dO2, self.b_f32["b_o"]); ops.colsum_(self.dFF, self.b_f32["b_ffn"])
+        ops.colsum_(self.dKV_adp, self.b_f32["b_adp"]); ops.colsum_(self.dKV_task, self.b_f32["b_task"])
         for k, t in self.b_f32.items():
             ops.cast_f32_bf16(t, out=G(k))
         ops.cast_f32_bf16(self.ln_dw, out=G("ln_w")); ops.cast_f32_bf16(self.ln_db, out=G("ln_b"))
