@@ -33,6 +33,7 @@ __device__ __forceinline__ f32x16 zero16() {
   for (int i = 0; i < 16; ++i) z[i] = 0.f;
   return z;
 }
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32 (args <= 0 here)
 // accumulator register -> row of the 32x32 tile (column = lane & 31)
 __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
@@ -129,17 +130,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
   u32x4 rk[TileGeo<D, 256>::NCH], rv[TileGeo<D, 256>::NCH];
   tile_prefetch<D, 256>(rk, kb, p.k_ss, 0, p.Sk, tid);
   tile_prefetch<D, 256>(rv, vb, p.v_ss, 0, p.Sk, tid);
+  bool kok_next = (lane & 31) < p.Sk && (!p.kmask || p.kmask[(long long)b * p.Sk + (lane & 31)]);
   for (int k0 = 0; k0 < kend; k0 += 32) {
     __syncthreads();
     tile_store<D, 256, G::LD>(rk, sK, tid);
     tile_store<D, 256, G::LD>(rv, sV, tid);
-    const int kk = k0 + (lane & 31);
-    const bool kok = kk < p.Sk && (!p.kmask || p.kmask[(long long)b * p.Sk + kk]);
-    const unsigned km = (unsigned)__ballot(kok);
+    const unsigned km = (unsigned)__ballot(kok_next);
     __syncthreads();
     if (k0 + 32 < kend) {
       tile_prefetch<D, 256>(rk, kb, p.k_ss, k0 + 32, p.Sk, tid);
       tile_prefetch<D, 256>(rv, vb, p.v_ss, k0 + 32, p.Sk, tid);
+      const int kk = k0 + 32 + (lane & 31);
+      kok_next = kk < p.Sk && (!p.kmask || p.kmask[(long long)b * p.Sk + kk]);
     }
     if (p.causal && k0 > q0 + 31) continue;  // wave-uniform: whole tile is in the future (barriers already passed)
 
@@ -150,21 +152,29 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
       S = mfma32(kf, qf[ks], S);
     }
     float mt = -INFINITY;
+    if (km == 0xffffffffu && (!p.causal || k0 + 31 <= q0)) {   // wave-uniform: whole tile visible to every query
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kr = acc_row(r, h);
-      const bool ok = ((km >> kr) & 1u) && (!p.causal || k0 + kr <= qi);
-      S[r] = ok ? S[r] * p.scale_log2 : -INFINITY;
-      mt = fmaxf(mt, S[r]);
+      for (int r = 0; r < 16; ++r) {
+        S[r] *= p.scale_log2;
+        mt = fmaxf(mt, S[r]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kr = acc_row(r, h);
+        const bool ok = ((km >> kr) & 1u) && (!p.causal || k0 + kr <= qi);
+        S[r] = ok ? S[r] * p.scale_log2 : -INFINITY;
+        mt = fmaxf(mt, S[r]);
+      }
     }
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     const float m_new = fmaxf(m_run, mt);
     const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = exp2f(m_run - m_safe);
+    const float alpha = fexp2(m_run - m_safe);
     float rs = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      S[r] = exp2f(S[r] - m_safe);
+      S[r] = fexp2(S[r] - m_safe);
       rs += S[r];
     }
     rs += __shfl_xor(rs, 32, 64);
@@ -252,17 +262,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
   u32x4 rk[TileGeo<D, 256>::NCH], rv[TileGeo<D, 256>::NCH];
   tile_prefetch<D, 256>(rk, kb, p.k_ss, 0, p.Sk, tid);
   tile_prefetch<D, 256>(rv, vb, p.v_ss, 0, p.Sk, tid);
+  bool kok_next = (lane & 31) < p.Sk && (!p.kmask || p.kmask[(long long)b * p.Sk + (lane & 31)]);
   for (int k0 = 0; k0 < kend; k0 += 32) {
     __syncthreads();
     tile_store<D, 256, G::LD>(rk, sK, tid);
     tile_store<D, 256, G::LD>(rv, sV, tid);
-    const int kk = k0 + (lane & 31);
-    const bool kok = kk < p.Sk && (!p.kmask || p.kmask[(long long)b * p.Sk + kk]);
-    const unsigned km = (unsigned)__ballot(kok);
+    const unsigned km = (unsigned)__ballot(kok_next);
     __syncthreads();
     if (k0 + 32 < kend) {
       tile_prefetch<D, 256>(rk, kb, p.k_ss, k0 + 32, p.Sk, tid);
       tile_prefetch<D, 256>(rv, vb, p.v_ss, k0 + 32, p.Sk, tid);
+      const int kk = k0 + 32 + (lane & 31);
+      kok_next = kk < p.Sk && (!p.kmask || p.kmask[(long long)b * p.Sk + kk]);
     }
     if (p.causal && k0 > q0 + 31) continue;
     f32x16 S = zero16(), dP = zero16();
@@ -277,7 +288,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
     for (int r = 0; r < 16; ++r) {
       const int kr = acc_row(r, h);
       const bool ok = ((km >> kr) & 1u) && (!p.causal || k0 + kr <= qi);
-      const float pr = ok ? exp2f(S[r] * p.scale_log2 - lse2) : 0.f;
+      const float pr = ok ? fexp2(S[r] * p.scale_log2 - lse2) : 0.f;
       S[r] = pr * (dP[r] - delta) * p.scale;  // dS^T
     }
 #pragma unroll
@@ -303,18 +314,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-// block = 2 waves = 64 keys of one (batch, kv head); sweeps the group's query heads x 32-query tiles.
+// One workgroup = the `grp` query heads of one kv head (GQA) x KT 32-key tiles: wave w -> (head w % grp, key tile
+// w / grp).  Every wave sweeps the 32-query tiles of ITS head with wave-private LDS tiles (no workgroup barrier in
+// the loop: 7-14 independent waves per CU hide each other's latency); the grp partial dK^T/dV^T accumulators of a key
+// tile are then summed through LDS (ds_add_f32) and written once - no global atomics, deterministic up to fp32 order.
 template <int D>
-__global__ __launch_bounds__(128) void attn_bwd_dkv_kernel(AttnP p) {
+__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int KT) {
   using G = Geo<D>;
-  __shared__ __attribute__((aligned(16))) bf16_t sQ[32 * G::LD];
-  __shared__ __attribute__((aligned(16))) bf16_t sdO[32 * G::LD];
-  __shared__ float sLse[32], sDelta[32];
+  constexpr int TILE = 32 * G::LD;                       // elements per LDS tile
+  constexpr int WAVE_BYTES = 2 * TILE * 2 + 256;         // Q tile, dO tile, lse[32], delta[32]
+  constexpr int ACC_LD = G::DV + 1;                      // padded: lanes (= keys) hit distinct banks
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
-  const int hkv = blockIdx.y, b = blockIdx.z, grp = p.Hq / p.Hkv;
-  const int kblk = blockIdx.x * 64, k0 = kblk + w * 32;
+  const int hh = w % grp, kt = w / grp;
+  const int hkv = blockIdx.y, b = blockIdx.z, hq = hkv * grp + hh;
+  const int k0 = (blockIdx.x * KT + kt) * 32;
   const int ki = k0 + (lane & 31), kc = min(ki, p.Sk - 1);
-  for (int i = tid; i < 32 * G::LD; i += 128) { sQ[i] = 0; sdO[i] = 0; }
+  bf16_t* sQ = reinterpret_cast<bf16_t*>(smem + w * WAVE_BYTES);
+  bf16_t* sdO = sQ + TILE;
+  float* sLse = reinterpret_cast<float*>(sdO + TILE);
+  float* sDelta = sLse + 32;
+  for (int i = lane; i < 2 * TILE; i += 64) sQ[i] = 0;   // pad columns stay zero (wave-private region)
 
   bf16x8 kf[G::KS], vf[G::KS];
   {
@@ -333,61 +353,97 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_kernel(AttnP p) {
 #pragma unroll
   for (int t = 0; t < G::DT; ++t) { dK[t] = zero16(); dV[t] = zero16(); }
 
-  const int qstart = p.causal ? (kblk / 32) * 32 : 0;
-  const int ntq = (p.Sq - qstart + 31) / 32, nit = grp * ntq;     // flattened (head, q-tile) iteration space
-  u32x4 rq[TileGeo<D, 128>::NCH], rdo[TileGeo<D, 128>::NCH];
-  {
-    const int hq0 = hkv * grp;
-    tile_prefetch<D, 128>(rq, p.q + (long long)b * p.q_sb + hq0 * D, p.q_ss, qstart, p.Sq, tid);
-    tile_prefetch<D, 128>(rdo, p.dout + (long long)b * p.do_sb + hq0 * D, p.do_ss, qstart, p.Sq, tid);
-  }
-  for (int it = 0; it < nit; ++it) {
-    const int hh = it / ntq, q0 = qstart + (it - hh * ntq) * 32;
-    const int hq = hkv * grp + hh;
+  if (k0 < p.Sk) {
+    const bf16_t* qb = p.q + (long long)b * p.q_sb + hq * D;
+    const bf16_t* db = p.dout + (long long)b * p.do_sb + hq * D;
     const long long sbase = ((long long)b * p.Hq + hq) * p.Sq;
-    __syncthreads();
-    tile_store<D, 128, G::LD>(rq, sQ, tid);
-    tile_store<D, 128, G::LD>(rdo, sdO, tid);
-    if (tid < 32) {
-      const int qq = min(q0 + tid, p.Sq - 1);
-      sLse[tid] = p.lse[sbase + qq] * 1.4426950408889634f;
-      sDelta[tid] = p.delta[sbase + qq];
+    const int qstart = p.causal ? k0 : 0;                 // k0 is a multiple of 32
+    u32x4 rq[TileGeo<D, 64>::NCH], rdo[TileGeo<D, 64>::NCH];
+    tile_prefetch<D, 64>(rq, qb, p.q_ss, qstart, p.Sq, lane);
+    tile_prefetch<D, 64>(rdo, db, p.do_ss, qstart, p.Sq, lane);
+    float lse_n = 0.f, delta_n = 0.f;
+    if (lane < 32) {
+      const int qq = min(qstart + lane, p.Sq - 1);
+      lse_n = p.lse[sbase + qq];
+      delta_n = p.delta[sbase + qq];
     }
-    __syncthreads();
-    if (it + 1 < nit) {
-      const int hn = (it + 1) / ntq, qn = qstart + ((it + 1) - hn * ntq) * 32;
-      tile_prefetch<D, 128>(rq, p.q + (long long)b * p.q_sb + (hkv * grp + hn) * D, p.q_ss, qn, p.Sq, tid);
-      tile_prefetch<D, 128>(rdo, p.dout + (long long)b * p.do_sb + (hkv * grp + hn) * D, p.do_ss, qn, p.Sq, tid);
-    }
-    if (p.causal && q0 + 31 < k0) continue;  // all queries of the tile precede this wave's keys
-    f32x16 S = zero16(), dP = zero16();
-#pragma unroll
-    for (int ks = 0; ks < G::KS; ++ks) {
-      const bf16x8 qf = *reinterpret_cast<const bf16x8*>(sQ + (lane & 31) * G::LD + 16 * ks + 8 * h);
-      const bf16x8 df = *reinterpret_cast<const bf16x8*>(sdO + (lane & 31) * G::LD + 16 * ks + 8 * h);
-      S = mfma32(qf, kf[ks], S);     // S[q x key]: A = Q rows, B = K^T
-      dP = mfma32(df, vf[ks], dP);   // dP[q x key] = dO . V^T
-    }
-    f32x16 dS;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int qr = acc_row(r, h), qq = q0 + qr;
-      const bool ok = kok && qq < p.Sq && (!p.causal || ki <= qq);
-      const float pr = ok ? exp2f(S[r] * p.scale_log2 - sLse[qr]) : 0.f;
-      S[r] = pr;
-      dS[r] = pr * (dP[r] - sDelta[qr]) * p.scale;
-    }
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const bf16x8 pf = pack_acc(S, s), dsf = pack_acc(dS, s);
-#pragma unroll
-      for (int t = 0; t < G::DT; ++t) {
-        dV[t] = mfma32(tr_frag(sdO, G::LD, s, 32 * t, lane), pf, dV[t]);  // dV^T[d x key] += dO^T . P
-        dK[t] = mfma32(tr_frag(sQ, G::LD, s, 32 * t, lane), dsf, dK[t]);  // dK^T[d x key] += Q^T . dS
+    for (int q0 = qstart; q0 < p.Sq; q0 += 32) {
+      tile_store<D, 64, G::LD>(rq, sQ, lane);
+      tile_store<D, 64, G::LD>(rdo, sdO, lane);
+      if (lane < 32) {
+        sLse[lane] = lse_n * 1.4426950408889634f;
+        sDelta[lane] = delta_n;
       }
+      if (q0 + 32 < p.Sq) {
+        tile_prefetch<D, 64>(rq, qb, p.q_ss, q0 + 32, p.Sq, lane);
+        tile_prefetch<D, 64>(rdo, db, p.do_ss, q0 + 32, p.Sq, lane);
+        if (lane < 32) {
+          const int qq = min(q0 + 32 + lane, p.Sq - 1);
+          lse_n = p.lse[sbase + qq];
+          delta_n = p.delta[sbase + qq];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // LDS tile written by this wave before it reads it
+      __builtin_amdgcn_wave_barrier();
+      f32x16 S = zero16(), dP = zero16();
+#pragma unroll
+      for (int ks = 0; ks < G::KS; ++ks) {
+        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(sQ + (lane & 31) * G::LD + 16 * ks + 8 * h);
+        const bf16x8 df = *reinterpret_cast<const bf16x8*>(sdO + (lane & 31) * G::LD + 16 * ks + 8 * h);
+        S = mfma32(qf, kf[ks], S);     // S[q x key]: A = Q rows, B = K^T
+        dP = mfma32(df, vf[ks], dP);   // dP[q x key] = dO . V^T
+      }
+      f32x16 dS;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qr = acc_row(r, h), qq = q0 + qr;
+        const bool ok = kok && qq < p.Sq && (!p.causal || ki <= qq);
+        const float pr = ok ? fexp2(S[r] * p.scale_log2 - sLse[qr]) : 0.f;
+        S[r] = pr;
+        dS[r] = pr * (dP[r] - sDelta[qr]) * p.scale;
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 pf = pack_acc(S, s), dsf = pack_acc(dS, s);
+#pragma unroll
+        for (int t = 0; t < G::DT; ++t) {
+          dV[t] = mfma32(tr_frag(sdO, G::LD, s, 32 * t, lane), pf, dV[t]);  // dV^T[d x key] += dO^T . P
+          dK[t] = mfma32(tr_frag(sQ, G::LD, s, 32 * t, lane), dsf, dK[t]);  // dK^T[d x key] += Q^T . dS
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // reads of this tile done before the next store
+      __builtin_amdgcn_wave_barrier();
     }
   }
-  if (ki < p.Sk) {
+  // ---- sum the grp heads of each key tile through LDS, then one wave per key tile writes bf16
+  float* acc = reinterpret_cast<float*>(smem) + kt * (2 * 32 * ACC_LD);
+  if (grp > 1) {
+    __syncthreads();                                      // every wave is done with its tiles: reuse the LDS
+    for (int i = tid; i < KT * 2 * 32 * ACC_LD; i += blockDim.x) reinterpret_cast<float*>(smem)[i] = 0.f;
+    __syncthreads();
+    if (k0 < p.Sk) {
+#pragma unroll
+      for (int t = 0; t < G::DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int d = 32 * t + acc_row(r, h);
+          atomicAdd(acc + (lane & 31) * ACC_LD + d, dK[t][r]);
+          atomicAdd(acc + 32 * ACC_LD + (lane & 31) * ACC_LD + d, dV[t][r]);
+        }
+    }
+    __syncthreads();
+    if (hh == 0) {
+#pragma unroll
+      for (int t = 0; t < G::DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int d = 32 * t + acc_row(r, h);
+          dK[t][r] = acc[(lane & 31) * ACC_LD + d];
+          dV[t][r] = acc[32 * ACC_LD + (lane & 31) * ACC_LD + d];
+        }
+    }
+  }
+  if (hh == 0 && ki < p.Sk) {
     bf16_t* okp = p.dk + (long long)b * p.dk_sb + (long long)ki * p.dk_ss + hkv * D;
     bf16_t* ovp = p.dv + (long long)b * p.dv_sb + (long long)ki * p.dv_ss + hkv * D;
 #pragma unroll
@@ -456,13 +512,25 @@ extern "C" int vla_attn_bwd(void* stream, const vla_attn_desc* d) {
   if (rc) return rc;
   VLA_REQUIRE(p.dh == 64 || p.dh == 72, "attn_bwd: dh 64 or 72 only");
   hipStream_t st = (hipStream_t)stream;
-  dim3 gq((p.Sq + 127) / 128, p.Hq, p.B), gk((p.Sk + 63) / 64, p.Hkv, p.B);
+  const int grp = p.Hq / p.Hkv;
+  VLA_REQUIRE(grp <= 8, "attn_bwd: at most 8 query heads per kv head");
+  const int KT = grp >= 4 ? 1 : 4 / grp;                   // waves per workgroup = grp * KT (4..8)
+  dim3 gq((p.Sq + 127) / 128, p.Hq, p.B), gk((p.Sk + 32 * KT - 1) / (32 * KT), p.Hkv, p.B);
+  const int ld = ((p.dh + 31) / 32 * 32 + 8);
+  const size_t lds = (size_t)grp * KT * (2 * 32 * ld * 2 + 256);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<72>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  VLA_REQUIRE(lds <= 160 * 1024, "attn_bwd: LDS budget exceeded");
   if (p.dh == 64) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(256), 0, st, p);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gk, dim3(128), 0, st, p);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gk, dim3(64 * grp * KT), lds, st, p, grp, KT);
   } else {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<72>, gq, dim3(256), 0, st, p);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<72>, gk, dim3(128), 0, st, p);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<72>, gk, dim3(64 * grp * KT), lds, st, p, grp, KT);
   }
   VLA_CHECK_LAUNCH("attn_bwd");
   return VLA_OK;
