@@ -88,6 +88,30 @@ def test_gemm_plain_bias(ops, M, N, K):
     check(out, O.linear(a.float(), b.float(), bias.float(), emu=True), name=f"gemm {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 192), (1000, 896, 896), (512, 384, 64), (2080, 1792, 896), (64, 7, 128)])
+def test_gemm_every_tile_config(ops, tile, M, N, K, monkeypatch):
+    """The three kernel instantiations (256x128x3-stage, 128x128x2, 128x64x3) must agree with the oracle on ragged
+    edges, K=64 (shorter than the pipeline depth) and long K; VLA_GEMM_TILE forces the choice."""
+    monkeypatch.setenv("VLA_GEMM_TILE", str(tile))
+    a, b, bias, r = gen(M, K, seed=1), gen(N, K, seed=2, scale=0.05), gen(N, seed=3), gen(M, N, seed=4)
+    out = ops.gemm_nt(a.to(DEV), b.to(DEV), bias=bias.to(DEV), residual=r.to(DEV), act=2)
+    y = torch.relu(O.linear(a.float(), b.float(), bias.float(), emu=True))
+    check(out, O.rnd(y + r.float(), True), name=f"gemm tile{tile} {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("tile", [1, 3])
+def test_gemm_swiglu_tile_configs(ops, tile, monkeypatch):
+    monkeypatch.setenv("VLA_GEMM_TILE", str(tile))
+    M, I, K = 330, 320, 256
+    x, wg, wu = gen(M, K, seed=12), gen(I, K, seed=13, scale=0.1), gen(I, K, seed=14, scale=0.1)
+    w = torch.stack([wg.view(I // 16, 16, K), wu.view(I // 16, 16, K)], dim=1).reshape(2 * I, K)
+    pre, h = ops.gemm_nt(x.to(DEV), w.to(DEV), act=ops.ACT_SWIGLU)
+    g, u = O.linear(x.float(), wg.float(), None, True), O.linear(x.float(), wu.float(), None, True)
+    check(h, O.rnd(O.rnd(g * torch.sigmoid(g), True) * u, True), name="swiglu h")
+    check(pre, torch.stack([g.view(M, I // 16, 16), u.view(M, I // 16, 16)], dim=2).reshape(M, 2 * I), name="swiglu pre")
+
+
 @pytest.mark.parametrize("act,oact", [(1, "gelu"), (2, "relu"), (3, "gelu_tanh")])
 def test_gemm_act_residual(ops, act, oact):
     M, N, K = 520, 256, 256

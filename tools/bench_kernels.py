@@ -32,7 +32,8 @@ def main():
     shapes = [("llm qkv", B * 352, 1152, 896, 0), ("llm o", B * 352, 896, 896, 0), ("llm gate_up(swiglu)", B * 352, 9728, 896, 4),
               ("llm down", B * 352, 896, 4864, 0), ("vit qkv", B * 256, 3456, 1152, 0), ("vit proj", B * 256, 1152, 1152, 0),
               ("vit fc1(gelu)", B * 256, 4352, 1152, 1), ("vit fc2", B * 256, 1152, 4352, 0), ("head task kv", B * 256, 1792, 896, 0),
-              ("head x-path", B * 8, 2688, 896, 0), ("square 4096", 4096, 4096, 4096, 0), ("square 8192", 8192, 8192, 8192, 0)]
+              ("head x-path", B * 8, 2688, 896, 0), ("llm dgu->dn (K=9728)", B * 352, 896, 9728, 0), ("llm d->dh", B * 352, 4864, 896, 0),
+              ("square 4096", 4096, 4096, 4096, 0), ("square 8192", 8192, 8192, 8192, 0)]
     for name, M, N, K, act in shapes:
         a = torch.randn(M, K, device=DEV).to(BF)
         w = (torch.randn(N, K, device=DEV) * 0.02).to(BF)
@@ -44,10 +45,15 @@ def main():
         else:
             out = torch.empty(M, N, device=DEV, dtype=BF)
             fn = lambda: ops.gemm_nt(a, w, bias=bias, act=act, out=out)
-        t = timeit(fn)
-        tf = 2.0 * M * N * K / t / 1e12
-        res.append(dict(kernel="gemm", name=name, M=M, N=N, K=K, us=t * 1e6, tflops=tf))
-        print(f"gemm {name:24s} M={M:6d} N={N:5d} K={K:5d}  {t*1e6:9.1f} us  {tf:7.1f} TF/s", flush=True)
+        line = f"gemm {name:24s} M={M:6d} N={N:5d} K={K:5d} "
+        for tile, tn in ((0, "auto"), (1, "256x128"), (2, "128x128"), (3, "128x64")):
+            os.environ["VLA_GEMM_TILE"] = str(tile)
+            t = timeit(fn)
+            tf = 2.0 * M * N * K / t / 1e12
+            res.append(dict(kernel="gemm", tile=tn, name=name, M=M, N=N, K=K, us=t * 1e6, tflops=tf))
+            line += f" | {tn} {t*1e6:7.1f}us {tf:6.1f}TF"
+        os.environ["VLA_GEMM_TILE"] = "0"
+        print(line, flush=True)
     # attention
     for name, Bn, S, Hq, Hkv, dh, causal in [("llm attn", B, 352, 14, 2, 64, True), ("vit attn", B, 256, 16, 16, 72, False)]:
         W = (Hq + 2 * Hkv) * dh

@@ -5,13 +5,21 @@
 // PrismaticProjector (modeling_prismatic.py:261-273), Qwen2 q/k/v/o/gate/up/down, the action head's Linears
 // (action_heads.py:337-410), and - with pre-transposed operands - their dX / dW products.
 //
-// Structure (cdna_hip_programming.md section 5): 128x128 block tile, BK=64, 4 waves (2x2), each wave a 64x64
-// sub-tile = 4x4 MFMA 16x16 tiles; A/B tiles stream HBM->LDS with global_load_lds_dwordx4 (1 KiB per
-// wave-instruction) into a double buffer; LDS image is linear with the 16-B-chunk XOR swizzle applied on the
-// SOURCE address and on the fragment read (rule 21); one barrier per K-tile, next tile's loads in flight under
-// the current tile's MFMAs.  Operands are swapped at the MFMA (A-operand := B rows) so each lane owns 4
-// consecutive n of one row m: the epilogue stages the wave's tile through LDS and stores whole 128-B row
-// segments with 16-B lanes.
+// Structure (cdna_hip_programming.md section 5):
+//   * block tile BM x BN x 64 with (BM/64) x 2 waves, each wave a 64 x (BN/2) sub-tile of 16x16 MFMA tiles;
+//   * A/B tiles stream HBM->LDS with global_load_lds_dwordx4 (1 KiB per wave-instruction) into a ring of STAGES
+//     buffers; the LDS image is linear with the 16-B-chunk XOR swizzle applied on the SOURCE address and on the
+//     fragment read (rule 21);
+//   * ONE raw s_barrier per K-tile; with STAGES=3 the loads run TWO K-tiles ahead and the loop waits with a COUNTED
+//     s_waitcnt vmcnt(pieces-per-stage) - never vmcnt(0) inside the loop ("Pipelining across barriers"): a tile's
+//     pieces are retired by every wave's own counted wait, the barrier then publishes them to the other waves and
+//     proves every wave has finished reading the buffer that the next stage overwrites;
+//   * operands are swapped at the MFMA (A-operand := B rows) so each lane owns 4 consecutive n of one row m: the
+//     epilogue stages the wave's tile through LDS and stores whole row segments with 16-B lanes;
+//   * XCD-aware bijective tile order (T1).
+// Three instantiations: 256x128 (8 waves, 3 stages, 144 KiB LDS, 1 block/CU) for the large GEMMs, 128x128 (4 waves,
+// 2 stages, 2 blocks/CU) and 128x64 (4 waves, 3 stages, 72 KiB, 2 blocks/CU) - the host picks per problem by a
+// wave-quantisation model (a 616-tile problem on 512 slots wastes 40 % of the machine with 128x128 tiles).
 //
 // Epilogue rounding points follow the reference under bf16 autocast: bf16(acc+bias) -> act -> bf16 -> (+residual) -> bf16.
 #include "common.h"
@@ -19,11 +27,8 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;        // 16 KiB per operand tile
-constexpr int BUF_BYTES = 2 * TILE_BYTES;      // A + B
-constexpr int LDS_BYTES = 2 * BUF_BYTES;       // double buffer = 64 KiB
-constexpr int EPI_STRIDE = 144;                // bytes per staged row (64 bf16 + 16 B pad, keeps 16-B alignment)
+constexpr int BK = 64;
+constexpr int EPI_PAD = 16;  // bytes of padding per staged epilogue row (keeps 16-B alignment, spreads banks)
 
 struct GemmP {
   const bf16_t* A; const bf16_t* B; bf16_t* C;
@@ -44,7 +49,25 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
+template <int BM, int BN, int STAGES>
+struct Cfg {
+  static constexpr int NW = (BM / 64) * 2;               // waves: (BM/64) along M x 2 along N
+  static constexpr int NTHREADS = NW * 64;
+  static constexpr int WTN = BN / 2;                     // wave tile: 64 x WTN
+  static constexpr int NT = WTN / 16;                    // 16-wide n tiles per wave (4 or 2)
+  static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+  static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int PIECES = STAGE_BYTES / 1024;      // 1 KiB LDS-DMA pieces per stage
+  static constexpr int PPW = PIECES / NW;                // pieces per wave per stage
+  static constexpr int EPI_STRIDE = WTN * 2 + EPI_PAD;   // bytes per staged output row
+  static constexpr int EPI_BYTES = NW * 64 * EPI_STRIDE;
+  static constexpr int LDS_BYTES = STAGES * STAGE_BYTES > EPI_BYTES ? STAGES * STAGE_BYTES : EPI_BYTES;
+  static_assert(PIECES % NW == 0, "pieces must divide evenly over the waves");
+};
+
+template <int BM, int BN, int STAGES>
+__global__ __launch_bounds__((BM / 64) * 128) void gemm_nt_kernel(GemmP p) {
+  using C = Cfg<BM, BN, STAGES>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -61,30 +84,30 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
   const bf16_t* Ab = p.A + (long long)z * p.sA;
   const bf16_t* Bb = p.B + (long long)z * p.sB;
 
-  // ---- staging addresses: piece pc = wid*4+i covers LDS rows 8pc..8pc+7; lane -> row 8pc+(lane>>3),
-  //      LDS chunk lane&7 holds global chunk (lane&7)^(row&7)
+  // ---- staging: piece pc (1 KiB = 8 LDS rows) of a stage; pieces [0, BM/8) are A rows, the rest B rows.
+  //      lane -> row 8pc + (lane>>3); LDS chunk lane&7 holds global chunk (lane&7) ^ (row&7)
   const int kc = ((lane & 7) ^ ((lane >> 3) & 7)) * 8;
-  const bf16_t* pa[4];
-  const bf16_t* pb[4];
+  const bf16_t* pp[C::PPW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wid * 4 + i) * 8 + (lane >> 3);
-    const int ra = min(m0 + row, p.M - 1), rb = min(n0 + row, p.N - 1);
-    pa[i] = Ab + (p.gA > 0 ? (long long)(ra / p.gA) * p.sgA + (long long)(ra % p.gA) * p.lda : (long long)ra * p.lda) + kc;
-    pb[i] = Bb + (long long)rb * p.ldb + kc;
+  for (int i = 0; i < C::PPW; ++i) {
+    const int pc = wid * C::PPW + i;                      // wave-uniform
+    if (pc < BM / 8) {
+      const int ra = min(m0 + pc * 8 + (lane >> 3), p.M - 1);
+      pp[i] = Ab + (p.gA > 0 ? (long long)(ra / p.gA) * p.sgA + (long long)(ra % p.gA) * p.lda : (long long)ra * p.lda) + kc;
+    } else {
+      const int rb = min(n0 + (pc - BM / 8) * 8 + (lane >> 3), p.N - 1);
+      pp[i] = Bb + (long long)rb * p.ldb + kc;
+    }
   }
   auto stage = [&](int buf, int k0) {
-    char* base = smem + buf * BUF_BYTES + wid * 4096;
+    char* base = smem + buf * C::STAGE_BYTES + wid * C::PPW * 1024;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      glds16(pa[i] + k0, base + i * 1024);
-      glds16(pb[i] + k0, base + TILE_BYTES + i * 1024);
-    }
+    for (int i = 0; i < C::PPW; ++i) glds16(pp[i] + k0, base + i * 1024);
   };
 
-  f32x4 acc[4][4];  // [ni][mi]
+  f32x4 acc[C::NT][4];  // [ni][mi]
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < C::NT; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -95,40 +118,52 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
   for (int s = 0; s < 2; ++s) foff[s] = frow * 128 + (((4 * s + (lane >> 4)) ^ (lane & 7)) << 4);
 
   const int nt = p.K / BK;
-  stage(0, 0);
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nt) stage(s, s * BK);
+  int buf = 0;
   for (int t = 0; t < nt; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // tile t landed for every wave; every wave is done reading buffer (t+1)&1
-    if (t + 1 < nt) stage((t + 1) & 1, (t + 1) * BK);
-    const char* sa = smem + (t & 1) * BUF_BYTES + wr * 64 * 128;
-    const char* sb = smem + (t & 1) * BUF_BYTES + TILE_BYTES + wc * 64 * 128;
+    // retire this wave's pieces of tile t; up to STAGES-2 younger tiles stay in flight
+    if (STAGES == 3 && t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // tile t visible to every wave; every wave is done reading tile t-1's buffer
+    asm volatile("" ::: "memory");
+    if (t + STAGES - 1 < nt) {
+      int nb = buf + STAGES - 1;
+      if (nb >= STAGES) nb -= STAGES;
+      stage(nb, (t + STAGES - 1) * BK);
+    }
+    const char* sa = smem + buf * C::STAGE_BYTES + wr * 64 * 128;
+    const char* sb = smem + buf * C::STAGE_BYTES + C::A_BYTES + wc * C::WTN * 128;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 fm[4], fn[4];
+      bf16x8 fm[4], fn[C::NT];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fm[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + foff[s]);
-        fn[i] = *reinterpret_cast<const bf16x8*>(sb + i * 16 * 128 + foff[s]);
-      }
+      for (int i = 0; i < 4; ++i) fm[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + foff[s]);
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
+      for (int i = 0; i < C::NT; ++i) fn[i] = *reinterpret_cast<const bf16x8*>(sb + i * 16 * 128 + foff[s]);
+#pragma unroll
+      for (int ni = 0; ni < C::NT; ++ni)
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[ni], fm[mi], acc[ni][mi], 0, 0, 0);
     }
+    if (++buf == STAGES) buf = 0;
   }
-  __syncthreads();  // all waves done with the operand tiles before the staging regions are overwritten
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // all waves done with the operand tiles before the staging regions are overwritten
+  asm volatile("" ::: "memory");
 
   // ---------------- epilogue ----------------
   // lane owns, for tile (ni, mi): m = 16mi + (lane&15), n = 16ni + 4(lane>>4) + {0..3}
-  const int wm0 = m0 + wr * 64, wn0 = n0 + wc * 64;
+  const int wm0 = m0 + wr * 64, wn0 = n0 + wc * C::WTN;
   const int lq = lane >> 4, lr = lane & 15;
   const bf16_t* bias = p.bias ? p.bias + (long long)z * p.sBias : nullptr;
-  char* reg = smem + wid * (64 * EPI_STRIDE);
+  char* reg = smem + wid * (64 * C::EPI_STRIDE);
 
-  float bv[4][4];
+  float bv[C::NT][4];
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni)
+  for (int ni = 0; ni < C::NT; ++ni)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = wn0 + ni * 16 + lq * 4 + j;
@@ -136,10 +171,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
     }
 
   if (p.act == VLA_ACT_SWIGLU) {
-    // columns interleaved in 16s: tiles ni=0,2 are gate, ni=1,3 the matching up columns
+    // columns interleaved in 16s: even tiles are gate, odd tiles the matching up columns
     bf16_t* C2 = p.C2 + (long long)z * p.sC2;
 #pragma unroll
-    for (int pr = 0; pr < 2; ++pr)
+    for (int pr = 0; pr < C::NT / 2; ++pr)
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
         const int m = wm0 + mi * 16 + lr;
@@ -161,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
     if (p.C == nullptr) return;
   } else {
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
+    for (int ni = 0; ni < C::NT; ++ni)
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -172,22 +207,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
         }
   }
 
-  // stage the wave's 64x64 tile (bf16) through its private LDS region, then store 16 B per lane
+  // stage the wave's 64 x WTN tile (bf16) through its private LDS region, then store 16 B per lane
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni)
+  for (int ni = 0; ni < C::NT; ++ni)
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
       uint2 o = {pack2(acc[ni][mi][0], acc[ni][mi][1]), pack2(acc[ni][mi][2], acc[ni][mi][3])};
-      *reinterpret_cast<uint2*>(reg + (mi * 16 + lr) * EPI_STRIDE + (ni * 16 + lq * 4) * 2) = o;
+      *reinterpret_cast<uint2*>(reg + (mi * 16 + lr) * C::EPI_STRIDE + (ni * 16 + lq * 4) * 2) = o;
     }
   bf16_t* Cb = p.C + (long long)z * p.sC;
   const bf16_t* Rb = p.R ? p.R + (long long)z * p.sR : nullptr;
   const bool vec_ok = ((p.ldc & 7) == 0) && (!Rb || (p.ldr & 7) == 0);
+  constexpr int CH = C::WTN / 8;        // 16-B chunks per staged row
+  constexpr int RPP = 64 / CH;          // rows per pass
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int row = it * 8 + (lane >> 3), ch = lane & 7;
+  for (int it = 0; it < CH; ++it) {
+    const int row = it * RPP + lane / CH, ch = lane % CH;
     const int m = wm0 + row, n = wn0 + ch * 8;
-    uint4 v = *reinterpret_cast<const uint4*>(reg + row * EPI_STRIDE + ch * 16);
+    uint4 v = *reinterpret_cast<const uint4*>(reg + row * C::EPI_STRIDE + ch * 16);
     if (m >= p.M || n >= p.N) continue;
     const int rrow = p.res_mod > 0 ? (m % p.res_mod) : m;
     const long long crow = p.gC > 0 ? (long long)(m / p.gC) * p.sgC + (long long)(m % p.gC) * p.ldc : (long long)m * p.ldc;
@@ -218,6 +255,40 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
   }
 }
 
+// Pick the tile by a wave-quantisation model: cost = rounds x (relative cost of one tile of that shape).
+// slots = blocks resident at once on 256 CUs; relative per-tile costs calibrated on MI355X (tools/bench_kernels.py).
+struct TileChoice { int bm, bn; };
+inline TileChoice choose_tile(int M, int N, int force) {
+  if (force == 1) return {256, 128};
+  if (force == 2) return {128, 128};
+  if (force == 3) return {128, 64};
+  auto rounds = [&](int bm, int bn, int slots) {
+    const long long t = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    return (double)((t + slots - 1) / slots);
+  };
+  const double c256 = rounds(256, 128, 256) * 0.80;         // 1 block/CU: a round covers as much output as 512 128x128 tiles
+  const double c128 = rounds(128, 128, 512) * 1.0;          // 2 blocks/CU
+  const double c64 = rounds(128, 64, 512) * 0.5 * 1.10;     // 2 blocks/CU, half the work, ~10 % less efficient
+  if (c256 <= c128 && c256 <= c64) return {256, 128};
+  if (c128 <= c64) return {128, 128};
+  return {128, 64};
+}
+
+template <int BM, int BN, int STAGES>
+int launch(const GemmP& p0, int M, int N, int batch, hipStream_t st) {
+  using C = Cfg<BM, BN, STAGES>;
+  GemmP p = p0;
+  p.tiles_n = (N + BN - 1) / BN;
+  p.ntiles = ((M + BM - 1) / BM) * p.tiles_n;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, STAGES>), dim3(p.ntiles, 1, batch), dim3(C::NTHREADS), C::LDS_BYTES, st, p);
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
@@ -238,26 +309,24 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   if (d->C && d->ldc % 8 == 0) VLA_REQUIRE(d->sC % 8 == 0, "gemm: sC must keep 16-B alignment");
   if (d->R && d->ldc % 8 == 0 && d->ldr % 8 == 0)
     VLA_REQUIRE(((uintptr_t)d->R & 15) == 0 && d->sR % 8 == 0, "gemm: R must be 16-B aligned");
+  VLA_REQUIRE(d->a_group >= 0 && d->c_group >= 0 && d->a_group_stride % 8 == 0 &&
+                  (d->c_group == 0 || d->ldc % 8 != 0 || d->c_group_stride % 8 == 0),
+              "gemm: row-group strides must keep 16-B alignment");
   GemmP p;
   p.A = (const bf16_t*)d->A; p.B = (const bf16_t*)d->B; p.C = (bf16_t*)d->C;
   p.bias = (const bf16_t*)d->bias; p.R = (const bf16_t*)d->R; p.C2 = (bf16_t*)d->C2;
   p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr;
   p.ldc2 = d->ldc2; p.res_mod = d->res_mod; p.act = d->act;
   p.sA = d->sA; p.sB = d->sB; p.sC = d->sC; p.sR = d->sR; p.sC2 = d->sC2; p.sBias = d->sBias;
-  const int tm = (d->M + BM - 1) / BM;
-  p.tiles_n = (d->N + BN - 1) / BN;
-  p.ntiles = tm * p.tiles_n;
+  p.tiles_n = p.ntiles = 0;
   p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
   p.gA = d->a_group; p.sgA = d->a_group_stride; p.gC = d->c_group; p.sgC = d->c_group_stride;
-  VLA_REQUIRE(d->a_group >= 0 && d->c_group >= 0 && d->a_group_stride % 8 == 0 && (d->c_group == 0 || d->ldc % 8 != 0 || d->c_group_stride % 8 == 0),
-              "gemm: row-group strides must keep 16-B alignment");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr_set = true;
-  }
-  dim3 grid(p.ntiles, 1, d->batch);
-  hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), LDS_BYTES, (hipStream_t)stream, p);
+  const char* e = getenv("VLA_GEMM_TILE");     // 0/unset auto, 1: 256x128, 2: 128x128, 3: 128x64  (benchmarking aid)
+  const TileChoice tc = choose_tile(d->M, d->N, e ? atoi(e) : 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (tc.bm == 256) launch<256, 128, 3>(p, d->M, d->N, d->batch, st);
+  else if (tc.bn == 128) launch<128, 128, 2>(p, d->M, d->N, d->batch, st);
+  else launch<128, 64, 3>(p, d->M, d->N, d->batch, st);
   VLA_CHECK_LAUNCH("gemm_bf16_nt");
   return VLA_OK;
 }
