@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
 // the loop: 7-14 independent waves per CU hide each other's latency); the grp partial dK^T/dV^T accumulators of a key
 // tile are then summed through LDS (ds_add_f32) and written once - no global atomics, deterministic up to fp32 order.
 template <int D>
-__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int KT) {
+__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int KT, int dbg) {
   using G = Geo<D>;
   constexpr int TILE = 32 * G::LD;                       // elements per LDS tile
   constexpr int WAVE_BYTES = 2 * TILE * 2 + 256;         // Q tile, dO tile, lse[32], delta[32]
@@ -368,6 +368,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int
       delta_n = p.delta[sbase + qq];
     }
     for (int q0 = qstart; q0 < p.Sq; q0 += 32) {
+      if ((dbg & 4) && q0 > qstart) break;
       tile_store<D, 64, G::LD>(rq, sQ, lane);
       tile_store<D, 64, G::LD>(rdo, sdO, lane);
       if (lane < 32) {
@@ -385,6 +386,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // LDS tile written by this wave before it reads it
       __builtin_amdgcn_wave_barrier();
+      if (!(dbg & 2)) {
       f32x16 S = zero16(), dP = zero16();
 #pragma unroll
       for (int ks = 0; ks < G::KS; ++ks) {
@@ -411,37 +413,39 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int
           dK[t] = mfma32(tr_frag(sQ, G::LD, s, 32 * t, lane), dsf, dK[t]);  // dK^T[d x key] += Q^T . dS
         }
       }
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // reads of this tile done before the next store
       __builtin_amdgcn_wave_barrier();
     }
   }
-  // ---- sum the grp heads of each key tile through LDS, then one wave per key tile writes bf16
-  float* acc = reinterpret_cast<float*>(smem) + kt * (2 * 32 * ACC_LD);
-  if (grp > 1) {
-    __syncthreads();                                      // every wave is done with its tiles: reuse the LDS
-    for (int i = tid; i < KT * 2 * 32 * ACC_LD; i += blockDim.x) reinterpret_cast<float*>(smem)[i] = 0.f;
-    __syncthreads();
-    if (k0 < p.Sk) {
+  // ---- sum the grp heads of each key tile: every wave parks its partial tile in LDS (its own slab, no atomics -
+  //      ds_add_f32 under 7-way contention cost 118 us here), then all threads add the grp slabs and store bf16.
+  if (grp > 1 && !(dbg & 1)) {
+    float* part = reinterpret_cast<float*>(smem) + w * (32 * ACC_LD);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      __syncthreads();                                    // tiles (pass 0) / previous pass's slabs are no longer read
 #pragma unroll
       for (int t = 0; t < G::DT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int d = 32 * t + acc_row(r, h);
-          atomicAdd(acc + (lane & 31) * ACC_LD + d, dK[t][r]);
-          atomicAdd(acc + 32 * ACC_LD + (lane & 31) * ACC_LD + d, dV[t][r]);
+        for (int r = 0; r < 16; ++r)
+          part[(lane & 31) * ACC_LD + 32 * t + acc_row(r, h)] = pass == 0 ? dK[t][r] : dV[t][r];
+      __syncthreads();
+      bf16_t* outp = pass == 0 ? p.dk : p.dv;
+      const long long o_sb = pass == 0 ? p.dk_sb : p.dv_sb;
+      const int o_ss = pass == 0 ? p.dk_ss : p.dv_ss;
+      for (int i = tid; i < KT * 32 * G::DV; i += blockDim.x) {
+        const int kt2 = i / (32 * G::DV), rem = i - kt2 * (32 * G::DV), key = rem / G::DV, d = rem - key * G::DV;
+        const int kg = (blockIdx.x * KT + kt2) * 32 + key;
+        if (kg < p.Sk && d < D) {
+          const float* src = reinterpret_cast<const float*>(smem) + (kt2 * grp) * (32 * ACC_LD) + key * ACC_LD + d;
+          float sum = 0.f;
+          for (int g = 0; g < grp; ++g) sum += src[g * (32 * ACC_LD)];
+          outp[(long long)b * o_sb + (long long)kg * o_ss + hkv * D + d] = f2bf(sum);
         }
+      }
     }
-    __syncthreads();
-    if (hh == 0) {
-#pragma unroll
-      for (int t = 0; t < G::DT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int d = 32 * t + acc_row(r, h);
-          dK[t][r] = acc[(lane & 31) * ACC_LD + d];
-          dV[t][r] = acc[32 * ACC_LD + (lane & 31) * ACC_LD + d];
-        }
-    }
+    return;
   }
   if (hh == 0 && ki < p.Sk) {
     bf16_t* okp = p.dk + (long long)b * p.dk_sb + (long long)ki * p.dk_ss + hkv * D;
@@ -525,12 +529,14 @@ extern "C" int vla_attn_bwd(void* stream, const vla_attn_desc* d) {
     attr_set = true;
   }
   VLA_REQUIRE(lds <= 160 * 1024, "attn_bwd: LDS budget exceeded");
+  const char* de = getenv("VLA_DKV_DBG");   // ablation aid (timing only, results invalid when set)
+  const int dbg = de ? atoi(de) : 0;
   if (p.dh == 64) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(256), 0, st, p);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gk, dim3(64 * grp * KT), lds, st, p, grp, KT);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gk, dim3(64 * grp * KT), lds, st, p, grp, KT, dbg);
   } else {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<72>, gq, dim3(256), 0, st, p);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<72>, gk, dim3(64 * grp * KT), lds, st, p, grp, KT);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<72>, gk, dim3(64 * grp * KT), lds, st, p, grp, KT, dbg);
   }
   VLA_CHECK_LAUNCH("attn_bwd");
   return VLA_OK;

@@ -255,23 +255,25 @@ __global__ __launch_bounds__((BM / 64) * 128) void gemm_nt_kernel(GemmP p) {
   }
 }
 
-// Pick the tile by a wave-quantisation model: cost = rounds x (relative cost of one tile of that shape).
-// slots = blocks resident at once on 256 CUs; relative per-tile costs calibrated on MI355X (tools/bench_kernels.py).
+// Pick the tile per problem.  Calibrated on MI355X (tools/bench_kernels.py, round 1):
+//  * 256x128 (3-stage, 1 block/CU) wins only when a tile's fixed prologue/epilogue is amortised by very wide N or by
+//    long K on a big square-ish problem (8192^3: 1062 vs 865 TF/s; N=9728,K=896: 654 vs 590);
+//  * between 128x128 (2 blocks/CU) and 128x64 the choice is wave quantisation: cost = rounds x per-round work, with the
+//    narrow tile ~10 % less efficient per FLOP on short K and ~35 % on long K (less operand reuse per LDS byte):
+//    M=11264,N=896,K=896 -> 616 tiles on 512 slots wastes 40 % with 128x128 (507 TF/s) vs 578 TF/s with 128x64.
 struct TileChoice { int bm, bn; };
-inline TileChoice choose_tile(int M, int N, int force) {
+inline TileChoice choose_tile(int M, int N, int K, int force) {
   if (force == 1) return {256, 128};
   if (force == 2) return {128, 128};
   if (force == 3) return {128, 64};
-  auto rounds = [&](int bm, int bn, int slots) {
+  if ((N >= 8192 && M >= 2048) || (M >= 4096 && N >= 4096 && K >= 2048)) return {256, 128};
+  auto rounds = [&](int bm, int bn) {
     const long long t = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
-    return (double)((t + slots - 1) / slots);
+    return (double)((t + 511) / 512);
   };
-  const double c256 = rounds(256, 128, 256) * 0.80;         // 1 block/CU: a round covers as much output as 512 128x128 tiles
-  const double c128 = rounds(128, 128, 512) * 1.0;          // 2 blocks/CU
-  const double c64 = rounds(128, 64, 512) * 0.5 * 1.10;     // 2 blocks/CU, half the work, ~10 % less efficient
-  if (c256 <= c128 && c256 <= c64) return {256, 128};
-  if (c128 <= c64) return {128, 128};
-  return {128, 64};
+  const double c128 = rounds(128, 128);
+  const double c64 = rounds(128, 64) * 0.5 * (K >= 4096 ? 1.35 : 1.10);
+  return c128 <= c64 ? TileChoice{128, 128} : TileChoice{128, 64};
 }
 
 template <int BM, int BN, int STAGES>
@@ -322,7 +324,7 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
   p.gA = d->a_group; p.sgA = d->a_group_stride; p.gC = d->c_group; p.sgC = d->c_group_stride;
   const char* e = getenv("VLA_GEMM_TILE");     // 0/unset auto, 1: 256x128, 2: 128x128, 3: 128x64  (benchmarking aid)
-  const TileChoice tc = choose_tile(d->M, d->N, e ? atoi(e) : 0);
+  const TileChoice tc = choose_tile(d->M, d->N, d->K, e ? atoi(e) : 0);
   hipStream_t st = (hipStream_t)stream;
   if (tc.bm == 256) launch<256, 128, 3>(p, d->M, d->N, d->batch, st);
   else if (tc.bn == 128) launch<128, 128, 2>(p, d->M, d->N, d->batch, st);
