@@ -652,8 +652,13 @@ class VLAEngine:
         self._dHS = None
         self.reducer = None        # ddp.FlatGradReducer when world_size > 1
 
-    # modeling_prismatic.py:596-655 (multimodal forward) + finetune.py:396-418
     def forward(self, batch: Dict[str, torch.Tensor], noise: Optional[torch.Tensor] = None):
+        """VLM forward + action head (finetune.py:336-411) -> predicted actions [B, chunk, 7]."""
+        self.forward_vlm(batch)
+        return self.head.forward(self.llm.HS, self.pos1, batch["proprio"], self.Np, noise)
+
+    # modeling_prismatic.py:596-655 (multimodal forward): fills llm.HS with the n+1 hidden states
+    def forward_vlm(self, batch: Dict[str, torch.Tensor]):
         cfg, llm = self.cfg, self.llm
         ids, labels, am = batch["input_ids"], batch["labels"], batch["attention_mask"]
         B, L = ids.shape
@@ -692,9 +697,7 @@ class VLAEngine:
         mm = torch.empty(B, S, device=self.device, dtype=torch.uint8)
         ops.embed_splice(ids, am.to(torch.uint8).contiguous(), self.qidx0, llm.embed, self.head.P.view("action_queries"), X0, mm, Np)
         llm.forward(B, S, mm)
-        pred = self.head.forward(llm.HS, self.pos1, batch["proprio"], Np, noise)
         self.B, self.S, self.Np = B, S, Np
-        return pred
 
     def loss_and_backward(self, pred, actions, gscale: float = 1.0):
         """L1 loss (finetune.py:418) + full backward into the flat grad buffer."""
