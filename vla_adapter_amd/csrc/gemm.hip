@@ -78,7 +78,14 @@ __global__ __launch_bounds__((BM / 64) * 128) void gemm_nt_kernel(GemmP p) {
   const int nwg = p.ntiles, bid = blockIdx.x;
   const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
   const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int bm = swz / p.tiles_n, bn = swz - bm * p.tiles_n;
+  // group-M order inside the XCD's run: GM row-panels x all column tiles, row index fastest, so the ~32-64 tiles an
+  // XCD has in flight form a GM x (32/GM) patch whose A panels stay in that XCD's 4 MiB L2 while B tiles stream once
+  // (row-major order re-streamed every B tile from beyond L2 for every row panel: 44 x 17 MB for the gate/up GEMM).
+  constexpr int GM = BM == 256 ? 4 : 8;
+  const int tiles_m = p.ntiles / p.tiles_n, per_group = GM * p.tiles_n;
+  const int grp = swz / per_group, rem = swz - grp * per_group;
+  const int gm = min(GM, tiles_m - grp * GM);
+  const int bm = grp * GM + rem % gm, bn = rem / gm;
   const int m0 = bm * BM, n0 = bn * BN;
   const int z = blockIdx.z;
   const bf16_t* Ab = p.A + (long long)z * p.sA;
@@ -185,7 +192,7 @@ __global__ __launch_bounds__((BM / 64) * 128) void gemm_nt_kernel(GemmP p) {
           const float u = rbf(acc[2 * pr + 1][mi][j] * p.alpha + bv[2 * pr + 1][j]);
           acc[2 * pr][mi][j] = g;
           acc[2 * pr + 1][mi][j] = u;
-          h[j] = rbf(silu(g)) * u;
+          h[j] = rbf(g * __builtin_amdgcn_rcpf(1.0f + __expf(-g))) * u;
         }
         const int hc = (wn0 >> 1) + pr * 16 + lq * 4;
         if (m < p.M && hc + 3 < (p.N >> 1)) {
@@ -256,8 +263,9 @@ __global__ __launch_bounds__((BM / 64) * 128) void gemm_nt_kernel(GemmP p) {
 }
 
 // Pick the tile per problem.  Calibrated on MI355X (tools/bench_kernels.py, round 1):
-//  * 256x128 (3-stage, 1 block/CU) wins only when a tile's fixed prologue/epilogue is amortised by very wide N or by
-//    long K on a big square-ish problem (8192^3: 1062 vs 865 TF/s; N=9728,K=896: 654 vs 590);
+//  * 256x128 (3-stage, 1 block/CU) only pays on huge squares (8192^3: 1061 vs 1041 TF/s); on the hot-path shapes the
+//    128x128 tile at 2 blocks/CU wins once the tile order is L2-friendly (N=9728,K=896: 744 vs 677 TF/s) because the
+//    second resident workgroup computes while the first one is in its epilogue;
 //  * between 128x128 (2 blocks/CU) and 128x64 the choice is wave quantisation: cost = rounds x per-round work, with the
 //    narrow tile ~10 % less efficient per FLOP on short K and ~35 % on long K (less operand reuse per LDS byte):
 //    M=11264,N=896,K=896 -> 616 tiles on 512 slots wastes 40 % with 128x128 (507 TF/s) vs 578 TF/s with 128x64.
@@ -266,7 +274,7 @@ inline TileChoice choose_tile(int M, int N, int K, int force) {
   if (force == 1) return {256, 128};
   if (force == 2) return {128, 128};
   if (force == 3) return {128, 64};
-  if ((N >= 8192 && M >= 2048) || (M >= 4096 && N >= 4096 && K >= 2048)) return {256, 128};
+  if (M >= 8192 && N >= 8192 && K >= 8192) return {256, 128};   // with group-M order 128x128 is within 2 % even there
   auto rounds = [&](int bm, int bn) {
     const long long t = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     return (double)((t + 511) / 512);
