@@ -294,7 +294,8 @@ def test_attention_bwd(ops, B, S, Hq, Hkv, dh, causal, masked):
 
 
 # ------------------------------------------------------------------ action-head attention
-@pytest.mark.parametrize("B,Ka,Kt,D", [(2, 65, 256, 896), (3, 65, 24, 64), (1, 65, 512, 896)])
+@pytest.mark.parametrize("B,Ka,Kt,D", [(2, 65, 256, 896), (3, 65, 24, 64), (1, 65, 512, 896), (2, 65, 40, 512), (5, 65, 16, 128),
+                                       (3, 65, 16, 256), (2, 65, 100, 1024)])
 def test_head_attention(ops, B, Ka, Kt, D):
     H, T = 8, 8
     dh = D // H
@@ -319,7 +320,7 @@ def test_head_attention(ops, B, Ka, Kt, D):
     (ref32 * hd(dout, T)).sum().backward()
     g3, ga, gt = torch.zeros_like(dx3), torch.zeros_like(da2), torch.zeros_like(dt2)
     dgate = torch.zeros(1, device=DEV)
-    ops.head_attn_bwd(dout.to(DEV), *args, gate.to(DEV), probs, dgate, g3[:, :, :D], g3[:, :, D:2 * D], g3[:, :, 2 * D:],
+    ops.head_attn_bwd(dout.to(DEV), out, *args, gate.to(DEV), probs, dgate, g3[:, :, :D], g3[:, :, D:2 * D], g3[:, :, 2 * D:],
                       ga[:, :, :D], ga[:, :, D:], gt[:, :, :D], gt[:, :, D:], H)
     un = lambda t, L: t.transpose(1, 2).reshape(B, L, D)
     check(g3[:, :, :D], un(q.grad, T), rel=1.5e-2, mx=6e-2, name="head dq")

@@ -7,18 +7,12 @@
 // thread per output column for PV / dQ; softmax rows reduced with wavefront shuffles.  Rounding points follow the
 // reference's bf16 module: bf16(q.k) -> bf16(* tanh g) -> bf16(/ sqrt dh) -> softmax -> bf16 -> bf16(P.V).
 #include "common.h"
+#include "head_attn_params.h"
 #include "../../include/vla_native.h"
 
 namespace {
 
 constexpr int TQ = 8;  // NUM_ACTIONS_CHUNK (LIBERO)
-
-struct HP {
-  const bf16_t* q; const bf16_t* ks; const bf16_t* vs; const bf16_t* ka; const bf16_t* va; const bf16_t* kt; const bf16_t* vt;
-  const bf16_t* gate; bf16_t* out; float* probs;
-  int B, T, Ka, Kt, H, dh, ld_q, ld_self, ld_adp, ld_task, ld_out;
-  const bf16_t* dout; bf16_t* dq; bf16_t* dks; bf16_t* dvs; bf16_t* dka; bf16_t* dva; bf16_t* dkt; bf16_t* dvt; float* dgate;
-};
 
 __device__ __forceinline__ const bf16_t* seg_row(const bf16_t* s0, const bf16_t* s1, const bf16_t* s2, const HP& p, int b,
                                                  int n, int hoff) {
@@ -225,7 +219,7 @@ __global__ __launch_bounds__(256) void head_attn_bwd_kernel(HP p) {
 int fill(HP& p, const vla_head_attn_desc* d, bool bwd) {
   VLA_REQUIRE(d && d->q && d->k_self && d->v_self && d->k_adp && d->v_adp && d->k_task && d->v_task && d->gate && d->probs,
               "head_attn: null tensor");
-  VLA_REQUIRE(d->T == TQ, "head_attn: T must be 8 (NUM_ACTIONS_CHUNK)");
+  VLA_REQUIRE(d->T >= 1 && d->T <= 32, "head_attn: T must be in 1..32");
   VLA_REQUIRE(d->B > 0 && d->Ka > 0 && d->Kt > 0 && d->H > 0 && d->dh > 0 && d->dh % 8 == 0 && d->dh <= 128, "head_attn: bad shape");
   VLA_REQUIRE(d->ld_q % 8 == 0 && d->ld_self % 8 == 0 && d->ld_adp % 8 == 0 && d->ld_task % 8 == 0 && d->ld_out % 8 == 0,
               "head_attn: row strides must be multiples of 8");
@@ -241,6 +235,7 @@ int fill(HP& p, const vla_head_attn_desc* d, bool bwd) {
   } else {
     VLA_REQUIRE(d->dout && d->dq && d->dk_self && d->dv_self && d->dk_adp && d->dv_adp && d->dk_task && d->dv_task,
                 "head_attn_bwd: null grad tensor");
+    p.out = (bf16_t*)d->out;   // forward output (needed by the MFMA backward for delta = rowsum(dO*O))
     p.dout = (const bf16_t*)d->dout; p.dq = (bf16_t*)d->dq; p.dks = (bf16_t*)d->dk_self; p.dvs = (bf16_t*)d->dv_self;
     p.dka = (bf16_t*)d->dk_adp; p.dva = (bf16_t*)d->dv_adp; p.dkt = (bf16_t*)d->dk_task; p.dvt = (bf16_t*)d->dv_task;
     p.dgate = d->dgate;
@@ -254,6 +249,12 @@ extern "C" int vla_head_attn_fwd(void* stream, const vla_head_attn_desc* d) {
   HP p{};
   int rc = fill(p, d, false);
   if (rc) return rc;
+  if (head_attn_mfma_supported(p) && !getenv("VLA_HEAD_ATTN_VALU")) {
+    head_attn_mfma_fwd(p, (hipStream_t)stream);
+    VLA_CHECK_LAUNCH("head_attn_fwd(mfma)");
+    return VLA_OK;
+  }
+  VLA_REQUIRE(p.T == TQ, "head_attn (VALU fallback): T must be 8");
   const int N = p.T + p.Ka + p.Kt;
   const size_t lds = (size_t)(TQ * p.dh + TQ * N) * sizeof(float);
   VLA_REQUIRE(lds <= 64 * 1024, "head_attn_fwd: key count too large for LDS");
@@ -266,6 +267,13 @@ extern "C" int vla_head_attn_bwd(void* stream, const vla_head_attn_desc* d) {
   HP p{};
   int rc = fill(p, d, true);
   if (rc) return rc;
+  if (head_attn_mfma_supported(p) && !getenv("VLA_HEAD_ATTN_VALU")) {
+    VLA_REQUIRE(p.out, "head_attn_bwd: the MFMA path needs the forward output (desc.out)");
+    head_attn_mfma_bwd(p, (hipStream_t)stream);
+    VLA_CHECK_LAUNCH("head_attn_bwd(mfma)");
+    return VLA_OK;
+  }
+  VLA_REQUIRE(p.T == TQ, "head_attn (VALU fallback): T must be 8");
   const int N = p.T + p.Ka + p.Kt;
   const size_t lds = (size_t)(2 * TQ * p.dh + 3 * TQ * N + 64) * sizeof(float);
   VLA_REQUIRE(lds <= 160 * 1024, "head_attn_bwd: key count too large for LDS");

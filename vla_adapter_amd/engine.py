@@ -537,7 +537,7 @@ class Head:
             g = self.dQKVx[i].view(B, T, 3 * D)
             ga = self.dKV_adp[i].view(B, Ka, 2 * D)
             gt = self.dKV_task[i].view(B, Kt, 2 * D)
-            ops.head_attn_bwd(dout.view(B, T, D), *args, gate, self.probs[i], self.dgate[i:i + 1], g[:, :, :D], g[:, :, D:2 * D],
+            ops.head_attn_bwd(dout.view(B, T, D), out, *args, gate, self.probs[i], self.dgate[i:i + 1], g[:, :, :D], g[:, :, D:2 * D],
                               g[:, :, 2 * D:], ga[:, :, :D], ga[:, :, D:], gt[:, :, :D], gt[:, :, D:], H)
 
     # ---- backward ---------------------------------------------------------------------------------------------

@@ -346,14 +346,13 @@ def head_attn_fwd(q, ks, vs, ka, va, kt, vt, gate, H: int = 8):
     return out, probs
 
 
-def head_attn_bwd(dout, q, ks, vs, ka, va, kt, vt, gate, probs, dgate_f32, dq, dks, dvs, dka, dva, dkt, dvt, H: int = 8):
-    """Gradient tensors are caller-provided views with the SAME row strides as their forward counterparts."""
-    _chk_bf16(dout, dq, dks, dvs, dka, dva, dkt, dvt)
-    d = head_attn_desc(q, ks, vs, ka, va, kt, vt, gate, probs, dout, H)
-    d.out = None
+def head_attn_bwd(dout, out, q, ks, vs, ka, va, kt, vt, gate, probs, dgate_f32, dq, dks, dvs, dka, dva, dkt, dvt, H: int = 8):
+    """``out`` = the forward output, ``probs`` = the forward's workspace.  Gradient tensors are caller-provided views
+    with the SAME row strides as their forward counterparts."""
+    _chk_bf16(dout, out, dq, dks, dvs, dka, dva, dkt, dvt)
+    d = head_attn_desc(q, ks, vs, ka, va, kt, vt, gate, probs, out, H)
     d.dout = dout.data_ptr()
-    assert dout.stride(1) == d.ld_out or True
-    d.ld_out = dout.stride(1)
+    assert dout.stride(1) == out.stride(1) and dout.stride(-1) == 1
     for g, f in ((dq, q), (dks, ks), (dvs, vs), (dka, ka), (dva, va), (dkt, kt), (dvt, vt)):
         assert g.stride(1) == f.stride(1) and g.stride(-1) == 1, "grad views must mirror forward strides"
     d.dq, d.dk_self, d.dv_self, d.dk_adp, d.dv_adp, d.dk_task, d.dv_task = (t.data_ptr() for t in (dq, dks, dvs, dka, dva, dkt, dvt))
