@@ -280,6 +280,7 @@ inline TileChoice choose_tile(int M, int N, int K, int force) {
     return (double)((t + 511) / 512);
   };
   const double c128 = rounds(128, 128);
+  if (c128 > 2.0) return {128, 128};        // quantisation only matters when the whole problem is 1-2 rounds of tiles
   const double c64 = rounds(128, 64) * 0.5 * (K >= 4096 ? 1.35 : 1.10);
   return c128 <= c64 ? TileChoice{128, 128} : TileChoice{128, 64};
 }
