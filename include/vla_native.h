@@ -47,6 +47,11 @@ typedef struct vla_gemm_desc {
    * (likewise C): lets a GEMM read/write the [B, first Np of S, D] window of a [B, S, D] tensor as one [B*Np, D] matrix */
   int a_group, c_group;
   long long a_group_stride, c_group_stride;
+  /* optional fused rotary embedding on output columns [0, rope_cols) (after bias, before residual): position =
+   * row % rope_T.  rope_mode 1: HF rotate_half, head dim 64, tables f32 [rope_T, 32] (Qwen2 q/k, see vla_rope_half);
+   * rope_mode 2: action-head interleaved pairs, tables f32 [rope_T, rope_dh] (see vla_rope_interleaved). */
+  int rope_mode, rope_T, rope_dh, rope_cols;
+  const float* rope_cos; const float* rope_sin;
 } vla_gemm_desc;
 
 /* C = epilogue(A . B^T).  Replaces nn.Linear forward and, with pre-transposed operands, its dX / dW products:
@@ -90,6 +95,9 @@ typedef struct vla_attn_desc {
   /* backward only */
   const void* dout; void* dq; void* dk; void* dv; float* delta; /* delta f32 [B,Hq,Sq] workspace */
   long long do_sb, dq_sb, dk_sb, dv_sb; int do_ss, dq_ss, dk_ss, dv_ss;
+  /* backward, optional: q/k were produced by rotate_half RoPE (tables f32 [S, 32], dh 64, position = sequence index):
+   * dq/dk are returned already mapped through its transpose, i.e. as gradients of the PRE-rotation projections */
+  const float* rope_cos; const float* rope_sin;
 } vla_attn_desc;
 
 /* softmax(scale * Q K^T + mask) V, GQA (Hq % Hkv == 0), causal and/or key-padding mask, dh in {64,72,112,128}.
@@ -161,6 +169,9 @@ typedef struct vla_head_attn_desc {
   /* backward */
   const void* dout; void* dq; void* dk_self; void* dv_self; void* dk_adp; void* dv_adp; void* dk_task; void* dv_task;
   float* dgate;       /* f32 scalar, += */
+  /* backward, optional: tables f32 [>= max(T,Ka,Kt), dh] of vla_rope_interleaved; dq and the three dk are then
+   * returned through the transpose of that RoPE map (positions restart per segment, action_heads.py:383-388) */
+  const float* rope_cos; const float* rope_sin;
 } vla_head_attn_desc;
 int vla_head_attn_fwd(void* stream, const vla_head_attn_desc* desc /* host */);
 int vla_head_attn_bwd(void* stream, const vla_head_attn_desc* desc /* host */);

@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(lib):
 def test_descriptor_layouts_match_header(lib):
     """ctypes struct sizes must match the C structs (x86-64 SysV): field counts/types are mirrored by hand."""
     from vla_adapter_amd import native
-    assert ctypes.sizeof(native.GemmDesc) == 6 * 8 + 11 * 4 + 4 + 6 * 8 + 4 + 2 * 4 + 4 + 2 * 8  # ptrs, ints(+pad), strides, alpha, groups(+pad), group strides
+    assert ctypes.sizeof(native.GemmDesc) == 6 * 8 + 11 * 4 + 4 + 6 * 8 + 4 + 2 * 4 + 4 + 2 * 8 + 4 * 4 + 2 * 8  # ptrs, ints(+pad), strides, alpha, groups(+pad), group strides, rope
     assert ctypes.sizeof(native.AttnDesc) % 8 == 0 and ctypes.sizeof(native.HeadAttnDesc) % 8 == 0
 
 

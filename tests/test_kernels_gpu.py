@@ -441,3 +441,82 @@ def test_adamw_bit_exact_vs_torch_golden(ops):
         ops.adamw_(p, g, m, v, step + 1, lr, b1, b2, eps, wd)
         assert torch.equal(f(p), torch.from_numpy(z["ps"][step])), f"AdamW params differ from torch at step {step}"
     assert torch.equal(f(m), torch.from_numpy(z["m"])) and torch.equal(f(v), torch.from_numpy(z["v"]))
+
+
+# ------------------------------------------------------------------ fused rotary embeddings
+def test_gemm_fused_rope_half(ops):
+    """QKV projection with the HF rotate_half RoPE applied in the GEMM epilogue == Linear then apply_rotary_pos_emb."""
+    B, S, H, KV, dh, K = 2, 40, 4, 2, 64, 128
+    N = (H + 2 * KV) * dh
+    x, w, bias = gen(B * S, K, seed=90), gen(N, K, seed=91, scale=0.1), gen(N, seed=92)
+    cos, sin = ops.rope_half_tables(S, dh, 1e6, DEV)
+    out = ops.gemm_nt(x.to(DEV), w.to(DEV), bias=bias.to(DEV), rope=(1, cos, sin, S, dh, (H + KV) * dh))
+    y = O.linear(x.float(), w.float(), bias.float(), True)
+    c, s = O.rope_half_tables(S, dh, 1e6, True)
+    q = O.rope_half(y[:, :H * dh].view(B, S, H, dh).transpose(1, 2), c, s, True).transpose(1, 2).reshape(B * S, H * dh)
+    k = O.rope_half(y[:, H * dh:(H + KV) * dh].view(B, S, KV, dh).transpose(1, 2), c, s, True).transpose(1, 2).reshape(B * S, KV * dh)
+    check(out, torch.cat([q, k, y[:, (H + KV) * dh:]], 1), name="gemm + rope_half")
+
+
+@pytest.mark.parametrize("tile", [2, 3])
+def test_gemm_fused_rope_interleaved(ops, tile, monkeypatch):
+    monkeypatch.setenv("VLA_GEMM_TILE", str(tile))
+    B, T, H, dh, K = 3, 21, 8, 16, 128
+    D = H * dh
+    x, w, bias = gen(B * T, K, seed=93), gen(2 * D, K, seed=94, scale=0.1), gen(2 * D, seed=95)
+    cos, sin = ops.rope_inter_tables(T + 5, dh, DEV)
+    out = ops.gemm_nt(x.to(DEV), w.to(DEV), bias=bias.to(DEV), rope=(2, cos, sin, T, dh, D))       # K half only
+    y = O.linear(x.float(), w.float(), bias.float(), True)
+    c, s = O.head_rope_tables(T, dh, True)
+    k = O.head_rope(y[:, :D].view(B, T, H, dh).transpose(1, 2), c, s, True).transpose(1, 2).reshape(B * T, D)
+    check(out, torch.cat([k, y[:, D:]], 1), name="gemm + interleaved rope")
+
+
+def test_attention_bwd_fused_inverse_rope(ops):
+    B, S, Hq, Hkv, dh = 2, 77, 4, 2, 64
+    qkv, q, k, v = _attn_inputs(B, S, Hq, Hkv, dh, 96)
+    dout = gen(B, S, Hq * dh, seed=97)
+    d = qkv.to(DEV)
+    qd, kd, vd = d[:, :, :Hq * dh], d[:, :, Hq * dh:(Hq + Hkv) * dh], d[:, :, (Hq + Hkv) * dh:]
+    o, lse = ops.attn_fwd(qd, kd, vd, Hq, Hkv, dh, True, None, want_lse=True)
+    cos, sin = ops.rope_half_tables(S, dh, 1e6, DEV)
+    g0, g1 = torch.zeros_like(d), torch.zeros_like(d)
+    sl = lambda t: (t[:, :, :Hq * dh], t[:, :, Hq * dh:(Hq + Hkv) * dh], t[:, :, (Hq + Hkv) * dh:])
+    ops.attn_bwd(dout.to(DEV), qd, kd, vd, o, lse, Hq, Hkv, dh, True, None, dq=sl(g0)[0], dk=sl(g0)[1], dv=sl(g0)[2])
+    ops.attn_bwd(dout.to(DEV), qd, kd, vd, o, lse, Hq, Hkv, dh, True, None, dq=sl(g1)[0], dk=sl(g1)[1], dv=sl(g1)[2], rope=(cos, sin))
+    # reference: exact fp32 inverse rotation of the un-fused gradients
+    c, s = O.rope_half_tables(S, dh, 1e6, True)
+    def inv(t, h):
+        x = f(t).view(B, S, h, dh).transpose(1, 2)
+        hh = dh // 2
+        rot = torch.cat([x[..., hh:], -x[..., :hh]], -1)
+        return (x * c + rot * s).transpose(1, 2).reshape(B, S, h * dh)
+    check(sl(g1)[0], inv(sl(g0)[0], Hq), rel=6e-3, mx=3e-2, name="dq through inverse rope")
+    check(sl(g1)[1], inv(sl(g0)[1], Hkv), rel=6e-3, mx=3e-2, name="dk through inverse rope")
+    assert torch.equal(f(sl(g1)[2]), f(sl(g0)[2]))
+
+
+@pytest.mark.parametrize("D", [896, 64])
+def test_head_attention_bwd_fused_rope_transpose(ops, D):
+    """MFMA path (dh 112) and VALU fallback (dh 8): dq / dk returned through the transpose of the head's RoPE map."""
+    B, Ka, Kt, H, T = 2, 65, 40, 8, 8
+    dh = D // H
+    x3, a2, t2 = gen(B, T, 3 * D, seed=50, scale=0.3), gen(B, Ka, 2 * D, seed=51, scale=0.3), gen(B, Kt, 2 * D, seed=52, scale=0.3)
+    gate, dout = torch.tensor([0.7]).to(BF).to(DEV), gen(B, T, D, seed=53).to(DEV)
+    dx3, da2, dt2 = x3.to(DEV), a2.to(DEV), t2.to(DEV)
+    args = (dx3[:, :, :D], dx3[:, :, D:2 * D], dx3[:, :, 2 * D:], da2[:, :, :D], da2[:, :, D:], dt2[:, :, :D], dt2[:, :, D:])
+    out, probs = ops.head_attn_fwd(*args, gate, H)
+    tabs = ops.rope_inter_tables(max(T, Ka, Kt), dh, DEV)
+    res = []
+    for rope in (None, tabs):
+        g3, ga, gt = torch.zeros_like(dx3), torch.zeros_like(da2), torch.zeros_like(dt2)
+        dg = torch.zeros(1, device=DEV)
+        ops.head_attn_bwd(dout, out, *args, gate, probs, dg, g3[:, :, :D], g3[:, :, D:2 * D], g3[:, :, 2 * D:], ga[:, :, :D], ga[:, :, D:],
+                          gt[:, :, :D], gt[:, :, D:], H, rope=rope)
+        res.append((g3, ga, gt))
+    (g3, ga, gt), (r3, ra, rt) = res
+    for unf, fus, L in ((g3[:, :, :D], r3[:, :, :D], T), (g3[:, :, D:2 * D], r3[:, :, D:2 * D], T), (ga[:, :, :D], ra[:, :, :D], Ka), (gt[:, :, :D], rt[:, :, :D], Kt)):
+        ref = unf.clone().contiguous().view(B * L, D)
+        ops.rope_inter_(ref, tabs[0], tabs[1], L, H, dh, 1)          # stand-alone transpose kernel on the un-fused gradient
+        check(fus.reshape(B * L, D), f(ref), rel=8e-3, mx=3e-2, name=f"fused rope transpose L={L}")
+    assert torch.equal(f(r3[:, :, 2 * D:]), f(g3[:, :, 2 * D:])) and torch.equal(f(ra[:, :, D:]), f(ga[:, :, D:]))

@@ -22,6 +22,7 @@ struct AttnP {
   int B, Sq, Sk, Hq, Hkv, dh, causal; float scale_log2;  // scale * log2(e)
   const bf16_t* dout; bf16_t* dq; bf16_t* dk; bf16_t* dv; float* delta; float scale;
   long long do_sb, dq_sb, dk_sb, dv_sb; int do_ss, dq_ss, dk_ss, dv_ss;
+  const float* rope_cos; const float* rope_sin;   // optional: return dq/dk already through the inverse rotate_half RoPE
 };
 
 // Tile staging split in two (cdna_hip_programming.md T14): the global loads of tile t+1 are issued into registers
@@ -265,6 +266,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
       for (int t = 0; t < G::DT; ++t) dQ[t] = mfma32(tr_frag(sK, G::LD, s, 32 * t, lane), df, dQ[t]);
     }
   }
+  if (p.rope_cos && G::DT == 2) {      // d/dx of y = x*cos + rotate_half(x)*sin : inverse rotation (D == 64: pairs are tiles 0/1)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int d = 8 * g + 4 * h + j;
+        const float c = p.rope_cos[(long long)qc * 32 + d], sn = p.rope_sin[(long long)qc * 32 + d];
+        const float a = dQ[0][4 * g + j], bb = dQ[G::DT - 1][4 * g + j];
+        dQ[0][4 * g + j] = a * c + bb * sn;
+        dQ[G::DT - 1][4 * g + j] = bb * c - a * sn;
+      }
+  }
   if (qi < p.Sq) {
     bf16_t* op = p.dq + (long long)b * p.dq_sb + (long long)qi * p.dq_ss + hq * D;
 #pragma unroll
@@ -408,11 +421,30 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int
           const float* src = reinterpret_cast<const float*>(smem) + (kt2 * grp) * (32 * ACC_LD) + key * ACC_LD + d;
           float sum = 0.f;
           for (int g = 0; g < grp; ++g) sum += src[g * (32 * ACC_LD)];
+          if (pass == 0 && p.rope_cos && D == 64) {          // inverse RoPE on dK: partner column d +- 32
+            const float* srp = src + (d < 32 ? 32 : -32);
+            float other = 0.f;
+            for (int g = 0; g < grp; ++g) other += srp[g * (32 * ACC_LD)];
+            const float c = p.rope_cos[(long long)kg * 32 + (d & 31)], sn = p.rope_sin[(long long)kg * 32 + (d & 31)];
+            sum = d < 32 ? sum * c + other * sn : sum * c - other * sn;
+          }
           outp[(long long)b * o_sb + (long long)kg * o_ss + hkv * D + d] = f2bf(sum);
         }
       }
     }
     return;
+  }
+  if (p.rope_cos && G::DT == 2) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int d = 8 * g + 4 * h + j;
+        const float c = p.rope_cos[(long long)kc * 32 + d], sn = p.rope_sin[(long long)kc * 32 + d];
+        const float a = dK[0][4 * g + j], bb = dK[G::DT - 1][4 * g + j];
+        dK[0][4 * g + j] = a * c + bb * sn;
+        dK[G::DT - 1][4 * g + j] = bb * c - a * sn;
+      }
   }
   if (hh == 0 && ki < p.Sk) {
     bf16_t* okp = p.dk + (long long)b * p.dk_sb + (long long)ki * p.dk_ss + hkv * D;
@@ -455,6 +487,8 @@ int fill(AttnP& p, const vla_attn_desc* d, bool bwd) {
     p.dout = (const bf16_t*)d->dout; p.dq = (bf16_t*)d->dq; p.dk = (bf16_t*)d->dk; p.dv = (bf16_t*)d->dv; p.delta = d->delta;
     p.do_sb = d->do_sb; p.dq_sb = d->dq_sb; p.dk_sb = d->dk_sb; p.dv_sb = d->dv_sb;
     p.do_ss = d->do_ss; p.dq_ss = d->dq_ss; p.dk_ss = d->dk_ss; p.dv_ss = d->dv_ss;
+    p.rope_cos = d->rope_cos; p.rope_sin = d->rope_sin;
+    if (d->rope_cos) VLA_REQUIRE(d->rope_sin && d->dh == 64 && d->Sq == d->Sk, "attn_bwd: fused inverse RoPE needs dh == 64 (tables f32 [S, 32])");
   }
   return VLA_OK;
 }

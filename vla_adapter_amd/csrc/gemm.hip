@@ -38,6 +38,7 @@ struct GemmP {
   int tiles_n, ntiles;
   float alpha;
   int gA, gC; long long sgA, sgC;  // row-group addressing: row r -> (r / g) * sg + (r % g) * ld
+  int rope_mode, rope_T, rope_dh, rope_cols; const float* rope_cos; const float* rope_sin;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -212,6 +213,43 @@ __global__ __launch_bounds__((BM / 64) * 128) void gemm_nt_kernel(GemmP p) {
           if (p.act != VLA_ACT_NONE) v = apply_act(rbf(v), p.act);
           acc[ni][mi][j] = v;
         }
+    // ---- fused rotary embedding on the projected q/k columns (saves a full read+write pass per projection)
+    if (p.rope_mode != 0 && wn0 < p.rope_cols) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int pos = min(wm0 + mi * 16 + lr, p.M - 1) % p.rope_T;
+        if (p.rope_mode == 2) {
+          // action_heads.py:125-146: pairs (2i, 2i+1), cos/sin tables of cat([f, f]) (different frequency per lane of a pair)
+#pragma unroll
+          for (int ni = 0; ni < C::NT; ++ni) {
+            const int d = (wn0 + ni * 16 + lq * 4) % p.rope_dh;
+            const float4 c = *reinterpret_cast<const float4*>(p.rope_cos + (long long)pos * p.rope_dh + d);
+            const float4 sn = *reinterpret_cast<const float4*>(p.rope_sin + (long long)pos * p.rope_dh + d);
+            const float x0 = rbf(acc[ni][mi][0]), x1 = rbf(acc[ni][mi][1]), x2 = rbf(acc[ni][mi][2]), x3 = rbf(acc[ni][mi][3]);
+            acc[ni][mi][0] = rbf(x0 * c.x) + rbf(-x1 * sn.x);
+            acc[ni][mi][1] = rbf(x1 * c.y) + rbf(x0 * sn.y);
+            acc[ni][mi][2] = rbf(x2 * c.z) + rbf(-x3 * sn.z);
+            acc[ni][mi][3] = rbf(x3 * c.w) + rbf(x2 * sn.w);
+          }
+        } else if (C::NT == 4) {
+          // HF rotate_half, head dim 64 == this wave's 64 columns: d <-> d+32 are tiles ni and ni+2 of the same lane
+          const int half = p.rope_dh >> 1;
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            const int d = ni * 16 + lq * 4;
+            const float4 c = *reinterpret_cast<const float4*>(p.rope_cos + (long long)pos * half + d);
+            const float4 sn = *reinterpret_cast<const float4*>(p.rope_sin + (long long)pos * half + d);
+            const float cc[4] = {c.x, c.y, c.z, c.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float a = rbf(acc[ni][mi][j]), b = rbf(acc[ni + 2][mi][j]);
+              acc[ni][mi][j] = rbf(a * cc[j]) + rbf(-b * ss[j]);
+              acc[ni + 2][mi][j] = rbf(b * cc[j]) + rbf(a * ss[j]);
+            }
+          }
+        }
+      }
+    }
   }
 
   // stage the wave's 64 x WTN tile (bf16) through its private LDS region, then store 16 B per lane
@@ -270,7 +308,8 @@ __global__ __launch_bounds__((BM / 64) * 128) void gemm_nt_kernel(GemmP p) {
 //    narrow tile ~10 % less efficient per FLOP on short K and ~35 % on long K (less operand reuse per LDS byte):
 //    M=11264,N=896,K=896 -> 616 tiles on 512 slots wastes 40 % with 128x128 (507 TF/s) vs 578 TF/s with 128x64.
 struct TileChoice { int bm, bn; };
-inline TileChoice choose_tile(int M, int N, int K, int force) {
+inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode) {
+  if (rope_mode == 1) return {128, 128};   // rotate_half pairs live in one wave's 64-column tile
   if (force == 1) return {256, 128};
   if (force == 2) return {128, 128};
   if (force == 3) return {128, 64};
@@ -332,8 +371,17 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   p.tiles_n = p.ntiles = 0;
   p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
   p.gA = d->a_group; p.sgA = d->a_group_stride; p.gC = d->c_group; p.sgC = d->c_group_stride;
+  p.rope_mode = d->rope_mode; p.rope_T = d->rope_T; p.rope_dh = d->rope_dh; p.rope_cols = d->rope_cols;
+  p.rope_cos = d->rope_cos; p.rope_sin = d->rope_sin;
+  if (d->rope_mode != 0) {
+    VLA_REQUIRE(d->rope_mode == 1 || d->rope_mode == 2, "gemm: rope_mode 0/1/2");
+    VLA_REQUIRE(d->rope_cos && d->rope_sin && d->rope_T > 0 && d->rope_dh > 0 && d->rope_dh % 4 == 0 && d->rope_cols % 64 == 0 &&
+                    (((uintptr_t)d->rope_cos | (uintptr_t)d->rope_sin) & 15) == 0 && d->act != VLA_ACT_SWIGLU,
+                "gemm: bad rope arguments");
+    if (d->rope_mode == 1) VLA_REQUIRE(d->rope_dh == 64, "gemm: fused rotate_half RoPE needs head dim 64");
+  }
   const char* e = getenv("VLA_GEMM_TILE");     // 0/unset auto, 1: 256x128, 2: 128x128, 3: 128x64  (benchmarking aid)
-  const TileChoice tc = choose_tile(d->M, d->N, d->K, e ? atoi(e) : 0);
+  const TileChoice tc = choose_tile(d->M, d->N, d->K, e ? atoi(e) : 0, d->rope_mode);
   hipStream_t st = (hipStream_t)stream;
   if (tc.bm == 256) launch<256, 128, 3>(p, d->M, d->N, d->batch, st);
   else if (tc.bn == 128) launch<128, 128, 2>(p, d->M, d->N, d->batch, st);

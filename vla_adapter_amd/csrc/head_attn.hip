@@ -239,6 +239,8 @@ int fill(HP& p, const vla_head_attn_desc* d, bool bwd) {
     p.dout = (const bf16_t*)d->dout; p.dq = (bf16_t*)d->dq; p.dks = (bf16_t*)d->dk_self; p.dvs = (bf16_t*)d->dv_self;
     p.dka = (bf16_t*)d->dk_adp; p.dva = (bf16_t*)d->dv_adp; p.dkt = (bf16_t*)d->dk_task; p.dvt = (bf16_t*)d->dv_task;
     p.dgate = d->dgate;
+    p.rope_cos = d->rope_cos; p.rope_sin = d->rope_sin;
+    if (d->rope_cos) VLA_REQUIRE(d->rope_sin && (((uintptr_t)d->rope_cos | (uintptr_t)d->rope_sin) & 15) == 0 && d->dh % 4 == 0, "head_attn_bwd: rope tables");
   }
   return VLA_OK;
 }
@@ -284,5 +286,12 @@ extern "C" int vla_head_attn_bwd(void* stream, const vla_head_attn_desc* d) {
   }
   hipLaunchKernelGGL(head_attn_bwd_kernel, dim3(p.B * p.H), dim3(256), lds, (hipStream_t)stream, p);
   VLA_CHECK_LAUNCH("head_attn_bwd");
+  if (p.rope_cos) {   // VALU fallback: apply the RoPE transpose with the stand-alone kernel (same contract as the MFMA path)
+    int rc = vla_rope_interleaved(stream, p.dq, p.rope_cos, p.rope_sin, p.B * p.T, p.T, p.H, p.dh, p.ld_q, 1);
+    if (!rc) rc = vla_rope_interleaved(stream, p.dks, p.rope_cos, p.rope_sin, p.B * p.T, p.T, p.H, p.dh, p.ld_self, 1);
+    if (!rc) rc = vla_rope_interleaved(stream, p.dka, p.rope_cos, p.rope_sin, p.B * p.Ka, p.Ka, p.H, p.dh, p.ld_adp, 1);
+    if (!rc) rc = vla_rope_interleaved(stream, p.dkt, p.rope_cos, p.rope_sin, p.B * p.Kt, p.Kt, p.H, p.dh, p.ld_task, 1);
+    if (rc) return rc;
+  }
   return VLA_OK;
 }

@@ -61,6 +61,26 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// transpose of the action head's RoPE map on a 32-row accumulator tile set (lane = row, registers = d): pairs (2i, 2i+1)
+template <int DT>
+__device__ __forceinline__ void rope_inter_bwd_acc(f32x16 (&X)[DT], const float* ct, const float* st, int pos, int dh, int D, int h) {
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d = 32 * t + 8 * g + 4 * h;
+      if (d < D) {
+        const float4 c = *reinterpret_cast<const float4*>(ct + (long long)pos * dh + d);
+        const float4 s = *reinterpret_cast<const float4*>(st + (long long)pos * dh + d);
+        const float a0 = X[t][4 * g], b0 = X[t][4 * g + 1], a1 = X[t][4 * g + 2], b1 = X[t][4 * g + 3];
+        X[t][4 * g] = a0 * c.x + b0 * s.y;
+        X[t][4 * g + 1] = b0 * c.y - a0 * s.x;
+        X[t][4 * g + 2] = a1 * c.z + b1 * s.w;
+        X[t][4 * g + 3] = b1 * c.w - a1 * s.z;
+      }
+    }
+}
+
 // score chain of the reference's bf16 module; returns the score in log2 domain (or -inf for padded keys)
 __device__ __forceinline__ float score_chain(float dot, bool gated, float tg, float rs, bool valid) {
   float s = rbf(dot);
@@ -226,6 +246,7 @@ __global__ __launch_bounds__(256) void head_dq_mfma(HP p) {
     }
     wave_lds_sync();
   }
+  if (p.rope_cos) rope_inter_bwd_acc<G::DT>(dQ, p.rope_cos, p.rope_sin, qc, D, D, h);
   if (qi < p.T) {
     bf16_t* op = p.dq + ((long long)b * p.T + qi) * p.ld_q + hoff;
 #pragma unroll
@@ -311,6 +332,10 @@ __global__ __launch_bounds__(256) void head_dkv_mfma(HP p) {
         dV[t] = mfma32(tr_frag(sdO, G::LD, s, 32 * t, lane), pf, dV[t]);   // dV^T[d x key] = dO^T . P
         dK[t] = mfma32(tr_frag(sQ, G::LD, s, 32 * t, lane), dsf, dK[t]);   // dK^T[d x key] = Q^T . dDot
       }
+    }
+    if (p.rope_cos) {
+      const int pos = kc < p.T ? kc : (kc < p.T + p.Ka ? kc - p.T : kc - p.T - p.Ka);   // positions restart per segment
+      rope_inter_bwd_acc<G::DT>(dK, p.rope_cos, p.rope_sin, pos, D, D, h);
     }
     if (key < N) {
       bf16_t* okp = const_cast<bf16_t*>(hrow(p.dks, p.dka, p.dkt, p, b, key, hoff));

@@ -7,6 +7,7 @@ struct HP {
   const bf16_t* gate; bf16_t* out; float* probs;
   int B, T, Ka, Kt, H, dh, ld_q, ld_self, ld_adp, ld_task, ld_out;
   const bf16_t* dout; bf16_t* dq; bf16_t* dks; bf16_t* dvs; bf16_t* dka; bf16_t* dva; bf16_t* dkt; bf16_t* dvt; float* dgate;
+  const float* rope_cos; const float* rope_sin;   // optional [>= max(T,Ka,Kt), dh]: fold the RoPE transpose into dq / dk
 };
 
 bool head_attn_mfma_supported(const HP& p);

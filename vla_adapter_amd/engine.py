@@ -251,9 +251,12 @@ class LLM:
             x = self.HS[i].view(M, D)
             self._rms(x, L["n1"], self.nbuf, self.R1[i])
             qkv = self.QKV[i]
-            ops.gemm_nt(self.nbuf, L["wqkv"], bias=L["bqkv"], out=qkv)
-            ops.rope_half_(qkv[:, :H * dh], self.cos, self.sin, S, H, dh)
-            ops.rope_half_(qkv[:, H * dh:(H + KV) * dh], self.cos, self.sin, S, KV, dh)
+            if dh == 64:          # RoPE fused into the projection's epilogue
+                ops.gemm_nt(self.nbuf, L["wqkv"], bias=L["bqkv"], out=qkv, rope=(1, self.cos, self.sin, S, dh, (H + KV) * dh))
+            else:
+                ops.gemm_nt(self.nbuf, L["wqkv"], bias=L["bqkv"], out=qkv)
+                ops.rope_half_(qkv[:, :H * dh], self.cos, self.sin, S, H, dh)
+                ops.rope_half_(qkv[:, H * dh:(H + KV) * dh], self.cos, self.sin, S, KV, dh)
             q3 = qkv.view(B, S, -1)
             self._attn_fwd(q3, i, B, S)
             x1 = self.X1[i]
@@ -300,9 +303,10 @@ class LLM:
             q, k, v = self._attn_views(q3)
             dq, dk, dv = self._attn_views(self.d_qkv.view(B, S, -1))
             ops.attn_bwd(dao.view(B, S, -1), q, k, v, self.AO[i].view(B, S, -1), self.LSE[i], H, KV, dh, True, self.kmask,
-                         dq=dq, dk=dk, dv=dv)
-            ops.rope_half_(self.d_qkv[:, :H * dh], self.cos, self.sin, S, H, dh, sign=-1)
-            ops.rope_half_(self.d_qkv[:, H * dh:(H + KV) * dh], self.cos, self.sin, S, KV, dh, sign=-1)
+                         dq=dq, dk=dk, dv=dv, rope=(self.cos, self.sin) if dh == 64 else None)
+            if dh != 64:
+                ops.rope_half_(self.d_qkv[:, :H * dh], self.cos, self.sin, S, H, dh, sign=-1)
+                ops.rope_half_(self.d_qkv[:, H * dh:(H + KV) * dh], self.cos, self.sin, S, KV, dh, sign=-1)
             ops.gemm_nt(self.d_qkv, L["wqkvT"], out=self.d_n)
             d_new = ops.rmsnorm_bwd(self.d_n, self.HS[i].view(M, D), L["n1"], self.R1[i], dres=d1, out=d)
             d, other = d_new, d1
@@ -365,10 +369,7 @@ class Head:
         self.pfc1_pad = z(D, 64)                   # proprio fc1 weight zero-padded to K=64
         self.dirty = True
         self._key = None
-        dh = D // self.H
-        self.rope_x = ops.rope_inter_tables(cfg.chunk, dh, device)
-        self.rope_a = ops.rope_inter_tables(NUM_TOKENS + 1, dh, device)
-        self.rope_t = {}
+        self.rope_tab = None     # f32 [max(T, Ka, Kt), dh] cos/sin tables (positions restart per segment: one table serves all)
 
     # ---- reference state-dict interop (file names / keys: finetune.py:527-572) -------------------------
     _BLK = [("q_proj", "w_x", "b_x", 0), ("k_self", "w_x", "b_x", 1), ("v_self", "w_x", "b_x", 2),
@@ -459,8 +460,7 @@ class Head:
         self.h_adpT, self.dKV_adpT = z(nb, D, self.AK), z(nb, 2 * D, self.AK)
         self.h_taskT, self.dKV_taskT = z(nb, D, self.TK), z(nb, 2 * D, self.TK)
         self.dh_adp = e(nb, B * Ka, D)
-        if Kt not in self.rope_t:
-            self.rope_t[Kt] = ops.rope_inter_tables(Kt, D // self.H, dev)
+        self.rope_tab = ops.rope_inter_tables(max(T, Ka, Kt), D // self.H, dev)
         self._key = (B, Kt)
 
     # ---- forward (action_heads.py:43-81, 111-121, 337-410) -------------------------------------------------
@@ -491,12 +491,12 @@ class Head:
         self.h_adp[:, :, :NUM_TOKENS] = tmp.view(nb, B, NUM_TOKENS, D)
         self.h_adp[:, :, NUM_TOKENS] = pf
         # K/V of the adapter and task segments for all blocks at once (batched over the 24 layers)
-        ops.gemm_nt(self.h_adp.view(nb, B * Ka, D), P.view("w_adp"), bias=P.view("b_adp"), out=self.KV_adp)
-        ops.rope_inter_(self.KV_adp.view(nb * B * Ka, 2 * D)[:, :D], *self.rope_a, Ka, H, dh, 0)
+        rc, rs_ = self.rope_tab       # RoPE (action_heads.py:383-388) is fused into the projections' epilogues (K halves only)
+        ops.gemm_nt(self.h_adp.view(nb, B * Ka, D), P.view("w_adp"), bias=P.view("b_adp"), out=self.KV_adp,
+                    rope=(2, rc, rs_, Ka, dh, D))
         for i in range(nb):   # task tokens = HS[i+1][:, :Np] read in place (row-group addressing)
             ops.gemm_nt(HS[i + 1].view(B * S, D)[:B * Kt], P.view("w_task")[i], bias=P.view("b_task")[i], out=self.KV_task[i],
-                        a_group=(Kt, S * D))
-        ops.rope_inter_(self.KV_task.view(nb * B * Kt, 2 * D)[:, :D], *self.rope_t[Kt], Kt, H, dh, 0)
+                        a_group=(Kt, S * D), rope=(2, rc, rs_, Kt, dh, D))
         # input: zeros (+ noise in the Training phase) -> LN -> fc1 -> ReLU   (action_heads.py:60-72, 113-115)
         if noise is not None:
             self.x_in.view(B, T, self.Din).copy_(noise.to(BF16)[None].expand(B, T, self.Din))
@@ -507,8 +507,7 @@ class Head:
         for i in range(nb):
             x = self.X[i]
             qkv = self.QKVx[i]
-            ops.gemm_nt(x, P.view("w_x")[i], bias=P.view("b_x")[i], out=qkv)
-            ops.rope_inter_(qkv[:, :2 * D], *self.rope_x, T, 2 * H, dh, 0)       # q and k_self share positions 0..T-1
+            ops.gemm_nt(x, P.view("w_x")[i], bias=P.view("b_x")[i], out=qkv, rope=(2, rc, rs_, T, dh, 2 * D))  # q, k_self: pos 0..T-1
             self._attn(i, fwd=True)
             ops.gemm_nt(self.AOx[i], P.view("w_o")[i], bias=P.view("b_o")[i], residual=x, out=self.O2[i])
             self._ln(self.O2[i], P.view("ln_w")[i], P.view("ln_b")[i], self.LNo[i], self.stats[i])
@@ -538,7 +537,7 @@ class Head:
             ga = self.dKV_adp[i].view(B, Ka, 2 * D)
             gt = self.dKV_task[i].view(B, Kt, 2 * D)
             ops.head_attn_bwd(dout.view(B, T, D), out, *args, gate, self.probs[i], self.dgate[i:i + 1], g[:, :, :D], g[:, :, D:2 * D],
-                              g[:, :, 2 * D:], ga[:, :, :D], ga[:, :, D:], gt[:, :, :D], gt[:, :, D:], H)
+                              g[:, :, 2 * D:], ga[:, :, :D], ga[:, :, D:], gt[:, :, :D], gt[:, :, D:], H, rope=self.rope_tab)
 
     # ---- backward ---------------------------------------------------------------------------------------------
     def backward(self, dpred: torch.Tensor, dHS: torch.Tensor):
@@ -565,8 +564,7 @@ class Head:
             do2 = self.dO2[i]
             self._ln_bwd(d_ln, self.O2[i], P.view("ln_w")[i], self.stats[i], do2, self.ln_dw[i], self.ln_db[i])
             d_ao = ops.gemm_nt(do2, self.T["w_o"][i])
-            self._attn(i, fwd=False, dout=d_ao)
-            ops.rope_inter_(self.dQKVx[i][:, :2 * D], *self.rope_x, T, 2 * H, dh, 1)
+            self._attn(i, fwd=False, dout=d_ao)          # returns dq / dk already through the RoPE transpose
             dx = ops.gemm_nt(self.dQKVx[i], self.T["w_x"][i], residual=do2)
         # input stage: relu -> fc1 -> layer_norm1 (input is noise/zeros: only parameter gradients)
         dy1 = ops.relu_bwd(dx, self.X[0])
@@ -574,9 +572,7 @@ class Head:
         G("fc1_w").copy_(self._dw(dy1, self.x_ln))
         d_xln = ops.gemm_nt(dy1, self._t(P.view("fc1_w")))
         ops.layernorm_bwd(d_xln, self.x_in, P.view("ln1_w"), self.st1, self.ln1_dw, self.ln1_db, want_dx=False)
-        # RoPE backward on the K halves, then everything that is batched over the 24 blocks
-        ops.rope_inter_(self.dKV_adp.view(nb * B * Ka, 2 * D)[:, :D], *self.rope_a, Ka, H, dh, 1)
-        ops.rope_inter_(self.dKV_task.view(nb * B * Kt, 2 * D)[:, :D], *self.rope_t[Kt], Kt, H, dh, 1)
+        # everything that is batched over the 24 blocks
         # d h_adapter -> scatter into dHS (action positions) + proprio token gradient
         ops.gemm_nt(self.dKV_adp, self.T["w_adp"], out=self.dh_adp)
         dha = self.dh_adp.view(nb, B, Ka, D)

@@ -25,7 +25,9 @@ class GemmDesc(C.Structure):
                 ("ldr", C.c_int), ("ldc2", C.c_int), ("res_mod", C.c_int), ("act", C.c_int), ("batch", C.c_int),
                 ("sA", C.c_longlong), ("sB", C.c_longlong), ("sC", C.c_longlong), ("sR", C.c_longlong),
                 ("sC2", C.c_longlong), ("sBias", C.c_longlong), ("alpha", C.c_float),
-                ("a_group", C.c_int), ("c_group", C.c_int), ("a_group_stride", C.c_longlong), ("c_group_stride", C.c_longlong)]
+                ("a_group", C.c_int), ("c_group", C.c_int), ("a_group_stride", C.c_longlong), ("c_group_stride", C.c_longlong),
+                ("rope_mode", C.c_int), ("rope_T", C.c_int), ("rope_dh", C.c_int), ("rope_cols", C.c_int),
+                ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p)]
 
 
 class AttnDesc(C.Structure):
@@ -37,7 +39,8 @@ class AttnDesc(C.Structure):
                 ("causal", C.c_int), ("scale", C.c_float),
                 ("dout", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p), ("delta", C.c_void_p),
                 ("do_sb", C.c_longlong), ("dq_sb", C.c_longlong), ("dk_sb", C.c_longlong), ("dv_sb", C.c_longlong),
-                ("do_ss", C.c_int), ("dq_ss", C.c_int), ("dk_ss", C.c_int), ("dv_ss", C.c_int)]
+                ("do_ss", C.c_int), ("dq_ss", C.c_int), ("dk_ss", C.c_int), ("dv_ss", C.c_int),
+                ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p)]
 
 
 class HeadAttnDesc(C.Structure):
@@ -49,7 +52,7 @@ class HeadAttnDesc(C.Structure):
                 ("gate_on_adapter", C.c_int),
                 ("dout", C.c_void_p), ("dq", C.c_void_p), ("dk_self", C.c_void_p), ("dv_self", C.c_void_p),
                 ("dk_adp", C.c_void_p), ("dv_adp", C.c_void_p), ("dk_task", C.c_void_p), ("dv_task", C.c_void_p),
-                ("dgate", C.c_void_p)]
+                ("dgate", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p)]
 
 
 _P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double

@@ -37,7 +37,7 @@ def _chk_bf16(*ts):
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_mod: int = 0, act: int = ACT_NONE,
             out: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, alpha: float = 1.0,
-            want_pre: bool = True, a_group=None, c_group=None) -> torch.Tensor:
+            want_pre: bool = True, a_group=None, c_group=None, rope=None) -> torch.Tensor:
     """C = epilogue(A @ B^T).  a: [M,K] or [batch,M,K] (row stride = a.stride(-2)); b: [N,K] or [batch,N,K].
     SwiGLU: returns (pre [.., N] or None, h [.., N/2])."""
     _chk_bf16(a, b, bias, residual, out, out2)
@@ -82,6 +82,12 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_m
         d.a_group, d.a_group_stride = a_group
     if c_group is not None:
         d.c_group, d.c_group_stride = c_group
+    if rope is not None:         # (mode, cos, sin, T, dh, ncols): fused rotary embedding on output columns [0, ncols)
+        mode, cos_t, sin_t, T, dh, ncols = rope
+        assert cos_t.dtype == torch.float32 and cos_t.is_contiguous() and sin_t.is_contiguous() and cos_t.shape[0] >= T
+        assert cos_t.shape[1] == (dh // 2 if mode == 1 else dh)
+        d.rope_mode, d.rope_T, d.rope_dh, d.rope_cols = mode, T, dh, ncols
+        d.rope_cos, d.rope_sin = cos_t.data_ptr(), sin_t.data_ptr()
     N.check(_lib().vla_gemm_bf16_nt(_st(), C.byref(d)), "gemm_bf16_nt")
     if act == ACT_SWIGLU:
         return out, out2
@@ -176,7 +182,7 @@ def attn_fwd(q, k, v, Hq: int, Hkv: int, dh: int, causal: bool, kmask=None, scal
 
 
 def attn_bwd(dout, q, k, v, o, lse, Hq: int, Hkv: int, dh: int, causal: bool, kmask=None,
-             scale: Optional[float] = None, dq=None, dk=None, dv=None):
+             scale: Optional[float] = None, dq=None, dk=None, dv=None, rope=None):
     _chk_bf16(dout, q, k, v, o)
     B, Sq, Sk = q.shape[0], q.shape[1], k.shape[1]
     dq = torch.empty(B, Sq, Hq * dh, device=q.device, dtype=BF16) if dq is None else dq
@@ -187,6 +193,9 @@ def attn_bwd(dout, q, k, v, o, lse, Hq: int, Hkv: int, dh: int, causal: bool, km
     d.dout, d.dq, d.dk, d.dv, d.delta = dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr()
     d.do_sb, d.dq_sb, d.dk_sb, d.dv_sb = dout.stride(0), dq.stride(0), dk.stride(0), dv.stride(0)
     d.do_ss, d.dq_ss, d.dk_ss, d.dv_ss = dout.stride(1), dq.stride(1), dk.stride(1), dv.stride(1)
+    if rope is not None:          # (cos, sin) f32 [S, dh/2]: dq/dk come back through the inverse rotate_half RoPE
+        assert rope[0].shape == (Sq, dh // 2) and rope[0].dtype == torch.float32
+        d.rope_cos, d.rope_sin = rope[0].data_ptr(), rope[1].data_ptr()
     N.check(_lib().vla_attn_bwd(_st(), C.byref(d)), "attn_bwd")
     return dq, dk, dv
 
@@ -346,7 +355,8 @@ def head_attn_fwd(q, ks, vs, ka, va, kt, vt, gate, H: int = 8):
     return out, probs
 
 
-def head_attn_bwd(dout, out, q, ks, vs, ka, va, kt, vt, gate, probs, dgate_f32, dq, dks, dvs, dka, dva, dkt, dvt, H: int = 8):
+def head_attn_bwd(dout, out, q, ks, vs, ka, va, kt, vt, gate, probs, dgate_f32, dq, dks, dvs, dka, dva, dkt, dvt, H: int = 8,
+                  rope=None):
     """``out`` = the forward output, ``probs`` = the forward's workspace.  Gradient tensors are caller-provided views
     with the SAME row strides as their forward counterparts."""
     _chk_bf16(dout, out, dq, dks, dvs, dka, dva, dkt, dvt)
@@ -357,6 +367,9 @@ def head_attn_bwd(dout, out, q, ks, vs, ka, va, kt, vt, gate, probs, dgate_f32, 
         assert g.stride(1) == f.stride(1) and g.stride(-1) == 1, "grad views must mirror forward strides"
     d.dq, d.dk_self, d.dv_self, d.dk_adp, d.dv_adp, d.dk_task, d.dv_task = (t.data_ptr() for t in (dq, dks, dvs, dka, dva, dkt, dvt))
     d.dgate = dgate_f32.data_ptr()
+    if rope is not None:          # (cos, sin) f32 [>= max(T,Ka,Kt), dh]: dq / dk come back through the RoPE transpose
+        assert rope[0].shape[0] >= max(q.shape[1], ka.shape[1], kt.shape[1]) and rope[0].shape[1] == d.dh
+        d.rope_cos, d.rope_sin = rope[0].data_ptr(), rope[1].data_ptr()
     N.check(_lib().vla_head_attn_bwd(_st(), C.byref(d)), "head_attn_bwd")
 
 
