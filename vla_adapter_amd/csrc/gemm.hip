@@ -66,7 +66,9 @@ struct Cfg {
   static_assert(PIECES % NW == 0, "pieces must divide evenly over the waves");
 };
 
-template <int BM, int BN, int STAGES>
+// ROPE is a compile-time switch (0 none / 1 rotate_half / 2 interleaved): the epilogue's extra registers and table
+// loads must not leak into the plain kernel that every other GEMM of the step runs.
+template <int BM, int BN, int STAGES, int ROPE>
 __global__ __launch_bounds__((BM / 64) * 128) void gemm_nt_kernel(GemmP p) {
   using C = Cfg<BM, BN, STAGES>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -214,11 +216,11 @@ __global__ __launch_bounds__((BM / 64) * 128) void gemm_nt_kernel(GemmP p) {
           acc[ni][mi][j] = v;
         }
     // ---- fused rotary embedding on the projected q/k columns (saves a full read+write pass per projection)
-    if (p.rope_mode != 0 && wn0 < p.rope_cols) {
+    if (ROPE != 0 && wn0 < p.rope_cols) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
         const int pos = min(wm0 + mi * 16 + lr, p.M - 1) % p.rope_T;
-        if (p.rope_mode == 2) {
+        if (ROPE == 2) {
           // action_heads.py:125-146: pairs (2i, 2i+1), cos/sin tables of cat([f, f]) (different frequency per lane of a pair)
 #pragma unroll
           for (int ni = 0; ni < C::NT; ++ni) {
@@ -231,7 +233,7 @@ __global__ __launch_bounds__((BM / 64) * 128) void gemm_nt_kernel(GemmP p) {
             acc[ni][mi][2] = rbf(x2 * c.z) + rbf(-x3 * sn.z);
             acc[ni][mi][3] = rbf(x3 * c.w) + rbf(x2 * sn.w);
           }
-        } else if (C::NT == 4) {
+        } else if (ROPE == 1 && C::NT == 4) {
           // HF rotate_half, head dim 64 == this wave's 64 columns: d <-> d+32 are tiles ni and ni+2 of the same lane
           const int half = p.rope_dh >> 1;
 #pragma unroll
@@ -310,7 +312,7 @@ __global__ __launch_bounds__((BM / 64) * 128) void gemm_nt_kernel(GemmP p) {
 struct TileChoice { int bm, bn; };
 inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode) {
   if (rope_mode == 1) return {128, 128};   // rotate_half pairs live in one wave's 64-column tile
-  if (force == 1) return {256, 128};
+  if (force == 1 && rope_mode == 0) return {256, 128};
   if (force == 2) return {128, 128};
   if (force == 3) return {128, 64};
   if (M >= 8192 && N >= 8192 && K >= 8192) return {256, 128};   // with group-M order 128x128 is within 2 % even there
@@ -324,7 +326,7 @@ inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode) {
   return c128 <= c64 ? TileChoice{128, 128} : TileChoice{128, 64};
 }
 
-template <int BM, int BN, int STAGES>
+template <int BM, int BN, int STAGES, int ROPE>
 int launch(const GemmP& p0, int M, int N, int batch, hipStream_t st) {
   using C = Cfg<BM, BN, STAGES>;
   GemmP p = p0;
@@ -332,10 +334,10 @@ int launch(const GemmP& p0, int M, int N, int batch, hipStream_t st) {
   p.ntiles = ((M + BM - 1) / BM) * p.tiles_n;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, STAGES, ROPE>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, STAGES>), dim3(p.ntiles, 1, batch), dim3(C::NTHREADS), C::LDS_BYTES, st, p);
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, STAGES, ROPE>), dim3(p.ntiles, 1, batch), dim3(C::NTHREADS), C::LDS_BYTES, st, p);
   return 0;
 }
 
@@ -383,9 +385,13 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   const char* e = getenv("VLA_GEMM_TILE");     // 0/unset auto, 1: 256x128, 2: 128x128, 3: 128x64  (benchmarking aid)
   const TileChoice tc = choose_tile(d->M, d->N, d->K, e ? atoi(e) : 0, d->rope_mode);
   hipStream_t st = (hipStream_t)stream;
-  if (tc.bm == 256) launch<256, 128, 3>(p, d->M, d->N, d->batch, st);
-  else if (tc.bn == 128) launch<128, 128, 2>(p, d->M, d->N, d->batch, st);
-  else launch<128, 64, 3>(p, d->M, d->N, d->batch, st);
+  if (d->rope_mode == 1) launch<128, 128, 2, 1>(p, d->M, d->N, d->batch, st);
+  else if (d->rope_mode == 2) {
+    if (tc.bn == 128) launch<128, 128, 2, 2>(p, d->M, d->N, d->batch, st);
+    else launch<128, 64, 3, 2>(p, d->M, d->N, d->batch, st);
+  } else if (tc.bm == 256) launch<256, 128, 3, 0>(p, d->M, d->N, d->batch, st);
+  else if (tc.bn == 128) launch<128, 128, 2, 0>(p, d->M, d->N, d->batch, st);
+  else launch<128, 64, 3, 0>(p, d->M, d->N, d->batch, st);
   VLA_CHECK_LAUNCH("gemm_bf16_nt");
   return VLA_OK;
 }

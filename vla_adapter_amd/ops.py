@@ -226,7 +226,7 @@ def rope_inter_tables(T: int, dh: int, device, base: float = 10000.0):
 
 def rope_inter_(x2d: torch.Tensor, cos_t, sin_t, T: int, nheads: int, dh: int, mode: int = 0):
     _chk_bf16(x2d)
-    assert x2d.stride(-1) == 1 and cos_t.shape == (T, dh)
+    assert x2d.stride(-1) == 1 and cos_t.shape[0] >= T and cos_t.shape[1] == dh
     N.check(_lib().vla_rope_interleaved(_st(), _p(x2d), _p(cos_t), _p(sin_t), x2d.shape[0], T, nheads, dh, x2d.stride(0),
                                         mode), "rope_interleaved")
     return x2d
