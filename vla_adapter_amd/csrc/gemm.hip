@@ -145,19 +145,23 @@ __global__ __launch_bounds__((BM / 64) * 128) void gemm_nt_kernel(GemmP p) {
     }
     const char* sa = smem + buf * C::STAGE_BYTES + wr * 64 * 128;
     const char* sb = smem + buf * C::STAGE_BYTES + C::A_BYTES + wc * C::WTN * 128;
+    // all fragment reads of the K-tile (both 32-deep k-steps) are issued up front: the second k-step's LDS latency
+    // hides under the first k-step's MFMAs instead of stalling between them
+    bf16x8 fm[2][4], fn[2][C::NT];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 fm[4], fn[C::NT];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fm[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + foff[s]);
+      for (int i = 0; i < 4; ++i) fm[s][i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + foff[s]);
 #pragma unroll
-      for (int i = 0; i < C::NT; ++i) fn[i] = *reinterpret_cast<const bf16x8*>(sb + i * 16 * 128 + foff[s]);
+      for (int i = 0; i < C::NT; ++i) fn[s][i] = *reinterpret_cast<const bf16x8*>(sb + i * 16 * 128 + foff[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int ni = 0; ni < C::NT; ++ni)
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[ni], fm[mi], acc[ni][mi], 0, 0, 0);
-    }
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[s][ni], fm[s][mi], acc[ni][mi], 0, 0, 0);
     if (++buf == STAGES) buf = 0;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -491,12 +491,16 @@ class Head:
         self.h_adp[:, :, :NUM_TOKENS] = tmp.view(nb, B, NUM_TOKENS, D)
         self.h_adp[:, :, NUM_TOKENS] = pf
         # K/V of the adapter and task segments for all blocks at once (batched over the 24 layers)
-        rc, rs_ = self.rope_tab       # RoPE (action_heads.py:383-388) is fused into the projections' epilogues (K halves only)
-        ops.gemm_nt(self.h_adp.view(nb, B * Ka, D), P.view("w_adp"), bias=P.view("b_adp"), out=self.KV_adp,
-                    rope=(2, rc, rs_, Ka, dh, D))
+        rc, rs_ = self.rope_tab
+        # K/V of the adapter and task segments for all blocks at once.  Their RoPE (action_heads.py:383-388) stays a
+        # stand-alone pass: ONE launch covers all 24 blocks (~0.1 ms), whereas a fused GEMM epilogue paid ~44 us of
+        # exposed table-load latency per block (measured with rocprofv3); the per-block x-path GEMM keeps it fused.
+        ops.gemm_nt(self.h_adp.view(nb, B * Ka, D), P.view("w_adp"), bias=P.view("b_adp"), out=self.KV_adp)
+        ops.rope_inter_(self.KV_adp.view(nb * B * Ka, 2 * D)[:, :D], rc, rs_, Ka, H, dh, 0)
         for i in range(nb):   # task tokens = HS[i+1][:, :Np] read in place (row-group addressing)
             ops.gemm_nt(HS[i + 1].view(B * S, D)[:B * Kt], P.view("w_task")[i], bias=P.view("b_task")[i], out=self.KV_task[i],
-                        a_group=(Kt, S * D), rope=(2, rc, rs_, Kt, dh, D))
+                        a_group=(Kt, S * D))
+        ops.rope_inter_(self.KV_task.view(nb * B * Kt, 2 * D)[:, :D], rc, rs_, Kt, H, dh, 0)
         # input: zeros (+ noise in the Training phase) -> LN -> fc1 -> ReLU   (action_heads.py:60-72, 113-115)
         if noise is not None:
             self.x_in.view(B, T, self.Din).copy_(noise.to(BF16)[None].expand(B, T, self.Din))
