@@ -18,7 +18,7 @@
 //     epilogue stages the wave's tile through LDS and stores whole row segments with 16-B lanes;
 //   * XCD-aware bijective tile order (T1).
 // Three instantiations: 256x128 (8 waves, 3 stages, 144 KiB LDS, 1 block/CU) for the large GEMMs, 128x128 (4 waves,
-// 2 stages, 2 blocks/CU) and 128x64 (4 waves, 3 stages, 72 KiB, 2 blocks/CU) - the host picks per problem by a
+// 2 stages, 2 blocks/CU) and 128x64 (4 waves, 2 stages, 48 KiB, 3 blocks/CU) - the host picks per problem by a
 // wave-quantisation model (a 616-tile problem on 512 slots wastes 40 % of the machine with 128x128 tiles).
 //
 // Epilogue rounding points follow the reference under bf16 autocast: bf16(acc+bias) -> act -> bf16 -> (+residual) -> bf16.
@@ -307,26 +307,21 @@ __global__ __launch_bounds__((BM / 64) * 128) void gemm_nt_kernel(GemmP p) {
 }
 
 // Pick the tile per problem.  Calibrated on MI355X (tools/bench_kernels.py, round 1):
-//  * 256x128 (3-stage, 1 block/CU) only pays on huge squares (8192^3: 1061 vs 1041 TF/s); on the hot-path shapes the
-//    128x128 tile at 2 blocks/CU wins once the tile order is L2-friendly (N=9728,K=896: 744 vs 677 TF/s) because the
-//    second resident workgroup computes while the first one is in its epilogue;
-//  * between 128x128 (2 blocks/CU) and 128x64 the choice is wave quantisation: cost = rounds x per-round work, with the
-//    narrow tile ~10 % less efficient per FLOP on short K and ~35 % on long K (less operand reuse per LDS byte):
-//    M=11264,N=896,K=896 -> 616 tiles on 512 slots wastes 40 % with 128x128 (507 TF/s) vs 578 TF/s with 128x64.
+//  * 256x128 (3-stage, 1 block/CU) only pays on huge squares (8192^3: 1136 vs 1069 TF/s);
+//  * 128x128 (2-stage, 2 blocks/CU = 512 resident tiles) vs 128x64 (2-stage, 3 blocks/CU = 768 resident half-tiles):
+//    wave quantisation decides.  cost = rounds x work per round; a round of narrow tiles covers 0.75x the output of a
+//    round of square tiles and is ~10 % (K <= 1152) to ~30 % (K >= 4096) less efficient per FLOP (measured).  E.g.
+//    M=11264,N=896,K=896: 616 square tiles = 2 rounds (2.0) vs 1232 narrow = 2 rounds x 0.75 x 1.1 (1.65): 625 vs 532 TF/s.
 struct TileChoice { int bm, bn; };
 inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode) {
   if (rope_mode == 1) return {128, 128};   // rotate_half pairs live in one wave's 64-column tile
   if (force == 1 && rope_mode == 0) return {256, 128};
   if (force == 2) return {128, 128};
   if (force == 3) return {128, 64};
-  if (M >= 8192 && N >= 8192 && K >= 8192) return {256, 128};   // with group-M order 128x128 is within 2 % even there
-  auto rounds = [&](int bm, int bn) {
-    const long long t = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
-    return (double)((t + 511) / 512);
-  };
-  const double c128 = rounds(128, 128);
-  if (c128 > 2.0) return {128, 128};        // quantisation only matters when the whole problem is 1-2 rounds of tiles
-  const double c64 = rounds(128, 64) * 0.5 * (K >= 4096 ? 1.35 : 1.10);
+  if (M >= 8192 && N >= 8192 && K >= 8192) return {256, 128};
+  const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128), t64 = (long long)((M + 127) / 128) * ((N + 63) / 64);
+  const double c128 = (double)((t128 + 511) / 512);
+  const double c64 = (double)((t64 + 767) / 768) * 0.75 * (K >= 4096 ? 1.3 : 1.1);
   return c128 <= c64 ? TileChoice{128, 128} : TileChoice{128, 64};
 }
 
@@ -392,10 +387,10 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   if (d->rope_mode == 1) launch<128, 128, 2, 1>(p, d->M, d->N, d->batch, st);
   else if (d->rope_mode == 2) {
     if (tc.bn == 128) launch<128, 128, 2, 2>(p, d->M, d->N, d->batch, st);
-    else launch<128, 64, 3, 2>(p, d->M, d->N, d->batch, st);
+    else launch<128, 64, 2, 2>(p, d->M, d->N, d->batch, st);
   } else if (tc.bm == 256) launch<256, 128, 3, 0>(p, d->M, d->N, d->batch, st);
   else if (tc.bn == 128) launch<128, 128, 2, 0>(p, d->M, d->N, d->batch, st);
-  else launch<128, 64, 3, 0>(p, d->M, d->N, d->batch, st);
+  else launch<128, 64, 2, 0>(p, d->M, d->N, d->batch, st);
   VLA_CHECK_LAUNCH("gemm_bf16_nt");
   return VLA_OK;
 }
