@@ -29,7 +29,7 @@ int vla_version(void);                 /* ABI version, currently 1 */
 const char* vla_last_error(void);      /* thread-local message of the last failing call */
 
 /* ---------------------------------------------------------------- GEMM */
-enum { VLA_ACT_NONE = 0, VLA_ACT_GELU = 1, VLA_ACT_RELU = 2, VLA_ACT_GELU_TANH = 3, VLA_ACT_SWIGLU = 4 };
+enum { VLA_ACT_NONE = 0, VLA_ACT_GELU = 1, VLA_ACT_RELU = 2, VLA_ACT_GELU_TANH = 3, VLA_ACT_SWIGLU = 4, VLA_ACT_SWIGLU_BWD = 5 };
 
 typedef struct vla_gemm_desc {
   const void* A;    /* [batch][M, K] bf16, row stride lda */
@@ -59,7 +59,9 @@ typedef struct vla_gemm_desc {
  * (:644-655), ProprioProjector (projectors.py:19-24), MLPResNet / MLPResNetBlock(_Pro) Linears
  * (action_heads.py:111-121, 337-410).  K % 64 == 0; lda, ldb % 8 == 0; M/N edges are handled.
  * VLA_ACT_SWIGLU: B rows interleaved in groups of 16 (rows 32t..32t+15 = gate[16t..], 32t+16.. = up[16t..]);
- * C (optional) receives the interleaved pre-activations, C2 the product. */
+ * C (optional) receives the interleaved pre-activations, C2 the product.
+ * VLA_ACT_SWIGLU_BWD: the product A.B^T is dH [M, N]; R = the forward's interleaved pre-activations GU [M, 2N];
+ * C receives dGU [M, 2N] (same interleave) - the SwiGLU backward fused into the dH GEMM, dH itself is never stored. */
 int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* desc /* host */);
 
 /* out[b][c, r] = in[b][r, c]; rows/cols of `in`; out has leading dim ldo >= rows (tail NOT touched: pre-zero it).

@@ -520,3 +520,23 @@ def test_head_attention_bwd_fused_rope_transpose(ops, D):
         ops.rope_inter_(ref, tabs[0], tabs[1], L, H, dh, 1)          # stand-alone transpose kernel on the un-fused gradient
         check(fus.reshape(B * L, D), f(ref), rel=8e-3, mx=3e-2, name=f"fused rope transpose L={L}")
     assert torch.equal(f(r3[:, :, 2 * D:]), f(g3[:, :, 2 * D:])) and torch.equal(f(ra[:, :, D:]), f(ga[:, :, D:]))
+
+
+def test_gemm_fused_swiglu_backward(ops):
+    """dGU from the fused epilogue == stand-alone swiglu_bwd(dH = d @ W_down)."""
+    M, D, I = 330, 128, 192
+    x, wg, wu = gen(M, D, seed=12), gen(I, D, seed=13, scale=0.1), gen(I, D, seed=14, scale=0.1)
+    w = torch.stack([wg.view(I // 16, 16, D), wu.view(I // 16, 16, D)], dim=1).reshape(2 * I, D)
+    gu, _ = ops.gemm_nt(x.to(DEV), w.to(DEV), act=ops.ACT_SWIGLU)
+    d, wdT = gen(M, D, seed=15), gen(I, D, seed=16, scale=0.1)          # wdT = W_down^T [I, D]
+    fused = ops.gemm_swiglu_bwd(d.to(DEV), wdT.to(DEV), gu)
+    dh = ops.gemm_nt(d.to(DEV), wdT.to(DEV))
+    ref = ops.swiglu_bwd(dh, gu)
+    check(fused, f(ref), rel=3e-3, name="fused swiglu bwd vs two-pass")
+    # and against autograd of the oracle math
+    G = f(gu).view(M, I // 16, 2, 16)
+    gg, uu = G[:, :, 0].reshape(M, I).requires_grad_(True), G[:, :, 1].reshape(M, I).requires_grad_(True)
+    dhr = O.linear(d.float(), wdT.float(), None, True)
+    ((gg * torch.sigmoid(gg)) * uu * dhr).sum().backward()
+    refa = torch.stack([gg.grad.view(M, I // 16, 16), uu.grad.view(M, I // 16, 16)], dim=2).reshape(M, 2 * I)
+    check(fused, refa, rel=5e-3, name="fused swiglu bwd vs autograd")

@@ -184,6 +184,53 @@ __global__ __launch_bounds__((BM / 64) * 128) void gemm_nt_kernel(GemmP p) {
       bv[ni][j] = (bias && n < p.N) ? bf2f(bias[n]) : 0.f;
     }
 
+  if (ROPE == 3) {
+    // ---- SwiGLU backward fused into the dH = dY.W_down GEMM (VLA_ACT_SWIGLU_BWD): the accumulator holds dH for this
+    // wave's 64 x 64 patch; read the matching interleaved pre-activations GU[m, 2I], emit dGU in the same layout.
+    // dH is never written (saves a 110 MB write + read per layer) and the stand-alone pass (548 MB of traffic) is gone.
+    const bf16_t* GU = p.R + (long long)z * p.sR;          // aux input rides in the residual slot, row stride ldr
+    bf16_t* Cb = p.C + (long long)z * p.sC;
+    constexpr int ROWB = 2 * C::WTN * 2 + 16;              // staged row: 2*WTN bf16 (+16 B pad)
+    char* reg2 = smem + wid * (32 * ROWB);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh) {
+        const int mi = 2 * half + mh;
+        const int m = min(wm0 + mi * 16 + lr, p.M - 1);
+#pragma unroll
+        for (int ni = 0; ni < C::NT; ++ni) {
+          const int hc = wn0 + ni * 16 + lq * 4;            // first of this lane's 4 h-columns
+          const long long go = (long long)m * p.ldr + (hc >> 4) * 32 + (hc & 15);
+          const bool ok = hc + 3 < p.N;
+          const uint2 gv = ok ? *reinterpret_cast<const uint2*>(GU + go) : uint2{0, 0};
+          const uint2 uv = ok ? *reinterpret_cast<const uint2*>(GU + go + 16) : uint2{0, 0};
+          const float gg[4] = {bf2f((bf16_t)(gv.x & 0xffff)), bf2f((bf16_t)(gv.x >> 16)), bf2f((bf16_t)(gv.y & 0xffff)), bf2f((bf16_t)(gv.y >> 16))};
+          const float uu[4] = {bf2f((bf16_t)(uv.x & 0xffff)), bf2f((bf16_t)(uv.x >> 16)), bf2f((bf16_t)(uv.y & 0xffff)), bf2f((bf16_t)(uv.y >> 16))};
+          float dg[4], du[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float d = rbf(acc[ni][mi][j] * p.alpha);
+            const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-gg[j]));
+            du[j] = d * gg[j] * sg;
+            dg[j] = d * uu[j] * (sg * (1.0f + gg[j] * (1.0f - sg)));
+          }
+          char* rowp = reg2 + (mh * 16 + lr) * ROWB + (ni * 32 + lq * 4) * 2;
+          *reinterpret_cast<uint2*>(rowp) = uint2{pack2(dg[0], dg[1]), pack2(dg[2], dg[3])};
+          *reinterpret_cast<uint2*>(rowp + 32) = uint2{pack2(du[0], du[1]), pack2(du[2], du[3])};
+        }
+      }
+      constexpr int CH2 = 2 * C::WTN / 8, RPP2 = 64 / CH2;   // 16-B chunks per staged row, rows per pass
+#pragma unroll
+      for (int it = 0; it < 32 / RPP2; ++it) {
+        const int row = it * RPP2 + lane / CH2, ch = lane % CH2;
+        const int m = wm0 + half * 32 + row, n2 = 2 * wn0 + ch * 8;
+        if (m < p.M && n2 + 8 <= 2 * p.N)
+          *reinterpret_cast<uint4*>(Cb + (long long)m * p.ldc + n2) = *reinterpret_cast<const uint4*>(reg2 + row * ROWB + ch * 16);
+      }
+    }
+    return;
+  }
   if (p.act == VLA_ACT_SWIGLU) {
     // columns interleaved in 16s: even tiles are gate, odd tiles the matching up columns
     bf16_t* C2 = p.C2 + (long long)z * p.sC2;
@@ -349,7 +396,11 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   VLA_REQUIRE(d->lda % 8 == 0 && d->ldb % 8 == 0, "gemm: lda/ldb must be multiples of 8 elements (16-B rows)");
   VLA_REQUIRE(((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->B & 15) == 0, "gemm: A/B must be 16-B aligned");
   VLA_REQUIRE(d->sA % 8 == 0 && d->sB % 8 == 0, "gemm: batch strides of A/B must keep 16-B alignment");
-  if (d->act == VLA_ACT_SWIGLU) {
+  if (d->act == VLA_ACT_SWIGLU_BWD) {
+    VLA_REQUIRE(d->C && d->R && !d->bias && d->rope_mode == 0 && d->N % 64 == 0 && d->ldc % 8 == 0 && d->ldr % 4 == 0 &&
+                    ((uintptr_t)d->R & 7) == 0 && d->c_group == 0 && d->res_mod == 0,
+                "gemm: swiglu_bwd needs C = dGU [M, 2N] (ldc%8), R = GU [M, 2N] (interleaved), N%64 == 0");
+  } else if (d->act == VLA_ACT_SWIGLU) {
     VLA_REQUIRE(d->C2 && d->N % 32 == 0 && d->ldc2 % 4 == 0 && ((uintptr_t)d->C2 & 7) == 0 && d->sC2 % 4 == 0,
                 "gemm: swiglu needs C2, N%32==0, ldc2%4==0");
     VLA_REQUIRE(!d->R, "gemm: swiglu epilogue takes no residual");
@@ -358,7 +409,7 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   }
   if (d->C) VLA_REQUIRE(((uintptr_t)d->C & 15) == 0 || (d->ldc % 8) != 0, "gemm: C must be 16-B aligned");
   if (d->C && d->ldc % 8 == 0) VLA_REQUIRE(d->sC % 8 == 0, "gemm: sC must keep 16-B alignment");
-  if (d->R && d->ldc % 8 == 0 && d->ldr % 8 == 0)
+  if (d->R && d->ldc % 8 == 0 && d->ldr % 8 == 0 && d->act != VLA_ACT_SWIGLU_BWD)
     VLA_REQUIRE(((uintptr_t)d->R & 15) == 0 && d->sR % 8 == 0, "gemm: R must be 16-B aligned");
   VLA_REQUIRE(d->a_group >= 0 && d->c_group >= 0 && d->a_group_stride % 8 == 0 &&
                   (d->c_group == 0 || d->ldc % 8 != 0 || d->c_group_stride % 8 == 0),
@@ -384,7 +435,8 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   const char* e = getenv("VLA_GEMM_TILE");     // 0/unset auto, 1: 256x128, 2: 128x128, 3: 128x64  (benchmarking aid)
   const TileChoice tc = choose_tile(d->M, d->N, d->K, e ? atoi(e) : 0, d->rope_mode);
   hipStream_t st = (hipStream_t)stream;
-  if (d->rope_mode == 1) launch<128, 128, 2, 1>(p, d->M, d->N, d->batch, st);
+  if (d->act == VLA_ACT_SWIGLU_BWD) launch<128, 128, 2, 3>(p, d->M, d->N, d->batch, st);
+  else if (d->rope_mode == 1) launch<128, 128, 2, 1>(p, d->M, d->N, d->batch, st);
   else if (d->rope_mode == 2) {
     if (tc.bn == 128) launch<128, 128, 2, 2>(p, d->M, d->N, d->batch, st);
     else launch<128, 64, 2, 2>(p, d->M, d->N, d->batch, st);

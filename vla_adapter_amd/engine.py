@@ -294,8 +294,11 @@ class LLM:
             L = self.layers[i]
             if i < n - 1:                                   # head contribution to the output of layer i
                 ops.add_(d, dHS[i + 1].view(M, D))
-            ops.gemm_nt(d, L["wdT"], out=self.d_h)
-            ops.swiglu_bwd(self.d_h, self.GU[i], out=self.d_gu)
+            if c.inter % 64 == 0:     # dH GEMM with the SwiGLU backward fused into its epilogue (dH never materialised)
+                ops.gemm_swiglu_bwd(d, L["wdT"], self.GU[i], out=self.d_gu)
+            else:
+                ops.gemm_nt(d, L["wdT"], out=self.d_h)
+                ops.swiglu_bwd(self.d_h, self.GU[i], out=self.d_gu)
             ops.gemm_nt(self.d_gu, L["wguT"], out=self.d_n)
             d1 = ops.rmsnorm_bwd(self.d_n, self.X1[i], L["n2"], self.R2[i], dres=d, out=other)
             dao = ops.gemm_nt(d1, L["woT"], out=self.d_n)

@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import native as N
-from .native import ACT_GELU, ACT_GELU_TANH, ACT_NONE, ACT_RELU, ACT_SWIGLU  # noqa: F401
+from .native import ACT_GELU, ACT_GELU_TANH, ACT_NONE, ACT_RELU, ACT_SWIGLU, ACT_SWIGLU_BWD  # noqa: F401
 
 BF16 = torch.bfloat16
 
@@ -91,6 +91,22 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_m
     N.check(_lib().vla_gemm_bf16_nt(_st(), C.byref(d)), "gemm_bf16_nt")
     if act == ACT_SWIGLU:
         return out, out2
+    return out
+
+
+def gemm_swiglu_bwd(d: torch.Tensor, w_downT: torch.Tensor, gu: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dGU[M, 2I] = swiglu'(GU) * (d[M, D] @ w_downT[I, D]^T): the dH GEMM with the SwiGLU backward in its epilogue."""
+    _chk_bf16(d, w_downT, gu, out)
+    M, K = d.shape
+    I = w_downT.shape[0]
+    assert gu.shape == (M, 2 * I) and gu.stride(-1) == 1 and w_downT.shape[1] == K
+    if out is None:
+        out = torch.empty_like(gu)
+    desc = N.GemmDesc()
+    desc.A, desc.B, desc.C, desc.R = d.data_ptr(), w_downT.data_ptr(), out.data_ptr(), gu.data_ptr()
+    desc.M, desc.N, desc.K, desc.lda, desc.ldb, desc.ldc, desc.ldr, desc.batch = M, I, K, d.stride(0), w_downT.stride(0), out.stride(0), gu.stride(0), 1
+    desc.act, desc.alpha = ACT_SWIGLU_BWD, 1.0
+    N.check(_lib().vla_gemm_bf16_nt(_st(), C.byref(desc)), "gemm_bf16_nt(swiglu_bwd)")
     return out
 
 
