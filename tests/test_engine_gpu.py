@@ -233,3 +233,17 @@ def test_llm_only_backward_identical_inputs(setup):
     sum((hs[i] * dH[i].float()).sum() for i in range(1, n + 1)).backward()
     assert rel(dx, xr.grad) < 2.5e-2, f"dX {rel(dx, xr.grad):.3e}"
     llm._buf_key = None      # other tests use a different (B, S)
+
+
+def test_pipelined_eager_matches_sequential(setup):
+    """Two-stream schedule (head trailing / leading the LLM by one layer) == sequential single-stream step."""
+    cfg, W, batch, _ = setup
+    from vla_adapter_amd import engine as E
+    e1, e2 = E.VLAEngine(cfg, W, DEV), E.VLAEngine(cfg, W, DEV)
+    for it in range(2):
+        l1 = e1.train_step(batch, 1e-3)[0].item()
+        l2 = e2.train_step_pipelined(batch, 1e-3, split=1)[0].item()
+        torch.cuda.synchronize()
+        assert abs(l1 - l2) <= 1e-6 + 2e-2 * it * abs(l1)
+        g1, g2 = e1.head.P.grad.float().cpu(), e2.head.P.grad.float().cpu()
+        assert (g1 - g2).norm() <= (2e-3 + 3e-2 * it) * g1.norm()

@@ -244,26 +244,37 @@ class LLM:
 
     def forward(self, B: int, S: int, kmask_u8: torch.Tensor):
         """HS[0] must already hold inputs_embeds [B,S,D].  Fills HS[1..n] (HF hidden_states semantics)."""
-        c = self.cfg
-        n, M, D, H, KV, dh = c.n_layers, B * S, c.d, c.heads, c.kv_heads, c.dh
-        self.kmask = kmask_u8
-        for i, L in enumerate(self.layers):
-            x = self.HS[i].view(M, D)
-            self._rms(x, L["n1"], self.nbuf, self.R1[i])
-            qkv = self.QKV[i]
-            if dh == 64:          # RoPE fused into the projection's epilogue
-                ops.gemm_nt(self.nbuf, L["wqkv"], bias=L["bqkv"], out=qkv, rope=(1, self.cos, self.sin, S, dh, (H + KV) * dh))
-            else:
-                ops.gemm_nt(self.nbuf, L["wqkv"], bias=L["bqkv"], out=qkv)
-                ops.rope_half_(qkv[:, :H * dh], self.cos, self.sin, S, H, dh)
-                ops.rope_half_(qkv[:, H * dh:(H + KV) * dh], self.cos, self.sin, S, KV, dh)
-            q3 = qkv.view(B, S, -1)
-            self._attn_fwd(q3, i, B, S)
-            x1 = self.X1[i]
-            ops.gemm_nt(self.AO[i], L["wo"], residual=x, out=x1)
-            self._rms(x1, L["n2"], self.nbuf, self.R2[i])
-            ops.gemm_nt(self.nbuf, L["wgu"], act=ACT_SWIGLU, out=self.GU[i], out2=self.hbuf)
-            ops.gemm_nt(self.hbuf, L["wd"], residual=x1, out=self.HS[self.out_slot(i)].view(M, D))
+        self.fwd_begin(B, S, kmask_u8)
+        for i in range(self.cfg.n_layers):
+            self.fwd_layer(i)
+        self.fwd_final()
+
+    def fwd_begin(self, B: int, S: int, kmask_u8: torch.Tensor):
+        self.kmask, self.B, self.S = kmask_u8, B, S
+
+    def fwd_layer(self, i: int):
+        c, B, S = self.cfg, self.B, self.S
+        M, D, H, KV, dh = B * S, c.d, c.heads, c.kv_heads, c.dh
+        L = self.layers[i]
+        x = self.HS[i].view(M, D)
+        self._rms(x, L["n1"], self.nbuf, self.R1[i])
+        qkv = self.QKV[i]
+        if dh == 64:          # RoPE fused into the projection's epilogue
+            ops.gemm_nt(self.nbuf, L["wqkv"], bias=L["bqkv"], out=qkv, rope=(1, self.cos, self.sin, S, dh, (H + KV) * dh))
+        else:
+            ops.gemm_nt(self.nbuf, L["wqkv"], bias=L["bqkv"], out=qkv)
+            ops.rope_half_(qkv[:, :H * dh], self.cos, self.sin, S, H, dh)
+            ops.rope_half_(qkv[:, H * dh:(H + KV) * dh], self.cos, self.sin, S, KV, dh)
+        self._attn_fwd(qkv.view(B, S, -1), i, B, S)
+        x1 = self.X1[i]
+        ops.gemm_nt(self.AO[i], L["wo"], residual=x, out=x1)
+        self._rms(x1, L["n2"], self.nbuf, self.R2[i])
+        ops.gemm_nt(self.nbuf, L["wgu"], act=ACT_SWIGLU, out=self.GU[i], out2=self.hbuf)
+        ops.gemm_nt(self.hbuf, L["wd"], residual=x1, out=self.HS[self.out_slot(i)].view(M, D))
+
+    def fwd_final(self):
+        """hidden_states[n] = final RMSNorm of the last layer's output (HF convention)."""
+        n, M, D = self.cfg.n_layers, self.B * self.S, self.cfg.d
         self._rms(self.HS[n + 1].view(M, D), self.norm, self.HS[n].view(M, D), self.RF)
 
     def _rms(self, x, w, out, rstd):
@@ -286,34 +297,43 @@ class LLM:
     def backward(self, dHS: torch.Tensor, B: int, S: int) -> torch.Tensor:
         """dHS [n+1, B, S, D]: gradient w.r.t. hidden_states[i] (i = 0..n, HF convention; [0] unused).
         Returns the gradient w.r.t. inputs_embeds [B,S,D] (frozen weights: no dW)."""
-        c = self.cfg
+        self.bwd_begin(dHS)
+        for i in range(self.cfg.n_layers - 1, -1, -1):
+            self.bwd_layer(i, dHS)
+        return self.bwd_result()
+
+    def bwd_begin(self, dHS: torch.Tensor):
+        n, M, D = self.cfg.n_layers, self.B * self.S, self.cfg.d
+        self._d = ops.rmsnorm_bwd(dHS[n].view(M, D), self.HS[n + 1].view(M, D), self.norm, self.RF, out=self.d_a)
+        self._other = self.d_b
+
+    def bwd_layer(self, i: int, dHS: torch.Tensor):
+        c, B, S = self.cfg, self.B, self.S
         n, M, D, H, KV, dh = c.n_layers, B * S, c.d, c.heads, c.kv_heads, c.dh
-        d = ops.rmsnorm_bwd(dHS[n].view(M, D), self.HS[n + 1].view(M, D), self.norm, self.RF, out=self.d_a)
-        other = self.d_b
-        for i in range(n - 1, -1, -1):
-            L = self.layers[i]
-            if i < n - 1:                                   # head contribution to the output of layer i
-                ops.add_(d, dHS[i + 1].view(M, D))
-            if c.inter % 64 == 0:     # dH GEMM with the SwiGLU backward fused into its epilogue (dH never materialised)
-                ops.gemm_swiglu_bwd(d, L["wdT"], self.GU[i], out=self.d_gu)
-            else:
-                ops.gemm_nt(d, L["wdT"], out=self.d_h)
-                ops.swiglu_bwd(self.d_h, self.GU[i], out=self.d_gu)
-            ops.gemm_nt(self.d_gu, L["wguT"], out=self.d_n)
-            d1 = ops.rmsnorm_bwd(self.d_n, self.X1[i], L["n2"], self.R2[i], dres=d, out=other)
-            dao = ops.gemm_nt(d1, L["woT"], out=self.d_n)
-            q3 = self.QKV[i].view(B, S, -1)
-            q, k, v = self._attn_views(q3)
-            dq, dk, dv = self._attn_views(self.d_qkv.view(B, S, -1))
-            ops.attn_bwd(dao.view(B, S, -1), q, k, v, self.AO[i].view(B, S, -1), self.LSE[i], H, KV, dh, True, self.kmask,
-                         dq=dq, dk=dk, dv=dv, rope=(self.cos, self.sin) if dh == 64 else None)
-            if dh != 64:
-                ops.rope_half_(self.d_qkv[:, :H * dh], self.cos, self.sin, S, H, dh, sign=-1)
-                ops.rope_half_(self.d_qkv[:, H * dh:(H + KV) * dh], self.cos, self.sin, S, KV, dh, sign=-1)
-            ops.gemm_nt(self.d_qkv, L["wqkvT"], out=self.d_n)
-            d_new = ops.rmsnorm_bwd(self.d_n, self.HS[i].view(M, D), L["n1"], self.R1[i], dres=d1, out=d)
-            d, other = d_new, d1
-        return d.view(B, S, D)
+        L, d, other = self.layers[i], self._d, self._other
+        if i < n - 1:                                   # head contribution to the output of layer i
+            ops.add_(d, dHS[i + 1].view(M, D))
+        if c.inter % 64 == 0:     # dH GEMM with the SwiGLU backward fused into its epilogue (dH never materialised)
+            ops.gemm_swiglu_bwd(d, L["wdT"], self.GU[i], out=self.d_gu)
+        else:
+            ops.gemm_nt(d, L["wdT"], out=self.d_h)
+            ops.swiglu_bwd(self.d_h, self.GU[i], out=self.d_gu)
+        ops.gemm_nt(self.d_gu, L["wguT"], out=self.d_n)
+        d1 = ops.rmsnorm_bwd(self.d_n, self.X1[i], L["n2"], self.R2[i], dres=d, out=other)
+        dao = ops.gemm_nt(d1, L["woT"], out=self.d_n)
+        q, k, v = self._attn_views(self.QKV[i].view(B, S, -1))
+        dq, dk, dv = self._attn_views(self.d_qkv.view(B, S, -1))
+        ops.attn_bwd(dao.view(B, S, -1), q, k, v, self.AO[i].view(B, S, -1), self.LSE[i], H, KV, dh, True, self.kmask,
+                     dq=dq, dk=dk, dv=dv, rope=(self.cos, self.sin) if dh == 64 else None)
+        if dh != 64:
+            ops.rope_half_(self.d_qkv[:, :H * dh], self.cos, self.sin, S, H, dh, sign=-1)
+            ops.rope_half_(self.d_qkv[:, H * dh:(H + KV) * dh], self.cos, self.sin, S, KV, dh, sign=-1)
+        ops.gemm_nt(self.d_qkv, L["wqkvT"], out=self.d_n)
+        d_new = ops.rmsnorm_bwd(self.d_n, self.HS[i].view(M, D), L["n1"], self.R1[i], dres=d1, out=d)
+        self._d, self._other = d_new, d1
+
+    def bwd_result(self) -> torch.Tensor:
+        return self._d.view(self.B, self.S, self.cfg.d)
 
 
 # ------------------------------------------------------------------------------------------------ trainable params
@@ -463,6 +483,8 @@ class Head:
         self.h_adpT, self.dKV_adpT = z(nb, D, self.AK), z(nb, 2 * D, self.AK)
         self.h_taskT, self.dKV_taskT = z(nb, D, self.TK), z(nb, 2 * D, self.TK)
         self.dh_adp = e(nb, B * Ka, D)
+        self.gtmp = e(B * NUM_TOKENS, D)
+        self.dpad = z(R, 64)
         self.rope_tab = ops.rope_inter_tables(max(T, Ka, Kt), D // self.H, dev)
         self._key = (B, Kt)
 
@@ -471,57 +493,65 @@ class Head:
                 noise: Optional[torch.Tensor] = None) -> torch.Tensor:
         """HS [>=nb+1, B, S, D] hidden states (HF indexing: block i reads HS[i+1]); pos1 int32 [B,64] = positions of
         the action-query hidden states in text coordinates (mask on labels[:,1:], finetune.py:351-353, 399-405);
-        proprio [B, Pd]; noise [chunk, 7*D] or None (phase Inference).  Returns predicted actions [B, chunk, 7]."""
-        cfg, P, D, nb, H = self.cfg, self.P, self.D, self.nb, self.H
+        proprio [B, Pd]; noise [chunk, 7*D] or None (phase Inference).  Returns predicted actions [B, chunk, 7].
+        Sequential composition of the per-layer pieces the pipelined schedule (VLAEngine.step_pipelined) interleaves
+        with the LLM on a second stream."""
+        self.fwd_begin(HS, pos1, proprio, Np, noise)
+        for i in range(self.nb):
+            self.fwd_layer(i)
+        return self.fwd_end()
+
+    def fwd_begin(self, HS, pos1, proprio, Np, noise=None):
+        """Everything that does not depend on the LLM's output: buffers, proprio projector, input stage
+        (zeros/noise -> LN -> fc1 -> ReLU, action_heads.py:60-72, 113-115)."""
+        cfg, P, D = self.cfg, self.P, self.D
         B, S = HS.shape[1], HS.shape[2]
-        T, Ka, Kt = cfg.chunk, NUM_TOKENS + 1, Np
-        self._alloc(B, Kt)
+        T = cfg.chunk
+        self._alloc(B, Np)
         self.refresh_transposes()
         self.HSref, self.Np, self.S, self.B = HS, Np, S, B
-        R, dh = B * T, D // H
         # proprio projector (projectors.py:19-24); proprio rounded to bf16 first (action_heads.py:53)
         self.pr_in[:, :cfg.proprio_dim] = proprio.to(BF16)
         self.pp_pre = ops.gemm_nt(self.pr_in, self.pfc1_pad, bias=P.view("p_fc1_b"))
         self.pp_act = ops.gelu_fwd(self.pp_pre)
-        pf = ops.gemm_nt(self.pp_act, P.view("p_fc2_w"), bias=P.view("p_fc2_b"))            # [B, D]
-        # adapter tokens: 64 action-query hidden states per layer + the proprio token (action_heads.py:347)
-        self.row_idx = (torch.arange(B, device=HS.device, dtype=torch.int32)[:, None] * S + Np + pos1).to(torch.int32)  # [B,64]
-        assert HS[1:nb + 1].is_contiguous()
-        hs_rows = HS[1:nb + 1].view(nb * B * S, D)
-        gidx = (torch.arange(nb, device=HS.device, dtype=torch.int32)[:, None, None] * (B * S) + self.row_idx[None]).reshape(-1)
-        tmp = torch.empty(nb * B * NUM_TOKENS, D, device=HS.device, dtype=BF16)
-        ops.gather_rows(hs_rows, gidx.contiguous(), tmp)
-        self.h_adp[:, :, :NUM_TOKENS] = tmp.view(nb, B, NUM_TOKENS, D)
-        self.h_adp[:, :, NUM_TOKENS] = pf
-        # K/V of the adapter and task segments for all blocks at once (batched over the 24 layers)
-        rc, rs_ = self.rope_tab
-        # K/V of the adapter and task segments for all blocks at once.  Their RoPE (action_heads.py:383-388) stays a
-        # stand-alone pass: ONE launch covers all 24 blocks (~0.1 ms), whereas a fused GEMM epilogue paid ~44 us of
-        # exposed table-load latency per block (measured with rocprofv3); the per-block x-path GEMM keeps it fused.
-        ops.gemm_nt(self.h_adp.view(nb, B * Ka, D), P.view("w_adp"), bias=P.view("b_adp"), out=self.KV_adp)
-        ops.rope_inter_(self.KV_adp.view(nb * B * Ka, 2 * D)[:, :D], rc, rs_, Ka, H, dh, 0)
-        for i in range(nb):   # task tokens = HS[i+1][:, :Np] read in place (row-group addressing)
-            ops.gemm_nt(HS[i + 1].view(B * S, D)[:B * Kt], P.view("w_task")[i], bias=P.view("b_task")[i], out=self.KV_task[i],
-                        a_group=(Kt, S * D))
-        ops.rope_inter_(self.KV_task.view(nb * B * Kt, 2 * D)[:, :D], rc, rs_, Kt, H, dh, 0)
-        # input: zeros (+ noise in the Training phase) -> LN -> fc1 -> ReLU   (action_heads.py:60-72, 113-115)
+        self.pf = ops.gemm_nt(self.pp_act, P.view("p_fc2_w"), bias=P.view("p_fc2_b"))       # [B, D]
+        # rows of the 64 action-query hidden states inside one [B*S, D] layer slab
+        self.row_idx = (torch.arange(B, device=HS.device, dtype=torch.int32)[:, None] * S + Np + pos1).to(torch.int32).contiguous()
         if noise is not None:
             self.x_in.view(B, T, self.Din).copy_(noise.to(BF16)[None].expand(B, T, self.Din))
         else:
             self.x_in.zero_()
         self.x_ln, self.st1 = ops.layernorm_fwd(self.x_in, P.view("ln1_w"), P.view("ln1_b"), 1e-5, want_stats=True)
         ops.gemm_nt(self.x_ln, P.view("fc1_w"), bias=P.view("fc1_b"), act=ACT_RELU, out=self.X[0])
-        for i in range(nb):
-            x = self.X[i]
-            qkv = self.QKVx[i]
-            ops.gemm_nt(x, P.view("w_x")[i], bias=P.view("b_x")[i], out=qkv, rope=(2, rc, rs_, T, dh, 2 * D))  # q, k_self: pos 0..T-1
-            self._attn(i, fwd=True)
-            ops.gemm_nt(self.AOx[i], P.view("w_o")[i], bias=P.view("b_o")[i], residual=x, out=self.O2[i])
-            self._ln(self.O2[i], P.view("ln_w")[i], P.view("ln_b")[i], self.LNo[i], self.stats[i])
-            ops.gemm_nt(self.LNo[i], P.view("w_ffn")[i], bias=P.view("b_ffn")[i], act=ACT_RELU, out=self.X[i + 1])
+
+    def fwd_layer(self, i: int):
+        """Block i (action_heads.py:337-410): needs hidden_states[i+1] of the LLM and the previous block's output."""
+        cfg, P, D, H = self.cfg, self.P, self.D, self.H
+        HS, B, S, Kt, Ka, T = self.HSref, self.B, self.S, self.Kt, self.Ka, cfg.chunk
+        dh = D // H
+        rc, rs_ = self.rope_tab
+        hs2 = HS[i + 1].view(B * S, D)
+        # adapter tokens: the 64 action-query hidden states + the proprio token (:347); K/V projections, RoPE on K
+        ops.gather_rows(hs2, self.row_idx.view(-1), self.gtmp)
+        self.h_adp[i, :, :NUM_TOKENS] = self.gtmp.view(B, NUM_TOKENS, D)
+        self.h_adp[i, :, NUM_TOKENS] = self.pf
+        ops.gemm_nt(self.h_adp[i].view(B * Ka, D), P.view("w_adp")[i], bias=P.view("b_adp")[i], out=self.KV_adp[i])
+        ops.rope_inter_(self.KV_adp[i][:, :D], rc, rs_, Ka, H, dh, 0)
+        # task tokens = HS[i+1][:, :Np] read in place (row-group addressing)
+        ops.gemm_nt(hs2[:B * Kt], P.view("w_task")[i], bias=P.view("b_task")[i], out=self.KV_task[i], a_group=(Kt, S * D))
+        ops.rope_inter_(self.KV_task[i][:, :D], rc, rs_, Kt, H, dh, 0)
+        x = self.X[i]
+        ops.gemm_nt(x, P.view("w_x")[i], bias=P.view("b_x")[i], out=self.QKVx[i], rope=(2, rc, rs_, T, dh, 2 * D))  # q, k_self
+        self._attn(i, fwd=True)
+        ops.gemm_nt(self.AOx[i], P.view("w_o")[i], bias=P.view("b_o")[i], residual=x, out=self.O2[i])
+        self._ln(self.O2[i], P.view("ln_w")[i], P.view("ln_b")[i], self.LNo[i], self.stats[i])
+        ops.gemm_nt(self.LNo[i], P.view("w_ffn")[i], bias=P.view("b_ffn")[i], act=ACT_RELU, out=self.X[i + 1])
+
+    def fwd_end(self) -> torch.Tensor:
+        P, nb = self.P, self.nb
         self.xf_ln, self.st2 = ops.layernorm_fwd(self.X[nb], P.view("ln2_w"), P.view("ln2_b"), 1e-5, want_stats=True)
         self.pred = ops.gemm_nt(self.xf_ln, P.view("fc2_w"), bias=P.view("fc2_b"))
-        return self.pred.view(B, T, cfg.action_dim)
+        return self.pred.view(self.B, self.cfg.chunk, self.cfg.action_dim)
 
     def _ln(self, x, w, b, y, stats):
         ops.N.check(ops._lib().vla_layernorm_fwd(ops._st(), ops._p(x), ops._p(w), ops._p(b), ops._p(y), ops._p(stats),
@@ -549,47 +579,59 @@ class Head:
     # ---- backward ---------------------------------------------------------------------------------------------
     def backward(self, dpred: torch.Tensor, dHS: torch.Tensor):
         """dpred [B, chunk, 7] bf16.  Writes parameter gradients into the flat grad buffer and the hidden-state
-        gradients into dHS [nb+1, B, S, D] (HF indexing; rows not touched by the head must be pre-zeroed)."""
-        cfg, P, D, nb, H = self.cfg, self.P, self.D, self.nb, self.H
-        B, S, Np, T, Ka, Kt, R = self.B, self.S, self.Np, cfg.chunk, self.Ka, self.Kt, self.R
-        dh, Da = D // H, cfg.action_dim
-        G = P.g
+        gradients into dHS [nb+1, B, S, D] (HF indexing; rows not touched by the head must be pre-zeroed).
+        Sequential composition of bwd_begin / bwd_layer / bwd_end."""
+        self.bwd_begin(dpred)
+        for i in range(self.nb - 1, -1, -1):
+            self.bwd_layer(i, dHS)
+        self.bwd_end()
+
+    def bwd_begin(self, dpred: torch.Tensor):
+        cfg, P, nb = self.cfg, self.P, self.nb
+        R, Da = self.R, cfg.action_dim
         for t in (self.dgate, self.ln_dw, self.ln_db, self.ln1_dw, self.ln1_db, self.ln2_dw, self.ln2_db, *self.b_f32.values()):
             t.zero_()
         dp = dpred.reshape(R, Da)
-        # fc2 / layer_norm2
-        dpad = torch.zeros(R, 64, device=dp.device, dtype=BF16)
-        dpad[:, :Da] = dp
+        self.dpad.zero_()
+        self.dpad[:, :Da] = dp
         ops.colsum_(dp, self.b_f32["fc2_b"])
-        G("fc2_w").copy_(self._dw(dp, self.xf_ln))
-        d_ln2 = ops.gemm_nt(dpad, self.fc2T)                                   # [R, D]
-        dx = ops.layernorm_bwd(d_ln2, self.X[nb], P.view("ln2_w"), self.st2, self.ln2_dw, self.ln2_db)
-        for i in range(nb - 1, -1, -1):
-            dff = self.dFF[i]
-            ops.N.check(ops._lib().vla_relu_bwd(ops._st(), ops._p(dx), ops._p(self.X[i + 1]), ops._p(dff), dx.numel()), "relu_bwd")
-            d_ln = ops.gemm_nt(dff, self.T["w_ffn"][i])
-            do2 = self.dO2[i]
-            self._ln_bwd(d_ln, self.O2[i], P.view("ln_w")[i], self.stats[i], do2, self.ln_dw[i], self.ln_db[i])
-            d_ao = ops.gemm_nt(do2, self.T["w_o"][i])
-            self._attn(i, fwd=False, dout=d_ao)          # returns dq / dk already through the RoPE transpose
-            dx = ops.gemm_nt(self.dQKVx[i], self.T["w_x"][i], residual=do2)
+        P.g("fc2_w").copy_(self._dw(dp, self.xf_ln))
+        d_ln2 = ops.gemm_nt(self.dpad, self.fc2T)                              # [R, D]
+        self.dx = ops.layernorm_bwd(d_ln2, self.X[nb], P.view("ln2_w"), self.st2, self.ln2_dw, self.ln2_db)
+
+    def bwd_layer(self, i: int, dHS: torch.Tensor):
+        """Backward of block i: the x-chain (critical path), then this layer's hidden-state gradients
+        dHS[i+1] (task rows written in place, action rows scattered) - all the LLM backward of layer i waits for."""
+        P, D, H = self.P, self.D, self.H
+        B, S, Kt, Ka = self.B, self.S, self.Kt, self.Ka
+        dff = self.dFF[i]
+        ops.N.check(ops._lib().vla_relu_bwd(ops._st(), ops._p(self.dx), ops._p(self.X[i + 1]), ops._p(dff), self.dx.numel()), "relu_bwd")
+        d_ln = ops.gemm_nt(dff, self.T["w_ffn"][i])
+        do2 = self.dO2[i]
+        self._ln_bwd(d_ln, self.O2[i], P.view("ln_w")[i], self.stats[i], do2, self.ln_dw[i], self.ln_db[i])
+        d_ao = ops.gemm_nt(do2, self.T["w_o"][i])
+        self._attn(i, fwd=False, dout=d_ao)          # returns dq / dk already through the RoPE transpose
+        self.dx = ops.gemm_nt(self.dQKVx[i], self.T["w_x"][i], residual=do2)
+        # d h_adapter -> action rows of dHS[i+1] (+ the proprio token's gradient); d h_task -> dHS[i+1][:, :Np] in place
+        ops.gemm_nt(self.dKV_adp[i], self.T["w_adp"][i], out=self.dh_adp[i])
+        dha = self.dh_adp[i].view(B, Ka, D)
+        self.gtmp.view(B, NUM_TOKENS, D).copy_(dha[:, :NUM_TOKENS])
+        ops.scatter_add_rows(self.gtmp, self.row_idx.view(-1), dHS[i + 1].view(B * S, D))
+        ops.gemm_nt(self.dKV_task[i], self.T["w_task"][i], out=dHS[i + 1].view(B * S, D)[:B * Kt], c_group=(Kt, S * D))
+
+    def bwd_end(self):
+        """Off the critical path: input stage, proprio projector, and every dW as batched NT GEMMs on transposed operands."""
+        cfg, P, D, nb = self.cfg, self.P, self.D, self.nb
+        B, Ka, Kt = self.B, self.Ka, self.Kt
+        G = P.g
         # input stage: relu -> fc1 -> layer_norm1 (input is noise/zeros: only parameter gradients)
-        dy1 = ops.relu_bwd(dx, self.X[0])
+        dy1 = ops.relu_bwd(self.dx, self.X[0])
         ops.colsum_(dy1, self.b_f32["fc1_b"])
         G("fc1_w").copy_(self._dw(dy1, self.x_ln))
         d_xln = ops.gemm_nt(dy1, self._t(P.view("fc1_w")))
         ops.layernorm_bwd(d_xln, self.x_in, P.view("ln1_w"), self.st1, self.ln1_dw, self.ln1_db, want_dx=False)
-        # everything that is batched over the 24 blocks
-        # d h_adapter -> scatter into dHS (action positions) + proprio token gradient
-        ops.gemm_nt(self.dKV_adp, self.T["w_adp"], out=self.dh_adp)
-        dha = self.dh_adp.view(nb, B, Ka, D)
-        gidx = (torch.arange(nb, device=dHS.device, dtype=torch.int32)[:, None, None] * (B * S) + self.row_idx[None]).reshape(-1).contiguous()
-        ops.scatter_add_rows(dha[:, :, :NUM_TOKENS].reshape(nb * B * NUM_TOKENS, D), gidx, dHS[1:nb + 1].view(nb * B * S, D))
-        d_pf = dha[:, :, NUM_TOKENS].float().sum(0).to(BF16)                   # [B, D] (sum over blocks)
-        # d h_task -> written in place into dHS[i+1][:, :Np]
-        for i in range(nb):
-            ops.gemm_nt(self.dKV_task[i], self.T["w_task"][i], out=dHS[i + 1].view(B * S, D)[:B * Kt], c_group=(Kt, S * D))
-        # proprio projector backward
+        # proprio projector backward (its token's gradient = sum over the blocks)
+        d_pf = self.dh_adp.view(nb, B, Ka, D)[:, :, NUM_TOKENS].float().sum(0).to(BF16)
         ops.colsum_(d_pf, self.b_f32["p_fc2_b"])
         G("p_fc2_w").copy_(self._dw(d_pf, self.pp_act))
         d_act = ops.gemm_nt(d_pf, self.T["p_fc2_w"])
@@ -662,6 +704,11 @@ class VLAEngine:
 
     # modeling_prismatic.py:596-655 (multimodal forward): fills llm.HS with the n+1 hidden states
     def forward_vlm(self, batch: Dict[str, torch.Tensor]):
+        mm = self._vision_and_embed(batch)
+        self.llm.forward(self.B, self.S, mm)
+
+    def _vision_and_embed(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """ViT(s) -> projector -> action masks -> embedding/query splice into llm.HS[0]; returns the key mask [B,S] u8."""
         cfg, llm = self.cfg, self.llm
         ids, labels, am = batch["input_ids"], batch["labels"], batch["attention_mask"]
         B, L = ids.shape
@@ -699,8 +746,8 @@ class VLAEngine:
         _, self.pos1, self.cnt1 = ops.action_mask(labels, 1)
         mm = torch.empty(B, S, device=self.device, dtype=torch.uint8)
         ops.embed_splice(ids, am.to(torch.uint8).contiguous(), self.qidx0, llm.embed, self.head.P.view("action_queries"), X0, mm, Np)
-        llm.forward(B, S, mm)
         self.B, self.S, self.Np = B, S, Np
+        return mm
 
     def loss_and_backward(self, pred, actions, gscale: float = 1.0):
         """L1 loss (finetune.py:418) + full backward into the flat grad buffer."""
@@ -738,47 +785,108 @@ class VLAEngine:
         self.optimizer_step(lr)
         return loss3
 
-    # ---- hipGraph path: the step is ~2000 launches of 15-350 us kernels, i.e. launch-bound from Python.  With static
-    # shapes and preallocated buffers the whole forward+backward is captured once and replayed (two graphs, cut where
-    # the data-parallel exchange of the head gradients is launched); AdamW stays outside (its bias corrections are
-    # host scalars that change every step).
-    def capture(self, batch: Dict[str, torch.Tensor], noise: Optional[torch.Tensor] = None, warmup: int = 2):
+    # ---- pipelined two-stream schedule + hipGraph replay -----------------------------------------------------------
+    # The action head is 3 % of the FLOPs but a chain of ~300 small dependent kernels (~9 ms when run alone): block i
+    # only needs hidden_states[i+1], so its forward trails the LLM forward by one layer on a SECOND stream, and its
+    # backward runs one block AHEAD of the LLM backward (which needs dHS[i+1] from block i).  The head's kernels fill
+    # the idle CUs / tile-quantisation tails of the LLM's large GEMMs instead of serialising with them.
+    # The step is captured in two hipGraphs cut where the data-parallel exchange of the (by then final) head gradients
+    # is launched; AdamW stays outside (host-side bias corrections change every step).
+    def _ensure_streams(self):
+        if getattr(self, "side", None) is None:
+            self.side = torch.cuda.Stream()
+
+    def _part_a(self, batch, noise, split: int):
+        """forward (LLM on the current stream, head on the side stream) + loss + head backward (side) overlapped with
+        the LLM backward of layers n-1 .. split (current stream).  Joins the side stream before returning."""
+        cfg, llm, head = self.cfg, self.llm, self.head
+        n, nb, D = cfg.llm.n_layers, cfg.num_blocks, cfg.llm.d
+        main, side = torch.cuda.current_stream(), self.side
+        mm = self._vision_and_embed(batch)
+        B, S, Np = self.B, self.S, self.Np
+        if self._dHS is None or self._dHS.shape[1:3] != (B, S):
+            self._dHS = torch.empty(n + 1, B, S, D, device=self.device, dtype=BF16)
+        self._dHS.zero_()
+        llm.fwd_begin(B, S, mm)
+        side.wait_stream(main)                                   # fork
+        with torch.cuda.stream(side):
+            head.fwd_begin(llm.HS, self.pos1, batch["proprio"], Np, noise)
+        for i in range(n):
+            llm.fwd_layer(i)
+            if i == n - 1:
+                llm.fwd_final()
+            if i < nb:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)                          # hidden_states[i+1] is ready
+                    head.fwd_layer(i)
+        fev = {}
+        with torch.cuda.stream(side):
+            pred = head.fwd_end()
+            loss3, dpred = ops.l1_loss(pred, batch["actions"].to(BF16), True, 1.0)
+            head.bwd_begin(dpred)
+            for i in range(nb - 1, -1, -1):
+                head.bwd_layer(i, self._dHS)
+                fev[i] = torch.cuda.Event()
+                fev[i].record(side)                              # dHS[i+1] is final
+            head.bwd_end()
+        if nb >= n:
+            main.wait_event(fev[n - 1])                          # gradient of the final-norm output comes from block n-1
+        llm.bwd_begin(self._dHS)
+        for i in range(n - 1, split - 1, -1):
+            if i < n - 1 and i < nb:
+                main.wait_event(fev[i])
+            llm.bwd_layer(i, self._dHS)
+        main.wait_stream(side)                                   # join: head gradients are final
+        self._fev = fev
+        return loss3
+
+    def _part_b(self, split: int):
+        llm, nb, n = self.llm, self.cfg.num_blocks, self.cfg.llm.n_layers
+        for i in range(min(split, n) - 1, -1, -1):
+            llm.bwd_layer(i, self._dHS)                          # dHS complete since part A joined the side stream
+        dX0 = llm.bwd_result()
+        dq = ops.action_query_grad(dX0.contiguous(), self.pos0, self.Np)
+        ops.cast_f32_bf16(dq, out=self.head.P.g("action_queries"))
+
+    def capture(self, batch: Dict[str, torch.Tensor], noise: Optional[torch.Tensor] = None, warmup: int = 2, split: Optional[int] = None):
         """``batch``/``noise`` become the static input buffers: copy new data INTO them before each replay."""
+        self._ensure_streams()
+        self._split = self.cfg.llm.n_layers // 3 if split is None else split
         self._static_batch, self._static_noise = batch, noise
         for _ in range(warmup):                      # allocate every buffer / set kernel attributes outside capture
             self.head.dirty = True
-            self._fwd_head_bwd(batch, noise)
-            self._llm_bwd()
+            self._part_a(batch, noise, self._split)
+            self._part_b(self._split)
         torch.cuda.synchronize()
         self.head.dirty = True
         self._g1, self._g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g1):
-            self._loss3 = self._fwd_head_bwd(batch, noise)
+            self._loss3 = self._part_a(batch, noise, self._split)
         with torch.cuda.graph(self._g2, pool=self._g1.pool()):
-            self._llm_bwd()
+            self._part_b(self._split)
         torch.cuda.synchronize()
 
-    def _fwd_head_bwd(self, batch, noise):
-        llm, head = self.llm, self.head
-        pred = self.forward(batch, noise)
-        B, S, D, n = self.B, self.S, self.cfg.llm.d, self.cfg.llm.n_layers
-        loss3, dpred = ops.l1_loss(pred, batch["actions"].to(BF16), True, 1.0)
-        if self._dHS is None or self._dHS.shape[1:3] != (B, S):
-            self._dHS = torch.empty(n + 1, B, S, D, device=self.device, dtype=BF16)
-        self._dHS.zero_()
-        head.backward(dpred, self._dHS)
+    def train_step_pipelined(self, batch, lr: float, noise=None, split: Optional[int] = None):
+        """Eager (un-captured) run of the two-stream schedule."""
+        self._ensure_streams()
+        sp = self.cfg.llm.n_layers // 3 if split is None else split
+        aq_off = self.head.P.offsets["action_queries"][0]
+        loss3 = self._part_a(batch, noise, sp)
+        if self.reducer is not None:
+            self.reducer.reduce_async(self.head.P.grad, 0, aq_off)
+        self._part_b(sp)
+        if self.reducer is not None:
+            self.reducer.reduce_async(self.head.P.grad, aq_off, None)
+        self.optimizer_step(lr)
         return loss3
-
-    def _llm_bwd(self):
-        dX0 = self.llm.backward(self._dHS, self.B, self.S)
-        dq = ops.action_query_grad(dX0.contiguous(), self.pos0, self.Np)
-        ops.cast_f32_bf16(dq, out=self.head.P.g("action_queries"))
 
     def train_step_graphed(self, lr: float):
         """Replay of the captured step on the static buffers (+ RCCL exchange + AdamW)."""
         aq_off = self.head.P.offsets["action_queries"][0]
         self._g1.replay()
-        if self.reducer is not None:
+        if self.reducer is not None:       # head/proprio grads are final: exchange them under the rest of the LLM backward
             self.reducer.reduce_async(self.head.P.grad, 0, aq_off)
         self._g2.replay()
         if self.reducer is not None:
