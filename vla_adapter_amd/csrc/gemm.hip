@@ -61,8 +61,11 @@ struct Cfg {
   static constexpr int PIECES = STAGE_BYTES / 1024;      // 1 KiB LDS-DMA pieces per stage
   static constexpr int PPW = PIECES / NW;                // pieces per wave per stage
   static constexpr int EPI_STRIDE = WTN * 2 + EPI_PAD;   // bytes per staged output row
-  static constexpr int EPI_BYTES = NW * 64 * EPI_STRIDE;
-  static constexpr int LDS_BYTES = STAGES * STAGE_BYTES > EPI_BYTES ? STAGES * STAGE_BYTES : EPI_BYTES;
+  static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
+  static constexpr int NHALF = NW * 64 * EPI_STRIDE <= LDS_BYTES ? 1 : 2;   // output staged in 1 or 2 row-halves per wave
+  static constexpr int EPI_ROWS = 64 / NHALF;
+  static constexpr int EPI_BYTES = NW * EPI_ROWS * EPI_STRIDE;
+  static_assert(EPI_BYTES <= LDS_BYTES, "epilogue staging must fit the operand ring");
   static_assert(PIECES % NW == 0, "pieces must divide evenly over the waves");
 };
 
@@ -84,7 +87,7 @@ __global__ __launch_bounds__((BM / 64) * 128) void gemm_nt_kernel(GemmP p) {
   // group-M order inside the XCD's run: GM row-panels x all column tiles, row index fastest, so the ~32-64 tiles an
   // XCD has in flight form a GM x (32/GM) patch whose A panels stay in that XCD's 4 MiB L2 while B tiles stream once
   // (row-major order re-streamed every B tile from beyond L2 for every row panel: 44 x 17 MB for the gate/up GEMM).
-  constexpr int GM = BM == 256 ? 4 : 8;
+  constexpr int GM = BM == 256 ? 4 : 8;   // A panels kept L2-resident per XCD
   const int tiles_m = p.ntiles / p.tiles_n, per_group = GM * p.tiles_n;
   const int grp = swz / per_group, rem = swz - grp * per_group;
   const int gm = min(GM, tiles_m - grp * GM);
@@ -145,23 +148,40 @@ __global__ __launch_bounds__((BM / 64) * 128) void gemm_nt_kernel(GemmP p) {
     }
     const char* sa = smem + buf * C::STAGE_BYTES + wr * 64 * 128;
     const char* sb = smem + buf * C::STAGE_BYTES + C::A_BYTES + wc * C::WTN * 128;
-    // all fragment reads of the K-tile (both 32-deep k-steps) are issued up front: the second k-step's LDS latency
-    // hides under the first k-step's MFMAs instead of stalling between them
-    bf16x8 fm[2][4], fn[2][C::NT];
+    if constexpr (C::NT <= 4) {
+      // all fragment reads of the K-tile (both 32-deep k-steps) are issued up front: the second k-step's LDS latency
+      // hides under the first k-step's MFMAs instead of stalling between them
+      bf16x8 fm[2][4], fn[2][C::NT];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < 2; ++s) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fm[s][i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + foff[s]);
+        for (int i = 0; i < 4; ++i) fm[s][i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + foff[s]);
 #pragma unroll
-      for (int i = 0; i < C::NT; ++i) fn[s][i] = *reinterpret_cast<const bf16x8*>(sb + i * 16 * 128 + foff[s]);
+        for (int i = 0; i < C::NT; ++i) fn[s][i] = *reinterpret_cast<const bf16x8*>(sb + i * 16 * 128 + foff[s]);
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int ni = 0; ni < C::NT; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[s][ni], fm[s][mi], acc[ni][mi], 0, 0, 0);
+    } else {
+      // 64 x 128 wave tile (128 accumulator registers): fragments per k-step, 12 reads feed 32 MFMAs
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 fm[4], fn[C::NT];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fm[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + foff[s]);
+#pragma unroll
+        for (int i = 0; i < C::NT; ++i) fn[i] = *reinterpret_cast<const bf16x8*>(sb + i * 16 * 128 + foff[s]);
+#pragma unroll
+        for (int ni = 0; ni < C::NT; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[ni], fm[mi], acc[ni][mi], 0, 0, 0);
+      }
     }
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int ni = 0; ni < C::NT; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[s][ni], fm[s][mi], acc[ni][mi], 0, 0, 0);
     if (++buf == STAGES) buf = 0;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -173,7 +193,7 @@ __global__ __launch_bounds__((BM / 64) * 128) void gemm_nt_kernel(GemmP p) {
   const int wm0 = m0 + wr * 64, wn0 = n0 + wc * C::WTN;
   const int lq = lane >> 4, lr = lane & 15;
   const bf16_t* bias = p.bias ? p.bias + (long long)z * p.sBias : nullptr;
-  char* reg = smem + wid * (64 * C::EPI_STRIDE);
+  char* reg = smem + wid * (C::EPI_ROWS * C::EPI_STRIDE);
 
   float bv[C::NT][4];
 #pragma unroll
@@ -305,48 +325,53 @@ __global__ __launch_bounds__((BM / 64) * 128) void gemm_nt_kernel(GemmP p) {
     }
   }
 
-  // stage the wave's 64 x WTN tile (bf16) through its private LDS region, then store 16 B per lane
-#pragma unroll
-  for (int ni = 0; ni < C::NT; ++ni)
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      uint2 o = {pack2(acc[ni][mi][0], acc[ni][mi][1]), pack2(acc[ni][mi][2], acc[ni][mi][3])};
-      *reinterpret_cast<uint2*>(reg + (mi * 16 + lr) * C::EPI_STRIDE + (ni * 16 + lq * 4) * 2) = o;
-    }
+  // stage the wave's 64 x WTN tile (bf16) through its private LDS region (NHALF passes), then store 16 B per lane
   bf16_t* Cb = p.C + (long long)z * p.sC;
   const bf16_t* Rb = p.R ? p.R + (long long)z * p.sR : nullptr;
   const bool vec_ok = ((p.ldc & 7) == 0) && (!Rb || (p.ldr & 7) == 0);
   constexpr int CH = C::WTN / 8;        // 16-B chunks per staged row
   constexpr int RPP = 64 / CH;          // rows per pass
+  constexpr int MIH = 4 / C::NHALF;     // 16-row m tiles per half
 #pragma unroll
-  for (int it = 0; it < CH; ++it) {
-    const int row = it * RPP + lane / CH, ch = lane % CH;
-    const int m = wm0 + row, n = wn0 + ch * 8;
-    uint4 v = *reinterpret_cast<const uint4*>(reg + row * C::EPI_STRIDE + ch * 16);
-    if (m >= p.M || n >= p.N) continue;
-    const int rrow = p.res_mod > 0 ? (m % p.res_mod) : m;
-    const long long crow = p.gC > 0 ? (long long)(m / p.gC) * p.sgC + (long long)(m % p.gC) * p.ldc : (long long)m * p.ldc;
-    if (vec_ok && n + 8 <= p.N) {
-      if (Rb) {
-        const uint4 rv = *reinterpret_cast<const uint4*>(Rb + (long long)rrow * p.ldr + n);
-        const unsigned a[4] = {v.x, v.y, v.z, v.w};
-        const unsigned b[4] = {rv.x, rv.y, rv.z, rv.w};
-        unsigned o[4];
+  for (int half = 0; half < C::NHALF; ++half) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          o[k] = pack2(bf2f((bf16_t)(a[k] & 0xffff)) + bf2f((bf16_t)(b[k] & 0xffff)),
-                       bf2f((bf16_t)(a[k] >> 16)) + bf2f((bf16_t)(b[k] >> 16)));
-        v = uint4{o[0], o[1], o[2], o[3]};
+    for (int ni = 0; ni < C::NT; ++ni)
+#pragma unroll
+      for (int mh = 0; mh < MIH; ++mh) {
+        const int mi = half * MIH + mh;
+        uint2 o = {pack2(acc[ni][mi][0], acc[ni][mi][1]), pack2(acc[ni][mi][2], acc[ni][mi][3])};
+        *reinterpret_cast<uint2*>(reg + (mh * 16 + lr) * C::EPI_STRIDE + (ni * 16 + lq * 4) * 2) = o;
       }
-      *reinterpret_cast<uint4*>(Cb + crow + n) = v;
-    } else {
-      const unsigned wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        if (n + k < p.N) {
-          float f = bf2f((bf16_t)((k & 1) ? (wv[k >> 1] >> 16) : (wv[k >> 1] & 0xffffu)));
-          if (Rb) f += bf2f(Rb[(long long)rrow * p.ldr + n + k]);
-          Cb[crow + n + k] = f2bf(f);
+    for (int it = 0; it < C::EPI_ROWS / RPP; ++it) {
+      const int row = it * RPP + lane / CH, ch = lane % CH;
+      const int m = wm0 + half * C::EPI_ROWS + row, n = wn0 + ch * 8;
+      uint4 v = *reinterpret_cast<const uint4*>(reg + row * C::EPI_STRIDE + ch * 16);
+      if (m >= p.M || n >= p.N) continue;
+      const int rrow = p.res_mod > 0 ? (m % p.res_mod) : m;
+      const long long crow = p.gC > 0 ? (long long)(m / p.gC) * p.sgC + (long long)(m % p.gC) * p.ldc : (long long)m * p.ldc;
+      if (vec_ok && n + 8 <= p.N) {
+        if (Rb) {
+          const uint4 rv = *reinterpret_cast<const uint4*>(Rb + (long long)rrow * p.ldr + n);
+          const unsigned a[4] = {v.x, v.y, v.z, v.w};
+          const unsigned b[4] = {rv.x, rv.y, rv.z, rv.w};
+          unsigned o[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            o[k] = pack2(bf2f((bf16_t)(a[k] & 0xffff)) + bf2f((bf16_t)(b[k] & 0xffff)),
+                         bf2f((bf16_t)(a[k] >> 16)) + bf2f((bf16_t)(b[k] >> 16)));
+          v = uint4{o[0], o[1], o[2], o[3]};
+        }
+        *reinterpret_cast<uint4*>(Cb + crow + n) = v;
+      } else {
+        const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (n + k < p.N) {
+            float f = bf2f((bf16_t)((k & 1) ? (wv[k >> 1] >> 16) : (wv[k >> 1] & 0xffffu)));
+            if (Rb) f += bf2f(Rb[(long long)rrow * p.ldr + n + k]);
+            Cb[crow + n + k] = f2bf(f);
+          }
         }
       }
     }
@@ -354,7 +379,8 @@ __global__ __launch_bounds__((BM / 64) * 128) void gemm_nt_kernel(GemmP p) {
 }
 
 // Pick the tile per problem.  Calibrated on MI355X (tools/bench_kernels.py, round 1):
-//  * 256x128 (3-stage, 1 block/CU) only pays on huge squares (8192^3: 1136 vs 1069 TF/s);
+//  * 256x256 (8 waves of 64x128, 1 block/CU) only pays on huge squares (8192^3: 1201 vs 1093 TF/s); 256x128x3-stage
+//    is kept as a forced option (VLA_GEMM_TILE=1);
 //  * 128x128 (2-stage, 2 blocks/CU = 512 resident tiles) vs 128x64 (2-stage, 3 blocks/CU = 768 resident half-tiles):
 //    wave quantisation decides.  cost = rounds x work per round; a round of narrow tiles covers 0.75x the output of a
 //    round of square tiles and is ~10 % (K <= 1152) to ~30 % (K >= 4096) less efficient per FLOP (measured).  E.g.
@@ -365,7 +391,8 @@ inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode) {
   if (force == 1 && rope_mode == 0) return {256, 128};
   if (force == 2) return {128, 128};
   if (force == 3) return {128, 64};
-  if (M >= 8192 && N >= 8192 && K >= 8192) return {256, 128};
+  if (force == 4 && rope_mode == 0) return {256, 256};
+  if (M >= 8192 && N >= 8192 && K >= 8192) return {256, 256};   // 64x128 wave tiles: 12 LDS reads per 32 MFMAs (1201 vs 1093 TF/s)
   const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128), t64 = (long long)((M + 127) / 128) * ((N + 63) / 64);
   const double c128 = (double)((t128 + 511) / 512);
   const double c64 = (double)((t64 + 767) / 768) * 0.75 * (K >= 4096 ? 1.3 : 1.1);
@@ -440,7 +467,8 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   else if (d->rope_mode == 2) {
     if (tc.bn == 128) launch<128, 128, 2, 2>(p, d->M, d->N, d->batch, st);
     else launch<128, 64, 2, 2>(p, d->M, d->N, d->batch, st);
-  } else if (tc.bm == 256) launch<256, 128, 3, 0>(p, d->M, d->N, d->batch, st);
+  } else if (tc.bm == 256 && tc.bn == 256) launch<256, 256, 2, 0>(p, d->M, d->N, d->batch, st);
+  else if (tc.bm == 256) launch<256, 128, 3, 0>(p, d->M, d->N, d->batch, st);
   else if (tc.bn == 128) launch<128, 128, 2, 0>(p, d->M, d->N, d->batch, st);
   else launch<128, 64, 2, 0>(p, d->M, d->N, d->batch, st);
   VLA_CHECK_LAUNCH("gemm_bf16_nt");
