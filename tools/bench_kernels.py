@@ -45,13 +45,13 @@ def main():
         else:
             out = torch.empty(M, N, device=DEV, dtype=BF)
             fn = lambda: ops.gemm_nt(a, w, bias=bias, act=act, out=out)
-        line = f"gemm {name:24s} M={M:6d} N={N:5d} K={K:5d} "
-        for tile, tn in ((0, "auto"), (4, "256x256"), (2, "128x128"), (3, "128x64")):
+        line = f"gemm {name:22s} {M:5d}x{N:4d}x{K:4d}"
+        for tile, tn in ((0, "auto"), (2, "128x128w8"), (5, "128x128w4"), (3, "128x64")):
             os.environ["VLA_GEMM_TILE"] = str(tile)
             t = timeit(fn)
             tf = 2.0 * M * N * K / t / 1e12
             res.append(dict(kernel="gemm", tile=tn, name=name, M=M, N=N, K=K, us=t * 1e6, tflops=tf))
-            line += f" | {tn} {t*1e6:7.1f}us {tf:6.1f}TF"
+            line += f" | {tn} {t*1e6:6.1f}us {tf:5.0f}TF"
         os.environ["VLA_GEMM_TILE"] = "0"
         print(line, flush=True)
     # attention

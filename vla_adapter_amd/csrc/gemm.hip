@@ -50,11 +50,11 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
-template <int BM, int BN, int STAGES>
+template <int BM, int BN, int STAGES, int WN = 2>
 struct Cfg {
-  static constexpr int NW = (BM / 64) * 2;               // waves: (BM/64) along M x 2 along N
+  static constexpr int NW = (BM / 64) * WN;              // waves: (BM/64) along M x WN along N
   static constexpr int NTHREADS = NW * 64;
-  static constexpr int WTN = BN / 2;                     // wave tile: 64 x WTN
+  static constexpr int WTN = BN / WN;                    // wave tile: 64 x WTN
   static constexpr int NT = WTN / 16;                    // 16-wide n tiles per wave (4 or 2)
   static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
@@ -71,13 +71,13 @@ struct Cfg {
 
 // ROPE is a compile-time switch (0 none / 1 rotate_half / 2 interleaved): the epilogue's extra registers and table
 // loads must not leak into the plain kernel that every other GEMM of the step runs.
-template <int BM, int BN, int STAGES, int ROPE>
-__global__ __launch_bounds__((BM / 64) * 128) void gemm_nt_kernel(GemmP p) {
-  using C = Cfg<BM, BN, STAGES>;
+template <int BM, int BN, int STAGES, int ROPE, int WN = 2>
+__global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
+  using C = Cfg<BM, BN, STAGES, WN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wid >> 1, wc = wid & 1;
+  const int wr = wid / WN, wc = wid - wr * WN;
 
   // XCD-aware bijective remap: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a
   // contiguous run of tiles so neighbouring tiles (same A row-panel) hit the same L2.
@@ -381,10 +381,10 @@ __global__ __launch_bounds__((BM / 64) * 128) void gemm_nt_kernel(GemmP p) {
 // Pick the tile per problem.  Calibrated on MI355X (tools/bench_kernels.py, round 1):
 //  * 256x256 (8 waves of 64x128, 1 block/CU) only pays on huge squares (8192^3: 1201 vs 1093 TF/s); 256x128x3-stage
 //    is kept as a forced option (VLA_GEMM_TILE=1);
-//  * 128x128 (2-stage, 2 blocks/CU = 512 resident tiles) vs 128x64 (2-stage, 3 blocks/CU = 768 resident half-tiles):
-//    wave quantisation decides.  cost = rounds x work per round; a round of narrow tiles covers 0.75x the output of a
-//    round of square tiles and is ~10 % (K <= 1152) to ~30 % (K >= 4096) less efficient per FLOP (measured).  E.g.
-//    M=11264,N=896,K=896: 616 square tiles = 2 rounds (2.0) vs 1232 narrow = 2 rounds x 0.75 x 1.1 (1.65): 625 vs 532 TF/s.
+//  * 128x128 with EIGHT waves (2x4 waves of 64x32, 2 blocks/CU = 16 waves/CU): the K-loop is latency/barrier bound
+//    (rocprofv3 PMC: SQ_WAIT_ANY 30-40 %, MFMA busy ~41 % with 4 waves), so more resident waves win over operand
+//    reuse per wave: +5..+40 % over the 4-wave 64x64 geometry on every hot shape;
+//  * 128x64 (4 waves, 3 blocks/CU) only for problems smaller than one round of tiles (the M=256 head GEMMs).
 struct TileChoice { int bm, bn; };
 inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode) {
   if (rope_mode == 1) return {128, 128};   // rotate_half pairs live in one wave's 64-column tile
@@ -392,25 +392,27 @@ inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode) {
   if (force == 2) return {128, 128};
   if (force == 3) return {128, 64};
   if (force == 4 && rope_mode == 0) return {256, 256};
+  if (force == 5 && rope_mode == 0) return {128, 129};   // 128x128 with 4 waves of 64x64 (the round-1 v1 geometry)
   if (M >= 8192 && N >= 8192 && K >= 8192) return {256, 256};   // 64x128 wave tiles: 12 LDS reads per 32 MFMAs (1201 vs 1093 TF/s)
-  const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128), t64 = (long long)((M + 127) / 128) * ((N + 63) / 64);
-  const double c128 = (double)((t128 + 511) / 512);
-  const double c64 = (double)((t64 + 767) / 768) * 0.75 * (K >= 4096 ? 1.3 : 1.1);
-  return c128 <= c64 ? TileChoice{128, 128} : TileChoice{128, 64};
+  // In situ (whole training step, same-box A/B) the 8-wave 128x128 geometry beats the narrow tile on every shape of
+  // the step, including the M=256 head GEMMs that overlap the LLM on the side stream (48.5 vs 49.5 vs 52.0 ms/step
+  // for always-square / mixed / always-narrow); the narrow tile stays available through VLA_GEMM_TILE=3.
+  (void)K;
+  return TileChoice{128, 128};
 }
 
-template <int BM, int BN, int STAGES, int ROPE>
+template <int BM, int BN, int STAGES, int ROPE, int WN = 2>
 int launch(const GemmP& p0, int M, int N, int batch, hipStream_t st) {
-  using C = Cfg<BM, BN, STAGES>;
+  using C = Cfg<BM, BN, STAGES, WN>;
   GemmP p = p0;
   p.tiles_n = (N + BN - 1) / BN;
   p.ntiles = ((M + BM - 1) / BM) * p.tiles_n;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, STAGES, ROPE>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, STAGES, ROPE, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, STAGES, ROPE>), dim3(p.ntiles, 1, batch), dim3(C::NTHREADS), C::LDS_BYTES, st, p);
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, STAGES, ROPE, WN>), dim3(p.ntiles, 1, batch), dim3(C::NTHREADS), C::LDS_BYTES, st, p);
   return 0;
 }
 
@@ -462,14 +464,15 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   const char* e = getenv("VLA_GEMM_TILE");     // 0/unset auto, 1: 256x128, 2: 128x128, 3: 128x64  (benchmarking aid)
   const TileChoice tc = choose_tile(d->M, d->N, d->K, e ? atoi(e) : 0, d->rope_mode);
   hipStream_t st = (hipStream_t)stream;
-  if (d->act == VLA_ACT_SWIGLU_BWD) launch<128, 128, 2, 3>(p, d->M, d->N, d->batch, st);
+  if (d->act == VLA_ACT_SWIGLU_BWD) launch<128, 128, 2, 3, 4>(p, d->M, d->N, d->batch, st);
   else if (d->rope_mode == 1) launch<128, 128, 2, 1>(p, d->M, d->N, d->batch, st);
   else if (d->rope_mode == 2) {
-    if (tc.bn == 128) launch<128, 128, 2, 2>(p, d->M, d->N, d->batch, st);
+    if (tc.bn == 128) launch<128, 128, 2, 2, 4>(p, d->M, d->N, d->batch, st);
     else launch<128, 64, 2, 2>(p, d->M, d->N, d->batch, st);
   } else if (tc.bm == 256 && tc.bn == 256) launch<256, 256, 2, 0>(p, d->M, d->N, d->batch, st);
   else if (tc.bm == 256) launch<256, 128, 3, 0>(p, d->M, d->N, d->batch, st);
-  else if (tc.bn == 128) launch<128, 128, 2, 0>(p, d->M, d->N, d->batch, st);
+  else if (tc.bn == 129) launch<128, 128, 2, 0>(p, d->M, d->N, d->batch, st);      // 4 waves of 64x64 (forced only)
+  else if (tc.bn == 128) launch<128, 128, 2, 0, 4>(p, d->M, d->N, d->batch, st);   // 8 waves (2x4) of 64x32
   else launch<128, 64, 2, 0>(p, d->M, d->N, d->batch, st);
   VLA_CHECK_LAUNCH("gemm_bf16_nt");
   return VLA_OK;

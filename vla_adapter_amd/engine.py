@@ -21,6 +21,7 @@ Layout decisions (MI355X-first, 288 GB HBM):
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -313,7 +314,7 @@ class LLM:
         L, d, other = self.layers[i], self._d, self._other
         if i < n - 1:                                   # head contribution to the output of layer i
             ops.add_(d, dHS[i + 1].view(M, D))
-        if c.inter % 64 == 0:     # dH GEMM with the SwiGLU backward fused into its epilogue (dH never materialised)
+        if c.inter % 64 == 0 and not os.environ.get("VLA_NO_FUSED_SWIGLU_BWD"):   # dH GEMM + SwiGLU backward in its epilogue
             ops.gemm_swiglu_bwd(d, L["wdT"], self.GU[i], out=self.d_gu)
         else:
             ops.gemm_nt(d, L["wdT"], out=self.d_h)
@@ -854,6 +855,8 @@ class VLAEngine:
         """``batch``/``noise`` become the static input buffers: copy new data INTO them before each replay."""
         self._ensure_streams()
         self._split = self.cfg.llm.n_layers // 3 if split is None else split
+        if os.environ.get("VLA_SPLIT"):
+            self._split = int(os.environ["VLA_SPLIT"])
         self._static_batch, self._static_noise = batch, noise
         for _ in range(warmup):                      # allocate every buffer / set kernel attributes outside capture
             self.head.dirty = True
