@@ -470,7 +470,7 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
     if (tc.bn == 128) launch<128, 128, 2, 2, 4>(p, d->M, d->N, d->batch, st);
     else launch<128, 64, 2, 2>(p, d->M, d->N, d->batch, st);
   } else if (tc.bm == 256 && tc.bn == 256) launch<256, 256, 2, 0>(p, d->M, d->N, d->batch, st);
-  else if (tc.bm == 256) launch<256, 128, 3, 0>(p, d->M, d->N, d->batch, st);
+  else if (tc.bm == 256) launch<256, 128, 3, 0, 4>(p, d->M, d->N, d->batch, st);   // 16 waves, loads two K-tiles ahead
   else if (tc.bn == 129) launch<128, 128, 2, 0>(p, d->M, d->N, d->batch, st);      // 4 waves of 64x64 (forced only)
   else if (tc.bn == 128) launch<128, 128, 2, 0, 4>(p, d->M, d->N, d->batch, st);   // 8 waves (2x4) of 64x32
   else launch<128, 64, 2, 0>(p, d->M, d->N, d->batch, st);
