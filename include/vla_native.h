@@ -52,6 +52,9 @@ typedef struct vla_gemm_desc {
    * rope_mode 2: action-head interleaved pairs, tables f32 [rope_T, rope_dh] (see vla_rope_interleaved). */
   int rope_mode, rope_T, rope_dh, rope_cols;
   const float* rope_cos; const float* rope_sin;
+  /* row-group addressing for R (0 = plain), same rule as a_group: the residual / the SwiGLU-backward pre-activations
+   * may be the [B, rows r0.. of S, N] window of a larger tensor (live-row LLM backward) */
+  int r_group; long long r_group_stride;
 } vla_gemm_desc;
 
 /* C = epilogue(A . B^T).  Replaces nn.Linear forward and, with pre-transposed operands, its dX / dW products:
@@ -80,9 +83,11 @@ int vla_layernorm_bwd(void* stream, const void* dy, const void* x, const void* w
 /* Qwen2RMSNorm: y = bf16(w * bf16(x * rsqrt(mean(x^2)+eps))) (transformers Qwen2RMSNorm.forward; call site
  * modeling_prismatic.py:644).  rstd (optional) f32 [rows]. */
 int vla_rmsnorm_fwd(void* stream, const void* x, const void* w, void* y, float* rstd, int rows, int cols, float eps);
-/* dx = rmsnorm backward (+ optional residual-stream gradient add: dx += dres).  No dw (frozen LLM). */
+/* dx = rmsnorm backward (+ optional residual-stream gradient add: dx += dres).  No dw (frozen LLM).
+ * dy/dres/dx are compact [rows, cols]; x_group > 0: row r of x / rstd is row (r / x_group) * x_group_rows + x_row0 +
+ * r % x_group of the forward's tensors (the live-row window [x_row0, x_row0 + x_group) of every sequence). */
 int vla_rmsnorm_bwd(void* stream, const void* dy, const void* x, const void* w, const float* rstd, const void* dres,
-                    void* dx, int rows, int cols);
+                    void* dx, int rows, int cols, int x_group, int x_group_rows, int x_row0);
 
 /* ---------------------------------------------------------------- attention (MFMA, flash-style) */
 typedef struct vla_attn_desc {
@@ -100,6 +105,11 @@ typedef struct vla_attn_desc {
   /* backward, optional: q/k were produced by rotate_half RoPE (tables f32 [S, 32], dh 64, position = sequence index):
    * dq/dk are returned already mapped through its transpose, i.e. as gradients of the PRE-rotation projections */
   const float* rope_cos; const float* rope_sin;
+  /* optional window (all 0 = plain): query i sits at sequence position q_off + i (causal masking and RoPE use that
+   * position; q/o/dout/dq point at the first live query row); lse is f32 [B, Hq, lse_hs] (0 -> Sq) indexed by i;
+   * backward: dK/dV are produced for keys >= dkv_k0 only, stored at row key - dkv_k0 of dk/dv.  With q_off = dkv_k0 = r0
+   * the backward costs only what the rows >= r0 of a causal sequence need (live-row backward of a frozen LLM). */
+  int q_off, dkv_k0, lse_hs;
 } vla_attn_desc;
 
 /* softmax(scale * Q K^T + mask) V, GQA (Hq % Hkv == 0), causal and/or key-padding mask, dh in {64,72,112,128}.
@@ -134,8 +144,9 @@ int vla_action_mask(void* stream, const long long* labels, int* qidx, int* pos, 
 int vla_embed_splice(void* stream, const long long* ids, const unsigned char* attn_mask, const int* qidx,
                      const void* table, const void* action_queries, void* out, unsigned char* mm_mask, int B, int L,
                      int Np, int D, int vocab);
-/* d action_queries[k] = sum_b dX[b, Np + pos[b,k]] (f32 [64, D]); backward of the splice. pos from shift=0 mask. */
-int vla_action_query_grad(void* stream, const void* dx, const int* pos, float* dq, int B, int S, int Np, int D);
+/* d action_queries[k] = sum_b dX[b, Np + pos[b,k]] (f32 [64, D]); backward of the splice. pos from shift=0 mask.
+ * dx holds the rows >= row0 of every sequence: bf16 [B, S, D] with S = (sequence length - row0). */
+int vla_action_query_grad(void* stream, const void* dx, const int* pos, float* dq, int B, int S, int Np, int D, int row0);
 /* out[i, :] = in[idx[i], :] (idx<0 -> zeros); bf16 rows of D elements. */
 int vla_gather_rows(void* stream, const void* in, const int* idx, void* out, int n, int D, int ldi, int ldo);
 /* out[idx[i], :] += in[i, :] (idx unique, idx<0 skipped). */

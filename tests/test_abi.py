@@ -35,11 +35,26 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.vla_version() == 1
 
 
-def test_descriptor_layouts_match_header(lib):
-    """ctypes struct sizes must match the C structs (x86-64 SysV): field counts/types are mirrored by hand."""
+def test_descriptor_layouts_match_header(lib, tmp_path):
+    """ctypes mirrors of the descriptor structs must match what a C compiler makes of include/vla_native.h:
+    same size and the same offset for every field (checked by compiling a probe with gcc)."""
+    import subprocess
     from vla_adapter_amd import native
-    assert ctypes.sizeof(native.GemmDesc) == 6 * 8 + 11 * 4 + 4 + 6 * 8 + 4 + 2 * 4 + 4 + 2 * 8 + 4 * 4 + 2 * 8  # ptrs, ints(+pad), strides, alpha, groups(+pad), group strides, rope
-    assert ctypes.sizeof(native.AttnDesc) % 8 == 0 and ctypes.sizeof(native.HeadAttnDesc) % 8 == 0
+    structs = {"vla_gemm_desc": native.GemmDesc, "vla_attn_desc": native.AttnDesc, "vla_head_attn_desc": native.HeadAttnDesc}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "vla_native.h")}"', "int main(void) {"]
+    for cname, cls in structs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src, exe = tmp_path / "probe.c", tmp_path / "probe"
+    src.write_text("\n".join(lines))
+    subprocess.run(["gcc", str(src), "-o", str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
 
 
 def test_argument_validation_without_gpu(lib):

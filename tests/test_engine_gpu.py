@@ -247,3 +247,51 @@ def test_pipelined_eager_matches_sequential(setup):
         assert abs(l1 - l2) <= 1e-6 + 2e-2 * it * abs(l1)
         g1, g2 = e1.head.P.grad.float().cpu(), e2.head.P.grad.float().cpu()
         assert (g1 - g2).norm() <= (2e-3 + 3e-2 * it) * g1.norm()
+
+
+def test_live_row_backward_equals_full_backward():
+    """Adapter-only fine-tune: the LLM backward restricted to the rows >= row0 (first action-query position rounded
+    down to 32) must give the SAME gradients for every trainable tensor as the full-sequence backward the reference's
+    autograd performs - and both must match the oracle's autograd gradient of action_queries."""
+    from vla_adapter_amd import engine as E, synthetic as S, ops
+    cfg = E.tiny_config()
+    W = S.make_weights(cfg, DEV, seed=3, std=0.05)
+    batch = S.make_batch(cfg, 3, DEV, seed=5, P=56, ragged=True)       # first action query at row >= 16 + 48 = 64
+    e_live, e_full = E.VLAEngine(cfg, W, DEV), E.VLAEngine(cfg, W, DEV)
+    e_full.full_llm_backward = True
+    grads = []
+    for e in (e_live, e_full):
+        pred = e.forward(batch, None)
+        e.loss_and_backward(pred, batch["actions"])
+        torch.cuda.synchronize()
+        grads.append(e.head.P.grad.float().cpu().clone())
+    assert e_live.live_row0() >= 64 and e_full.live_row0() == 0
+    assert e_live._dHS.shape[2] == e_live.S - e_live.live_row0() and e_full._dHS.shape[2] == e_full.S
+    aq = e_live.head.P.offsets["action_queries"][0]
+    assert torch.equal(grads[0][aq:], grads[1][aq:]), "action_queries gradient must not depend on the dead rows"
+    # head / proprio grads: identical computation except fp32 atomic orders of the bias / LayerNorm reductions
+    assert (grads[0][:aq] - grads[1][:aq]).norm() <= 2e-3 * grads[1][:aq].norm()
+    # and against the oracle's full autograd
+    out, OW = _oracle_run(cfg, W, batch, None, True, cfg.num_blocks)
+    _, dpred = ops.l1_loss(e_live.head.pred.view(3, cfg.chunk, cfg.action_dim), batch["actions"].to(BF), True)
+    out["pred"].backward(dpred.float().cpu())
+    r = rel(e_live.head.P.g("action_queries"), OW["action_queries"].grad)
+    assert r < 6e-2, f"action_queries grad (live-row backward) vs oracle autograd: {r:.3e}"
+
+
+def test_graph_replay_guards_frozen_row_window():
+    """A captured step freezes row0; replaying it on a batch whose action queries start earlier must poison the loss."""
+    from vla_adapter_amd import engine as E, synthetic as S
+    cfg = E.tiny_config()
+    W = S.make_weights(cfg, DEV, seed=3, std=0.05)
+    batch = S.make_batch(cfg, 2, DEV, seed=6, P=56)
+    eng = E.VLAEngine(cfg, W, DEV)
+    eng.capture(batch, None)
+    assert eng._row0 == 64
+    assert torch.isfinite(eng.train_step_graphed(1e-3)).all()
+    short = S.make_batch(cfg, 2, DEV, seed=7, P=56)
+    lab, ids = short["labels"], short["input_ids"]          # same shapes, action block moved 30 tokens earlier in row 1
+    lab[1], ids[1] = torch.roll(lab[1], -30), torch.roll(ids[1], -30)
+    for k in batch:
+        batch[k].copy_(short[k])
+    assert torch.isnan(eng.train_step_graphed(1e-3)).all()

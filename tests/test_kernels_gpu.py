@@ -540,3 +540,72 @@ def test_gemm_fused_swiglu_backward(ops):
     ((gg * torch.sigmoid(gg)) * uu * dhr).sum().backward()
     refa = torch.stack([gg.grad.view(M, I // 16, 16), uu.grad.view(M, I // 16, 16)], dim=2).reshape(M, 2 * I)
     check(fused, refa, rel=5e-3, name="fused swiglu bwd vs autograd")
+
+
+# ------------------------------------------------------------------------------------------------ live-row windows
+# Row-window forms used by the live-row LLM backward (engine.LLM.backward): each must reproduce, bit for bit, the rows
+# >= row0 of the full-sequence op (same instructions in the same order per row).
+@pytest.mark.parametrize("B,S,Hq,Hkv,dh,row0,masked,rope", [(2, 96, 4, 2, 64, 32, False, True), (2, 352, 14, 2, 64, 288, True, True),
+                                                            (1, 120, 4, 2, 64, 64, True, False), (2, 100, 2, 2, 72, 32, False, False)])
+def test_attention_bwd_live_rows(ops, B, S, Hq, Hkv, dh, row0, masked, rope):
+    qkv, q, k, v = _attn_inputs(B, S, Hq, Hkv, dh, 140)
+    dout = gen(B, S, Hq * dh, seed=141).to(DEV)
+    dout[:, :row0] = 0                      # dead rows carry no gradient: then full and windowed backward must agree
+    km = torch.ones(B, S, dtype=torch.bool)
+    if masked:
+        km[0, S - 9:] = False
+    d = qkv.to(DEV)
+    a, b = Hq * dh, (Hq + Hkv) * dh
+    qd, kd, vd = d[:, :, :a], d[:, :, a:b], d[:, :, b:]
+    kmd = km.to(torch.uint8).to(DEV) if masked else None
+    o, lse = ops.attn_fwd(qd, kd, vd, Hq, Hkv, dh, True, kmd, want_lse=True)
+    rp = ops.rope_half_tables(S, dh, 1e6, DEV) if rope else None
+    full = torch.zeros_like(d)
+    ops.attn_bwd(dout, qd, kd, vd, o, lse, Hq, Hkv, dh, True, kmd, dq=full[:, :, :a], dk=full[:, :, a:b], dv=full[:, :, b:], rope=rp)
+    R = S - row0
+    win = torch.zeros(B, R, d.shape[-1], dtype=BF, device=DEV)
+    ops.attn_bwd(dout[:, row0:].contiguous(), qd[:, row0:], kd, vd, o[:, row0:], lse, Hq, Hkv, dh, True, kmd,
+                 dq=win[:, :, :a], dk=win[:, :, a:b], dv=win[:, :, b:], rope=rp, row0=row0)
+    assert torch.equal(win[:, :, :a], full[:, row0:, :a]), "dq rows >= row0"
+    assert torch.equal(win[:, :, a:b], full[:, row0:, a:b]), "dk rows >= row0"
+    assert torch.equal(win[:, :, b:], full[:, row0:, b:]), "dv rows >= row0"
+
+
+def test_rmsnorm_bwd_row_window(ops):
+    B, S, D, r0 = 3, 40, 256, 8
+    x, w = gen(B * S, D, seed=150), (1 + 0.1 * gen(D, seed=151).float()).to(BF)
+    dy, dres = gen(B * S, D, seed=152), gen(B * S, D, seed=153)
+    _, rstd = ops.rmsnorm_fwd(x.to(DEV), w.to(DEV), 1e-6, want_rstd=True)
+    full = ops.rmsnorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), rstd, dres.to(DEV))
+    cut = lambda t: t.view(B, S, D)[:, r0:].contiguous().view(-1, D).to(DEV)
+    win = ops.rmsnorm_bwd(cut(dy), x.to(DEV), w.to(DEV), rstd, cut(dres), x_rows=(S - r0, S, r0))
+    assert torch.equal(win.view(B, S - r0, D), full.view(B, S, D)[:, r0:])
+
+
+def test_gemm_row_group_residual_and_swiglu_bwd_window(ops):
+    B, S, r0, D, I = 3, 50, 18, 128, 192
+    R = S - r0
+    # residual read through a row window
+    a, w, res = gen(B * R, D, seed=160), gen(D, D, seed=161, scale=0.1), gen(B * S, D, seed=162)
+    resd = res.to(DEV)
+    out = ops.gemm_nt(a.to(DEV), w.to(DEV), residual=resd[r0:], r_group=(R, S * D))
+    ref = ops.gemm_nt(a.to(DEV), w.to(DEV), residual=resd.view(B, S, D)[:, r0:].contiguous().view(B * R, D))
+    assert torch.equal(out, ref)
+    # SwiGLU backward epilogue reading the forward's pre-activations through a row window
+    gu, dd, wdT = gen(B * S, 2 * I, seed=163).to(DEV), gen(B * R, D, seed=164).to(DEV), gen(I, D, seed=165, scale=0.1).to(DEV)
+    win = ops.gemm_swiglu_bwd(dd, wdT, gu[r0:], gu_group=(R, S * 2 * I))
+    ref = ops.gemm_swiglu_bwd(dd, wdT, gu.view(B, S, 2 * I)[:, r0:].contiguous().view(B * R, 2 * I))
+    assert torch.equal(win, ref)
+
+
+def test_action_query_grad_row_window(ops):
+    B, P, Np, D, r0 = 3, 40, 16, 64, 32
+    L = P + 64
+    labels = torch.full((B, L), -100, dtype=torch.int64)
+    labels[:, P - 1:] = 151400
+    labels[:, P - 1] = 77
+    _, pos, _ = ops.action_mask(labels.to(DEV), 0)
+    dx = gen(B, L + Np, D, seed=170).to(DEV)
+    full = ops.action_query_grad(dx, pos, Np)
+    win = ops.action_query_grad(dx[:, r0:].contiguous(), pos, Np, r0)
+    assert torch.equal(full, win)

@@ -23,6 +23,9 @@ struct AttnP {
   const bf16_t* dout; bf16_t* dq; bf16_t* dk; bf16_t* dv; float* delta; float scale;
   long long do_sb, dq_sb, dk_sb, dv_sb; int do_ss, dq_ss, dk_ss, dv_ss;
   const float* rope_cos; const float* rope_sin;   // optional: return dq/dk already through the inverse rotate_half RoPE
+  int q_off;    // query i sits at sequence position q_off + i (causal: key j visible iff j <= q_off + i)
+  int dkv_k0;   // dK/dV are produced for keys >= dkv_k0 only and stored at row (key - dkv_k0)
+  int lse_hs;   // head stride of lse (f32 [B, Hq, lse_hs], query i at index i)
 };
 
 // Tile staging split in two (cdna_hip_programming.md T14): the global loads of tile t+1 are issued into registers
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
   for (int t = 0; t < G::DT; ++t) O[t] = zero16();
   float m_run = -INFINITY, l_run = 0.f;
 
-  const int kend = p.causal ? min(p.Sk, qblk + 128) : p.Sk;
+  const int kend = p.causal ? min(p.Sk, qblk + 128 + p.q_off) : p.Sk;
   const bf16_t* kb = p.k + (long long)b * p.k_sb + hkv * D;
   const bf16_t* vb = p.v + (long long)b * p.v_sb + hkv * D;
   u32x4 rk[TileGeo<D, 256>::NCH], rv[TileGeo<D, 256>::NCH];
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
       const int kk = k0 + 32 + (lane & 31);
       kok_next = kk < p.Sk && (!p.kmask || p.kmask[(long long)b * p.Sk + kk]);
     }
-    if (p.causal && k0 > q0 + 31) continue;  // wave-uniform: whole tile is in the future (barriers already passed)
+    if (p.causal && k0 > q0 + 31 + p.q_off) continue;  // wave-uniform: whole tile is in the future (barriers already passed)
 
     f32x16 S = zero16();
 #pragma unroll
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
       S = mfma32(kf, qf[ks], S);
     }
     float mt = -INFINITY;
-    if (km == 0xffffffffu && (!p.causal || k0 + 31 <= q0)) {   // wave-uniform: whole tile visible to every query
+    if (km == 0xffffffffu && (!p.causal || k0 + 31 <= q0 + p.q_off)) {   // wave-uniform: whole tile visible to every query
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         S[r] *= p.scale_log2;
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int kr = acc_row(r, h);
-        const bool ok = ((km >> kr) & 1u) && (!p.causal || k0 + kr <= qi);
+        const bool ok = ((km >> kr) & 1u) && (!p.causal || k0 + kr <= qi + p.q_off);
         S[r] = ok ? S[r] * p.scale_log2 : -INFINITY;
         mt = fmaxf(mt, S[r]);
       }
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
         }
       }
     if (p.lse && h == 0)
-      p.lse[((long long)b * p.Hq + hq) * p.Sq + qi] = l_run > 0.f ? (m_run + log2f(l_run)) * 0.6931471805599453f : -INFINITY;
+      p.lse[((long long)b * p.Hq + hq) * p.lse_hs + qi] = l_run > 0.f ? (m_run + log2f(l_run)) * 0.6931471805599453f : -INFINITY;
   }
 }
 
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
     }
   }
   const long long sidx = ((long long)b * p.Hq + hq) * p.Sq + qc;
-  const float lse2 = p.lse[sidx] * 1.4426950408889634f;  // natural -> log2 domain
+  const float lse2 = p.lse[((long long)b * p.Hq + hq) * p.lse_hs + qc] * 1.4426950408889634f;  // natural -> log2 domain
   // delta = rowsum(dO * O): each half-wave owns the d-chunks 16ks+8h.. of its query row; published for the dK/dV pass
   float delta = 0.f;
   {
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
 #pragma unroll
   for (int t = 0; t < G::DT; ++t) dQ[t] = zero16();
 
-  const int kend = p.causal ? min(p.Sk, qblk + 128) : p.Sk;
+  const int kend = p.causal ? min(p.Sk, qblk + 128 + p.q_off) : p.Sk;
   const bf16_t* kb = p.k + (long long)b * p.k_sb + hkv * D;
   const bf16_t* vb = p.v + (long long)b * p.v_sb + hkv * D;
   u32x4 rk[TileGeo<D, 256>::NCH], rv[TileGeo<D, 256>::NCH];
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
       const int kk = k0 + 32 + (lane & 31);
       kok_next = kk < p.Sk && (!p.kmask || p.kmask[(long long)b * p.Sk + kk]);
     }
-    if (p.causal && k0 > q0 + 31) continue;
+    if (p.causal && k0 > q0 + 31 + p.q_off) continue;
     f32x16 S = zero16(), dP = zero16();
 #pragma unroll
     for (int ks = 0; ks < G::KS; ++ks) {
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int kr = acc_row(r, h);
-      const bool ok = ((km >> kr) & 1u) && (!p.causal || k0 + kr <= qi);
+      const bool ok = ((km >> kr) & 1u) && (!p.causal || k0 + kr <= qi + p.q_off);
       const float pr = ok ? fexp2(S[r] * p.scale_log2 - lse2) : 0.f;
       S[r] = pr * (dP[r] - delta) * p.scale;  // dS^T
     }
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int d = 8 * g + 4 * h + j;
-        const float c = p.rope_cos[(long long)qc * 32 + d], sn = p.rope_sin[(long long)qc * 32 + d];
+        const float c = p.rope_cos[(long long)(qc + p.q_off) * 32 + d], sn = p.rope_sin[(long long)(qc + p.q_off) * 32 + d];
         const float a = dQ[0][4 * g + j], bb = dQ[G::DT - 1][4 * g + j];
         dQ[0][4 * g + j] = a * c + bb * sn;
         dQ[G::DT - 1][4 * g + j] = bb * c - a * sn;
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
   const int hh = w % grp, kt = w / grp;
   const int hkv = blockIdx.y, b = blockIdx.z, hq = hkv * grp + hh;
-  const int k0 = (blockIdx.x * KT + kt) * 32;
+  const int k0 = p.dkv_k0 + (blockIdx.x * KT + kt) * 32;
   const int ki = k0 + (lane & 31), kc = min(ki, p.Sk - 1);
   bf16_t* sQ = reinterpret_cast<bf16_t*>(smem + w * WAVE_BYTES);
   bf16_t* sdO = sQ + TILE;
@@ -336,15 +339,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int
   if (k0 < p.Sk) {
     const bf16_t* qb = p.q + (long long)b * p.q_sb + hq * D;
     const bf16_t* db = p.dout + (long long)b * p.do_sb + hq * D;
-    const long long sbase = ((long long)b * p.Hq + hq) * p.Sq;
-    const int qstart = p.causal ? k0 : 0;                 // k0 is a multiple of 32
+    const long long sbase = ((long long)b * p.Hq + hq) * p.Sq, lbase = ((long long)b * p.Hq + hq) * p.lse_hs;
+    const int qstart = p.causal ? max(k0 - p.q_off, 0) : 0;   // k0, q_off are multiples of 32
     u32x4 rq[TileGeo<D, 64>::NCH], rdo[TileGeo<D, 64>::NCH];
     tile_prefetch<D, 64>(rq, qb, p.q_ss, qstart, p.Sq, lane);
     tile_prefetch<D, 64>(rdo, db, p.do_ss, qstart, p.Sq, lane);
     float lse_n = 0.f, delta_n = 0.f;
     if (lane < 32) {
       const int qq = min(qstart + lane, p.Sq - 1);
-      lse_n = p.lse[sbase + qq];
+      lse_n = p.lse[lbase + qq];
       delta_n = p.delta[sbase + qq];
     }
     for (int q0 = qstart; q0 < p.Sq; q0 += 32) {
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int
         tile_prefetch<D, 64>(rdo, db, p.do_ss, q0 + 32, p.Sq, lane);
         if (lane < 32) {
           const int qq = min(q0 + 32 + lane, p.Sq - 1);
-          lse_n = p.lse[sbase + qq];
+          lse_n = p.lse[lbase + qq];
           delta_n = p.delta[sbase + qq];
         }
       }
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int qr = acc_row(r, h), qq = q0 + qr;
-        const bool ok = kok && qq < p.Sq && (!p.causal || ki <= qq);
+        const bool ok = kok && qq < p.Sq && (!p.causal || ki <= qq + p.q_off);
         const float pr = ok ? fexp2(S[r] * p.scale_log2 - sLse[qr]) : 0.f;
         S[r] = pr;
         dS[r] = pr * (dP[r] - sDelta[qr]) * p.scale;
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int
       const int o_ss = pass == 0 ? p.dk_ss : p.dv_ss;
       for (int i = tid; i < KT * 32 * G::DV; i += blockDim.x) {
         const int kt2 = i / (32 * G::DV), rem = i - kt2 * (32 * G::DV), key = rem / G::DV, d = rem - key * G::DV;
-        const int kg = (blockIdx.x * KT + kt2) * 32 + key;
+        const int kg = p.dkv_k0 + (blockIdx.x * KT + kt2) * 32 + key;
         if (kg < p.Sk && d < D) {
           const float* src = reinterpret_cast<const float*>(smem) + (kt2 * grp) * (32 * ACC_LD) + key * ACC_LD + d;
           float sum = 0.f;
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int
             const float c = p.rope_cos[(long long)kg * 32 + (d & 31)], sn = p.rope_sin[(long long)kg * 32 + (d & 31)];
             sum = d < 32 ? sum * c + other * sn : sum * c - other * sn;
           }
-          outp[(long long)b * o_sb + (long long)kg * o_ss + hkv * D + d] = f2bf(sum);
+          outp[(long long)b * o_sb + (long long)(kg - p.dkv_k0) * o_ss + hkv * D + d] = f2bf(sum);
         }
       }
     }
@@ -447,8 +450,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int
       }
   }
   if (hh == 0 && ki < p.Sk) {
-    bf16_t* okp = p.dk + (long long)b * p.dk_sb + (long long)ki * p.dk_ss + hkv * D;
-    bf16_t* ovp = p.dv + (long long)b * p.dv_sb + (long long)ki * p.dv_ss + hkv * D;
+    bf16_t* okp = p.dk + (long long)b * p.dk_sb + (long long)(ki - p.dkv_k0) * p.dk_ss + hkv * D;
+    bf16_t* ovp = p.dv + (long long)b * p.dv_sb + (long long)(ki - p.dkv_k0) * p.dv_ss + hkv * D;
 #pragma unroll
     for (int t = 0; t < G::DT; ++t)
 #pragma unroll
@@ -478,6 +481,10 @@ int fill(AttnP& p, const vla_attn_desc* d, bool bwd) {
   p.q_ss = d->q_ss; p.k_ss = d->k_ss; p.v_ss = d->v_ss; p.o_ss = d->o_ss;
   p.B = d->B; p.Sq = d->Sq; p.Sk = d->Sk; p.Hq = d->Hq; p.Hkv = d->Hkv; p.dh = d->dh; p.causal = d->causal;
   p.scale = d->scale; p.scale_log2 = d->scale * 1.4426950408889634f;
+  p.q_off = d->q_off; p.dkv_k0 = d->dkv_k0; p.lse_hs = d->lse_hs > 0 ? d->lse_hs : d->Sq;
+  VLA_REQUIRE(d->q_off >= 0 && d->q_off % 32 == 0 && (d->q_off == 0 || (d->causal && d->q_off + d->Sq <= d->Sk)),
+              "attn: q_off must be a multiple of 32, causal only, q_off + Sq <= Sk");
+  VLA_REQUIRE(d->dkv_k0 >= 0 && d->dkv_k0 % 32 == 0 && d->dkv_k0 < d->Sk && p.lse_hs >= d->Sq, "attn: bad dkv_k0 / lse_hs");
   if (bwd) {
     VLA_REQUIRE(d->dout && d->dq && d->dk && d->dv && d->delta && d->lse, "attn_bwd: null tensor");
     VLA_REQUIRE(d->do_ss % 8 == 0 && d->do_sb % 8 == 0 && ((uintptr_t)d->dout & 15) == 0, "attn_bwd: dout alignment");
@@ -488,7 +495,7 @@ int fill(AttnP& p, const vla_attn_desc* d, bool bwd) {
     p.do_sb = d->do_sb; p.dq_sb = d->dq_sb; p.dk_sb = d->dk_sb; p.dv_sb = d->dv_sb;
     p.do_ss = d->do_ss; p.dq_ss = d->dq_ss; p.dk_ss = d->dk_ss; p.dv_ss = d->dv_ss;
     p.rope_cos = d->rope_cos; p.rope_sin = d->rope_sin;
-    if (d->rope_cos) VLA_REQUIRE(d->rope_sin && d->dh == 64 && d->Sq == d->Sk, "attn_bwd: fused inverse RoPE needs dh == 64 (tables f32 [S, 32])");
+    if (d->rope_cos) VLA_REQUIRE(d->rope_sin && d->dh == 64 && d->Sq + d->q_off == d->Sk, "attn_bwd: fused inverse RoPE needs dh == 64 (tables f32 [Sk, 32])");
   }
   return VLA_OK;
 }
@@ -520,7 +527,7 @@ extern "C" int vla_attn_bwd(void* stream, const vla_attn_desc* d) {
   const int grp = p.Hq / p.Hkv;
   VLA_REQUIRE(grp <= 8, "attn_bwd: at most 8 query heads per kv head");
   const int KT = grp >= 4 ? 1 : 4 / grp;                   // waves per workgroup = grp * KT (4..8)
-  dim3 gq((p.Sq + 127) / 128, p.Hq, p.B), gk((p.Sk + 32 * KT - 1) / (32 * KT), p.Hkv, p.B);
+  dim3 gq((p.Sq + 127) / 128, p.Hq, p.B), gk((p.Sk - p.dkv_k0 + 32 * KT - 1) / (32 * KT), p.Hkv, p.B);
   const int ld = ((p.dh + 31) / 32 * 32 + 8);
   const size_t lds = (size_t)grp * KT * (2 * 32 * ld * 2 + 256);
   static bool attr_set = false;

@@ -85,14 +85,15 @@ __global__ void embed_splice_kernel(const long long* __restrict__ ids, const uns
 }
 
 __global__ void action_query_grad_kernel(const bf16_t* __restrict__ dx, const int* __restrict__ pos, float* __restrict__ dq,
-                                         int B, int S, int Np, int D) {
+                                         int B, int S, int Np, int D, int row0) {
   const int k = blockIdx.x;
   for (int d = threadIdx.x; d < D; d += blockDim.x) {
     float a = 0.f;
     for (int b = 0; b < B; ++b) {
       const int j = pos[b * 64 + k];
       if (j < 0) continue;
-      const int s = j == 0 ? 0 : Np + j;
+      const int s = (j == 0 ? 0 : Np + j) - row0;    // dx holds the rows >= row0 of every sequence
+      if (s < 0) continue;                            // caller guarantees row0 <= first action position
       a += bf2f(dx[((long long)b * S + s) * D + d]);
     }
     dq[k * D + d] = a;
@@ -353,9 +354,10 @@ extern "C" int vla_embed_splice(void* stream, const long long* ids, const unsign
   return VLA_OK;
 }
 
-extern "C" int vla_action_query_grad(void* stream, const void* dx, const int* pos, float* dq, int B, int S, int Np, int D) {
-  VLA_REQUIRE(dx && pos && dq && B > 0 && S > Np && D > 0, "action_query_grad: bad args");
-  hipLaunchKernelGGL(action_query_grad_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dx, pos, dq, B, S, Np, D);
+extern "C" int vla_action_query_grad(void* stream, const void* dx, const int* pos, float* dq, int B, int S, int Np, int D,
+                                     int row0) {
+  VLA_REQUIRE(dx && pos && dq && B > 0 && S > 0 && S + row0 > Np && D > 0 && row0 >= 0, "action_query_grad: bad args");
+  hipLaunchKernelGGL(action_query_grad_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dx, pos, dq, B, S, Np, D, row0);
   VLA_CHECK_LAUNCH("action_query_grad");
   return VLA_OK;
 }

@@ -37,7 +37,7 @@ struct GemmP {
   long long sA, sB, sC, sR, sC2, sBias;
   int tiles_n, ntiles;
   float alpha;
-  int gA, gC; long long sgA, sgC;  // row-group addressing: row r -> (r / g) * sg + (r % g) * ld
+  int gA, gC, gR; long long sgA, sgC, sgR;  // row-group addressing: row r -> (r / g) * sg + (r % g) * ld
   int rope_mode, rope_T, rope_dh, rope_cols; const float* rope_cos; const float* rope_sin;
 };
 
@@ -221,7 +221,8 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
 #pragma unroll
         for (int ni = 0; ni < C::NT; ++ni) {
           const int hc = wn0 + ni * 16 + lq * 4;            // first of this lane's 4 h-columns
-          const long long go = (long long)m * p.ldr + (hc >> 4) * 32 + (hc & 15);
+          const long long go = (p.gR > 0 ? (long long)(m / p.gR) * p.sgR + (long long)(m % p.gR) * p.ldr : (long long)m * p.ldr) +
+                               (hc >> 4) * 32 + (hc & 15);
           const bool ok = hc + 3 < p.N;
           const uint2 gv = ok ? *reinterpret_cast<const uint2*>(GU + go) : uint2{0, 0};
           const uint2 uv = ok ? *reinterpret_cast<const uint2*>(GU + go + 16) : uint2{0, 0};
@@ -348,11 +349,12 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
       const int m = wm0 + half * C::EPI_ROWS + row, n = wn0 + ch * 8;
       uint4 v = *reinterpret_cast<const uint4*>(reg + row * C::EPI_STRIDE + ch * 16);
       if (m >= p.M || n >= p.N) continue;
-      const int rrow = p.res_mod > 0 ? (m % p.res_mod) : m;
+      const long long roff = p.res_mod > 0 ? (long long)(m % p.res_mod) * p.ldr
+                             : p.gR > 0 ? (long long)(m / p.gR) * p.sgR + (long long)(m % p.gR) * p.ldr : (long long)m * p.ldr;
       const long long crow = p.gC > 0 ? (long long)(m / p.gC) * p.sgC + (long long)(m % p.gC) * p.ldc : (long long)m * p.ldc;
       if (vec_ok && n + 8 <= p.N) {
         if (Rb) {
-          const uint4 rv = *reinterpret_cast<const uint4*>(Rb + (long long)rrow * p.ldr + n);
+          const uint4 rv = *reinterpret_cast<const uint4*>(Rb + roff + n);
           const unsigned a[4] = {v.x, v.y, v.z, v.w};
           const unsigned b[4] = {rv.x, rv.y, rv.z, rv.w};
           unsigned o[4];
@@ -369,7 +371,7 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
         for (int k = 0; k < 8; ++k) {
           if (n + k < p.N) {
             float f = bf2f((bf16_t)((k & 1) ? (wv[k >> 1] >> 16) : (wv[k >> 1] & 0xffffu)));
-            if (Rb) f += bf2f(Rb[(long long)rrow * p.ldr + n + k]);
+            if (Rb) f += bf2f(Rb[roff + n + k]);
             Cb[crow + n + k] = f2bf(f);
           }
         }
@@ -452,6 +454,9 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   p.tiles_n = p.ntiles = 0;
   p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
   p.gA = d->a_group; p.sgA = d->a_group_stride; p.gC = d->c_group; p.sgC = d->c_group_stride;
+  p.gR = d->r_group; p.sgR = d->r_group_stride;
+  VLA_REQUIRE(d->r_group >= 0 && d->r_group_stride % 8 == 0 && (d->r_group == 0 || d->res_mod == 0),
+              "gemm: r_group stride must keep 16-B alignment; r_group and res_mod are exclusive");
   p.rope_mode = d->rope_mode; p.rope_T = d->rope_T; p.rope_dh = d->rope_dh; p.rope_cols = d->rope_cols;
   p.rope_cos = d->rope_cos; p.rope_sin = d->rope_sin;
   if (d->rope_mode != 0) {

@@ -181,14 +181,15 @@ template <int NCH>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                           const bf16_t* __restrict__ w, const float* __restrict__ rstd_in,
                                                           const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
-                                                          int rows, int cols) {
+                                                          int rows, int cols, int xg, int xgr, int xr0) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  const long long xrow = xg > 0 ? (long long)(row / xg) * xgr + xr0 + (row % xg) : row;   // row of x / rstd
   uint4 vx[NCH], vd[NCH];
-  load_row<NCH>(x + (long long)row * cols, cols, lane, vx);
+  load_row<NCH>(x + xrow * cols, cols, lane, vx);
   load_row<NCH>(dy + (long long)row * cols, cols, lane, vd);
-  const float rstd = rstd_in[row];
+  const float rstd = rstd_in[xrow];
   float s = 0.f;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
@@ -285,13 +286,15 @@ extern "C" int vla_rmsnorm_fwd(void* stream, const void* x, const void* w, void*
 }
 
 extern "C" int vla_rmsnorm_bwd(void* stream, const void* dy, const void* x, const void* w, const float* rstd,
-                               const void* dres, void* dx, int rows, int cols) {
+                               const void* dres, void* dx, int rows, int cols, int x_group, int x_group_rows, int x_row0) {
   VLA_REQUIRE(dy && x && w && rstd && dx && rows > 0 && cols > 0, "rmsnorm_bwd: null/empty");
+  VLA_REQUIRE(x_group >= 0 && (x_group == 0 || (x_row0 >= 0 && x_row0 + x_group <= x_group_rows)), "rmsnorm_bwd: bad row window");
   VLA_REQUIRE(cols % 8 == 0 && cols <= 8192, "rmsnorm_bwd: cols%8==0");
   const int n = nch_for(cols);
   dim3 grid((rows + 3) / 4);
 #define CALL(N) hipLaunchKernelGGL(rmsnorm_bwd_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, \
-                                   (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, rows, cols)
+                                   (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)dres, (bf16_t*)dx, rows, cols, \
+                                   x_group, x_group_rows, x_row0)
   DISPATCH_NCH(n, CALL)
 #undef CALL
   VLA_CHECK_LAUNCH("rmsnorm_bwd");

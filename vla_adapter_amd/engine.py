@@ -295,46 +295,68 @@ class LLM:
         d = ops._attn_desc(q, k, v, o, self.LSE[i], self.kmask, True, c.dh ** -0.5, c.heads, c.kv_heads, c.dh)
         ops.N.check(ops._lib().vla_attn_fwd(ops._st(), C.byref(d)), "attn_fwd")
 
-    def backward(self, dHS: torch.Tensor, B: int, S: int) -> torch.Tensor:
-        """dHS [n+1, B, S, D]: gradient w.r.t. hidden_states[i] (i = 0..n, HF convention; [0] unused).
-        Returns the gradient w.r.t. inputs_embeds [B,S,D] (frozen weights: no dW)."""
-        self.bwd_begin(dHS)
+    # ---- backward: dX only (frozen weights), restricted to the LIVE rows ------------------------------------------
+    # The only trainable tensor upstream of the LLM is `action_queries`, spliced in at sequence positions >= r_first
+    # (after tok0 + patches + prompt).  Causal attention makes row i of every hidden state a function of the input rows
+    # <= i only, so d loss / d inputs_embeds[rows >= r0] depends on d loss / d hidden[rows >= r0] alone, for any
+    # r0 <= r_first: the gradient rows < r0 flow exclusively into frozen inputs (patch / prompt embeddings) and are dead.
+    # torch.autograd (the reference) computes them anyway because it prunes by tensor, not by row.  `row0` selects the
+    # window; every op below works on compact [B * (S - row0), .] gradients and reads the forward's tensors through
+    # row-window addressing.  row0 = 0 is the plain full-sequence backward (needed as soon as ViT / projector / LoRA
+    # weights train).  The surviving gradients are the same numbers either way (tests/test_engine_gpu.py).
+    def backward(self, dHS: torch.Tensor, B: int, S: int, row0: int = 0) -> torch.Tensor:
+        """dHS [n+1, B, S - row0, D]: gradient w.r.t. rows >= row0 of hidden_states[i] (i = 0..n, HF convention; [0]
+        unused).  Returns the gradient w.r.t. rows >= row0 of inputs_embeds, [B, S - row0, D] (frozen weights: no dW)."""
+        self.bwd_begin(dHS, row0)
         for i in range(self.cfg.n_layers - 1, -1, -1):
             self.bwd_layer(i, dHS)
         return self.bwd_result()
 
-    def bwd_begin(self, dHS: torch.Tensor):
-        n, M, D = self.cfg.n_layers, self.B * self.S, self.cfg.d
-        self._d = ops.rmsnorm_bwd(dHS[n].view(M, D), self.HS[n + 1].view(M, D), self.norm, self.RF, out=self.d_a)
-        self._other = self.d_b
+    def bwd_begin(self, dHS: torch.Tensor, row0: int = 0):
+        n, S, D = self.cfg.n_layers, self.S, self.cfg.d
+        assert 0 <= row0 < S and row0 % 32 == 0, "live-row window must start on a multiple of 32"
+        self.r0, self.Rl = row0, S - row0
+        Mr = self.B * self.Rl
+        assert tuple(dHS.shape[1:]) == (self.B, self.Rl, D)
+        self._win = (self.Rl, S, row0)                        # (rows per sequence, sequence rows, first row)
+        self._d = ops.rmsnorm_bwd(dHS[n].view(Mr, D), self.HS[n + 1].view(-1, D), self.norm, self.RF, out=self.d_a[:Mr],
+                                  x_rows=self._win)
+        self._other = self.d_b[:Mr]
 
     def bwd_layer(self, i: int, dHS: torch.Tensor):
-        c, B, S = self.cfg, self.B, self.S
-        n, M, D, H, KV, dh = c.n_layers, B * S, c.d, c.heads, c.kv_heads, c.dh
+        c, B, S, r0, R = self.cfg, self.B, self.S, self.r0, self.Rl
+        n, M, D, H, KV, dh, I = c.n_layers, B * S, c.d, c.heads, c.kv_heads, c.dh, c.inter
+        Mr = B * R
         L, d, other = self.layers[i], self._d, self._other
         if i < n - 1:                                   # head contribution to the output of layer i
-            ops.add_(d, dHS[i + 1].view(M, D))
-        if c.inter % 64 == 0 and not os.environ.get("VLA_NO_FUSED_SWIGLU_BWD"):   # dH GEMM + SwiGLU backward in its epilogue
-            ops.gemm_swiglu_bwd(d, L["wdT"], self.GU[i], out=self.d_gu)
+            ops.add_(d, dHS[i + 1].view(Mr, D))
+        gu_live = self.GU[i][r0:]                       # first sequence's window; the others by row-group addressing
+        d_gu, d_n = self.d_gu[:Mr], self.d_n[:Mr]
+        if I % 64 == 0 and not os.environ.get("VLA_NO_FUSED_SWIGLU_BWD"):   # dH GEMM + SwiGLU backward in its epilogue
+            ops.gemm_swiglu_bwd(d, L["wdT"], gu_live, out=d_gu, gu_group=(R, S * 2 * I))
         else:
-            ops.gemm_nt(d, L["wdT"], out=self.d_h)
-            ops.swiglu_bwd(self.d_h, self.GU[i], out=self.d_gu)
-        ops.gemm_nt(self.d_gu, L["wguT"], out=self.d_n)
-        d1 = ops.rmsnorm_bwd(self.d_n, self.X1[i], L["n2"], self.R2[i], dres=d, out=other)
-        dao = ops.gemm_nt(d1, L["woT"], out=self.d_n)
+            ops.gemm_nt(d, L["wdT"], out=self.d_h[:Mr])
+            gu_c = self.GU[i].view(B, S, 2 * I)[:, r0:].contiguous().view(Mr, 2 * I) if r0 else self.GU[i]
+            ops.swiglu_bwd(self.d_h[:Mr], gu_c, out=d_gu)
+        ops.gemm_nt(d_gu, L["wguT"], out=d_n)
+        d1 = ops.rmsnorm_bwd(d_n, self.X1[i], L["n2"], self.R2[i], dres=d, out=other, x_rows=self._win)
+        dao = ops.gemm_nt(d1, L["woT"], out=d_n)
         q, k, v = self._attn_views(self.QKV[i].view(B, S, -1))
-        dq, dk, dv = self._attn_views(self.d_qkv.view(B, S, -1))
-        ops.attn_bwd(dao.view(B, S, -1), q, k, v, self.AO[i].view(B, S, -1), self.LSE[i], H, KV, dh, True, self.kmask,
-                     dq=dq, dk=dk, dv=dv, rope=(self.cos, self.sin) if dh == 64 else None)
+        W = self.QKV.shape[-1]
+        d_qkv = self.d_qkv[:Mr]
+        dq, dk, dv = self._attn_views(d_qkv.view(B, R, W))
+        ops.attn_bwd(dao.view(B, R, -1), q[:, r0:], k, v, self.AO[i].view(B, S, -1)[:, r0:], self.LSE[i], H, KV, dh, True,
+                     self.kmask, dq=dq, dk=dk, dv=dv, rope=(self.cos, self.sin) if dh == 64 else None, row0=r0)
         if dh != 64:
-            ops.rope_half_(self.d_qkv[:, :H * dh], self.cos, self.sin, S, H, dh, sign=-1)
-            ops.rope_half_(self.d_qkv[:, H * dh:(H + KV) * dh], self.cos, self.sin, S, KV, dh, sign=-1)
-        ops.gemm_nt(self.d_qkv, L["wqkvT"], out=self.d_n)
-        d_new = ops.rmsnorm_bwd(self.d_n, self.HS[i].view(M, D), L["n1"], self.R1[i], dres=d1, out=d)
+            cs, sn = self.cos[r0:], self.sin[r0:]
+            ops.rope_half_(d_qkv[:, :H * dh], cs, sn, R, H, dh, sign=-1)
+            ops.rope_half_(d_qkv[:, H * dh:(H + KV) * dh], cs, sn, R, KV, dh, sign=-1)
+        ops.gemm_nt(d_qkv, L["wqkvT"], out=d_n)
+        d_new = ops.rmsnorm_bwd(d_n, self.HS[i].view(M, D), L["n1"], self.R1[i], dres=d1, out=d, x_rows=self._win)
         self._d, self._other = d_new, d1
 
     def bwd_result(self) -> torch.Tensor:
-        return self._d.view(self.B, self.S, self.cfg.d)
+        return self._d.view(self.B, self.Rl, self.cfg.d)
 
 
 # ------------------------------------------------------------------------------------------------ trainable params
@@ -510,7 +532,7 @@ class Head:
         T = cfg.chunk
         self._alloc(B, Np)
         self.refresh_transposes()
-        self.HSref, self.Np, self.S, self.B = HS, Np, S, B
+        self.HSref, self.Np, self.S, self.B, self.pos1 = HS, Np, S, B, pos1
         # proprio projector (projectors.py:19-24); proprio rounded to bf16 first (action_heads.py:53)
         self.pr_in[:, :cfg.proprio_dim] = proprio.to(BF16)
         self.pp_pre = ops.gemm_nt(self.pr_in, self.pfc1_pad, bias=P.view("p_fc1_b"))
@@ -578,18 +600,24 @@ class Head:
                               g[:, :, 2 * D:], ga[:, :, :D], ga[:, :, D:], gt[:, :, :D], gt[:, :, D:], H, rope=self.rope_tab)
 
     # ---- backward ---------------------------------------------------------------------------------------------
-    def backward(self, dpred: torch.Tensor, dHS: torch.Tensor):
+    def backward(self, dpred: torch.Tensor, dHS: torch.Tensor, row0: int = 0):
         """dpred [B, chunk, 7] bf16.  Writes parameter gradients into the flat grad buffer and the hidden-state
-        gradients into dHS [nb+1, B, S, D] (HF indexing; rows not touched by the head must be pre-zeroed).
+        gradients into dHS [nb+1, B, S - row0, D] (HF indexing; rows not touched by the head must be pre-zeroed).
         Sequential composition of bwd_begin / bwd_layer / bwd_end."""
-        self.bwd_begin(dpred)
+        self.bwd_begin(dpred, row0)
         for i in range(self.nb - 1, -1, -1):
             self.bwd_layer(i, dHS)
         self.bwd_end()
 
-    def bwd_begin(self, dpred: torch.Tensor):
+    def bwd_begin(self, dpred: torch.Tensor, row0: int = 0):
+        """row0: first live row of the LLM backward (LLM.backward); dHS handed to bwd_layer is [nb+1, B, S - row0, D].
+        row0 > 0 also means nothing upstream of the task tokens trains: their dX is dead and skipped."""
         cfg, P, nb = self.cfg, self.P, self.nb
         R, Da = self.R, cfg.action_dim
+        self.row0 = row0
+        loc = self.Np + self.pos1.to(torch.int32) - row0          # [B, 64] row inside the live window (or < 0: dead row)
+        base = torch.arange(self.B, device=loc.device, dtype=torch.int32)[:, None] * (self.S - row0)
+        self.row_idx_live = torch.where((loc >= 0) & (self.pos1 >= 0), base + loc, torch.full_like(loc, -1)).to(torch.int32).contiguous()
         for t in (self.dgate, self.ln_dw, self.ln_db, self.ln1_dw, self.ln1_db, self.ln2_dw, self.ln2_db, *self.b_f32.values()):
             t.zero_()
         dp = dpred.reshape(R, Da)
@@ -617,8 +645,9 @@ class Head:
         ops.gemm_nt(self.dKV_adp[i], self.T["w_adp"][i], out=self.dh_adp[i])
         dha = self.dh_adp[i].view(B, Ka, D)
         self.gtmp.view(B, NUM_TOKENS, D).copy_(dha[:, :NUM_TOKENS])
-        ops.scatter_add_rows(self.gtmp, self.row_idx.view(-1), dHS[i + 1].view(B * S, D))
-        ops.gemm_nt(self.dKV_task[i], self.T["w_task"][i], out=dHS[i + 1].view(B * S, D)[:B * Kt], c_group=(Kt, S * D))
+        ops.scatter_add_rows(self.gtmp, self.row_idx_live.view(-1), dHS[i + 1].view(-1, D))
+        if self.row0 == 0:
+            ops.gemm_nt(self.dKV_task[i], self.T["w_task"][i], out=dHS[i + 1].view(B * S, D)[:B * Kt], c_group=(Kt, S * D))
 
     def bwd_end(self):
         """Off the critical path: input stage, proprio projector, and every dW as batched NT GEMMs on transposed operands."""
@@ -696,6 +725,10 @@ class VLAEngine:
         self.proj = {k: g(k) for k in weights["proj"]}
         self.step_count = 0
         self._dHS = None
+        # adapter-only fine-tune: the LLM backward only has to cover the rows that can reach `action_queries`
+        # (LLM.backward).  VLA_FULL_LLM_BWD=1 / full_llm_backward=True runs the reference-shaped full-sequence backward.
+        self.full_llm_backward = bool(int(os.environ.get("VLA_FULL_LLM_BWD", "0")))
+        self._row0 = None          # frozen by capture(); None = derive from every batch (one host sync)
         self.reducer = None        # ddp.FlatGradReducer when world_size > 1
 
     def forward(self, batch: Dict[str, torch.Tensor], noise: Optional[torch.Tensor] = None):
@@ -750,20 +783,42 @@ class VLAEngine:
         self.B, self.S, self.Np = B, S, Np
         return mm
 
-    def loss_and_backward(self, pred, actions, gscale: float = 1.0):
-        """L1 loss (finetune.py:418) + full backward into the flat grad buffer."""
-        llm, head = self.llm, self.head
-        B, S, Np, D, n = self.B, self.S, self.Np, self.cfg.llm.d, self.cfg.llm.n_layers
-        loss3, dpred = ops.l1_loss(pred, actions.to(BF16), True, gscale)
-        if self._dHS is None or self._dHS.shape[1:3] != (B, S):
-            self._dHS = torch.empty(n + 1, B, S, D, device=self.device, dtype=BF16)
+    def live_row0(self) -> int:
+        """First sequence row the backward has to cover: the largest multiple of 32 not above the first action-query
+        position of any sample of the current batch (0 = whole sequence).  Reads the mask positions back (host sync)."""
+        if self.full_llm_backward:
+            return 0
+        first = self.pos0[:, 0]
+        if bool((self.cnt0 < 1).any()):
+            return 0
+        return (self.Np + int(first.min())) // 32 * 32
+
+    def _row0_guard(self, row0: int) -> torch.Tensor:
+        """NaN if a sample of the current batch has an action query before row0 (a captured graph is replayed with a
+        frozen row0), else 0 - added to the reported loss so that a violated assumption cannot pass silently."""
+        first = torch.where(self.cnt0 > 0, self.pos0[:, 0] + self.Np, torch.zeros_like(self.cnt0)).min()
+        return torch.where(first < row0, torch.full((), float("nan"), device=self.device), torch.zeros((), device=self.device))
+
+    def _dhs(self, row0: int) -> torch.Tensor:
+        B, S, D, n = self.B, self.S, self.cfg.llm.d, self.cfg.llm.n_layers
+        if self._dHS is None or tuple(self._dHS.shape[1:3]) != (B, S - row0):
+            self._dHS = torch.empty(n + 1, B, S - row0, D, device=self.device, dtype=BF16)
         self._dHS.zero_()
-        head.backward(dpred, self._dHS)
+        return self._dHS
+
+    def loss_and_backward(self, pred, actions, gscale: float = 1.0):
+        """L1 loss (finetune.py:418) + backward into the flat grad buffer."""
+        llm, head = self.llm, self.head
+        B, S, Np = self.B, self.S, self.Np
+        loss3, dpred = ops.l1_loss(pred, actions.to(BF16), True, gscale)
+        row0 = self.live_row0()
+        dHS = self._dhs(row0)
+        head.backward(dpred, dHS, row0)
         aq_off = head.P.offsets["action_queries"][0]
         if self.reducer is not None:       # head/proprio grads are final: exchange them under the LLM backward
             self.reducer.reduce_async(head.P.grad, 0, aq_off)
-        dX0 = llm.backward(self._dHS, B, S)
-        dq = ops.action_query_grad(dX0.contiguous(), self.pos0, Np)
+        dX0 = llm.backward(dHS, B, S, row0)
+        dq = ops.action_query_grad(dX0.contiguous(), self.pos0, Np, row0)
         ops.cast_f32_bf16(dq, out=head.P.g("action_queries"))
         if self.reducer is not None:
             self.reducer.reduce_async(head.P.grad, aq_off, None)
@@ -805,9 +860,9 @@ class VLAEngine:
         main, side = torch.cuda.current_stream(), self.side
         mm = self._vision_and_embed(batch)
         B, S, Np = self.B, self.S, self.Np
-        if self._dHS is None or self._dHS.shape[1:3] != (B, S):
-            self._dHS = torch.empty(n + 1, B, S, D, device=self.device, dtype=BF16)
-        self._dHS.zero_()
+        row0 = self._row0 if self._row0 is not None else self.live_row0()
+        self._row0_used = row0
+        dHS = self._dhs(row0)
         llm.fwd_begin(B, S, mm)
         side.wait_stream(main)                                   # fork
         with torch.cuda.stream(side):
@@ -826,19 +881,21 @@ class VLAEngine:
         with torch.cuda.stream(side):
             pred = head.fwd_end()
             loss3, dpred = ops.l1_loss(pred, batch["actions"].to(BF16), True, 1.0)
-            head.bwd_begin(dpred)
+            if row0:
+                loss3 += self._row0_guard(row0)
+            head.bwd_begin(dpred, row0)
             for i in range(nb - 1, -1, -1):
-                head.bwd_layer(i, self._dHS)
+                head.bwd_layer(i, dHS)
                 fev[i] = torch.cuda.Event()
                 fev[i].record(side)                              # dHS[i+1] is final
             head.bwd_end()
         if nb >= n:
             main.wait_event(fev[n - 1])                          # gradient of the final-norm output comes from block n-1
-        llm.bwd_begin(self._dHS)
+        llm.bwd_begin(dHS, row0)
         for i in range(n - 1, split - 1, -1):
             if i < n - 1 and i < nb:
                 main.wait_event(fev[i])
-            llm.bwd_layer(i, self._dHS)
+            llm.bwd_layer(i, dHS)
         main.wait_stream(side)                                   # join: head gradients are final
         self._fev = fev
         return loss3
@@ -848,7 +905,7 @@ class VLAEngine:
         for i in range(min(split, n) - 1, -1, -1):
             llm.bwd_layer(i, self._dHS)                          # dHS complete since part A joined the side stream
         dX0 = llm.bwd_result()
-        dq = ops.action_query_grad(dX0.contiguous(), self.pos0, self.Np)
+        dq = ops.action_query_grad(dX0.contiguous(), self.pos0, self.Np, self._row0_used)
         ops.cast_f32_bf16(dq, out=self.head.P.g("action_queries"))
 
     def capture(self, batch: Dict[str, torch.Tensor], noise: Optional[torch.Tensor] = None, warmup: int = 2, split: Optional[int] = None):
@@ -858,6 +915,9 @@ class VLAEngine:
         if os.environ.get("VLA_SPLIT"):
             self._split = int(os.environ["VLA_SPLIT"])
         self._static_batch, self._static_noise = batch, noise
+        self._row0 = None
+        self._vision_and_embed(batch)                # masks of the capture batch -> the frozen live-row window
+        self._row0 = self.live_row0()
         for _ in range(warmup):                      # allocate every buffer / set kernel attributes outside capture
             self.head.dirty = True
             self._part_a(batch, noise, self._split)

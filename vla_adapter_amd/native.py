@@ -27,7 +27,8 @@ class GemmDesc(C.Structure):
                 ("sC2", C.c_longlong), ("sBias", C.c_longlong), ("alpha", C.c_float),
                 ("a_group", C.c_int), ("c_group", C.c_int), ("a_group_stride", C.c_longlong), ("c_group_stride", C.c_longlong),
                 ("rope_mode", C.c_int), ("rope_T", C.c_int), ("rope_dh", C.c_int), ("rope_cols", C.c_int),
-                ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p)]
+                ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
+                ("r_group", C.c_int), ("r_group_stride", C.c_longlong)]
 
 
 class AttnDesc(C.Structure):
@@ -40,7 +41,8 @@ class AttnDesc(C.Structure):
                 ("dout", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p), ("delta", C.c_void_p),
                 ("do_sb", C.c_longlong), ("dq_sb", C.c_longlong), ("dk_sb", C.c_longlong), ("dv_sb", C.c_longlong),
                 ("do_ss", C.c_int), ("dq_ss", C.c_int), ("dk_ss", C.c_int), ("dv_ss", C.c_int),
-                ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p)]
+                ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
+                ("q_off", C.c_int), ("dkv_k0", C.c_int), ("lse_hs", C.c_int)]
 
 
 class HeadAttnDesc(C.Structure):
@@ -63,7 +65,7 @@ _PROTOS = {
     "vla_layernorm_fwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F], _I),
     "vla_layernorm_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I], _I),
     "vla_rmsnorm_fwd": ([_P, _P, _P, _P, _P, _I, _I, _F], _I),
-    "vla_rmsnorm_bwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I], _I),
+    "vla_rmsnorm_bwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I], _I),
     "vla_attn_fwd": ([_P, C.POINTER(AttnDesc)], _I),
     "vla_attn_bwd": ([_P, C.POINTER(AttnDesc)], _I),
     "vla_rope_half": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I], _I),
@@ -71,7 +73,7 @@ _PROTOS = {
     "vla_im2col_patch": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I], _I),
     "vla_action_mask": ([_P, _P, _P, _P, _P, _I, _I, _I], _I),
     "vla_embed_splice": ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I], _I),
-    "vla_action_query_grad": ([_P, _P, _P, _P, _I, _I, _I, _I], _I),
+    "vla_action_query_grad": ([_P, _P, _P, _P, _I, _I, _I, _I, _I], _I),
     "vla_gather_rows": ([_P, _P, _P, _P, _I, _I, _I, _I], _I),
     "vla_scatter_add_rows": ([_P, _P, _P, _P, _I, _I, _I, _I], _I),
     "vla_add_bf16": ([_P, _P, _P, _P, _L], _I),

@@ -37,7 +37,7 @@ def _chk_bf16(*ts):
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_mod: int = 0, act: int = ACT_NONE,
             out: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, alpha: float = 1.0,
-            want_pre: bool = True, a_group=None, c_group=None, rope=None) -> torch.Tensor:
+            want_pre: bool = True, a_group=None, c_group=None, r_group=None, rope=None) -> torch.Tensor:
     """C = epilogue(A @ B^T).  a: [M,K] or [batch,M,K] (row stride = a.stride(-2)); b: [N,K] or [batch,N,K].
     SwiGLU: returns (pre [.., N] or None, h [.., N/2])."""
     _chk_bf16(a, b, bias, residual, out, out2)
@@ -75,13 +75,15 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_m
         d.sBias = bias.stride(0) if bias.dim() == 2 else 0
     if residual is not None:
         assert residual.stride(-1) == 1 and residual.shape[-1] == Nn
-        assert res_mod > 0 or tuple(residual.shape) == tuple(shape)
+        assert res_mod > 0 or r_group is not None or tuple(residual.shape) == tuple(shape)
         d.R, d.ldr = residual.data_ptr(), residual.stride(-2)
         d.sR = residual.stride(0) if (batched and residual.dim() == 3) else 0
     if a_group is not None:      # (rows per group, stride between groups): a = first row-group view [g, K]
         d.a_group, d.a_group_stride = a_group
     if c_group is not None:
         d.c_group, d.c_group_stride = c_group
+    if r_group is not None:
+        d.r_group, d.r_group_stride = r_group
     if rope is not None:         # (mode, cos, sin, T, dh, ncols): fused rotary embedding on output columns [0, ncols)
         mode, cos_t, sin_t, T, dh, ncols = rope
         assert cos_t.dtype == torch.float32 and cos_t.is_contiguous() and sin_t.is_contiguous() and cos_t.shape[0] >= T
@@ -94,18 +96,25 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_m
     return out
 
 
-def gemm_swiglu_bwd(d: torch.Tensor, w_downT: torch.Tensor, gu: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """dGU[M, 2I] = swiglu'(GU) * (d[M, D] @ w_downT[I, D]^T): the dH GEMM with the SwiGLU backward in its epilogue."""
+def gemm_swiglu_bwd(d: torch.Tensor, w_downT: torch.Tensor, gu: torch.Tensor, out: Optional[torch.Tensor] = None,
+                    gu_group=None) -> torch.Tensor:
+    """dGU[M, 2I] = swiglu'(GU) * (d[M, D] @ w_downT[I, D]^T): the dH GEMM with the SwiGLU backward in its epilogue.
+    gu_group=(rows per group, element stride between groups): ``gu`` is then the first row-group window of a larger
+    tensor (row m of the product reads gu row (m // g) * stride + (m % g) * ld)."""
     _chk_bf16(d, w_downT, gu, out)
     M, K = d.shape
     I = w_downT.shape[0]
-    assert gu.shape == (M, 2 * I) and gu.stride(-1) == 1 and w_downT.shape[1] == K
+    assert gu.shape[-1] == 2 * I and gu.stride(-1) == 1 and w_downT.shape[1] == K
+    assert gu_group is not None or gu.shape[0] == M
     if out is None:
-        out = torch.empty_like(gu)
+        out = torch.empty(M, 2 * I, device=d.device, dtype=BF16)
+    assert out.shape == (M, 2 * I)
     desc = N.GemmDesc()
     desc.A, desc.B, desc.C, desc.R = d.data_ptr(), w_downT.data_ptr(), out.data_ptr(), gu.data_ptr()
     desc.M, desc.N, desc.K, desc.lda, desc.ldb, desc.ldc, desc.ldr, desc.batch = M, I, K, d.stride(0), w_downT.stride(0), out.stride(0), gu.stride(0), 1
     desc.act, desc.alpha = ACT_SWIGLU_BWD, 1.0
+    if gu_group is not None:
+        desc.r_group, desc.r_group_stride = gu_group
     N.check(_lib().vla_gemm_bf16_nt(_st(), C.byref(desc)), "gemm_bf16_nt(swiglu_bwd)")
     return out
 
@@ -160,13 +169,22 @@ def rmsnorm_fwd(x, w, eps: float, want_rstd: bool = False, out=None):
     return (y, rstd) if want_rstd else y
 
 
-def rmsnorm_bwd(dy, x, w, rstd, dres=None, out=None):
+def rmsnorm_bwd(dy, x, w, rstd, dres=None, out=None, x_rows=None):
+    """dy/dres/out compact [rows, cols].  x_rows=(group, group_rows, row0): x / rstd are the forward's full tensors and
+    compact row r maps to row (r // group) * group_rows + row0 + r % group (live-row window of every sequence)."""
     _chk_bf16(dy, x, w, dres)
     cols = x.shape[-1]
     assert x.is_contiguous() and dy.is_contiguous()
-    rows = x.numel() // cols
-    dx = torch.empty_like(x) if out is None else out
-    N.check(_lib().vla_rmsnorm_bwd(_st(), _p(dy), _p(x), _p(w), _p(rstd), _p(dres), _p(dx), rows, cols), "rmsnorm_bwd")
+    rows = dy.numel() // cols
+    g, gr, r0 = x_rows if x_rows is not None else (0, 0, 0)
+    if x_rows is None:
+        assert x.numel() == dy.numel()
+    else:
+        assert rows % g == 0 and (rows // g) * gr * cols <= x.numel() and rstd.numel() * cols >= (rows // g) * gr * cols
+    dx = torch.empty_like(dy) if out is None else out
+    if dres is not None:
+        assert dres.is_contiguous() and dres.numel() >= dy.numel()
+    N.check(_lib().vla_rmsnorm_bwd(_st(), _p(dy), _p(x), _p(w), _p(rstd), _p(dres), _p(dx), rows, cols, g, gr, r0), "rmsnorm_bwd")
     return dx
 
 
@@ -198,19 +216,27 @@ def attn_fwd(q, k, v, Hq: int, Hkv: int, dh: int, causal: bool, kmask=None, scal
 
 
 def attn_bwd(dout, q, k, v, o, lse, Hq: int, Hkv: int, dh: int, causal: bool, kmask=None,
-             scale: Optional[float] = None, dq=None, dk=None, dv=None, rope=None):
+             scale: Optional[float] = None, dq=None, dk=None, dv=None, rope=None, row0: int = 0):
+    """row0 > 0 (causal only, multiple of 32): live-row backward.  q/o/dout/dq are the [B, Sk - row0, ...] windows
+    (views) of the rows >= row0, k/v the full [B, Sk, ...] tensors, lse the forward's full [B, Hq, Sk]; dk/dv are
+    produced for the keys >= row0 only ([B, Sk - row0, ...]).  Exactly the gradients the rows >= row0 receive."""
     _chk_bf16(dout, q, k, v, o)
     B, Sq, Sk = q.shape[0], q.shape[1], k.shape[1]
+    assert Sq + row0 == Sk or row0 == 0
     dq = torch.empty(B, Sq, Hq * dh, device=q.device, dtype=BF16) if dq is None else dq
-    dk = torch.empty(B, Sk, Hkv * dh, device=q.device, dtype=BF16) if dk is None else dk
-    dv = torch.empty(B, Sk, Hkv * dh, device=q.device, dtype=BF16) if dv is None else dv
+    dk = torch.empty(B, Sk - row0, Hkv * dh, device=q.device, dtype=BF16) if dk is None else dk
+    dv = torch.empty(B, Sk - row0, Hkv * dh, device=q.device, dtype=BF16) if dv is None else dv
     delta = torch.empty(B, Hq, Sq, device=q.device, dtype=torch.float32)
     d = _attn_desc(q, k, v, o, lse, kmask, causal, scale if scale is not None else dh ** -0.5, Hq, Hkv, dh)
+    if row0:
+        assert causal and row0 % 32 == 0 and lse.shape == (B, Hq, Sk) and lse.is_contiguous()
+        d.q_off, d.dkv_k0, d.lse_hs = row0, row0, Sk
+        d.lse = lse.data_ptr() + 4 * row0
     d.dout, d.dq, d.dk, d.dv, d.delta = dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr()
     d.do_sb, d.dq_sb, d.dk_sb, d.dv_sb = dout.stride(0), dq.stride(0), dk.stride(0), dv.stride(0)
     d.do_ss, d.dq_ss, d.dk_ss, d.dv_ss = dout.stride(1), dq.stride(1), dk.stride(1), dv.stride(1)
     if rope is not None:          # (cos, sin) f32 [S, dh/2]: dq/dk come back through the inverse rotate_half RoPE
-        assert rope[0].shape == (Sq, dh // 2) and rope[0].dtype == torch.float32
+        assert rope[0].shape == (Sk, dh // 2) and rope[0].dtype == torch.float32
         d.rope_cos, d.rope_sin = rope[0].data_ptr(), rope[1].data_ptr()
     N.check(_lib().vla_attn_bwd(_st(), C.byref(d)), "attn_bwd")
     return dq, dk, dv
@@ -277,11 +303,12 @@ def embed_splice(ids, attn_mask_u8, qidx, table, action_queries, out, mm_mask, N
                                     _p(mm_mask), B, L, Np, D, table.shape[0]), "embed_splice")
 
 
-def action_query_grad(dx, pos, Np: int) -> torch.Tensor:
+def action_query_grad(dx, pos, Np: int, row0: int = 0) -> torch.Tensor:
+    """dx [B, S - row0, D]: the rows >= row0 of the gradient w.r.t. inputs_embeds."""
     B, S, D = dx.shape
     assert dx.is_contiguous()
     dq = torch.empty(64, D, device=dx.device, dtype=torch.float32)
-    N.check(_lib().vla_action_query_grad(_st(), _p(dx), _p(pos), _p(dq), B, S, Np, D), "action_query_grad")
+    N.check(_lib().vla_action_query_grad(_st(), _p(dx), _p(pos), _p(dq), B, S, Np, D, row0), "action_query_grad")
     return dq
 
 
