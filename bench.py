@@ -53,22 +53,38 @@ def measure_gemm_roofline(eng, batch, noise, lr, reps=10):
         calls[sig][0] += 1
         return r
 
-    ops.gemm_nt = rec
+    orig_sw = ops.gemm_swiglu_bwd
+
+    def rec_sw(d_, w_, gu_, out=None, gu_group=None):        # the dH GEMM with the SwiGLU backward in its epilogue
+        r = orig_sw(d_, w_, gu_, out=out, gu_group=gu_group)
+        sig = (tuple(d_.shape), tuple(w_.shape), d_.stride(-2), w_.stride(-2), 5, False, True)
+        if sig not in calls:
+            calls[sig] = [0, gemm_flops_of_call(d_, w_, False), d_, w_, dict(_swiglu_bwd=(gu_, r, gu_group))]
+        calls[sig][0] += 1
+        return r
+
+    def replay(a, b, kw):
+        if "_swiglu_bwd" in kw:
+            gu_, out_, grp = kw["_swiglu_bwd"]
+            return orig_sw(a, b, gu_, out=out_, gu_group=grp)
+        return orig(a, b, **kw)
+
+    ops.gemm_nt, ops.gemm_swiglu_bwd = rec, rec_sw
     try:
         eng.train_step(batch, lr, noise)
         torch.cuda.synchronize()
     finally:
-        ops.gemm_nt = orig
+        ops.gemm_nt, ops.gemm_swiglu_bwd = orig, orig_sw
     total_t = total_f = 0.0
     n = 0
     per = []
     for sig, (cnt, fl, a, b, kw) in calls.items():
         for _ in range(2):
-            orig(a, b, **kw)
+            replay(a, b, kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            orig(a, b, **kw)
+            replay(a, b, kw)
         e1.record()
         torch.cuda.synchronize()
         t = e0.elapsed_time(e1) * 1e-3 / reps
@@ -147,6 +163,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE config: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=1)
+    ap.add_argument("--no-full-backward", action="store_true", help="skip the extra timing of the reference-shaped full LLM backward")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
     args = ap.parse_args()
 
@@ -178,10 +195,12 @@ def main():
         step = lambda: eng.train_step_graphed(lr)
     for _ in range(args.warmup):
         step()
+    eng.flush()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss3 = step()
+    eng.flush()          # the graphed step defers its RCCL exchange + AdamW into the next step: K steps = K updates
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -190,7 +209,29 @@ def main():
         dt = t.item()
     ms = dt / args.steps * 1e3
     value = world * B * args.steps / dt
-    fl = flops.step_flops_per_sample(cfg, L=P + 64)
+    row0 = eng.live_row0()
+    fl = flops.step_flops_per_sample(cfg, L=P + 64, row0=row0)
+    full_bwd = None
+    if world == 1 and not args.eager and row0 > 0 and not args.no_full_backward:
+        # the same step with the reference-shaped backward (every row of the frozen LLM gets dX, task-token dX included):
+        # what torch.autograd executes; identical parameter gradients (tests/test_engine_gpu.py), more FLOPs
+        eng.full_llm_backward = True
+        eng.capture(batch, noise)
+        for _ in range(2):
+            step()
+        eng.flush()
+        sync()
+        t1 = time.perf_counter()
+        nfull = max(3, args.steps // 2)
+        for _ in range(nfull):
+            step()
+        eng.flush()
+        sync()
+        dtf = (time.perf_counter() - t1) / nfull
+        full_bwd = {"value": round(B / dtf, 2), "unit": "samples/s", "ms_per_step": round(dtf * 1e3, 3), "steps": nfull,
+                    "step_tflops": round(fl["step"] * B / dtf / 1e12, 1),
+                    "frac_of_bf16_mfma_peak": round(fl["step"] * B / dtf / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
+        eng.full_llm_backward = False
     if rank == 0:
         roof = measure_gemm_roofline(eng, batch, noise, lr)
         cpu = None
@@ -205,10 +246,15 @@ def main():
                                    "1 image (256 patches) + 32-token prompt + 64 action queries (S=352)",
                        "global_batch": world * B, "per_gpu_batch": B, "seq_len": cfg.n_patches + P + 64,
                        "parallelism": f"dp{world}", "weights": "random-init", "launch": "eager" if args.eager else "hipGraph replay",
+                       "llm_backward": (f"live rows >= {row0} of {cfg.n_patches + P + 64} (gradient rows that only reach frozen inputs are "
+                                        "not computed; parameter gradients identical)") if row0 else "all rows",
                        "final_loss": round(float(loss3[0]), 5)},
             "samples_per_s_per_gpu": round(value / world, 2),
-            "step_algorithmic_tflops_per_gpu": round(fl["step"] * B / (ms * 1e-3) / 1e12, 1),
-            "step_frac_of_bf16_mfma_peak": round(fl["step"] * B / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            # FLOPs really executed per step (vla_adapter_amd/flops.py `step_live`) over the measured step time
+            "step_executed_tflops_per_gpu": round(fl["step_live"] * B / (ms * 1e-3) / 1e12, 1),
+            "step_frac_of_bf16_mfma_peak": round(fl["step_live"] * B / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "gflop_per_sample": {"executed": round(fl["step_live"] / 1e9, 1), "autograd_convention": round(fl["step"] / 1e9, 1)},
+            "full_backward_variant": full_bwd,
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 MFMA NT GEMM, all launches of one step)",
                          "achieved": round(roof["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(roof["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),

@@ -158,7 +158,10 @@ def test_graph_replay_matches_eager(setup):
     g1, p1 = e1.head.P.grad.float().cpu().clone(), e1.head.P.data.float().cpu().clone()
     e2.capture(batch, None)
     l2 = e2.train_step_graphed(1e-3)[0].item()
+    p_before = e2.head.P.data.clone()
+    e2.flush()                                   # the graphed step leaves its AdamW update pending until the next step / flush
     torch.cuda.synchronize()
+    assert not torch.equal(p_before, e2.head.P.data)
     g2, p2 = e2.head.P.grad.float().cpu(), e2.head.P.data.float().cpu()
     assert abs(l1 - l2) < 1e-6
     assert (g1 - g2).norm() <= 2e-3 * g1.norm()
@@ -242,7 +245,7 @@ def test_pipelined_eager_matches_sequential(setup):
     e1, e2 = E.VLAEngine(cfg, W, DEV), E.VLAEngine(cfg, W, DEV)
     for it in range(2):
         l1 = e1.train_step(batch, 1e-3)[0].item()
-        l2 = e2.train_step_pipelined(batch, 1e-3, split=1)[0].item()
+        l2 = e2.train_step_pipelined(batch, 1e-3)[0].item()
         torch.cuda.synchronize()
         assert abs(l1 - l2) <= 1e-6 + 2e-2 * it * abs(l1)
         g1, g2 = e1.head.P.grad.float().cpu(), e2.head.P.grad.float().cpu()

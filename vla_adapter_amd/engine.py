@@ -743,8 +743,13 @@ class VLAEngine:
 
     def _vision_and_embed(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         """ViT(s) -> projector -> action masks -> embedding/query splice into llm.HS[0]; returns the key mask [B,S] u8."""
+        self._vision(batch)
+        return self._embed(batch)
+
+    def _vision(self, batch: Dict[str, torch.Tensor]):
+        """Frozen part that reads NO trainable tensor: ViT(s) + projector, written into rows 1..Np of llm.HS[0]."""
         cfg, llm = self.cfg, self.llm
-        ids, labels, am = batch["input_ids"], batch["labels"], batch["attention_mask"]
+        ids = batch["input_ids"]
         B, L = ids.shape
         Np, D = cfg.n_patches, cfg.llm.d
         S = L + Np
@@ -775,7 +780,18 @@ class VLAEngine:
             ops.gemm_nt(h, self.proj["fc3.weight"], bias=self.proj["fc3.bias"], out=dst[:B * Np], c_group=(Np, S * D))
         else:
             ops.gemm_nt(h, self.proj["fc2.weight"], bias=self.proj["fc2.bias"], out=dst[:B * Np], c_group=(Np, S * D))
-        # masks + embedding splice (train_utils.py:8-41; modeling_prismatic.py:601-636)
+        self.B, self.S, self.Np = B, S, Np
+
+    def _embed(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """Action masks + embedding gather + action-query splice (train_utils.py:8-41; modeling_prismatic.py:601-636)
+        into rows 0 and Np+1.. of llm.HS[0] (reads the trainable `action_queries`); returns the key mask [B,S] u8."""
+        cfg, llm = self.cfg, self.llm
+        ids, labels, am = batch["input_ids"], batch["labels"], batch["attention_mask"]
+        B, L = ids.shape
+        Np = cfg.n_patches
+        S = L + Np
+        llm._alloc(B, S)
+        X0 = llm.HS[0]
         self.qidx0, self.pos0, self.cnt0 = ops.action_mask(labels, 0)
         _, self.pos1, self.cnt1 = ops.action_mask(labels, 1)
         mm = torch.empty(B, S, device=self.device, dtype=torch.uint8)
@@ -852,16 +868,18 @@ class VLAEngine:
         if getattr(self, "side", None) is None:
             self.side = torch.cuda.Stream()
 
-    def _part_a(self, batch, noise, split: int):
+    def _fwd_bwd(self, batch, noise, vision: bool = True):
         """forward (LLM on the current stream, head on the side stream) + loss + head backward (side) overlapped with
-        the LLM backward of layers n-1 .. split (current stream).  Joins the side stream before returning."""
+        the LLM backward (current stream) + action-query gradient.  Joins the side stream before returning.
+        vision=False: rows 1..Np of llm.HS[0] already hold the projected patches (the vision graph ran)."""
         cfg, llm, head = self.cfg, self.llm, self.head
-        n, nb, D = cfg.llm.n_layers, cfg.num_blocks, cfg.llm.d
+        n, nb = cfg.llm.n_layers, cfg.num_blocks
         main, side = torch.cuda.current_stream(), self.side
-        mm = self._vision_and_embed(batch)
+        if vision:
+            self._vision(batch)
+        mm = self._embed(batch)
         B, S, Np = self.B, self.S, self.Np
         row0 = self._row0 if self._row0 is not None else self.live_row0()
-        self._row0_used = row0
         dHS = self._dhs(row0)
         llm.fwd_begin(B, S, mm)
         side.wait_stream(main)                                   # fork
@@ -892,67 +910,64 @@ class VLAEngine:
         if nb >= n:
             main.wait_event(fev[n - 1])                          # gradient of the final-norm output comes from block n-1
         llm.bwd_begin(dHS, row0)
-        for i in range(n - 1, split - 1, -1):
+        for i in range(n - 1, -1, -1):
             if i < n - 1 and i < nb:
                 main.wait_event(fev[i])
             llm.bwd_layer(i, dHS)
+        dX0 = llm.bwd_result()
+        dq = ops.action_query_grad(dX0.contiguous(), self.pos0, Np, row0)
+        ops.cast_f32_bf16(dq, out=head.P.g("action_queries"))
         main.wait_stream(side)                                   # join: head gradients are final
-        self._fev = fev
         return loss3
 
-    def _part_b(self, split: int):
-        llm, nb, n = self.llm, self.cfg.num_blocks, self.cfg.llm.n_layers
-        for i in range(min(split, n) - 1, -1, -1):
-            llm.bwd_layer(i, self._dHS)                          # dHS complete since part A joined the side stream
-        dX0 = llm.bwd_result()
-        dq = ops.action_query_grad(dX0.contiguous(), self.pos0, self.Np, self._row0_used)
-        ops.cast_f32_bf16(dq, out=self.head.P.g("action_queries"))
-
-    def capture(self, batch: Dict[str, torch.Tensor], noise: Optional[torch.Tensor] = None, warmup: int = 2, split: Optional[int] = None):
+    # Data-parallel schedule of the captured step.  The gradient exchange of step k (one bucketed RCCL all-reduce of the
+    # flat gradient buffer on its own stream) is NOT waited for at the end of step k: step k+1 first replays the vision
+    # graph - ViT + projector, ~25 % of the step, which read no trainable tensor - and only then waits for the exchange,
+    # applies AdamW and replays the rest.  Same arithmetic as synchronous DP (every use of a parameter sees the updated
+    # value); the all-reduce is hidden under the next step's ViT instead of under a backward tail that the live-row
+    # LLM backward has made too short to hide it.  `flush()` applies the last pending update.
+    def capture(self, batch: Dict[str, torch.Tensor], noise: Optional[torch.Tensor] = None, warmup: int = 2):
         """``batch``/``noise`` become the static input buffers: copy new data INTO them before each replay."""
         self._ensure_streams()
-        self._split = self.cfg.llm.n_layers // 3 if split is None else split
-        if os.environ.get("VLA_SPLIT"):
-            self._split = int(os.environ["VLA_SPLIT"])
         self._static_batch, self._static_noise = batch, noise
         self._row0 = None
         self._vision_and_embed(batch)                # masks of the capture batch -> the frozen live-row window
         self._row0 = self.live_row0()
         for _ in range(warmup):                      # allocate every buffer / set kernel attributes outside capture
             self.head.dirty = True
-            self._part_a(batch, noise, self._split)
-            self._part_b(self._split)
+            self._fwd_bwd(batch, noise)
         torch.cuda.synchronize()
         self.head.dirty = True
-        self._g1, self._g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g1):
-            self._loss3 = self._part_a(batch, noise, self._split)
-        with torch.cuda.graph(self._g2, pool=self._g1.pool()):
-            self._part_b(self._split)
+        self._g_vis, self._g_rest = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_vis):
+            self._vision(batch)
+        with torch.cuda.graph(self._g_rest, pool=self._g_vis.pool()):
+            self._loss3 = self._fwd_bwd(batch, noise, vision=False)
         torch.cuda.synchronize()
+        self._pending_lr = None
 
-    def train_step_pipelined(self, batch, lr: float, noise=None, split: Optional[int] = None):
+    def train_step_pipelined(self, batch, lr: float, noise=None):
         """Eager (un-captured) run of the two-stream schedule."""
         self._ensure_streams()
-        sp = self.cfg.llm.n_layers // 3 if split is None else split
-        aq_off = self.head.P.offsets["action_queries"][0]
-        loss3 = self._part_a(batch, noise, sp)
+        loss3 = self._fwd_bwd(batch, noise)
         if self.reducer is not None:
-            self.reducer.reduce_async(self.head.P.grad, 0, aq_off)
-        self._part_b(sp)
-        if self.reducer is not None:
-            self.reducer.reduce_async(self.head.P.grad, aq_off, None)
+            self.reducer.reduce_async(self.head.P.grad, 0, None)
         self.optimizer_step(lr)
         return loss3
 
     def train_step_graphed(self, lr: float):
-        """Replay of the captured step on the static buffers (+ RCCL exchange + AdamW)."""
-        aq_off = self.head.P.offsets["action_queries"][0]
-        self._g1.replay()
-        if self.reducer is not None:       # head/proprio grads are final: exchange them under the rest of the LLM backward
-            self.reducer.reduce_async(self.head.P.grad, 0, aq_off)
-        self._g2.replay()
+        """Replay of the captured step on the static buffers.  The parameter update of THIS step (RCCL exchange +
+        AdamW) is left pending and applied inside the next call, after that step's vision graph - or by flush()."""
+        self._g_vis.replay()
+        self.flush()
+        self._g_rest.replay()
         if self.reducer is not None:
-            self.reducer.reduce_async(self.head.P.grad, aq_off, None)
-        self.optimizer_step(lr)
+            self.reducer.reduce_async(self.head.P.grad, 0, None)
+        self._pending_lr = lr
         return self._loss3
+
+    def flush(self):
+        """Apply the pending parameter update of the last train_step_graphed (no-op if none)."""
+        if getattr(self, "_pending_lr", None) is not None:
+            self.optimizer_step(self._pending_lr)
+            self._pending_lr = None

@@ -157,7 +157,10 @@ def finetune(cfg: FinetuneConfig) -> dict:
             log.append(dict(step=step, loss_value=l[0], curr_action_l1_loss=l[1], next_actions_l1_loss=l[2], lr=lr))
             if rank == 0:
                 print(json.dumps(log[-1]), flush=True)
-        if rank == 0 and step > 0 and step % cfg.save_freq == 0:
-            save_training_checkpoint(cfg, run_dir, step, eng)
+        if step > 0 and step % cfg.save_freq == 0:
+            eng.flush()                      # the graphed step leaves its parameter update pending (engine.capture)
+            if rank == 0:
+                save_training_checkpoint(cfg, run_dir, step, eng)
+    eng.flush()
     torch.cuda.synchronize()
     return dict(log=log, seconds=time.time() - t0, steps=cfg.max_steps, world=world)

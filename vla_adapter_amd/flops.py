@@ -1,9 +1,15 @@
 """Algorithmic FLOP model of the fine-tune hot path: the single source for roofline.achieved.
 
 2 FLOPs per MAC.  Excluded (never computed by this build, dead work in the reference): the last ViT block, the
-lm_head, film_gen, hidden_states[0].  Backward convention: dX GEMMs for every op downstream of a trainable tensor
-(action_queries sits at the LLM input -> the whole LLM needs dX), dW GEMMs only for trainable weights, attention
-backward = 2x attention forward.
+lm_head, film_gen, hidden_states[0].  Two backward conventions are reported side by side:
+
+* ``step`` (what torch.autograd executes in the reference): dX GEMMs for every op downstream of a
+  trainable tensor (action_queries sits at the LLM input -> the whole LLM gets dX over all S rows), dW GEMMs only for
+  trainable weights, attention backward = 2x attention forward.
+* ``step_live`` (what this build executes by default): the same, minus the gradient rows that can only reach frozen
+  inputs - LLM backward over the rows >= row0 only (engine.LLM.backward) and no dX for the head's task-token
+  projections.  Identical parameter gradients, fewer FLOPs; throughput fractions quoted against this number count
+  only work that was really done.
 """
 from __future__ import annotations
 
@@ -37,17 +43,31 @@ def head_fwd(cfg: VLACfg) -> float:
     return cfg.num_blocks * (2 * D * D * (5 * T + 2 * (A + 1) + 2 * Kt) + 4 * T * (T + A + 1 + Kt) * D) + 2 * T * cfg.action_dim * D * D
 
 
-def step_flops_per_sample(cfg: VLACfg, L: int = 96) -> dict:
-    """Adapter-only fine-tune (BASELINE configs 2/3): frozen ViT + projector forward only; LLM forward + dX; head x3."""
+def llm_attn_bwd_live(cfg: VLACfg, S: int, row0: int) -> float:
+    """dQ for the queries >= row0 over their visible keys + dK/dV for the keys >= row0 from the queries >= them:
+    (QK^T recompute, dP, dQ) on the [row0, S) x [0, S) causal trapezoid, (dK, dV) on the [row0, S)^2 causal triangle,
+    2 * dh FLOPs per (query, key, head) pair and product."""
+    c = cfg.llm
+    R = S - row0
+    trapezoid = R * row0 + R * (R + 1) / 2
+    triangle = R * (R + 1) / 2
+    return c.n_layers * c.heads * 2 * c.dh * (3 * trapezoid + 2 * triangle)
+
+
+def step_flops_per_sample(cfg: VLACfg, L: int = 96, row0: int = 0) -> dict:
+    """Adapter-only fine-tune (BASELINE configs 2/3): frozen ViT + projector forward only; LLM forward + dX; head x3.
+    row0 = first live row of the LLM backward (engine.VLAEngine.live_row0)."""
     S = cfg.n_patches + L
     vit = sum(vit_fwd(c) for c in cfg.vit) * cfg.n_img
     proj, lin, att, head = proj_fwd(cfg), llm_linear_fwd(cfg, S), llm_attn_fwd(cfg, S), head_fwd(cfg)
     total = vit + proj + 2 * lin + 3 * att + 3 * head
+    task_dx = cfg.num_blocks * 2 * cfg.n_patches * 2 * cfg.llm.d * cfg.llm.d        # dX of k_task / v_task (dead when row0 > 0)
+    live = vit + proj + lin * (1 + (S - row0) / S) + att + llm_attn_bwd_live(cfg, S, row0) + 3 * head - (task_dx if row0 else 0)
     return dict(vit_fwd=vit, proj_fwd=proj, llm_linear_fwd=lin, llm_attn_fwd=att, head_fwd=head, forward=vit + proj + lin + att + head,
-                step=total)
+                step=total, step_live=live if row0 else total)
 
 
 if __name__ == "__main__":
     from .engine import config2
-    for k, v in step_flops_per_sample(config2()).items():
+    for k, v in step_flops_per_sample(config2(), row0=288).items():
         print(f"{k:16s} {v / 1e9:10.1f} GF/sample")
