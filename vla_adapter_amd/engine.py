@@ -492,11 +492,18 @@ class Head:
         self.dO2, self.dFF = e(nb, R, D), e(nb, R, D)
         self.probs = e(nb, B, self.H, T, T + Ka + Kt, dt=torch.float32)
         self.stats = e(nb, R, 2, dt=torch.float32)
-        self.dgate = z(nb, dt=torch.float32)
-        self.ln_dw, self.ln_db = z(nb, D, dt=torch.float32), z(nb, D, dt=torch.float32)
-        self.b_f32 = {k: z(*self.P.offsets[k][1], dt=torch.float32) for k in ("b_x", "b_adp", "b_task", "b_o", "b_ffn", "fc1_b", "fc2_b", "p_fc1_b", "p_fc2_b")}
-        self.ln1_dw, self.ln1_db = z(self.Din, dt=torch.float32), z(self.Din, dt=torch.float32)
-        self.ln2_dw, self.ln2_db = z(D, dt=torch.float32), z(D, dt=torch.float32)
+        # fp32 gradient accumulators (bias column sums, LayerNorm dw/db, gate): views of ONE buffer, zeroed by one fill
+        bkeys = ("b_x", "b_adp", "b_task", "b_o", "b_ffn", "fc1_b", "fc2_b", "p_fc1_b", "p_fc2_b")
+        shapes = [("dgate", (nb,)), ("ln_dw", (nb, D)), ("ln_db", (nb, D)), ("ln1_dw", (self.Din,)), ("ln1_db", (self.Din,)),
+                  ("ln2_dw", (D,)), ("ln2_db", (D,))] + [("b:" + k, tuple(self.P.offsets[k][1])) for k in bkeys]
+        self.acc32 = z(sum(rup(math.prod(sh), 4) for _, sh in shapes), dt=torch.float32)
+        off, views = 0, {}
+        for name, sh in shapes:
+            views[name] = self.acc32[off:off + math.prod(sh)].view(sh)
+            off += rup(math.prod(sh), 4)
+        self.dgate, self.ln_dw, self.ln_db = views["dgate"], views["ln_dw"], views["ln_db"]
+        self.ln1_dw, self.ln1_db, self.ln2_dw, self.ln2_db = views["ln1_dw"], views["ln1_db"], views["ln2_dw"], views["ln2_db"]
+        self.b_f32 = {k: views["b:" + k] for k in bkeys}
         self.x_in = z(R, self.Din)
         self.pr_in = z(B, 64)
         # transposed operands for the batched dW products (K-dim = rows, zero-padded to a multiple of 64)
@@ -604,10 +611,19 @@ class Head:
         """dpred [B, chunk, 7] bf16.  Writes parameter gradients into the flat grad buffer and the hidden-state
         gradients into dHS [nb+1, B, S - row0, D] (HF indexing; rows not touched by the head must be pre-zeroed).
         Sequential composition of bwd_begin / bwd_layer / bwd_end."""
+        self.prep_backward(self.pos1, self.Np, self.B, self.S, row0)
         self.bwd_begin(dpred, row0)
         for i in range(self.nb - 1, -1, -1):
             self.bwd_layer(i, dHS)
         self.bwd_end()
+
+    def prep_backward(self, pos1: torch.Tensor, Np: int, B: int, S: int, row0: int):
+        """Scatter indices of the action-row gradients inside the live window [row0, S) of every sequence (-1: dead row).
+        Depends on the batch only, so the step schedule runs it long before the backward."""
+        loc = Np + pos1.to(torch.int32) - row0                     # [B, 64] row inside the live window (or < 0: dead row)
+        base = torch.arange(B, device=loc.device, dtype=torch.int32)[:, None] * (S - row0)
+        self.row_idx_live = torch.where((loc >= 0) & (pos1 >= 0), base + loc, torch.full_like(loc, -1)).to(torch.int32).contiguous()
+        self._prep_key = (B, S, Np, row0)
 
     def bwd_begin(self, dpred: torch.Tensor, row0: int = 0):
         """row0: first live row of the LLM backward (LLM.backward); dHS handed to bwd_layer is [nb+1, B, S - row0, D].
@@ -615,11 +631,8 @@ class Head:
         cfg, P, nb = self.cfg, self.P, self.nb
         R, Da = self.R, cfg.action_dim
         self.row0 = row0
-        loc = self.Np + self.pos1.to(torch.int32) - row0          # [B, 64] row inside the live window (or < 0: dead row)
-        base = torch.arange(self.B, device=loc.device, dtype=torch.int32)[:, None] * (self.S - row0)
-        self.row_idx_live = torch.where((loc >= 0) & (self.pos1 >= 0), base + loc, torch.full_like(loc, -1)).to(torch.int32).contiguous()
-        for t in (self.dgate, self.ln_dw, self.ln_db, self.ln1_dw, self.ln1_db, self.ln2_dw, self.ln2_db, *self.b_f32.values()):
-            t.zero_()
+        assert getattr(self, "_prep_key", None) == (self.B, self.S, self.Np, row0), "prep_backward() first"
+        self.acc32.zero_()                                         # every fp32 gradient accumulator in one fill
         dp = dpred.reshape(R, Da)
         self.dpad.zero_()
         self.dpad[:, :Da] = dp
@@ -859,66 +872,130 @@ class VLAEngine:
 
     # ---- pipelined two-stream schedule + hipGraph replay -----------------------------------------------------------
     # The action head is 3 % of the FLOPs but a chain of ~300 small dependent kernels (~9 ms when run alone): block i
-    # only needs hidden_states[i+1], so its forward trails the LLM forward by one layer on a SECOND stream, and its
-    # backward runs one block AHEAD of the LLM backward (which needs dHS[i+1] from block i).  The head's kernels fill
-    # the idle CUs / tile-quantisation tails of the LLM's large GEMMs instead of serialising with them.
-    # The step is captured in two hipGraphs cut where the data-parallel exchange of the (by then final) head gradients
-    # is launched; AdamW stays outside (host-side bias corrections change every step).
+    # only needs hidden_states[i+1], so its forward trails the LLM forward on a SECOND stream and its backward runs AHEAD
+    # of the LLM backward (which needs dHS[i+1] from block i).  The head's kernels fill the idle CUs / tile-quantisation
+    # tails of the LLM's large GEMMs instead of serialising with them.
+    #
+    # The step is cut into SEGMENTS, each living on exactly one stream ("M": vision/LLM, "H": head); segments are
+    # ordered so that every event is recorded before it is waited on.  Eagerly a segment is a Python call under its
+    # stream; captured, every segment is its own single-stream (linear) hipGraph and the cross-stream edges are plain
+    # hipEvents between graph launches.  (One multi-stream hipGraph of the whole step was measured to serialise the two
+    # backward chains in the runtime's graph executor - rocprofv3 trace, tools/timeline.py: LLM backward started only
+    # after the head backward's last kernel - so the overlap is not left to it.)  Layer chunks are short next to the
+    # forward->backward turn-around (little pipeline fill/drain) and longer elsewhere (fewer graph launches).
     def _ensure_streams(self):
         if getattr(self, "side", None) is None:
             self.side = torch.cuda.Stream()
+            self._cap_main = torch.cuda.Stream()       # capture stream of the "M" graphs (replayed on the current stream)
 
-    def _fwd_bwd(self, batch, noise, vision: bool = True):
-        """forward (LLM on the current stream, head on the side stream) + loss + head backward (side) overlapped with
-        the LLM backward (current stream) + action-query gradient.  Joins the side stream before returning.
-        vision=False: rows 1..Np of llm.HS[0] already hold the projected patches (the vision graph ran)."""
+    @staticmethod
+    def _chunks(n: int, sizes) -> List[Tuple[int, int]]:
+        """[lo, hi) layer ranges covering 0..n with the given chunk sizes (last size repeats / is clipped)."""
+        out, lo, k = [], 0, 0
+        while lo < n:
+            sz = sizes[min(k, len(sizes) - 1)]
+            out.append((lo, min(n, lo + sz)))
+            lo, k = out[-1][1], k + 1
+        return out
+
+    def _prep_backward(self, batch):
+        """Everything the backward needs that depends only on the batch (runs at the start of the step, off the
+        forward->backward turn-around): live-row window, zeroed dHS, guard, scatter indices, bf16 targets."""
+        row0 = self._row0 if self._row0 is not None else self.live_row0()
+        self._row0_used = row0
+        self._dhs(row0)
+        self._guard = self._row0_guard(row0) if row0 else None
+        self.head.prep_backward(self.pos1, self.Np, self.B, self.S, row0)
+        self._actions_bf = batch["actions"].to(BF16)
+
+    def _segments(self, batch, noise):
+        """[(stream 'M'|'H', fn, wait_key|None, signal_key|None)] for everything after the vision stage."""
         cfg, llm, head = self.cfg, self.llm, self.head
         n, nb = cfg.llm.n_layers, cfg.num_blocks
+        assert nb <= n
+        # long chunks at the bottom layers, single layers at the top: the head's last forward chunk and first backward
+        # chunk (the serial turn-around) stay short; the backward walks the same ranges top-down
+        fch = self._chunks(n, [4] * max(0, (n - 4) // 4) + [2, 1, 1]) if n >= 8 else self._chunks(n, [1])
+        segs = []
+
+        def m_fwd(c, lo, hi):
+            def fn():
+                if c == 0:
+                    mm = self._embed(batch)
+                    self._prep_backward(batch)
+                    llm.fwd_begin(self.B, self.S, mm)
+                for i in range(lo, hi):
+                    llm.fwd_layer(i)
+                if hi == n:
+                    llm.fwd_final()
+            return fn
+
+        def h_fwd(c, lo, hi, last):
+            def fn():
+                if c == 0:
+                    head.fwd_begin(llm.HS, self.pos1, batch["proprio"], self.Np, noise)
+                for i in range(lo, min(hi, nb)):
+                    head.fwd_layer(i)
+                if last:
+                    pred = head.fwd_end()
+                    self._loss3, dpred = ops.l1_loss(pred, self._actions_bf, True, 1.0)
+                    if self._guard is not None:
+                        self._loss3 += self._guard
+                    head.bwd_begin(dpred, self._row0_used)
+            return fn
+
+        def h_bwd(lo, hi):
+            def fn():
+                for i in range(min(hi, nb) - 1, lo - 1, -1):
+                    head.bwd_layer(i, self._dHS)
+            return fn
+
+        def m_bwd(lo, hi, first, last):
+            def fn():
+                if first:
+                    llm.bwd_begin(self._dHS, self._row0_used)
+                for i in range(hi - 1, lo - 1, -1):
+                    llm.bwd_layer(i, self._dHS)
+                if last:
+                    dq = ops.action_query_grad(llm.bwd_result().contiguous(), self.pos0, self.Np, self._row0_used)
+                    ops.cast_f32_bf16(dq, out=head.P.g("action_queries"))
+            return fn
+
+        for c, (lo, hi) in enumerate(fch):
+            segs.append(("M", m_fwd(c, lo, hi), None, ("f", c)))
+            segs.append(("H", h_fwd(c, lo, hi, c == len(fch) - 1), ("f", c), None))
+        for k, (lo, hi) in enumerate(reversed(fch)):
+            segs.append(("H", h_bwd(lo, hi), None, ("b", k)))
+            segs.append(("M", m_bwd(lo, hi, k == 0, k == len(fch) - 1), ("b", k), None))
+        segs.append(("H", head.bwd_end, None, ("end", 0)))
+        segs.append(("M", None, ("end", 0), None))              # join: head gradients are final (no work of its own)
+        return segs
+
+    def _run_segments(self, segs, graphs=None):
         main, side = torch.cuda.current_stream(), self.side
+        side.wait_stream(main)                                   # fork (inputs / previous AdamW are ordered before the head)
+        ev = {}
+        for k, (st, fn, wait, signal) in enumerate(segs):
+            stream = main if st == "M" else side
+            with torch.cuda.stream(stream):
+                if wait is not None:
+                    stream.wait_event(ev[wait])
+                if fn is None:
+                    pass
+                elif graphs is None:
+                    fn()
+                else:
+                    graphs[k].replay()
+                if signal is not None:
+                    ev[signal] = torch.cuda.Event()
+                    ev[signal].record(stream)
+
+    def _fwd_bwd(self, batch, noise, vision: bool = True):
+        """Eager run of the two-stream schedule (vision stage first unless the vision graph already ran)."""
         if vision:
             self._vision(batch)
-        mm = self._embed(batch)
-        B, S, Np = self.B, self.S, self.Np
-        row0 = self._row0 if self._row0 is not None else self.live_row0()
-        dHS = self._dhs(row0)
-        llm.fwd_begin(B, S, mm)
-        side.wait_stream(main)                                   # fork
-        with torch.cuda.stream(side):
-            head.fwd_begin(llm.HS, self.pos1, batch["proprio"], Np, noise)
-        for i in range(n):
-            llm.fwd_layer(i)
-            if i == n - 1:
-                llm.fwd_final()
-            if i < nb:
-                ev = torch.cuda.Event()
-                ev.record(main)
-                with torch.cuda.stream(side):
-                    side.wait_event(ev)                          # hidden_states[i+1] is ready
-                    head.fwd_layer(i)
-        fev = {}
-        with torch.cuda.stream(side):
-            pred = head.fwd_end()
-            loss3, dpred = ops.l1_loss(pred, batch["actions"].to(BF16), True, 1.0)
-            if row0:
-                loss3 += self._row0_guard(row0)
-            head.bwd_begin(dpred, row0)
-            for i in range(nb - 1, -1, -1):
-                head.bwd_layer(i, dHS)
-                fev[i] = torch.cuda.Event()
-                fev[i].record(side)                              # dHS[i+1] is final
-            head.bwd_end()
-        if nb >= n:
-            main.wait_event(fev[n - 1])                          # gradient of the final-norm output comes from block n-1
-        llm.bwd_begin(dHS, row0)
-        for i in range(n - 1, -1, -1):
-            if i < n - 1 and i < nb:
-                main.wait_event(fev[i])
-            llm.bwd_layer(i, dHS)
-        dX0 = llm.bwd_result()
-        dq = ops.action_query_grad(dX0.contiguous(), self.pos0, Np, row0)
-        ops.cast_f32_bf16(dq, out=head.P.g("action_queries"))
-        main.wait_stream(side)                                   # join: head gradients are final
-        return loss3
+        self._run_segments(self._segments(batch, noise))
+        return self._loss3
 
     # Data-parallel schedule of the captured step.  The gradient exchange of step k (one bucketed RCCL all-reduce of the
     # flat gradient buffer on its own stream) is NOT waited for at the end of step k: step k+1 first replays the vision
@@ -938,11 +1015,23 @@ class VLAEngine:
             self._fwd_bwd(batch, noise)
         torch.cuda.synchronize()
         self.head.dirty = True
-        self._g_vis, self._g_rest = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_vis):
+        # one memory pool per stream: graphs sharing a pool are replayed strictly in capture order on ONE stream, so the
+        # allocator's reuse of freed capture-time temporaries stays race-free while the two streams overlap
+        pools = {"M": torch.cuda.graph_pool_handle(), "H": torch.cuda.graph_pool_handle()}
+        cap = {"M": self._cap_main, "H": self.side}
+        self._g_vis = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_vis, pool=pools["M"], stream=cap["M"]):
             self._vision(batch)
-        with torch.cuda.graph(self._g_rest, pool=self._g_vis.pool()):
-            self._loss3 = self._fwd_bwd(batch, noise, vision=False)
+        self._segs = self._segments(batch, noise)
+        self._graphs = []
+        for st, fn, _, _ in self._segs:
+            if fn is None:
+                self._graphs.append(None)
+                continue
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pools[st], stream=cap[st]):
+                fn()
+            self._graphs.append(g)
         torch.cuda.synchronize()
         self._pending_lr = None
 
@@ -960,7 +1049,7 @@ class VLAEngine:
         AdamW) is left pending and applied inside the next call, after that step's vision graph - or by flush()."""
         self._g_vis.replay()
         self.flush()
-        self._g_rest.replay()
+        self._run_segments(self._segs, self._graphs)
         if self.reducer is not None:
             self.reducer.reduce_async(self.head.P.grad, 0, None)
         self._pending_lr = lr
