@@ -971,7 +971,8 @@ class VLAEngine:
         segs.append(("M", None, ("end", 0), None))              # join: head gradients are final (no work of its own)
         return segs
 
-    def _run_segments(self, segs, graphs=None):
+    def _run_segments(self, segs, graphs=None, timeline=None):
+        """timeline: optional list that receives (stream, index, start_event, end_event) per segment (timing events)."""
         main, side = torch.cuda.current_stream(), self.side
         side.wait_stream(main)                                   # fork (inputs / previous AdamW are ordered before the head)
         ev = {}
@@ -980,12 +981,19 @@ class VLAEngine:
             with torch.cuda.stream(stream):
                 if wait is not None:
                     stream.wait_event(ev[wait])
+                if timeline is not None:
+                    t0 = torch.cuda.Event(enable_timing=True)
+                    t0.record(stream)
                 if fn is None:
                     pass
                 elif graphs is None:
                     fn()
                 else:
                     graphs[k].replay()
+                if timeline is not None:
+                    t1 = torch.cuda.Event(enable_timing=True)
+                    t1.record(stream)
+                    timeline.append((st, k, t0, t1))
                 if signal is not None:
                     ev[signal] = torch.cuda.Event()
                     ev[signal].record(stream)
@@ -1049,7 +1057,7 @@ class VLAEngine:
         AdamW) is left pending and applied inside the next call, after that step's vision graph - or by flush()."""
         self._g_vis.replay()
         self.flush()
-        self._run_segments(self._segs, self._graphs)
+        self._run_segments(self._segs, self._graphs, getattr(self, "_timeline", None))
         if self.reducer is not None:
             self.reducer.reduce_async(self.head.P.grad, 0, None)
         self._pending_lr = lr
