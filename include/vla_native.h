@@ -55,6 +55,9 @@ typedef struct vla_gemm_desc {
   /* row-group addressing for R (0 = plain), same rule as a_group: the residual / the SwiGLU-backward pre-activations
    * may be the [B, rows r0.. of S, N] window of a larger tensor (live-row LLM backward) */
   int r_group; long long r_group_stride;
+  /* optional: rows m of C with (m % c_live_mod) < c_live_from are NOT stored (c_live_mod 0 = store all).  Used for
+   * tensors kept only for a live-row backward: the SwiGLU pre-activations of the rows the backward never visits. */
+  int c_live_mod, c_live_from;
 } vla_gemm_desc;
 
 /* C = epilogue(A . B^T).  Replaces nn.Linear forward and, with pre-transposed operands, its dX / dW products:

@@ -88,7 +88,7 @@ def test_gemm_plain_bias(ops, M, N, K):
     check(out, O.linear(a.float(), b.float(), bias.float(), emu=True), name=f"gemm {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("M,N,K", [(300, 200, 192), (1000, 896, 896), (512, 384, 64), (2080, 1792, 896), (64, 7, 128)])
 def test_gemm_every_tile_config(ops, tile, M, N, K, monkeypatch):
     """The three kernel instantiations (256x128x3-stage, 128x128x2, 128x64x3) must agree with the oracle on ragged
@@ -609,3 +609,19 @@ def test_action_query_grad_row_window(ops):
     full = ops.action_query_grad(dx, pos, Np)
     win = ops.action_query_grad(dx[:, r0:].contiguous(), pos, Np, r0)
     assert torch.equal(full, win)
+
+
+def test_gemm_live_row_store_and_bias_paths(ops):
+    """c_live: rows m with m % period < first are left untouched, the others equal the plain GEMM; bias vector/scalar
+    fetch paths (8-B aligned slice vs odd offset) agree."""
+    B, S, r0, D, N = 3, 40, 24, 128, 200
+    a, w = gen(B * S, D, seed=180), gen(N, D, seed=181, scale=0.1)
+    bias_buf = gen(N + 1, seed=182).to(DEV)
+    ref = ops.gemm_nt(a.to(DEV), w.to(DEV), bias=bias_buf[:N].contiguous())
+    ref_odd = ops.gemm_nt(a.to(DEV), w.to(DEV), bias=bias_buf[1:])            # 2-B aligned only: scalar fetch path
+    chk = ops.gemm_nt(a.to(DEV), w.to(DEV), bias=bias_buf[1:].contiguous().clone())
+    assert torch.equal(ref_odd, chk)
+    out = torch.full((B * S, N), 7.0, dtype=BF, device=DEV)
+    ops.gemm_nt(a.to(DEV), w.to(DEV), bias=bias_buf[:N].contiguous(), out=out, c_live=(S, r0))
+    o3, r3 = out.view(B, S, N), ref.view(B, S, N)
+    assert torch.equal(o3[:, r0:], r3[:, r0:]) and bool((o3[:, :r0] == 7.0).all())

@@ -38,6 +38,7 @@ struct GemmP {
   int tiles_n, ntiles;
   float alpha;
   int gA, gC, gR; long long sgA, sgC, sgR;  // row-group addressing: row r -> (r / g) * sg + (r % g) * ld
+  int c_live_mod, c_live_from;              // C rows with (m % c_live_mod) < c_live_from are not stored
   int rope_mode, rope_T, rope_dh, rope_cols; const float* rope_cos; const float* rope_sin;
 };
 
@@ -69,9 +70,30 @@ struct Cfg {
   static_assert(PIECES % NW == 0, "pieces must divide evenly over the waves");
 };
 
+// ---- explicit LDS fragment reads for the software-pipelined main loop (PIPE): the compiler re-uses fragment registers
+// and parks a full s_waitcnt lgkmcnt(0) in front of every MFMA group; issuing ds_read_b128 by hand with counted
+// waits keeps one k-step of fragments in flight underneath the previous k-step's MFMAs.
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read128(unsigned addr) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+// wait until at most N LDS reads are outstanding; the fragments are tied to the statement so no MFMA consuming them
+// can be scheduled above it
+template <int N>
+__device__ __forceinline__ void lgkm_wait6(bf16x8& a0, bf16x8& a1, bf16x8& a2, bf16x8& a3, bf16x8& b0, bf16x8& b1) {
+  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait8(bf16x8& a0, bf16x8& a1, bf16x8& a2, bf16x8& a3, bf16x8& b0, bf16x8& b1, bf16x8& b2,
+                                           bf16x8& b3) {
+  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) : "n"(N));
+}
+
 // ROPE is a compile-time switch (0 none / 1 rotate_half / 2 interleaved): the epilogue's extra registers and table
 // loads must not leak into the plain kernel that every other GEMM of the step runs.
-template <int BM, int BN, int STAGES, int ROPE, int WN = 2>
+template <int BM, int BN, int STAGES, int ROPE, int WN = 2, int PIPE = 0>
 __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
   using C = Cfg<BM, BN, STAGES, WN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -130,7 +152,108 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
 #pragma unroll
   for (int s = 0; s < 2; ++s) foff[s] = frow * 128 + (((4 * s + (lane >> 4)) ^ (lane & 7)) << 4);
 
+  // epilogue coordinates: lane owns, for tile (ni, mi): m = 16mi + (lane&15), n = 16ni + 4(lane>>4) + {0..3}.
+  // The bias slice is fetched HERE (one 8-B load per n-tile) so its latency hides under the main loop; fetched in the
+  // epilogue it cost a dependent global load per element right on every tile's tail.
+  const int wm0 = m0 + wr * 64, wn0 = n0 + wc * C::WTN;
+  const int lq = lane >> 4, lr = lane & 15;
+  const bf16_t* bias = p.bias ? p.bias + (long long)z * p.sBias : nullptr;
+  float bv[C::NT][4];
+  {
+    const bool bvec = bias && (((size_t)bias & 7) == 0);
+#pragma unroll
+    for (int ni = 0; ni < C::NT; ++ni) {
+      const int n = wn0 + ni * 16 + lq * 4;
+      if (bvec && n + 3 < p.N) {
+        const uint2 b2 = *reinterpret_cast<const uint2*>(bias + n);
+        bv[ni][0] = bf2f((bf16_t)(b2.x & 0xffff)); bv[ni][1] = bf2f((bf16_t)(b2.x >> 16));
+        bv[ni][2] = bf2f((bf16_t)(b2.y & 0xffff)); bv[ni][3] = bf2f((bf16_t)(b2.y >> 16));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[ni][j] = (bias && n + j < p.N) ? bf2f(bias[n + j]) : 0.f;
+      }
+    }
+  }
+
   const int nt = p.K / BK;
+  if constexpr (PIPE != 0) {
+    // ---- software-pipelined main loop (2 stages, NT 2 or 4).  Per K-tile t (LDS buffer t&1):
+    //   issue DMA of tile t+1 -> other buffer | issue reads of k-step 1 | MFMAs of k-step 0 (its reads were issued one
+    //   half-iteration earlier) | vmcnt(0) + lgkmcnt(0) + barrier | issue reads of k-step 0 of tile t+1 | MFMAs of k-step 1
+    static_assert(STAGES == 2 && (C::NT == 2 || C::NT == 4), "PIPE: 2 stages, NT 2 or 4");
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned aoff = lds0 + wr * 64 * 128, boff = lds0 + C::A_BYTES + wc * C::WTN * 128;
+    const unsigned a_s0 = aoff + foff[0], a_s1 = aoff + foff[1], b_s0 = boff + foff[0], b_s1 = boff + foff[1];
+    bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+    auto rd = [&](bf16x8* fa, bf16x8* fb, unsigned a, unsigned b) {
+      fa[0] = lds_read128<0>(a); fa[1] = lds_read128<2048>(a); fa[2] = lds_read128<4096>(a); fa[3] = lds_read128<6144>(a);
+      fb[0] = lds_read128<0>(b); fb[1] = lds_read128<2048>(b);
+      if constexpr (C::NT == 4) { fb[2] = lds_read128<4096>(b); fb[3] = lds_read128<6144>(b); }
+    };
+    auto mm = [&](const bf16x8* fa, const bf16x8* fb) {
+#pragma unroll
+      for (int ni = 0; ni < C::NT; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
+    };
+    constexpr int NR = 4 + C::NT;                     // LDS reads per k-step
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    rd(fa0, fb0, a_s0, b_s0);
+    for (int t = 0; t < nt; ++t) {
+      const unsigned cur = (t & 1) * C::STAGE_BYTES, nxt = C::STAGE_BYTES - cur;
+      if (t + 1 < nt) stage((t + 1) & 1, (t + 1) * BK);
+      rd(fa1, fb1, a_s1 + cur, b_s1 + cur);
+      if constexpr (C::NT == 4) lgkm_wait8<NR>(fa0[0], fa0[1], fa0[2], fa0[3], fb0[0], fb0[1], fb0[2], fb0[3]);
+      else lgkm_wait6<NR>(fa0[0], fa0[1], fa0[2], fa0[3], fb0[0], fb0[1]);
+      mm(fa0, fb0);
+      __builtin_amdgcn_sched_barrier(0);          // keep k-step 0's MFMAs above the waits (they cover the read latency)
+      if constexpr (C::NT == 4) lgkm_wait8<0>(fa1[0], fa1[1], fa1[2], fa1[3], fb1[0], fb1[1], fb1[2], fb1[3]);
+      else lgkm_wait6<0>(fa1[0], fa1[1], fa1[2], fa1[3], fb1[0], fb1[1]);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // tile t+1 visible to all; every wave is done reading tile t's buffer
+      asm volatile("" ::: "memory");
+      if (t + 1 < nt) rd(fa0, fb0, a_s0 + nxt, b_s0 + nxt);
+      __builtin_amdgcn_sched_barrier(0);          // next tile's first reads are in flight before k-step 1's MFMAs start
+      mm(fa1, fb1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else if constexpr (STAGES == 1) {
+    // ---- single LDS buffer: 32 KiB per workgroup -> 4 workgroups (32 waves) per CU.  The fragments of tile t sit in
+    // registers while the DMA of tile t+1 refills the buffer underneath tile t's MFMAs; everything else is hidden by
+    // the other resident workgroups.
+    static_assert(C::NT <= 4, "single stage: NT <= 4");
+    const char* sa = smem + wr * 64 * 128;
+    const char* sb = smem + C::A_BYTES + wc * C::WTN * 128;
+    stage(0, 0);
+    for (int t = 0; t < nt; ++t) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                         // tile t landed and is visible to every wave
+      asm volatile("" ::: "memory");
+      bf16x8 fm[2][4], fn[2][C::NT];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fm[s][i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + foff[s]);
+#pragma unroll
+        for (int i = 0; i < C::NT; ++i) fn[s][i] = *reinterpret_cast<const bf16x8*>(sb + i * 16 * 128 + foff[s]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                         // every wave holds its fragments: the buffer may be refilled
+      asm volatile("" ::: "memory");
+      if (t + 1 < nt) stage(0, (t + 1) * BK);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int ni = 0; ni < C::NT; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[s][ni], fm[s][mi], acc[ni][mi], 0, 0, 0);
+    }
+  } else {
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < nt) stage(s, s * BK);
@@ -184,25 +307,13 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
     }
     if (++buf == STAGES) buf = 0;
   }
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // all waves done with the operand tiles before the staging regions are overwritten
   asm volatile("" ::: "memory");
 
   // ---------------- epilogue ----------------
-  // lane owns, for tile (ni, mi): m = 16mi + (lane&15), n = 16ni + 4(lane>>4) + {0..3}
-  const int wm0 = m0 + wr * 64, wn0 = n0 + wc * C::WTN;
-  const int lq = lane >> 4, lr = lane & 15;
-  const bf16_t* bias = p.bias ? p.bias + (long long)z * p.sBias : nullptr;
   char* reg = smem + wid * (C::EPI_ROWS * C::EPI_STRIDE);
-
-  float bv[C::NT][4];
-#pragma unroll
-  for (int ni = 0; ni < C::NT; ++ni)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = wn0 + ni * 16 + lq * 4 + j;
-      bv[ni][j] = (bias && n < p.N) ? bf2f(bias[n]) : 0.f;
-    }
 
   if (ROPE == 3) {
     // ---- SwiGLU backward fused into the dH = dY.W_down GEMM (VLA_ACT_SWIGLU_BWD): the accumulator holds dH for this
@@ -349,6 +460,7 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
       const int m = wm0 + half * C::EPI_ROWS + row, n = wn0 + ch * 8;
       uint4 v = *reinterpret_cast<const uint4*>(reg + row * C::EPI_STRIDE + ch * 16);
       if (m >= p.M || n >= p.N) continue;
+      if (p.c_live_mod > 0 && (m % p.c_live_mod) < p.c_live_from) continue;   // row never read again (live-row backward)
       const long long roff = p.res_mod > 0 ? (long long)(m % p.res_mod) * p.ldr
                              : p.gR > 0 ? (long long)(m / p.gR) * p.sgR + (long long)(m % p.gR) * p.ldr : (long long)m * p.ldr;
       const long long crow = p.gC > 0 ? (long long)(m / p.gC) * p.sgC + (long long)(m % p.gC) * p.ldc : (long long)m * p.ldc;
@@ -388,22 +500,29 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
 //    reuse per wave: +5..+40 % over the 4-wave 64x64 geometry on every hot shape;
 //  * 128x64 (4 waves, 3 blocks/CU) only for problems smaller than one round of tiles (the M=256 head GEMMs).
 struct TileChoice { int bm, bn; };
-inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode) {
+inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode, int batch = 1) {
   if (rope_mode == 1) return {128, 128};   // rotate_half pairs live in one wave's 64-column tile
   if (force == 1 && rope_mode == 0) return {256, 128};
   if (force == 2) return {128, 128};
   if (force == 3) return {128, 64};
   if (force == 4 && rope_mode == 0) return {256, 256};
   if (force == 5 && rope_mode == 0) return {128, 129};   // 128x128 with 4 waves of 64x64 (the round-1 v1 geometry)
+  if (force == 6 && rope_mode == 0) return {128, 130};   // 128x128, 8 waves, software-pipelined fragment reads
+  if (force == 7 && rope_mode == 0) return {128, 131};   // 128x128, 4 waves of 64x64, software-pipelined
+  if (force == 8 && rope_mode == 0) return {256, 131};   // 256x128, 8 waves of 64x64, software-pipelined
+  if (force == 9 && rope_mode == 0) return {128, 132};   // 128x128, 8 waves, single LDS buffer (4 workgroups per CU)
   if (M >= 8192 && N >= 8192 && K >= 8192) return {256, 256};   // 64x128 wave tiles: 12 LDS reads per 32 MFMAs (1201 vs 1093 TF/s)
   // In situ (whole training step, same-box A/B) the 8-wave 128x128 geometry beats the narrow tile on every shape of
   // the step, including the M=256 head GEMMs that overlap the LLM on the side stream (48.5 vs 49.5 vs 52.0 ms/step
   // for always-square / mixed / always-narrow); the narrow tile stays available through VLA_GEMM_TILE=3.
-  (void)K;
+  // Exception: long-K problems that fill less than half the chip with square tiles (the live-row gate/up dX GEMM:
+  // M 2048, N 896, K 9728 -> 112 tiles): the narrow tile doubles the number of K loops in flight.
+  const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128) * batch;
+  if (tiles <= 128 && K >= 4096 && N % 64 == 0 && !getenv("VLA_NO_NARROW_LONGK")) return TileChoice{128, 64};
   return TileChoice{128, 128};
 }
 
-template <int BM, int BN, int STAGES, int ROPE, int WN = 2>
+template <int BM, int BN, int STAGES, int ROPE, int WN = 2, int PIPE = 0>
 int launch(const GemmP& p0, int M, int N, int batch, hipStream_t st) {
   using C = Cfg<BM, BN, STAGES, WN>;
   GemmP p = p0;
@@ -411,10 +530,10 @@ int launch(const GemmP& p0, int M, int N, int batch, hipStream_t st) {
   p.ntiles = ((M + BM - 1) / BM) * p.tiles_n;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, STAGES, ROPE, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, STAGES, ROPE, WN, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, STAGES, ROPE, WN>), dim3(p.ntiles, 1, batch), dim3(C::NTHREADS), C::LDS_BYTES, st, p);
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, STAGES, ROPE, WN, PIPE>), dim3(p.ntiles, 1, batch), dim3(C::NTHREADS), C::LDS_BYTES, st, p);
   return 0;
 }
 
@@ -455,6 +574,9 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
   p.gA = d->a_group; p.sgA = d->a_group_stride; p.gC = d->c_group; p.sgC = d->c_group_stride;
   p.gR = d->r_group; p.sgR = d->r_group_stride;
+  p.c_live_mod = d->c_live_mod; p.c_live_from = d->c_live_from;
+  VLA_REQUIRE(d->c_live_mod >= 0 && d->c_live_from >= 0 && (d->c_live_mod == 0 || d->c_live_from < d->c_live_mod),
+              "gemm: c_live_from must lie inside c_live_mod");
   VLA_REQUIRE(d->r_group >= 0 && d->r_group_stride % 8 == 0 && (d->r_group == 0 || d->res_mod == 0),
               "gemm: r_group stride must keep 16-B alignment; r_group and res_mod are exclusive");
   p.rope_mode = d->rope_mode; p.rope_T = d->rope_T; p.rope_dh = d->rope_dh; p.rope_cols = d->rope_cols;
@@ -467,7 +589,7 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
     if (d->rope_mode == 1) VLA_REQUIRE(d->rope_dh == 64, "gemm: fused rotate_half RoPE needs head dim 64");
   }
   const char* e = getenv("VLA_GEMM_TILE");     // 0/unset auto, 1: 256x128, 2: 128x128, 3: 128x64  (benchmarking aid)
-  const TileChoice tc = choose_tile(d->M, d->N, d->K, e ? atoi(e) : 0, d->rope_mode);
+  const TileChoice tc = choose_tile(d->M, d->N, d->K, e ? atoi(e) : 0, d->rope_mode, d->batch);
   hipStream_t st = (hipStream_t)stream;
   if (d->act == VLA_ACT_SWIGLU_BWD) launch<128, 128, 2, 3, 4>(p, d->M, d->N, d->batch, st);
   else if (d->rope_mode == 1) launch<128, 128, 2, 1>(p, d->M, d->N, d->batch, st);
@@ -475,8 +597,12 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
     if (tc.bn == 128) launch<128, 128, 2, 2, 4>(p, d->M, d->N, d->batch, st);
     else launch<128, 64, 2, 2>(p, d->M, d->N, d->batch, st);
   } else if (tc.bm == 256 && tc.bn == 256) launch<256, 256, 2, 0>(p, d->M, d->N, d->batch, st);
+  else if (tc.bm == 256 && tc.bn == 131) launch<256, 128, 2, 0, 2, 1>(p, d->M, d->N, d->batch, st);
   else if (tc.bm == 256) launch<256, 128, 3, 0, 4>(p, d->M, d->N, d->batch, st);   // 16 waves, loads two K-tiles ahead
   else if (tc.bn == 129) launch<128, 128, 2, 0>(p, d->M, d->N, d->batch, st);      // 4 waves of 64x64 (forced only)
+  else if (tc.bn == 130) launch<128, 128, 2, 0, 4, 1>(p, d->M, d->N, d->batch, st);
+  else if (tc.bn == 132) launch<128, 128, 1, 0, 4>(p, d->M, d->N, d->batch, st);
+  else if (tc.bm == 128 && tc.bn == 131) launch<128, 128, 2, 0, 2, 1>(p, d->M, d->N, d->batch, st);
   else if (tc.bn == 128) launch<128, 128, 2, 0, 4>(p, d->M, d->N, d->batch, st);   // 8 waves (2x4) of 64x32
   else launch<128, 64, 2, 0>(p, d->M, d->N, d->batch, st);
   VLA_CHECK_LAUNCH("gemm_bf16_nt");

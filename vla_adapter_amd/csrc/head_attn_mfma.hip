@@ -176,11 +176,10 @@ __global__ __launch_bounds__(256) void head_fwd_mfma(HP p) {
 
 // ------------------------------------------------------------------------------------------------ dQ (+ gate gradient)
 template <int D>
-__global__ __launch_bounds__(256) void head_dq_mfma(HP p) {
+__device__ __forceinline__ void head_dq_body(const HP& p, const int blk, char* smem) {
   using G = HG<D>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = lane >> 5;
-  const int gid = blockIdx.x * 4 + w;
+  const int gid = blk * 4 + w;
   if (gid >= p.B * p.H) return;
   const int b = gid / p.H, hd = gid - b * p.H, hoff = hd * D, N = p.T + p.Ka + p.Kt;
   bf16_t* sK = reinterpret_cast<bf16_t*>(smem + w * G::WAVE_BYTES);
@@ -202,9 +201,8 @@ __global__ __launch_bounds__(256) void head_dq_mfma(HP p) {
     }
     delta += __shfl_xor(delta, 32, 64);
   }
-  float* slot = p.probs + (long long)gid * p.T * N;        // [0,T): LSE (forward), [T,2T): delta (for the dK/dV pass)
+  const float* slot = p.probs + (long long)gid * p.T * N;  // [0,T): LSE (forward)
   const float lse2 = slot[qc] * 1.4426950408889634f;
-  if (h == 0 && qi < p.T) slot[p.T + qi] = delta;
   const float g0 = bf2f(p.gate[0]);
   const float tg = rbf(tanhf(g0)), rs = sqrtf((float)D), irs = 1.f / rs;
   f32x16 dQ[G::DT];
@@ -269,12 +267,11 @@ __global__ __launch_bounds__(256) void head_dq_mfma(HP p) {
 
 // ------------------------------------------------------------------------------------------------ dK, dV
 template <int D>
-__global__ __launch_bounds__(256) void head_dkv_mfma(HP p) {
+__device__ __forceinline__ void head_dkv_body(const HP& p, const int blk, char* smem) {
   using G = HG<D>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = lane >> 5;
   const int N = p.T + p.Ka + p.Kt, ntile = (N + 31) / 32;
-  const int wgid = blockIdx.x * 4 + w;                 // one wave per (sample, head, 32-key tile): every tile's dK/dV is
+  const int wgid = blk * 4 + w;                        // one wave per (sample, head, 32-key tile): every tile's dK/dV is
   if (wgid >= p.B * p.H * ntile) return;               // independent, so the pass is embarrassingly parallel
   const int gid = wgid / ntile, n0 = (wgid - gid * ntile) * 32;
   const int b = gid / p.H, hd = gid - b * p.H, hoff = hd * D;
@@ -294,7 +291,27 @@ __global__ __launch_bounds__(256) void head_dkv_mfma(HP p) {
   const float* slot = p.probs + (long long)gid * p.T * N;
   if (lane < 32) {
     sLse[lane] = lane < p.T ? slot[lane] * 1.4426950408889634f : 0.f;
-    sDelta[lane] = lane < p.T ? slot[p.T + lane] : 0.f;
+    sDelta[lane] = 0.f;
+  }
+  wave_lds_sync();
+  // delta[q] = rowsum(dO * O), recomputed here (8 lanes per query row) so that this pass does not depend on the dQ pass:
+  // both run as ONE launch (the dQ waves are few and long, the dK/dV waves many and short)
+  for (int r0 = 0; r0 < p.T; r0 += 8) {
+    const int r = r0 + (lane >> 3), part = lane & 7;
+    float acc = 0.f;
+    if (r < p.T) {
+      const long long ro = ((long long)b * p.T + r);
+      for (int ch = part; ch < G::CPR; ch += 8) {
+        const bf16x8 ov = *reinterpret_cast<const bf16x8*>(p.out + ro * p.ld_out + hoff + ch * 8);
+        const bf16x8 dv = *reinterpret_cast<const bf16x8*>(sdO + r * G::LD + ch * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += bf2f((bf16_t)ov[j]) * bf2f((bf16_t)dv[j]);
+      }
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (part == 0 && r < p.T) sDelta[r] = acc;
   }
   wave_lds_sync();
   const float tg = rbf(tanhf(bf2f(p.gate[0]))), rs = sqrtf((float)D), irs = 1.f / rs;
@@ -356,6 +373,14 @@ __global__ __launch_bounds__(256) void head_dkv_mfma(HP p) {
   }
 }
 
+// dQ (+ gate) and dK/dV in one launch: blocks [0, ndq) run the dQ body, the rest the dK/dV body
+template <int D>
+__global__ __launch_bounds__(256) void head_bwd_mfma(HP p, int ndq) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)blockIdx.x < ndq) head_dq_body<D>(p, blockIdx.x, smem);
+  else head_dkv_body<D>(p, blockIdx.x - ndq, smem);
+}
+
 template <int D>
 void launch_fwd(const HP& p, hipStream_t st) {
   const size_t lds = 4 * HG<D>::WAVE_BYTES;
@@ -365,14 +390,13 @@ template <int D>
 void launch_bwd(const HP& p, hipStream_t st) {
   const size_t lds = 4 * HG<D>::WAVE_BYTES;
   const int ntile = (p.T + p.Ka + p.Kt + 31) / 32;
-  hipLaunchKernelGGL(head_dq_mfma<D>, dim3((p.B * p.H + 3) / 4), dim3(256), lds, st, p);
-  hipLaunchKernelGGL(head_dkv_mfma<D>, dim3((p.B * p.H * ntile + 3) / 4), dim3(256), lds, st, p);
+  const int ndq = (p.B * p.H + 3) / 4, ndkv = (p.B * p.H * ntile + 3) / 4;
+  hipLaunchKernelGGL(head_bwd_mfma<D>, dim3(ndq + ndkv), dim3(256), lds, st, p, ndq);
 }
 template <int D>
 void set_attrs() {
   (void)hipFuncSetAttribute((const void*)head_fwd_mfma<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * HG<D>::WAVE_BYTES);
-  (void)hipFuncSetAttribute((const void*)head_dq_mfma<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * HG<D>::WAVE_BYTES);
-  (void)hipFuncSetAttribute((const void*)head_dkv_mfma<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * HG<D>::WAVE_BYTES);
+  (void)hipFuncSetAttribute((const void*)head_bwd_mfma<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * HG<D>::WAVE_BYTES);
 }
 void set_all_attrs() {
   static bool done = false;

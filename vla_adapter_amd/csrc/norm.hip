@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_wb_kernel(const bf16_t* __r
   if (c >= cols) return;
   const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
   float aw = 0.f, ab = 0.f;
+#pragma unroll 4
   for (int r = r0; r < r1; ++r) {
     const float d = bf2f(dy[(long long)r * lddy + c]);
     const float xh = (bf2f(x[(long long)r * ldx + c]) - stats[2 * r]) * stats[2 * r + 1];
@@ -261,7 +262,9 @@ extern "C" int vla_layernorm_bwd(void* stream, const void* dy, const void* x, co
     VLA_CHECK_LAUNCH("layernorm_bwd_dx");
   }
   if (dw || db) {
-    const int rows_per = 64;
+    // short serial row loops (the kernel sits on the action head's backward critical chain with rows = 256):
+    // rows/32 per block, clamped to [8, 64]; partial sums meet through fp32 atomics
+    const int rows_per = rows / 32 < 8 ? 8 : (rows / 32 > 64 ? 64 : rows / 32);
     dim3 grid((cols + 255) / 256, (rows + rows_per - 1) / rows_per);
     hipLaunchKernelGGL(layernorm_bwd_wb_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                        (const bf16_t*)x, stats, dw, db, rows, cols, ldx, lddy, rows_per);

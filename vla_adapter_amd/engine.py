@@ -218,6 +218,7 @@ class LLM:
         self.norm = g("norm.weight")
         self.embed = g("embed_tokens.weight")
         self._buf_key = None
+        self.gu_row0 = 0
 
     def _alloc(self, B: int, S: int):
         if self._buf_key == (B, S):
@@ -243,15 +244,18 @@ class LLM:
         n = self.cfg.n_layers
         return i + 1 if i < n - 1 else n + 1
 
-    def forward(self, B: int, S: int, kmask_u8: torch.Tensor):
+    def forward(self, B: int, S: int, kmask_u8: torch.Tensor, keep_from_row: int = 0):
         """HS[0] must already hold inputs_embeds [B,S,D].  Fills HS[1..n] (HF hidden_states semantics)."""
-        self.fwd_begin(B, S, kmask_u8)
+        self.fwd_begin(B, S, kmask_u8, keep_from_row)
         for i in range(self.cfg.n_layers):
             self.fwd_layer(i)
         self.fwd_final()
 
-    def fwd_begin(self, B: int, S: int, kmask_u8: torch.Tensor):
+    def fwd_begin(self, B: int, S: int, kmask_u8: torch.Tensor, keep_from_row: int = 0):
+        """keep_from_row: the backward of this forward will only visit the rows >= keep_from_row of every sequence
+        (LLM.backward row0 >= keep_from_row); backward-only tensors skip the rows below it."""
         self.kmask, self.B, self.S = kmask_u8, B, S
+        self.gu_row0 = keep_from_row
 
     def fwd_layer(self, i: int):
         c, B, S = self.cfg, self.B, self.S
@@ -270,7 +274,9 @@ class LLM:
         x1 = self.X1[i]
         ops.gemm_nt(self.AO[i], L["wo"], residual=x, out=x1)
         self._rms(x1, L["n2"], self.nbuf, self.R2[i])
-        ops.gemm_nt(self.nbuf, L["wgu"], act=ACT_SWIGLU, out=self.GU[i], out2=self.hbuf)
+        # the pre-activations are kept for the backward only: rows below the live window are never read again
+        ops.gemm_nt(self.nbuf, L["wgu"], act=ACT_SWIGLU, out=self.GU[i], out2=self.hbuf,
+                    c_live=(S, self.gu_row0) if self.gu_row0 else None)
         ops.gemm_nt(self.hbuf, L["wd"], residual=x1, out=self.HS[self.out_slot(i)].view(M, D))
 
     def fwd_final(self):
@@ -315,6 +321,7 @@ class LLM:
     def bwd_begin(self, dHS: torch.Tensor, row0: int = 0):
         n, S, D = self.cfg.n_layers, self.S, self.cfg.d
         assert 0 <= row0 < S and row0 % 32 == 0, "live-row window must start on a multiple of 32"
+        assert row0 >= self.gu_row0, "the forward dropped backward-only rows this window needs"
         self.r0, self.Rl = row0, S - row0
         Mr = self.B * self.Rl
         assert tuple(dHS.shape[1:]) == (self.B, self.Rl, D)
@@ -744,15 +751,17 @@ class VLAEngine:
         self._row0 = None          # frozen by capture(); None = derive from every batch (one host sync)
         self.reducer = None        # ddp.FlatGradReducer when world_size > 1
 
-    def forward(self, batch: Dict[str, torch.Tensor], noise: Optional[torch.Tensor] = None):
+    def forward(self, batch: Dict[str, torch.Tensor], noise: Optional[torch.Tensor] = None, for_training: bool = False):
         """VLM forward + action head (finetune.py:336-411) -> predicted actions [B, chunk, 7]."""
-        self.forward_vlm(batch)
+        self.forward_vlm(batch, for_training)
         return self.head.forward(self.llm.HS, self.pos1, batch["proprio"], self.Np, noise)
 
     # modeling_prismatic.py:596-655 (multimodal forward): fills llm.HS with the n+1 hidden states
-    def forward_vlm(self, batch: Dict[str, torch.Tensor]):
+    def forward_vlm(self, batch: Dict[str, torch.Tensor], for_training: bool = False):
+        """for_training: a loss_and_backward() follows - backward-only tensors are kept for its live rows only
+        (reads the mask positions back: one host sync, eager path)."""
         mm = self._vision_and_embed(batch)
-        self.llm.forward(self.B, self.S, mm)
+        self.llm.forward(self.B, self.S, mm, self.live_row0() if for_training else 0)
 
     def _vision_and_embed(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         """ViT(s) -> projector -> action masks -> embedding/query splice into llm.HS[0]; returns the key mask [B,S] u8."""
@@ -865,7 +874,7 @@ class VLAEngine:
         self.head.dirty = True
 
     def train_step(self, batch, lr: float, noise=None):
-        pred = self.forward(batch, noise)
+        pred = self.forward(batch, noise, for_training=True)
         loss3 = self.loss_and_backward(pred, batch["actions"])
         self.optimizer_step(lr)
         return loss3
@@ -923,7 +932,7 @@ class VLAEngine:
                 if c == 0:
                     mm = self._embed(batch)
                     self._prep_backward(batch)
-                    llm.fwd_begin(self.B, self.S, mm)
+                    llm.fwd_begin(self.B, self.S, mm, self._row0_used)
                 for i in range(lo, hi):
                     llm.fwd_layer(i)
                 if hi == n:

@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
                 ("a_group", C.c_int), ("c_group", C.c_int), ("a_group_stride", C.c_longlong), ("c_group_stride", C.c_longlong),
                 ("rope_mode", C.c_int), ("rope_T", C.c_int), ("rope_dh", C.c_int), ("rope_cols", C.c_int),
                 ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
-                ("r_group", C.c_int), ("r_group_stride", C.c_longlong)]
+                ("r_group", C.c_int), ("r_group_stride", C.c_longlong), ("c_live_mod", C.c_int), ("c_live_from", C.c_int)]
 
 
 class AttnDesc(C.Structure):

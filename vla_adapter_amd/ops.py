@@ -37,7 +37,7 @@ def _chk_bf16(*ts):
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_mod: int = 0, act: int = ACT_NONE,
             out: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, alpha: float = 1.0,
-            want_pre: bool = True, a_group=None, c_group=None, r_group=None, rope=None) -> torch.Tensor:
+            want_pre: bool = True, a_group=None, c_group=None, r_group=None, rope=None, c_live=None) -> torch.Tensor:
     """C = epilogue(A @ B^T).  a: [M,K] or [batch,M,K] (row stride = a.stride(-2)); b: [N,K] or [batch,N,K].
     SwiGLU: returns (pre [.., N] or None, h [.., N/2])."""
     _chk_bf16(a, b, bias, residual, out, out2)
@@ -84,6 +84,8 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_m
         d.c_group, d.c_group_stride = c_group
     if r_group is not None:
         d.r_group, d.r_group_stride = r_group
+    if c_live is not None:       # (period, first live row): rows m of C with m % period < first are not stored
+        d.c_live_mod, d.c_live_from = c_live
     if rope is not None:         # (mode, cos, sin, T, dh, ncols): fused rotary embedding on output columns [0, ncols)
         mode, cos_t, sin_t, T, dh, ncols = rope
         assert cos_t.dtype == torch.float32 and cos_t.is_contiguous() and sin_t.is_contiguous() and cos_t.shape[0] >= T
