@@ -298,3 +298,28 @@ def test_graph_replay_guards_frozen_row_window():
     for k in batch:
         batch[k].copy_(short[k])
     assert torch.isnan(eng.train_step_graphed(1e-3)).all()
+
+
+def test_graphed_vision_lead_uses_staged_pixels():
+    """Captured mode runs the vision stage of step k+1 during step k on the pixels handed to stage_next_pixels():
+    two graphed steps on batches A then B must reproduce two eager steps on A then B."""
+    from vla_adapter_amd import engine as E, synthetic as S
+    cfg = E.tiny_config()
+    W = S.make_weights(cfg, DEV, seed=3, std=0.05)
+    A, Bb = S.make_batch(cfg, 2, DEV, seed=11, P=40), S.make_batch(cfg, 2, DEV, seed=12, P=40)
+    e1, e2 = E.VLAEngine(cfg, W, DEV), E.VLAEngine(cfg, W, DEV)
+    la = e1.train_step(A, 1e-3)[0].item()
+    lb = e1.train_step(Bb, 1e-3)[0].item()
+    static = {k: v.clone() for k, v in A.items()}
+    e2.capture(static, None)
+    e2.stage_next_pixels(Bb["pixel_values"])          # vision of step 2 runs inside step 1
+    ga = e2.train_step_graphed(1e-3)[0].item()
+    for k in static:                                   # step 2 trains on batch B (its pixels were staged one step ahead)
+        static[k].copy_(Bb[k])
+    gb = e2.train_step_graphed(1e-3)[0].item()
+    e2.flush()
+    torch.cuda.synchronize()
+    assert abs(ga - la) < 1e-6, (ga, la)
+    assert abs(gb - lb) <= 2e-2 * abs(lb), (gb, lb)
+    assert abs(la - lb) > 1e-3, "the two batches must differ for the check to mean anything"
+    assert (e1.head.P.data.float() - e2.head.P.data.float()).norm() <= 2e-3 * e1.head.P.data.float().norm()

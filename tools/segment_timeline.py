@@ -25,7 +25,7 @@ end = torch.cuda.Event(enable_timing=True)
 end.record()
 eng.flush()
 torch.cuda.synchronize()
-print(f"step (vision + adamw + segments): {ref.elapsed_time(end):.3f} ms")
+print(f"step (adamw + segments, vision of the next step inside): {ref.elapsed_time(end):.3f} ms")
 for st, k, t0, t1 in eng._timeline:
-    seg = eng._segs[k]
+    seg = eng._segs[k] if k >= 0 else ("V", None, "after seg %d" % eng._vis_after, "vision of the next step")
     print(f"{st} seg {k:2d}  start {ref.elapsed_time(t0):7.3f}  end {ref.elapsed_time(t1):7.3f}  dur {t0.elapsed_time(t1):6.3f}  wait={seg[2]} signal={seg[3]}")

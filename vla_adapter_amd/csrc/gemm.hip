@@ -22,6 +22,7 @@
 // wave-quantisation model (a 616-tile problem on 512 slots wastes 40 % of the machine with 128x128 tiles).
 //
 // Epilogue rounding points follow the reference under bf16 autocast: bf16(acc+bias) -> act -> bf16 -> (+residual) -> bf16.
+#include <type_traits>
 #include "common.h"
 #include "../../include/vla_native.h"
 
@@ -89,6 +90,14 @@ template <int N>
 __device__ __forceinline__ void lgkm_wait8(bf16x8& a0, bf16x8& a1, bf16x8& a2, bf16x8& a3, bf16x8& b0, bf16x8& b1, bf16x8& b2,
                                            bf16x8& b3) {
   asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) : "n"(N));
+}
+
+template <int N>
+__device__ __forceinline__ void lgkm_wait12(bf16x8& a0, bf16x8& a1, bf16x8& a2, bf16x8& a3, bf16x8& b0, bf16x8& b1, bf16x8& b2,
+                                            bf16x8& b3, bf16x8& b4, bf16x8& b5, bf16x8& b6, bf16x8& b7) {
+  asm volatile("s_waitcnt lgkmcnt(%12)"
+               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7)
+               : "n"(N));
 }
 
 // ROPE is a compile-time switch (0 none / 1 rotate_half / 2 interleaved): the epilogue's extra registers and table
@@ -180,15 +189,24 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
     // ---- software-pipelined main loop (2 stages, NT 2 or 4).  Per K-tile t (LDS buffer t&1):
     //   issue DMA of tile t+1 -> other buffer | issue reads of k-step 1 | MFMAs of k-step 0 (its reads were issued one
     //   half-iteration earlier) | vmcnt(0) + lgkmcnt(0) + barrier | issue reads of k-step 0 of tile t+1 | MFMAs of k-step 1
-    static_assert(STAGES == 2 && (C::NT == 2 || C::NT == 4), "PIPE: 2 stages, NT 2 or 4");
+    static_assert(STAGES == 2 && (C::NT == 2 || C::NT == 4 || C::NT == 8), "PIPE: 2 stages, NT 2, 4 or 8");
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     const unsigned aoff = lds0 + wr * 64 * 128, boff = lds0 + C::A_BYTES + wc * C::WTN * 128;
     const unsigned a_s0 = aoff + foff[0], a_s1 = aoff + foff[1], b_s0 = boff + foff[0], b_s1 = boff + foff[1];
-    bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+    bf16x8 fa0[4], fb0[8], fa1[4], fb1[8];
     auto rd = [&](bf16x8* fa, bf16x8* fb, unsigned a, unsigned b) {
       fa[0] = lds_read128<0>(a); fa[1] = lds_read128<2048>(a); fa[2] = lds_read128<4096>(a); fa[3] = lds_read128<6144>(a);
       fb[0] = lds_read128<0>(b); fb[1] = lds_read128<2048>(b);
-      if constexpr (C::NT == 4) { fb[2] = lds_read128<4096>(b); fb[3] = lds_read128<6144>(b); }
+      if constexpr (C::NT >= 4) { fb[2] = lds_read128<4096>(b); fb[3] = lds_read128<6144>(b); }
+      if constexpr (C::NT == 8) {
+        fb[4] = lds_read128<8192>(b); fb[5] = lds_read128<10240>(b); fb[6] = lds_read128<12288>(b); fb[7] = lds_read128<14336>(b);
+      }
+    };
+    auto wait_on = [&](bf16x8* fa, bf16x8* fb, auto tag) {
+      constexpr int N = decltype(tag)::value;
+      if constexpr (C::NT == 8) lgkm_wait12<N>(fa[0], fa[1], fa[2], fa[3], fb[0], fb[1], fb[2], fb[3], fb[4], fb[5], fb[6], fb[7]);
+      else if constexpr (C::NT == 4) lgkm_wait8<N>(fa[0], fa[1], fa[2], fa[3], fb[0], fb[1], fb[2], fb[3]);
+      else lgkm_wait6<N>(fa[0], fa[1], fa[2], fa[3], fb[0], fb[1]);
     };
     auto mm = [&](const bf16x8* fa, const bf16x8* fb) {
 #pragma unroll
@@ -207,12 +225,10 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
       const unsigned cur = (t & 1) * C::STAGE_BYTES, nxt = C::STAGE_BYTES - cur;
       if (t + 1 < nt) stage((t + 1) & 1, (t + 1) * BK);
       rd(fa1, fb1, a_s1 + cur, b_s1 + cur);
-      if constexpr (C::NT == 4) lgkm_wait8<NR>(fa0[0], fa0[1], fa0[2], fa0[3], fb0[0], fb0[1], fb0[2], fb0[3]);
-      else lgkm_wait6<NR>(fa0[0], fa0[1], fa0[2], fa0[3], fb0[0], fb0[1]);
+      wait_on(fa0, fb0, std::integral_constant<int, NR>{});
       mm(fa0, fb0);
       __builtin_amdgcn_sched_barrier(0);          // keep k-step 0's MFMAs above the waits (they cover the read latency)
-      if constexpr (C::NT == 4) lgkm_wait8<0>(fa1[0], fa1[1], fa1[2], fa1[3], fb1[0], fb1[1], fb1[2], fb1[3]);
-      else lgkm_wait6<0>(fa1[0], fa1[1], fa1[2], fa1[3], fb1[0], fb1[1]);
+      wait_on(fa1, fb1, std::integral_constant<int, 0>{});
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();   // tile t+1 visible to all; every wave is done reading tile t's buffer
       asm volatile("" ::: "memory");
@@ -511,6 +527,8 @@ inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode, int
   if (force == 7 && rope_mode == 0) return {128, 131};   // 128x128, 4 waves of 64x64, software-pipelined
   if (force == 8 && rope_mode == 0) return {256, 131};   // 256x128, 8 waves of 64x64, software-pipelined
   if (force == 9 && rope_mode == 0) return {128, 132};   // 128x128, 8 waves, single LDS buffer (4 workgroups per CU)
+  if (force == 10 && rope_mode == 0) return {256, 133};  // 256x256, 8 waves of 64x128, software-pipelined
+  if (force == 11 && rope_mode == 0) return {256, 134};  // 256x128, 4 waves of 64x128 (1 per SIMD), software-pipelined
   if (M >= 8192 && N >= 8192 && K >= 8192) return {256, 256};   // 64x128 wave tiles: 12 LDS reads per 32 MFMAs (1201 vs 1093 TF/s)
   // In situ (whole training step, same-box A/B) the 8-wave 128x128 geometry beats the narrow tile on every shape of
   // the step, including the M=256 head GEMMs that overlap the LLM on the side stream (48.5 vs 49.5 vs 52.0 ms/step
@@ -598,6 +616,8 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
     else launch<128, 64, 2, 2>(p, d->M, d->N, d->batch, st);
   } else if (tc.bm == 256 && tc.bn == 256) launch<256, 256, 2, 0>(p, d->M, d->N, d->batch, st);
   else if (tc.bm == 256 && tc.bn == 131) launch<256, 128, 2, 0, 2, 1>(p, d->M, d->N, d->batch, st);
+  else if (tc.bm == 256 && tc.bn == 133) launch<256, 256, 2, 0, 2, 1>(p, d->M, d->N, d->batch, st);
+  else if (tc.bm == 256 && tc.bn == 134) launch<256, 128, 2, 0, 1, 1>(p, d->M, d->N, d->batch, st);
   else if (tc.bm == 256) launch<256, 128, 3, 0, 4>(p, d->M, d->N, d->batch, st);   // 16 waves, loads two K-tiles ahead
   else if (tc.bn == 129) launch<128, 128, 2, 0>(p, d->M, d->N, d->batch, st);      // 4 waves of 64x64 (forced only)
   else if (tc.bn == 130) launch<128, 128, 2, 0, 4, 1>(p, d->M, d->N, d->batch, st);

@@ -769,7 +769,8 @@ class VLAEngine:
         return self._embed(batch)
 
     def _vision(self, batch: Dict[str, torch.Tensor]):
-        """Frozen part that reads NO trainable tensor: ViT(s) + projector, written into rows 1..Np of llm.HS[0]."""
+        """Frozen part that reads NO trainable tensor: ViT(s) + projector -> self.patches [B, Np, D] (its own buffer, so
+        that the vision stage of the NEXT step can run while the current step is still using llm.HS)."""
         cfg, llm = self.cfg, self.llm
         ids = batch["input_ids"]
         B, L = ids.shape
@@ -796,12 +797,14 @@ class VLAEngine:
         # projector (modeling_prismatic.py:261-273); the last Linear writes straight into the multimodal sequence
         f2 = feats.view(B * Np, -1)
         h = ops.gemm_nt(f2, self.proj["fc1.weight"], bias=self.proj["fc1.bias"], act=ACT_GELU)
-        dst = X0.view(B * S, D)[1:]
+        if getattr(self, "patches", None) is None or tuple(self.patches.shape) != (B, Np, D):
+            self.patches = torch.empty(B, Np, D, device=self.device, dtype=BF16)
+        dst = self.patches.view(B * Np, D)
         if cfg.fused:
             h = ops.gemm_nt(h, self.proj["fc2.weight"], bias=self.proj["fc2.bias"], act=ACT_GELU)
-            ops.gemm_nt(h, self.proj["fc3.weight"], bias=self.proj["fc3.bias"], out=dst[:B * Np], c_group=(Np, S * D))
+            ops.gemm_nt(h, self.proj["fc3.weight"], bias=self.proj["fc3.bias"], out=dst)
         else:
-            ops.gemm_nt(h, self.proj["fc2.weight"], bias=self.proj["fc2.bias"], out=dst[:B * Np], c_group=(Np, S * D))
+            ops.gemm_nt(h, self.proj["fc2.weight"], bias=self.proj["fc2.bias"], out=dst)
         self.B, self.S, self.Np = B, S, Np
 
     def _embed(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
@@ -814,6 +817,7 @@ class VLAEngine:
         S = L + Np
         llm._alloc(B, S)
         X0 = llm.HS[0]
+        X0[:, 1:Np + 1].copy_(self.patches)                      # projected patches: sequence rows 1..Np
         self.qidx0, self.pos0, self.cnt0 = ops.action_mask(labels, 0)
         _, self.pos1, self.cnt1 = ops.action_mask(labels, 1)
         mm = torch.empty(B, S, device=self.device, dtype=torch.uint8)
@@ -894,8 +898,9 @@ class VLAEngine:
     # forward->backward turn-around (little pipeline fill/drain) and longer elsewhere (fewer graph launches).
     def _ensure_streams(self):
         if getattr(self, "side", None) is None:
-            self.side = torch.cuda.Stream()
+            self.side = torch.cuda.Stream(priority=-1)  # the head chain is latency-critical: high priority
             self._cap_main = torch.cuda.Stream()       # capture stream of the "M" graphs (replayed on the current stream)
+            self.vis_stream = torch.cuda.Stream()      # vision stage of the NEXT step (fills the backward's idle CUs)
 
     @staticmethod
     def _chunks(n: int, sizes) -> List[Tuple[int, int]]:
@@ -976,12 +981,12 @@ class VLAEngine:
         for k, (lo, hi) in enumerate(reversed(fch)):
             segs.append(("H", h_bwd(lo, hi), None, ("b", k)))
             segs.append(("M", m_bwd(lo, hi, k == 0, k == len(fch) - 1), ("b", k), None))
-        segs.append(("H", head.bwd_end, None, ("end", 0)))
-        segs.append(("M", None, ("end", 0), None))              # join: head gradients are final (no work of its own)
+        segs.append(("H", head.bwd_end, None, ("end", 0)))      # the caller joins on this event (head gradients final)
         return segs
 
-    def _run_segments(self, segs, graphs=None, timeline=None):
-        """timeline: optional list that receives (stream, index, start_event, end_event) per segment (timing events)."""
+    def _run_segments(self, segs, graphs=None, timeline=None, hooks=None):
+        """timeline: optional list that receives (stream, index, start_event, end_event) per segment (timing events).
+        hooks: {segment index: fn(event)} called right after that segment was enqueued, with an event recorded behind it."""
         main, side = torch.cuda.current_stream(), self.side
         side.wait_stream(main)                                   # fork (inputs / previous AdamW are ordered before the head)
         ev = {}
@@ -1006,12 +1011,18 @@ class VLAEngine:
                 if signal is not None:
                     ev[signal] = torch.cuda.Event()
                     ev[signal].record(stream)
+                if hooks is not None and k in hooks:
+                    hev = ev[signal] if signal is not None else torch.cuda.Event()
+                    if signal is None:
+                        hev.record(stream)
+                    hooks[k](hev)
+        return ev[("end", 0)]
 
     def _fwd_bwd(self, batch, noise, vision: bool = True):
         """Eager run of the two-stream schedule (vision stage first unless the vision graph already ran)."""
         if vision:
             self._vision(batch)
-        self._run_segments(self._segments(batch, noise))
+        torch.cuda.current_stream().wait_event(self._run_segments(self._segments(batch, noise)))   # join
         return self._loss3
 
     # Data-parallel schedule of the captured step.  The gradient exchange of step k (one bucketed RCCL all-reduce of the
@@ -1034,11 +1045,15 @@ class VLAEngine:
         self.head.dirty = True
         # one memory pool per stream: graphs sharing a pool are replayed strictly in capture order on ONE stream, so the
         # allocator's reuse of freed capture-time temporaries stays race-free while the two streams overlap
-        pools = {"M": torch.cuda.graph_pool_handle(), "H": torch.cuda.graph_pool_handle()}
+        pools = {"M": torch.cuda.graph_pool_handle(), "H": torch.cuda.graph_pool_handle(), "V": torch.cuda.graph_pool_handle()}
         cap = {"M": self._cap_main, "H": self.side}
+        # vision stage: reads the staged pixels of the NEXT batch (stage_next_pixels), writes self.patches
+        self._next_px = batch["pixel_values"].clone()
+        self._px_stage = batch["pixel_values"].clone()
         self._g_vis = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_vis, pool=pools["M"], stream=cap["M"]):
-            self._vision(batch)
+        with torch.cuda.graph(self._g_vis, pool=pools["V"], stream=self.vis_stream):
+            self._vision(dict(batch, pixel_values=self._px_stage))
+        self._vis_ev = None
         self._segs = self._segments(batch, noise)
         self._graphs = []
         for st, fn, _, _ in self._segs:
@@ -1051,6 +1066,37 @@ class VLAEngine:
             self._graphs.append(g)
         torch.cuda.synchronize()
         self._pending_lr = None
+        # the vision stage of step k+1 starts behind this forward segment of step k (default: the last one, i.e. it runs
+        # under the backward, whose two dependent kernel chains leave most CUs idle)
+        m_fwd = [k for k, sg in enumerate(self._segs) if sg[0] == "M" and sg[3] is not None and sg[3][0] == "f"]
+        self._vis_after = m_fwd[min(len(m_fwd) - 1, max(0, int(os.environ.get("VLA_VIS_AFTER", len(m_fwd) - 1))))]
+        self._launch_vision()                        # vision stage of the FIRST step (the pixels given to capture)
+
+    def stage_next_pixels(self, pixel_values: torch.Tensor):
+        """Captured mode: pixels of the batch AFTER the one the next train_step_graphed() call trains on (its vision stage
+        runs during that call).  Without staging, the pixels given to capture() are reused."""
+        self._next_px.copy_(pixel_values)
+
+    def _launch_vision(self, after_event=None):
+        """Enqueue the vision stage (ViT + projector -> self.patches) of the staged pixels on the vision stream."""
+        V, cur = self.vis_stream, torch.cuda.current_stream()
+        if after_event is not None:
+            V.wait_event(after_event)           # self.patches of the running step has been consumed (_embed)
+        else:
+            V.wait_stream(cur)
+        tl = getattr(self, "_timeline", None)
+        with torch.cuda.stream(V):
+            if tl is not None:
+                t0 = torch.cuda.Event(enable_timing=True)
+                t0.record(V)
+            self._px_stage.copy_(self._next_px)
+            self._px_copied = torch.cuda.Event()
+            self._px_copied.record(V)
+            self._g_vis.replay()
+            self._vis_ev = torch.cuda.Event(enable_timing=tl is not None)
+            self._vis_ev.record(V)
+            if tl is not None:
+                tl.append(("V", -1, t0, self._vis_ev))
 
     def train_step_pipelined(self, batch, lr: float, noise=None):
         """Eager (un-captured) run of the two-stream schedule."""
@@ -1064,16 +1110,21 @@ class VLAEngine:
     def train_step_graphed(self, lr: float):
         """Replay of the captured step on the static buffers.  The parameter update of THIS step (RCCL exchange +
         AdamW) is left pending and applied inside the next call, after that step's vision graph - or by flush()."""
-        self._g_vis.replay()
+        cur = torch.cuda.current_stream()
         self.flush()
-        self._run_segments(self._segs, self._graphs, getattr(self, "_timeline", None))
+        cur.wait_event(self._vis_ev)           # patches of THIS step (computed during the previous call)
+        self._h_end = self._run_segments(self._segs, self._graphs, getattr(self, "_timeline", None),
+                                         hooks={self._vis_after: lambda ev: self._launch_vision(ev)})
+        cur.wait_event(self._px_copied)        # later writes to the staging source are ordered behind the vision copy
         if self.reducer is not None:
-            self.reducer.reduce_async(self.head.P.grad, 0, None)
+            self.reducer.stream.wait_event(self._h_end)          # head gradients final (side stream) ...
+            self.reducer.reduce_async(self.head.P.grad, 0, None)  # ... and everything on the current stream
         self._pending_lr = lr
         return self._loss3
 
     def flush(self):
         """Apply the pending parameter update of the last train_step_graphed (no-op if none)."""
         if getattr(self, "_pending_lr", None) is not None:
+            torch.cuda.current_stream().wait_event(self._h_end)   # join the head stream of the pending step
             self.optimizer_step(self._pending_lr)
             self._pending_lr = None
