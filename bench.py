@@ -170,6 +170,7 @@ def main():
     from vla_adapter_amd import ddp, engine as E, flops, synthetic as S
     rank, local, world = ddp.init_process_group_from_env()
     assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    local = local % torch.cuda.device_count()      # ranks > GPUs only in the gloo rehearsal on a one-GPU box
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     cfg = E.config2()

@@ -1,0 +1,22 @@
+"""Two ranks on ONE GPU through gloo (RCCL refuses two ranks per device): functional rehearsal of the captured
+data-parallel step - deferred update, early head-gradient exchange, vision lead - ending with identical parameters
+on both ranks (tools/ddp_rehearsal.py asserts it)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_rank_captured_step_keeps_ranks_in_sync():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, VLA_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join("tools", "ddp_rehearsal.py")],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("] ok") == 2, r.stdout[-3000:]

@@ -6,9 +6,10 @@ Divergence: the reference calls ``action_head.module.predict_action`
 the head's gradients; this build all-reduces them (mathematically correct DP).
 
 MI355X-first design: all trainable parameters live in ONE flat bf16 buffer (engine.FlatParams), so the exchange is
-a handful of large collectives instead of thousands of small ones.  The head/proprio gradients are final as soon
-as ``Head.backward`` returns, i.e. BEFORE the ~25 ms frozen-LLM backward: their all-reduce is launched on a side
-stream and hidden completely under that backward; only the 64x896 action-query gradient is reduced at the end.
+a handful of large collectives instead of thousands of small ones.  In the captured step the head/proprio gradients
+(437 MB) are final when the head stream ends - before the LLM backward and the next step's vision stage have
+finished: their all-reduce is launched from that event on its own stream and runs underneath them; only the 64x896
+action-query gradient is reduced at the very end.  The update itself is applied at the start of the next step.
 Bucket size defaults to 64 MiB (xGMI is point-to-point, 7 links x ~153 GB/s: large messages amortise the per-
 collective latency; ring all-reduce is per-link bound).  The 1/N scale is folded into the AdamW kernel.
 """
@@ -28,8 +29,8 @@ def init_process_group_from_env(backend: Optional[str] = None) -> Tuple[int, int
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:   # VLA_DIST_BACKEND=gloo: functional rehearsal of the multi-rank path where RCCL cannot run
+            backend = os.environ.get("VLA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -53,15 +54,19 @@ class FlatGradReducer:
         self.stream = torch.cuda.Stream() if torch.cuda.is_available() else None
         self._pending = False
 
-    def reduce_async(self, flat: torch.Tensor, start: int = 0, end: Optional[int] = None):
-        """Launch the all-reduce of flat[start:end] after everything already enqueued on the current stream."""
+    def reduce_async(self, flat: torch.Tensor, start: int = 0, end: Optional[int] = None, after_event=None):
+        """Launch the all-reduce of flat[start:end] after everything already enqueued on the current stream - or, with
+        ``after_event``, as soon as that event fires (the slice was produced on another stream and is final there)."""
         if self.world == 1:
             return
         end = flat.numel() if end is None else end
         view = flat[start:end]
         ranges = bucket_ranges(view.numel(), self.bucket_bytes // view.element_size())
         if self.stream is not None and flat.is_cuda:
-            self.stream.wait_stream(torch.cuda.current_stream())
+            if after_event is not None:
+                self.stream.wait_event(after_event)
+            else:
+                self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
                 for a, b in ranges:
                     dist.all_reduce(view[a:b], op=dist.ReduceOp.SUM, group=self.group)

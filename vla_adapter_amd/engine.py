@@ -1117,8 +1117,11 @@ class VLAEngine:
                                          hooks={self._vis_after: lambda ev: self._launch_vision(ev)})
         cur.wait_event(self._px_copied)        # later writes to the staging source are ordered behind the vision copy
         if self.reducer is not None:
-            self.reducer.stream.wait_event(self._h_end)          # head gradients final (side stream) ...
-            self.reducer.reduce_async(self.head.P.grad, 0, None)  # ... and everything on the current stream
+            aq_off = self.head.P.offsets["action_queries"][0]
+            # head / proprio gradients are final when the head stream ends: their exchange starts there, underneath the
+            # rest of the LLM backward and the next step's vision stage; the action-query gradient follows the LLM backward
+            self.reducer.reduce_async(self.head.P.grad, 0, aq_off, after_event=self._h_end)
+            self.reducer.reduce_async(self.head.P.grad, aq_off, None)
         self._pending_lr = lr
         return self._loss3
 
