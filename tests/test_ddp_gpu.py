@@ -19,4 +19,4 @@ def test_two_rank_captured_step_keeps_ranks_in_sync():
                         "127.0.0.1", "--master-port", str(port), os.path.join("tools", "ddp_rehearsal.py")],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert r.stdout.count("] ok") == 2, r.stdout[-3000:]
+    assert r.stdout.count("ranks-in-sync-ok") == 2, r.stdout[-3000:]

@@ -88,7 +88,7 @@ def test_gemm_plain_bias(ops, M, N, K):
     check(out, O.linear(a.float(), b.float(), bias.float(), emu=True), name=f"gemm {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("M,N,K", [(300, 200, 192), (1000, 896, 896), (512, 384, 64), (2080, 1792, 896), (64, 7, 128)])
 def test_gemm_every_tile_config(ops, tile, M, N, K, monkeypatch):
     """The three kernel instantiations (256x128x3-stage, 128x128x2, 128x64x3) must agree with the oracle on ragged

@@ -46,7 +46,7 @@ def main():
             out = torch.empty(M, N, device=DEV, dtype=BF)
             fn = lambda: ops.gemm_nt(a, w, bias=bias, act=act, out=out)
         line = f"gemm {name:22s} {M:5d}x{N:4d}x{K:4d}"
-        for tile, tn in ((0, "auto"), (9, "128x128 1stage"), (10, "256x256w8p"), (11, "256x128w4p"), (4, "256x256")):
+        for tile, tn in ((0, "auto"), (1, "256x128w16"), (4, "256x256"), (3, "128x64")):
             os.environ["VLA_GEMM_TILE"] = str(tile)
             t = timeit(fn)
             tf = 2.0 * M * N * K / t / 1e12

@@ -13,7 +13,8 @@ from vla_adapter_amd import ddp, engine as E, synthetic as S  # noqa: E402
 
 
 def log(*a):
-    print(f"[rank {os.environ.get('RANK')}]", *a, flush=True)
+    sys.stdout.write(f"[rank {os.environ.get('RANK')}] " + " ".join(str(x) for x in a) + "\n")   # one write: lines stay whole
+    sys.stdout.flush()
 
 
 rank, local, world = ddp.init_process_group_from_env()
@@ -51,4 +52,4 @@ log("max |param - mean over ranks| =", err)
 assert err == 0.0, "ranks diverged"
 dist.barrier()
 dist.destroy_process_group()
-log("ok")
+log("ranks-in-sync-ok")

@@ -22,7 +22,6 @@
 // wave-quantisation model (a 616-tile problem on 512 slots wastes 40 % of the machine with 128x128 tiles).
 //
 // Epilogue rounding points follow the reference under bf16 autocast: bf16(acc+bias) -> act -> bf16 -> (+residual) -> bf16.
-#include <type_traits>
 #include "common.h"
 #include "../../include/vla_native.h"
 
@@ -71,38 +70,9 @@ struct Cfg {
   static_assert(PIECES % NW == 0, "pieces must divide evenly over the waves");
 };
 
-// ---- explicit LDS fragment reads for the software-pipelined main loop (PIPE): the compiler re-uses fragment registers
-// and parks a full s_waitcnt lgkmcnt(0) in front of every MFMA group; issuing ds_read_b128 by hand with counted
-// waits keeps one k-step of fragments in flight underneath the previous k-step's MFMAs.
-template <int OFF>
-__device__ __forceinline__ bf16x8 lds_read128(unsigned addr) {
-  bf16x8 v;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-  return v;
-}
-// wait until at most N LDS reads are outstanding; the fragments are tied to the statement so no MFMA consuming them
-// can be scheduled above it
-template <int N>
-__device__ __forceinline__ void lgkm_wait6(bf16x8& a0, bf16x8& a1, bf16x8& a2, bf16x8& a3, bf16x8& b0, bf16x8& b1) {
-  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1) : "n"(N));
-}
-template <int N>
-__device__ __forceinline__ void lgkm_wait8(bf16x8& a0, bf16x8& a1, bf16x8& a2, bf16x8& a3, bf16x8& b0, bf16x8& b1, bf16x8& b2,
-                                           bf16x8& b3) {
-  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) : "n"(N));
-}
-
-template <int N>
-__device__ __forceinline__ void lgkm_wait12(bf16x8& a0, bf16x8& a1, bf16x8& a2, bf16x8& a3, bf16x8& b0, bf16x8& b1, bf16x8& b2,
-                                            bf16x8& b3, bf16x8& b4, bf16x8& b5, bf16x8& b6, bf16x8& b7) {
-  asm volatile("s_waitcnt lgkmcnt(%12)"
-               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7)
-               : "n"(N));
-}
-
 // ROPE is a compile-time switch (0 none / 1 rotate_half / 2 interleaved): the epilogue's extra registers and table
 // loads must not leak into the plain kernel that every other GEMM of the step runs.
-template <int BM, int BN, int STAGES, int ROPE, int WN = 2, int PIPE = 0>
+template <int BM, int BN, int STAGES, int ROPE, int WN = 2>
 __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
   using C = Cfg<BM, BN, STAGES, WN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -185,91 +155,6 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
   }
 
   const int nt = p.K / BK;
-  if constexpr (PIPE != 0) {
-    // ---- software-pipelined main loop (2 stages, NT 2 or 4).  Per K-tile t (LDS buffer t&1):
-    //   issue DMA of tile t+1 -> other buffer | issue reads of k-step 1 | MFMAs of k-step 0 (its reads were issued one
-    //   half-iteration earlier) | vmcnt(0) + lgkmcnt(0) + barrier | issue reads of k-step 0 of tile t+1 | MFMAs of k-step 1
-    static_assert(STAGES == 2 && (C::NT == 2 || C::NT == 4 || C::NT == 8), "PIPE: 2 stages, NT 2, 4 or 8");
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    const unsigned aoff = lds0 + wr * 64 * 128, boff = lds0 + C::A_BYTES + wc * C::WTN * 128;
-    const unsigned a_s0 = aoff + foff[0], a_s1 = aoff + foff[1], b_s0 = boff + foff[0], b_s1 = boff + foff[1];
-    bf16x8 fa0[4], fb0[8], fa1[4], fb1[8];
-    auto rd = [&](bf16x8* fa, bf16x8* fb, unsigned a, unsigned b) {
-      fa[0] = lds_read128<0>(a); fa[1] = lds_read128<2048>(a); fa[2] = lds_read128<4096>(a); fa[3] = lds_read128<6144>(a);
-      fb[0] = lds_read128<0>(b); fb[1] = lds_read128<2048>(b);
-      if constexpr (C::NT >= 4) { fb[2] = lds_read128<4096>(b); fb[3] = lds_read128<6144>(b); }
-      if constexpr (C::NT == 8) {
-        fb[4] = lds_read128<8192>(b); fb[5] = lds_read128<10240>(b); fb[6] = lds_read128<12288>(b); fb[7] = lds_read128<14336>(b);
-      }
-    };
-    auto wait_on = [&](bf16x8* fa, bf16x8* fb, auto tag) {
-      constexpr int N = decltype(tag)::value;
-      if constexpr (C::NT == 8) lgkm_wait12<N>(fa[0], fa[1], fa[2], fa[3], fb[0], fb[1], fb[2], fb[3], fb[4], fb[5], fb[6], fb[7]);
-      else if constexpr (C::NT == 4) lgkm_wait8<N>(fa[0], fa[1], fa[2], fa[3], fb[0], fb[1], fb[2], fb[3]);
-      else lgkm_wait6<N>(fa[0], fa[1], fa[2], fa[3], fb[0], fb[1]);
-    };
-    auto mm = [&](const bf16x8* fa, const bf16x8* fb) {
-#pragma unroll
-      for (int ni = 0; ni < C::NT; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni], fa[mi], acc[ni][mi], 0, 0, 0);
-    };
-    constexpr int NR = 4 + C::NT;                     // LDS reads per k-step
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    rd(fa0, fb0, a_s0, b_s0);
-    for (int t = 0; t < nt; ++t) {
-      const unsigned cur = (t & 1) * C::STAGE_BYTES, nxt = C::STAGE_BYTES - cur;
-      if (t + 1 < nt) stage((t + 1) & 1, (t + 1) * BK);
-      rd(fa1, fb1, a_s1 + cur, b_s1 + cur);
-      wait_on(fa0, fb0, std::integral_constant<int, NR>{});
-      mm(fa0, fb0);
-      __builtin_amdgcn_sched_barrier(0);          // keep k-step 0's MFMAs above the waits (they cover the read latency)
-      wait_on(fa1, fb1, std::integral_constant<int, 0>{});
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();   // tile t+1 visible to all; every wave is done reading tile t's buffer
-      asm volatile("" ::: "memory");
-      if (t + 1 < nt) rd(fa0, fb0, a_s0 + nxt, b_s0 + nxt);
-      __builtin_amdgcn_sched_barrier(0);          // next tile's first reads are in flight before k-step 1's MFMAs start
-      mm(fa1, fb1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  } else if constexpr (STAGES == 1) {
-    // ---- single LDS buffer: 32 KiB per workgroup -> 4 workgroups (32 waves) per CU.  The fragments of tile t sit in
-    // registers while the DMA of tile t+1 refills the buffer underneath tile t's MFMAs; everything else is hidden by
-    // the other resident workgroups.
-    static_assert(C::NT <= 4, "single stage: NT <= 4");
-    const char* sa = smem + wr * 64 * 128;
-    const char* sb = smem + C::A_BYTES + wc * C::WTN * 128;
-    stage(0, 0);
-    for (int t = 0; t < nt; ++t) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                         // tile t landed and is visible to every wave
-      asm volatile("" ::: "memory");
-      bf16x8 fm[2][4], fn[2][C::NT];
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fm[s][i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + foff[s]);
-#pragma unroll
-        for (int i = 0; i < C::NT; ++i) fn[s][i] = *reinterpret_cast<const bf16x8*>(sb + i * 16 * 128 + foff[s]);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                         // every wave holds its fragments: the buffer may be refilled
-      asm volatile("" ::: "memory");
-      if (t + 1 < nt) stage(0, (t + 1) * BK);
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int ni = 0; ni < C::NT; ++ni)
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[s][ni], fm[s][mi], acc[ni][mi], 0, 0, 0);
-    }
-  } else {
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < nt) stage(s, s * BK);
@@ -322,7 +207,6 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
       }
     }
     if (++buf == STAGES) buf = 0;
-  }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // all waves done with the operand tiles before the staging regions are overwritten
@@ -523,12 +407,6 @@ inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode, int
   if (force == 3) return {128, 64};
   if (force == 4 && rope_mode == 0) return {256, 256};
   if (force == 5 && rope_mode == 0) return {128, 129};   // 128x128 with 4 waves of 64x64 (the round-1 v1 geometry)
-  if (force == 6 && rope_mode == 0) return {128, 130};   // 128x128, 8 waves, software-pipelined fragment reads
-  if (force == 7 && rope_mode == 0) return {128, 131};   // 128x128, 4 waves of 64x64, software-pipelined
-  if (force == 8 && rope_mode == 0) return {256, 131};   // 256x128, 8 waves of 64x64, software-pipelined
-  if (force == 9 && rope_mode == 0) return {128, 132};   // 128x128, 8 waves, single LDS buffer (4 workgroups per CU)
-  if (force == 10 && rope_mode == 0) return {256, 133};  // 256x256, 8 waves of 64x128, software-pipelined
-  if (force == 11 && rope_mode == 0) return {256, 134};  // 256x128, 4 waves of 64x128 (1 per SIMD), software-pipelined
   if (M >= 8192 && N >= 8192 && K >= 8192) return {256, 256};   // 64x128 wave tiles: 12 LDS reads per 32 MFMAs (1201 vs 1093 TF/s)
   // In situ (whole training step, same-box A/B) the 8-wave 128x128 geometry beats the narrow tile on every shape of
   // the step, including the M=256 head GEMMs that overlap the LLM on the side stream (48.5 vs 49.5 vs 52.0 ms/step
@@ -540,7 +418,7 @@ inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode, int
   return TileChoice{128, 128};
 }
 
-template <int BM, int BN, int STAGES, int ROPE, int WN = 2, int PIPE = 0>
+template <int BM, int BN, int STAGES, int ROPE, int WN = 2>
 int launch(const GemmP& p0, int M, int N, int batch, hipStream_t st) {
   using C = Cfg<BM, BN, STAGES, WN>;
   GemmP p = p0;
@@ -548,10 +426,10 @@ int launch(const GemmP& p0, int M, int N, int batch, hipStream_t st) {
   p.ntiles = ((M + BM - 1) / BM) * p.tiles_n;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, STAGES, ROPE, WN, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, STAGES, ROPE, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, STAGES, ROPE, WN, PIPE>), dim3(p.ntiles, 1, batch), dim3(C::NTHREADS), C::LDS_BYTES, st, p);
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, STAGES, ROPE, WN>), dim3(p.ntiles, 1, batch), dim3(C::NTHREADS), C::LDS_BYTES, st, p);
   return 0;
 }
 
@@ -615,14 +493,8 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
     if (tc.bn == 128) launch<128, 128, 2, 2, 4>(p, d->M, d->N, d->batch, st);
     else launch<128, 64, 2, 2>(p, d->M, d->N, d->batch, st);
   } else if (tc.bm == 256 && tc.bn == 256) launch<256, 256, 2, 0>(p, d->M, d->N, d->batch, st);
-  else if (tc.bm == 256 && tc.bn == 131) launch<256, 128, 2, 0, 2, 1>(p, d->M, d->N, d->batch, st);
-  else if (tc.bm == 256 && tc.bn == 133) launch<256, 256, 2, 0, 2, 1>(p, d->M, d->N, d->batch, st);
-  else if (tc.bm == 256 && tc.bn == 134) launch<256, 128, 2, 0, 1, 1>(p, d->M, d->N, d->batch, st);
   else if (tc.bm == 256) launch<256, 128, 3, 0, 4>(p, d->M, d->N, d->batch, st);   // 16 waves, loads two K-tiles ahead
   else if (tc.bn == 129) launch<128, 128, 2, 0>(p, d->M, d->N, d->batch, st);      // 4 waves of 64x64 (forced only)
-  else if (tc.bn == 130) launch<128, 128, 2, 0, 4, 1>(p, d->M, d->N, d->batch, st);
-  else if (tc.bn == 132) launch<128, 128, 1, 0, 4>(p, d->M, d->N, d->batch, st);
-  else if (tc.bm == 128 && tc.bn == 131) launch<128, 128, 2, 0, 2, 1>(p, d->M, d->N, d->batch, st);
   else if (tc.bn == 128) launch<128, 128, 2, 0, 4>(p, d->M, d->N, d->batch, st);   // 8 waves (2x4) of 64x32
   else launch<128, 64, 2, 0>(p, d->M, d->N, d->batch, st);
   VLA_CHECK_LAUNCH("gemm_bf16_nt");
