@@ -65,3 +65,60 @@ def test_finetune_entry_point_tiny(tmp_path):
     assert "action_head--10_checkpoint.pt" in names and "proprio_projector--10_checkpoint.pt" in names
     sd = torch.load([f for f in files if f.endswith("action_head--10_checkpoint.pt")][0], weights_only=True)
     assert "model.mlp_resnet_blocks.0.q_proj.weight" in sd and "model.fc2.bias" in sd
+
+
+def test_predict_action_batch1_inference_matches_oracle():
+    """OpenVLAForActionPrediction.predict_action (modeling_prismatic.py:892-972): prompt ids + 64 placeholder ids + stop id,
+    fake labels marking the 64 action positions, forward in phase Inference, q01/q99 un-normalisation.  The oracle runs
+    the same prepared batch; replayed (captured) calls must reproduce the first (eager-warmed) one, and new inputs must
+    flow through the static buffers."""
+    import numpy as np
+    from vla_adapter_amd import constants as K, engine as E, synthetic as S
+    from vla_adapter_amd.action_heads import L1RegressionActionHead
+    from vla_adapter_amd.modeling_prismatic import OpenVLAForActionPrediction
+    from vla_adapter_amd.projectors import ProprioProjector
+    cfg = E.tiny_config()
+    W = S.make_weights(cfg, DEV, seed=5, std=0.05)
+    stats = {"libero_object": {"action": {"q01": [-0.5, -0.4, -0.3, -0.2, -0.1, -0.6, 0.0], "q99": [0.5, 0.6, 0.7, 0.8, 0.9, 0.4, 1.0],
+                                          "min": [-1] * 7, "max": [1] * 7, "mask": [True] * 6 + [False]}}}
+    vla = OpenVLAForActionPrediction(cfg, W, DEV, norm_stats=stats)
+    g = torch.Generator().manual_seed(31)
+    ids = torch.randint(3, 700, (1, 19), generator=g)
+    px = torch.randn(1, 3, cfg.vit[0].img, cfg.vit[0].img, generator=g).clamp_(-3, 3)
+    proprio = np.linspace(-0.5, 0.5, 8).astype(np.float32)
+    head = L1RegressionActionHead(input_dim=cfg.llm.d, hidden_dim=cfg.llm.d, action_dim=7, num_task_tokens=cfg.n_patches,
+                                  use_pro_version=True, device=DEV, num_blocks=cfg.num_blocks)
+    head.load_state_dict(W["head"], W["proprio"])
+    pp = ProprioProjector(cfg.llm.d, 8, DEV)
+    pp.load_state_dict(W["proprio"])
+    call = lambda i, p: vla.predict_action(input_ids=i, unnorm_key="libero_object", proprio=proprio, proprio_projector=pp,
+                                           action_head=head, pixel_values=p.to(BF), attention_mask=torch.ones_like(i, dtype=torch.bool))
+    act, hid = call(ids, px)
+    assert act.shape == (cfg.chunk, 7) and tuple(hid.shape) == (1, 1, K.NUM_TOKENS, cfg.llm.d)
+    act2, _ = call(ids, px)                                   # graph replay
+    assert np.array_equal(act, act2)
+    # oracle on the same prepared inputs
+    pids, pam, plab = OpenVLAForActionPrediction.prepare_inference_inputs(ids, torch.ones_like(ids, dtype=torch.bool))
+    assert pids.shape[1] == 19 + 65 and int((plab > K.ACTION_TOKEN_BEGIN_IDX).sum()) == 64 and int(plab[0, -1]) == K.STOP_INDEX
+    f = lambda sd: {k: v.float().cpu() for k, v in sd.items()}
+    llm = f(W["llm"])
+    OW = dict(vit=[f(s) for s in W["vit"]], proj=f(W["proj"]), llm=llm, embed=llm["embed_tokens.weight"],
+              action_queries=W["action_queries"].float().cpu(), head=f(W["head"]), proprio=f(W["proprio"]))
+    ocfg = dict(vit=[v.as_oracle() for v in cfg.vit], fused=cfg.fused, llm=cfg.llm.as_oracle(), n_img=cfg.n_img, pro=cfg.pro,
+                num_blocks=cfg.num_blocks)
+    cb = dict(input_ids=pids, labels=plab, attention_mask=pam.bool(), pixel_values=px.to(BF).float(),
+              proprio=torch.tensor(proprio).to(BF).float()[None], actions=torch.zeros(1, cfg.chunk, 7))
+    ref = O.vla_forward(cb, OW, ocfg, emu=True, noise=None)["pred"].reshape(cfg.chunk, 7).to(BF).float().numpy()
+    st = stats["libero_object"]["action"]
+    lo, hi, mk = np.array(st["q01"]), np.array(st["q99"]), np.array(st["mask"])
+    ref_un = np.where(mk, 0.5 * (ref + 1) * (hi - lo + 1e-8) + lo, ref)
+    err = np.linalg.norm(act - ref_un) / np.linalg.norm(ref_un)
+    assert err < 2e-2, err
+    assert np.allclose(act[:, 6], np.asarray(vla.engine.predict.__self__._predict_graphs[next(iter(vla.engine._predict_graphs))][2]
+                                             .float().cpu().numpy()[0, :, 6]))          # masked dim stays normalised
+    # different inputs through the same captured graph
+    ids2, px2 = torch.randint(3, 700, (1, 19), generator=g), torch.randn(1, 3, cfg.vit[0].img, cfg.vit[0].img, generator=g).clamp_(-3, 3)
+    act3, _ = call(ids2, px2)
+    assert not np.allclose(act3, act) and len(vla.engine._predict_graphs) == 1
+    with pytest.raises(NotImplementedError):
+        vla.predict_action(input_ids=ids, action_head=None, pixel_values=px, attention_mask=torch.ones_like(ids))

@@ -33,6 +33,7 @@ class L1RegressionActionHead:
         sd = {k.replace("module.", "", 1) if k.startswith("module.") else k: v for k, v in sd.items()}
         pp = proprio_sd if proprio_sd is not None else {k: v for k, v in self.head.proprio_views().items()}
         self.head.load_state_dicts(sd, pp)
+        self._version = getattr(self, "_version", 0) + 1          # predict_action reloads the engine's copy when this moves
 
     def predict_action(self, actions_hidden_states: torch.Tensor, proprio=None, proprio_projector=None, phase="Inference",
                        noise: Optional[torch.Tensor] = None) -> torch.Tensor:

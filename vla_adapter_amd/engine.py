@@ -470,16 +470,30 @@ class Head:
         sd.update(self.film)
         return sd
 
+    # `dirty` is raised whenever the flat parameter buffer changed (AdamW, checkpoint load); it expands into two stale
+    # marks: the K-padded proprio fc1 weight the FORWARD reads, and the W^T operands only the BACKWARD reads.
+    @property
+    def dirty(self) -> bool:
+        return self._stale_fwd or self._stale_bwd
+
+    @dirty.setter
+    def dirty(self, v: bool):
+        self._stale_fwd = self._stale_bwd = bool(v)
+
+    def refresh_forward_operands(self):
+        if self._stale_fwd:
+            self.pfc1_pad[:, :self.cfg.proprio_dim] = self.P.view("p_fc1_w")
+            self._stale_fwd = False
+
     def refresh_transposes(self):
-        if not self.dirty:
+        if not self._stale_bwd:
             return
         P = self.P
         for k in ("w_x", "w_adp", "w_task", "w_o", "w_ffn"):
             ops.transpose(P.view(k), out=self.T[k])
         ops.transpose(P.view("p_fc2_w"), out=self.T["p_fc2_w"])
         self.fc2T[:, :self.cfg.action_dim] = P.view("fc2_w").t()
-        self.pfc1_pad[:, :self.cfg.proprio_dim] = P.view("p_fc1_w")
-        self.dirty = False
+        self._stale_bwd = False
 
     def _alloc(self, B: int, Kt: int):
         if self._key == (B, Kt):
@@ -545,7 +559,7 @@ class Head:
         B, S = HS.shape[1], HS.shape[2]
         T = cfg.chunk
         self._alloc(B, Np)
-        self.refresh_transposes()
+        self.refresh_forward_operands()
         self.HSref, self.Np, self.S, self.B, self.pos1 = HS, Np, S, B, pos1
         # proprio projector (projectors.py:19-24); proprio rounded to bf16 first (action_heads.py:53)
         self.pr_in[:, :cfg.proprio_dim] = proprio.to(BF16)
@@ -639,6 +653,7 @@ class Head:
         R, Da = self.R, cfg.action_dim
         self.row0 = row0
         assert getattr(self, "_prep_key", None) == (self.B, self.S, self.Np, row0), "prep_backward() first"
+        self.refresh_transposes()                                  # W^T operands of the dX products (stale after AdamW)
         self.acc32.zero_()                                         # every fp32 gradient accumulator in one fill
         dp = dpred.reshape(R, Da)
         self.dpad.zero_()
@@ -755,6 +770,31 @@ class VLAEngine:
         """VLM forward + action head (finetune.py:336-411) -> predicted actions [B, chunk, 7]."""
         self.forward_vlm(batch, for_training)
         return self.head.forward(self.llm.HS, self.pos1, batch["proprio"], self.Np, noise)
+
+    # ---- batch-1 inference (modeling_prismatic.py:892-972): forward only, captured per input shape ------------------
+    def predict(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """Forward pass in phase "Inference" (no input perturbation) -> normalised actions [B, chunk, action_dim] bf16.
+        The kernel sequence of one (B, L) shape is captured into a hipGraph on first use and replayed on static input
+        buffers afterwards: at batch 1 the ~700 launches of the forward are launch-bound otherwise."""
+        key = (tuple(batch["input_ids"].shape), tuple(batch["pixel_values"].shape), batch["pixel_values"].dtype)
+        cache = self.__dict__.setdefault("_predict_graphs", {})
+        if os.environ.get("VLA_PREDICT_EAGER"):
+            return self.forward(batch, None)
+        if key not in cache:
+            static = {k: v.clone() for k, v in batch.items()}
+            for _ in range(2):                       # allocate buffers / set kernel attributes outside the capture
+                self.forward(static, None)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self.forward(static, None)
+            cache[key] = (g, static, out)
+        g, static, out = cache[key]
+        for k, v in batch.items():
+            static[k].copy_(v)
+        self.head.refresh_forward_operands()     # parameters may have changed since the capture (no-op when fresh)
+        g.replay()
+        return out
 
     # modeling_prismatic.py:596-655 (multimodal forward): fills llm.HS with the n+1 hidden states
     def forward_vlm(self, batch: Dict[str, torch.Tensor], for_training: bool = False):
@@ -1075,6 +1115,8 @@ class VLAEngine:
     def stage_next_pixels(self, pixel_values: torch.Tensor):
         """Captured mode: pixels of the batch AFTER the one the next train_step_graphed() call trains on (its vision stage
         runs during that call).  Without staging, the pixels given to capture() are reused."""
+        if getattr(self, "_px_copied", None) is not None:
+            torch.cuda.current_stream().wait_event(self._px_copied)   # the vision stream has taken its copy of the old pixels
         self._next_px.copy_(pixel_values)
 
     def _launch_vision(self, after_event=None):

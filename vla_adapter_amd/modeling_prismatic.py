@@ -81,8 +81,86 @@ class OpenVLAForActionPrediction:
 
     __call__ = forward
 
-    def predict_action(self, *a, **k):
-        raise NotImplementedError("batch-1 inference predict_action (modeling_prismatic.py:892-972) is a 'next' row (SURVEY 8f-1)")
+    # ---- batch-1 inference (modeling_prismatic.py:892-972; driver experiments/robot/openvla_utils.py:737-825) ------
+    @staticmethod
+    def _check_unnorm_key(norm_stats, unnorm_key):                                # modeling_prismatic.py:975-990
+        if unnorm_key is None:
+            assert len(norm_stats) == 1, ("Your model was trained on more than one dataset, please pass a `unnorm_key` from the "
+                                          f"following options to choose the statistics used for un-normalizing actions: {norm_stats.keys()}")
+            unnorm_key = next(iter(norm_stats.keys()))
+        assert unnorm_key in norm_stats, ("The `unnorm_key` you chose is not in the set of available dataset statistics, "
+                                          f"please choose from: {norm_stats.keys()}")
+        return unnorm_key
+
+    def get_action_dim(self, unnorm_key=None) -> int:
+        return len(self.norm_stats[self._check_unnorm_key(self.norm_stats, unnorm_key)]["action"]["min"])
+
+    def get_action_stats(self, unnorm_key=None):
+        return self.norm_stats[self._check_unnorm_key(self.norm_stats, unnorm_key)]["action"]
+
+    def _unnormalize_actions(self, normalized_actions, unnorm_key=None):          # modeling_prismatic.py:784-805
+        import numpy as np
+        from . import constants as K
+        st = self.get_action_stats(unnorm_key)
+        if K.ACTION_PROPRIO_NORMALIZATION_TYPE == "bounds":
+            mask = st.get("mask", np.ones_like(st["min"], dtype=bool))
+            high, low = np.array(st["max"]), np.array(st["min"])
+        elif K.ACTION_PROPRIO_NORMALIZATION_TYPE == "bounds_q99":
+            mask = st.get("mask", np.ones_like(st["q01"], dtype=bool))
+            high, low = np.array(st["q99"]), np.array(st["q01"])
+        else:
+            raise ValueError("Unsupported action/proprio normalization type detected!")
+        return np.where(mask, 0.5 * (normalized_actions + 1) * (high - low + 1e-8) + low, normalized_actions)
+
+    @staticmethod
+    def prepare_inference_inputs(input_ids: torch.Tensor, attention_mask: torch.Tensor):
+        """_prepare_input_for_action_prediction + _prepare_labels_for_action_prediction (:747-782): append the 64
+        placeholder action ids (value 1) and the stop id, fake labels that mark exactly those 64 positions."""
+        from . import constants as K
+        B, L0 = input_ids.shape
+        ids = torch.cat([input_ids, torch.ones(B, K.NUM_TOKENS, dtype=input_ids.dtype, device=input_ids.device),
+                         torch.full((B, 1), K.STOP_INDEX, dtype=input_ids.dtype, device=input_ids.device)], dim=-1)
+        am = torch.cat([attention_mask, torch.ones(B, ids.shape[-1] - L0, dtype=attention_mask.dtype, device=attention_mask.device)], dim=-1)
+        labels = torch.full_like(ids, K.IGNORE_INDEX)
+        labels[:, L0:] = K.ACTION_TOKEN_BEGIN_IDX + 1
+        labels[:, -1] = K.STOP_INDEX
+        return ids, am, labels
+
+    def predict_action(self, input_ids=None, unnorm_key=None, proprio=None, proprio_projector=None, action_head=None,
+                       noisy_action_projector=None, use_film: bool = False, **kwargs):
+        """Same call as the reference (``pixel_values`` / ``attention_mask`` in kwargs, batch 1): returns
+        (un-normalised actions ndarray [chunk, action_dim], action hidden states [1, 1, 64, D] of the last layer).
+        ``action_head`` / ``proprio_projector``: this package's mirrors (their parameters are loaded into the engine) or
+        ``True`` for the parameters the engine already holds (trained in place).  The discrete-token branch
+        (``action_head=None`` -> lm_head argmax) is not built."""
+        import numpy as np
+        if use_film or noisy_action_projector is not None:
+            raise NotImplementedError("FiLM / diffusion heads are outside the accelerated path")
+        if action_head is None:
+            raise NotImplementedError("discrete-token action prediction needs the lm_head (SURVEY 8f-4); pass the L1 regression head")
+        assert input_ids.shape[0] == 1, "Generation with batch size > 1 is not currently supported!"     # :700-703
+        eng, dev = self.engine, self.device
+        if action_head is not True:
+            sd = action_head.state_dict()
+            psd = proprio_projector.state_dict() if (proprio_projector is not None and proprio_projector is not True) else {
+                k: v for k, v in eng.head.proprio_views().items()}
+            key = (id(action_head), id(proprio_projector), getattr(action_head, "_version", 0), getattr(proprio_projector, "_version", 0))
+            if getattr(self, "_loaded_head", None) != key:
+                eng.head.load_state_dicts(sd, psd)
+                self._loaded_head = key
+        ids, am, labels = self.prepare_inference_inputs(input_ids.to(dev), kwargs["attention_mask"].to(dev))
+        use_proprio = proprio_projector is not None and proprio is not None
+        assert use_proprio, "the regression head dereferences proprio and its projector (action_heads.py:53-54)"
+        pr = torch.as_tensor(np.asarray(proprio), dtype=torch.float32, device=dev).reshape(1, -1)
+        batch = dict(input_ids=ids, labels=labels, attention_mask=am.bool(), pixel_values=kwargs["pixel_values"].to(dev).contiguous(),
+                     proprio=pr)
+        pred = eng.predict(batch)                                                   # [1, chunk, action_dim] bf16
+        normalized = pred.reshape(self.cfg.chunk, self.cfg.action_dim).float().cpu().numpy()
+        n, Np = self.cfg.llm.n_layers, self.cfg.n_patches
+        s0 = Np + input_ids.shape[-1] - 1                                           # NUM_PATCHES + NUM_PROMPT_TOKENS (:856)
+        from . import constants as K
+        hid = eng.llm.HS[n][:, s0:s0 + K.NUM_TOKENS].reshape(1, 1, K.NUM_TOKENS, -1)
+        return self._unnormalize_actions(normalized, unnorm_key), hid
 
 
 class PrismaticVLM:

@@ -21,6 +21,7 @@ class ProprioProjector:
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
         for k in self.params:
             self.params[k] = sd[k.replace("module.", "")].to(self.device, BF16).contiguous()   # DDP prefix stripped (finetune.py:132-154)
+        self._version = getattr(self, "_version", 0) + 1
 
     def forward(self, proprio: torch.Tensor) -> torch.Tensor:
         B = proprio.shape[0]
