@@ -70,11 +70,13 @@ def measure_gemm_roofline(eng, batch, noise, lr, reps=10):
         return orig(a, b, **kw)
 
     ops.gemm_nt, ops.gemm_swiglu_bwd = rec, rec_sw
+    reducer, eng.reducer = eng.reducer, None      # rank-0-only probe step: it must not issue collectives
     try:
         eng.train_step(batch, lr, noise)
         torch.cuda.synchronize()
     finally:
         ops.gemm_nt, ops.gemm_swiglu_bwd = orig, orig_sw
+        eng.reducer = reducer
     total_t = total_f = 0.0
     n = 0
     per = []
