@@ -172,10 +172,17 @@ def test_graph_replay_matches_eager(setup):
     assert abs(l3 - l1b) <= 2e-2 * abs(l1b)
 
 
-def test_head_only_parity_identical_inputs(setup):
-    """Head forward/backward on IDENTICAL hidden states (N(0,1) inputs: a deliberately harsh, peaky-softmax regime)."""
+@pytest.mark.parametrize("pro", [True, False])
+def test_head_only_parity_identical_inputs(setup, pro):
+    """Head forward/backward on IDENTICAL hidden states (N(0,1) inputs: a deliberately harsh, peaky-softmax regime), for
+    MLPResNetBlock_Pro and for the original MLPResNetBlock (shared k/v projections, no RoPE: action_heads.py:168-283)."""
     cfg, W, batch, _ = setup
-    from vla_adapter_amd import ops, engine as E
+    from vla_adapter_amd import ops, engine as E, synthetic as S
+    if not pro:
+        cfg = E.tiny_config()
+        cfg.pro = False
+        W = S.make_weights(cfg, DEV, seed=3, std=0.05)
+        assert "model.mlp_resnet_blocks.0.k_proj.weight" in W["head"] and "model.mlp_resnet_blocks.0.k_task.weight" not in W["head"]
     eng = E.VLAEngine(cfg, W, DEV)        # fresh parameters (the shared engine has taken an optimiser step)
     B, L = batch["input_ids"].shape
     Np, D, nb = cfg.n_patches, cfg.llm.d, cfg.num_blocks
@@ -193,7 +200,7 @@ def test_head_only_parity_identical_inputs(setup):
     hp, pp = f(W["head"]), f(W["proprio"])
     hs = HS.float().requires_grad_(True)
     mlhs = O.regroup_hidden_states([hs[i] for i in range(nb + 1)], batch["labels"].cpu(), Np)
-    ref = O.head_predict_action(mlhs, batch["proprio"].cpu().to(BF).float(), hp, pp, Np, True, None, True, nb)
+    ref = O.head_predict_action(mlhs, batch["proprio"].cpu().to(BF).float(), hp, pp, Np, pro, None, True, nb)
     assert rel(pred, ref) < 6e-3, f"head pred {rel(pred, ref):.3e}"
     ref.backward(dpred.float())
     gmax = max(v.grad.norm().item() for v in hp.values() if v.grad is not None)
@@ -323,3 +330,33 @@ def test_graphed_vision_lead_uses_staged_pixels():
     assert abs(gb - lb) <= 2e-2 * abs(lb), (gb, lb)
     assert abs(la - lb) > 1e-3, "the two batches must differ for the check to mean anything"
     assert (e1.head.P.data.float() - e2.head.P.data.float()).norm() <= 2e-3 * e1.head.P.data.float().norm()
+
+
+def test_original_head_block_end_to_end():
+    """use_pro_version=False (MLPResNetBlock, action_heads.py:168-283) through the whole engine: forward parity with the
+    oracle, shared k/v gradient = sum over the three segments (checked against autograd), captured step trains."""
+    from vla_adapter_amd import engine as E, synthetic as S, ops
+    cfg = E.tiny_config()
+    cfg.pro = False
+    W = S.make_weights(cfg, DEV, seed=13, std=0.05)
+    batch = S.make_batch(cfg, 2, DEV, seed=14, P=40)
+    eng = E.VLAEngine(cfg, W, DEV)
+    pred = eng.forward(batch, None)
+    eng.loss_and_backward(pred, batch["actions"])
+    torch.cuda.synchronize()
+    out, OW = _oracle_run(cfg, W, batch, None, True, cfg.num_blocks)
+    assert rel(pred, out["pred"]) < 1.5e-2, rel(pred, out["pred"])
+    _, dpred = ops.l1_loss(pred, batch["actions"].to(BF), True)
+    out["pred"].backward(dpred.float().cpu())
+    g = eng.head.named_views(eng.head.P.grad)
+    gmax = max(v.grad.norm().item() for v in OW["head"].values() if v.grad is not None)
+    for name in ("k_proj", "v_proj", "q_proj", "o_proj"):
+        k = f"model.mlp_resnet_blocks.1.{name}.weight"
+        ref = OW["head"][k].grad
+        err = (g[k].float().cpu() - ref).norm().item()
+        assert err <= 6e-2 * ref.norm().item() or err <= 1e-3 * gmax, (k, err / ref.norm().item())
+    e2 = E.VLAEngine(cfg, W, DEV)
+    e2.capture(batch, None)
+    losses = [e2.train_step_graphed(2e-3)[0].item() for _ in range(12)]
+    e2.flush()
+    assert losses[-1] < 0.8 * losses[0], losses

@@ -17,11 +17,8 @@ class L1RegressionActionHead:
     def __init__(self, input_dim=4096, hidden_dim=4096, action_dim=7, num_task_tokens=512, use_pro_version=False, device="cuda",
                  num_blocks: int = 24):
         assert input_dim == hidden_dim, "the reference always passes llm_dim for both (finetune.py:884-896)"
-        if not use_pro_version:
-            raise NotImplementedError("native head implements MLPResNetBlock_Pro (use_pro_version=True, the reference default); "
-                                      "the original block exists in the oracle only")
         self.num_task_tokens, self.action_dim, self.hidden_dim = num_task_tokens, action_dim, hidden_dim
-        cfg = E.VLACfg(llm=E.LLMCfg(d=hidden_dim), num_blocks=num_blocks, action_dim=action_dim, pro=True)
+        cfg = E.VLACfg(llm=E.LLMCfg(d=hidden_dim), num_blocks=num_blocks, action_dim=action_dim, pro=bool(use_pro_version))
         self.head = E.Head(cfg, device)
         self.device = device
 

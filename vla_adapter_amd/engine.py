@@ -391,21 +391,24 @@ class FlatParams:
 
 
 class Head:
-    """L1RegressionActionHead (Pro blocks) + ProprioProjector + action_queries: the trainable set of the
-    adapter-only fine-tune (action_heads.py:21-121, 287-410; projectors.py:6-24; modeling_prismatic.py:375-376)."""
+    """L1RegressionActionHead + ProprioProjector + action_queries: the trainable set of the adapter-only fine-tune
+    (action_heads.py:21-121; projectors.py:6-24; modeling_prismatic.py:375-376).  cfg.pro selects the block:
+    MLPResNetBlock_Pro (:287-410, the reference default) - separate k/v projections per segment, RoPE on q/k - or the
+    original MLPResNetBlock (:168-283) - ONE k_proj / v_proj shared by the three segments, no RoPE.  Both put the
+    tanh(gating_factor) on the task-token segment and share every kernel; the original block simply reads its k|v
+    weights (rows D..3D of the fused q|k|v matrix) for all three segments and sums their three gradients."""
 
     H = 8
 
     def __init__(self, cfg: VLACfg, device):
-        assert cfg.pro, "only MLPResNetBlock_Pro (use_pro_version=True, the reference default) is implemented natively"
-        self.cfg, self.device = cfg, device
+        self.cfg, self.device, self.pro = cfg, device, cfg.pro
         D, nb, Da, Pd = cfg.llm.d, cfg.num_blocks, cfg.action_dim, cfg.proprio_dim
         assert D % 64 == 0 and (D // self.H) % 8 == 0
         self.D, self.nb, self.Din = D, nb, Da * D
         assert self.Din % 64 == 0
-        spec = [("w_x", (nb, 3 * D, D)), ("b_x", (nb, 3 * D)),        # q_proj | k_self | v_self
-                ("w_adp", (nb, 2 * D, D)), ("b_adp", (nb, 2 * D)),    # k_adapter | v_adapter
-                ("w_task", (nb, 2 * D, D)), ("b_task", (nb, 2 * D)),  # k_task | v_task
+        seg = [("w_adp", (nb, 2 * D, D)), ("b_adp", (nb, 2 * D)),    # k_adapter | v_adapter
+               ("w_task", (nb, 2 * D, D)), ("b_task", (nb, 2 * D))] if cfg.pro else []   # k_task | v_task
+        spec = [("w_x", (nb, 3 * D, D)), ("b_x", (nb, 3 * D))] + seg + [   # q_proj | k_self | v_self   (orig: q | k | v)
                 ("w_o", (nb, D, D)), ("b_o", (nb, D)), ("w_ffn", (nb, D, D)), ("b_ffn", (nb, D)),
                 ("ln_w", (nb, D)), ("ln_b", (nb, D)), ("gate", (nb, 8)),
                 ("ln1_w", (self.Din,)), ("ln1_b", (self.Din,)), ("fc1_w", (D, self.Din)), ("fc1_b", (D,)),
@@ -416,8 +419,9 @@ class Head:
         self.film = {}            # film_gen.0.{weight,bias}: in the state dict, never used, never updated (:327-329)
         # transposed copies for the dX products (rebuilt after every optimiser step)
         z = lambda *s: torch.zeros(*s, device=device, dtype=BF16)
-        self.T = dict(w_x=z(nb, D, 3 * D), w_adp=z(nb, D, 2 * D), w_task=z(nb, D, 2 * D), w_o=z(nb, D, D), w_ffn=z(nb, D, D),
-                      p_fc2_w=z(D, D))
+        self.T = dict(w_x=z(nb, D, 3 * D), w_o=z(nb, D, D), w_ffn=z(nb, D, D), p_fc2_w=z(D, D))
+        if cfg.pro:
+            self.T.update(w_adp=z(nb, D, 2 * D), w_task=z(nb, D, 2 * D))
         self.fc2T = z(D, 64)                       # fc2^T zero-padded to K=64
         self.pfc1_pad = z(D, 64)                   # proprio fc1 weight zero-padded to K=64
         self.dirty = True
@@ -425,10 +429,23 @@ class Head:
         self.rope_tab = None     # f32 [max(T, Ka, Kt), dh] cos/sin tables (positions restart per segment: one table serves all)
 
     # ---- reference state-dict interop (file names / keys: finetune.py:527-572) -------------------------
-    _BLK = [("q_proj", "w_x", "b_x", 0), ("k_self", "w_x", "b_x", 1), ("v_self", "w_x", "b_x", 2),
-            ("k_adapter", "w_adp", "b_adp", 0), ("v_adapter", "w_adp", "b_adp", 1),
-            ("k_task", "w_task", "b_task", 0), ("v_task", "w_task", "b_task", 1),
-            ("o_proj", "w_o", "b_o", 0), ("ffn.1", "w_ffn", "b_ffn", 0)]
+    _BLK_PRO = [("q_proj", "w_x", "b_x", 0), ("k_self", "w_x", "b_x", 1), ("v_self", "w_x", "b_x", 2),
+                ("k_adapter", "w_adp", "b_adp", 0), ("v_adapter", "w_adp", "b_adp", 1),
+                ("k_task", "w_task", "b_task", 0), ("v_task", "w_task", "b_task", 1),
+                ("o_proj", "w_o", "b_o", 0), ("ffn.1", "w_ffn", "b_ffn", 0)]
+    _BLK_ORIG = [("q_proj", "w_x", "b_x", 0), ("k_proj", "w_x", "b_x", 1), ("v_proj", "w_x", "b_x", 2),
+                 ("o_proj", "w_o", "b_o", 0), ("ffn.1", "w_ffn", "b_ffn", 0)]
+
+    @property
+    def _BLK(self):
+        return self._BLK_PRO if self.pro else self._BLK_ORIG
+
+    def _kv(self, which: str, i: int):
+        """(weight [2D, D], bias [2D], transposed weight [D, 2D]) of the k|v projection of segment `which` in block i."""
+        D = self.D
+        if self.pro:
+            return self.P.view("w_" + which)[i], self.P.view("b_" + which)[i], self.T["w_" + which][i]
+        return self.P.view("w_x")[i, D:], self.P.view("b_x")[i, D:], self.T["w_x"][i][:, D:]
 
     def named_views(self, buf=None) -> Dict[str, torch.Tensor]:
         """Reference-named views ('model.mlp_resnet_blocks.N.q_proj.weight', ...) into the flat buffer."""
@@ -489,7 +506,7 @@ class Head:
         if not self._stale_bwd:
             return
         P = self.P
-        for k in ("w_x", "w_adp", "w_task", "w_o", "w_ffn"):
+        for k in (("w_x", "w_adp", "w_task", "w_o", "w_ffn") if self.pro else ("w_x", "w_o", "w_ffn")):
             ops.transpose(P.view(k), out=self.T[k])
         ops.transpose(P.view("p_fc2_w"), out=self.T["p_fc2_w"])
         self.fc2T[:, :self.cfg.action_dim] = P.view("fc2_w").t()
@@ -514,7 +531,7 @@ class Head:
         self.probs = e(nb, B, self.H, T, T + Ka + Kt, dt=torch.float32)
         self.stats = e(nb, R, 2, dt=torch.float32)
         # fp32 gradient accumulators (bias column sums, LayerNorm dw/db, gate): views of ONE buffer, zeroed by one fill
-        bkeys = ("b_x", "b_adp", "b_task", "b_o", "b_ffn", "fc1_b", "fc2_b", "p_fc1_b", "p_fc2_b")
+        bkeys = tuple(k for k in ("b_x", "b_adp", "b_task", "b_o", "b_ffn", "fc1_b", "fc2_b", "p_fc1_b", "p_fc2_b") if k in self.P.offsets)
         shapes = [("dgate", (nb,)), ("ln_dw", (nb, D)), ("ln_db", (nb, D)), ("ln1_dw", (self.Din,)), ("ln1_db", (self.Din,)),
                   ("ln2_dw", (D,)), ("ln2_db", (D,))] + [("b:" + k, tuple(self.P.offsets[k][1])) for k in bkeys]
         self.acc32 = z(sum(rup(math.prod(sh), 4) for _, sh in shapes), dt=torch.float32)
@@ -586,13 +603,18 @@ class Head:
         ops.gather_rows(hs2, self.row_idx.view(-1), self.gtmp)
         self.h_adp[i, :, :NUM_TOKENS] = self.gtmp.view(B, NUM_TOKENS, D)
         self.h_adp[i, :, NUM_TOKENS] = self.pf
-        ops.gemm_nt(self.h_adp[i].view(B * Ka, D), P.view("w_adp")[i], bias=P.view("b_adp")[i], out=self.KV_adp[i])
-        ops.rope_inter_(self.KV_adp[i][:, :D], rc, rs_, Ka, H, dh, 0)
+        wa, ba, _ = self._kv("adp", i)
+        ops.gemm_nt(self.h_adp[i].view(B * Ka, D), wa, bias=ba, out=self.KV_adp[i])
         # task tokens = HS[i+1][:, :Np] read in place (row-group addressing)
-        ops.gemm_nt(hs2[:B * Kt], P.view("w_task")[i], bias=P.view("b_task")[i], out=self.KV_task[i], a_group=(Kt, S * D))
-        ops.rope_inter_(self.KV_task[i][:, :D], rc, rs_, Kt, H, dh, 0)
+        wt, bt, _ = self._kv("task", i)
+        ops.gemm_nt(hs2[:B * Kt], wt, bias=bt, out=self.KV_task[i], a_group=(Kt, S * D))
         x = self.X[i]
-        ops.gemm_nt(x, P.view("w_x")[i], bias=P.view("b_x")[i], out=self.QKVx[i], rope=(2, rc, rs_, T, dh, 2 * D))  # q, k_self
+        if self.pro:      # RoPE (positions restart per segment) on q and on every segment's k; the original block has none
+            ops.rope_inter_(self.KV_adp[i][:, :D], rc, rs_, Ka, H, dh, 0)
+            ops.rope_inter_(self.KV_task[i][:, :D], rc, rs_, Kt, H, dh, 0)
+            ops.gemm_nt(x, P.view("w_x")[i], bias=P.view("b_x")[i], out=self.QKVx[i], rope=(2, rc, rs_, T, dh, 2 * D))  # q, k_self
+        else:
+            ops.gemm_nt(x, P.view("w_x")[i], bias=P.view("b_x")[i], out=self.QKVx[i])
         self._attn(i, fwd=True)
         ops.gemm_nt(self.AOx[i], P.view("w_o")[i], bias=P.view("b_o")[i], residual=x, out=self.O2[i])
         self._ln(self.O2[i], P.view("ln_w")[i], P.view("ln_b")[i], self.LNo[i], self.stats[i])
@@ -625,7 +647,8 @@ class Head:
             ga = self.dKV_adp[i].view(B, Ka, 2 * D)
             gt = self.dKV_task[i].view(B, Kt, 2 * D)
             ops.head_attn_bwd(dout.view(B, T, D), out, *args, gate, self.probs[i], self.dgate[i:i + 1], g[:, :, :D], g[:, :, D:2 * D],
-                              g[:, :, 2 * D:], ga[:, :, :D], ga[:, :, D:], gt[:, :, :D], gt[:, :, D:], H, rope=self.rope_tab)
+                              g[:, :, 2 * D:], ga[:, :, :D], ga[:, :, D:], gt[:, :, :D], gt[:, :, D:], H,
+                              rope=self.rope_tab if self.pro else None)
 
     # ---- backward ---------------------------------------------------------------------------------------------
     def backward(self, dpred: torch.Tensor, dHS: torch.Tensor, row0: int = 0):
@@ -677,12 +700,12 @@ class Head:
         self._attn(i, fwd=False, dout=d_ao)          # returns dq / dk already through the RoPE transpose
         self.dx = ops.gemm_nt(self.dQKVx[i], self.T["w_x"][i], residual=do2)
         # d h_adapter -> action rows of dHS[i+1] (+ the proprio token's gradient); d h_task -> dHS[i+1][:, :Np] in place
-        ops.gemm_nt(self.dKV_adp[i], self.T["w_adp"][i], out=self.dh_adp[i])
+        ops.gemm_nt(self.dKV_adp[i], self._kv("adp", i)[2], out=self.dh_adp[i])
         dha = self.dh_adp[i].view(B, Ka, D)
         self.gtmp.view(B, NUM_TOKENS, D).copy_(dha[:, :NUM_TOKENS])
         ops.scatter_add_rows(self.gtmp, self.row_idx_live.view(-1), dHS[i + 1].view(-1, D))
         if self.row0 == 0:
-            ops.gemm_nt(self.dKV_task[i], self.T["w_task"][i], out=dHS[i + 1].view(B * S, D)[:B * Kt], c_group=(Kt, S * D))
+            ops.gemm_nt(self.dKV_task[i], self._kv("task", i)[2], out=dHS[i + 1].view(B * S, D)[:B * Kt], c_group=(Kt, S * D))
 
     def bwd_end(self):
         """Off the critical path: input stage, proprio projector, and every dW as batched NT GEMMs on transposed operands."""
@@ -713,10 +736,17 @@ class Head:
         ops.gemm_nt(self.dQKVxT, self.XT, out=G("w_x"))
         ops.gemm_nt(self.dO2T, self.AOxT, out=G("w_o"))
         ops.gemm_nt(self.dFFT, self.LNoT, out=G("w_ffn"))
-        ops.gemm_nt(self.dKV_adpT, self.h_adpT, out=G("w_adp"))
-        ops.gemm_nt(self.dKV_taskT, self.h_taskT, out=G("w_task"))
         ops.colsum_(self.dQKVx, self.b_f32["b_x"]); ops.colsum_(self.dO2, self.b_f32["b_o"]); ops.colsum_(self.dFF, self.b_f32["b_ffn"])
-        ops.colsum_(self.dKV_adp, self.b_f32["b_adp"]); ops.colsum_(self.dKV_task, self.b_f32["b_task"])
+        if self.pro:
+            ops.gemm_nt(self.dKV_adpT, self.h_adpT, out=G("w_adp"))
+            ops.gemm_nt(self.dKV_taskT, self.h_taskT, out=G("w_task"))
+            ops.colsum_(self.dKV_adp, self.b_f32["b_adp"]); ops.colsum_(self.dKV_task, self.b_f32["b_task"])
+        else:             # shared k_proj / v_proj: the three segments' gradients add up (autograd accumulates them in bf16 too)
+            gkv = G("w_x")[:, self.D:]
+            ops.gemm_nt(self.dKV_adpT, self.h_adpT, out=gkv, residual=gkv)
+            ops.gemm_nt(self.dKV_taskT, self.h_taskT, out=gkv, residual=gkv)
+            bkv = self.b_f32["b_x"][:, self.D:]
+            ops.colsum_(self.dKV_adp, bkv); ops.colsum_(self.dKV_task, bkv)
         for k, t in self.b_f32.items():
             ops.cast_f32_bf16(t, out=G(k))
         ops.cast_f32_bf16(self.ln_dw, out=G("ln_w")); ops.cast_f32_bf16(self.ln_db, out=G("ln_b"))

@@ -361,7 +361,7 @@ def swiglu_bwd(dh, gu, out=None):
 def colsum_(x, out_f32):
     """x [rows, cols] or [batch, rows, cols] (bf16) -> out_f32 [cols] / [batch, cols] += column sums."""
     if x.dim() == 3:
-        assert out_f32.shape == (x.shape[0], x.shape[2]) and out_f32.is_contiguous() and x.stride(-1) == 1
+        assert out_f32.shape == (x.shape[0], x.shape[2]) and out_f32.stride(-1) == 1 and x.stride(-1) == 1
         N.check(_lib().vla_colsum_bf16(_st(), _p(x), _p(out_f32), x.shape[1], x.shape[2], x.stride(1), x.shape[0], x.stride(0),
                                        out_f32.stride(0)), "colsum")
     else:

@@ -66,12 +66,15 @@ def head_weights(cfg: VLACfg, gen, device, std=0.02):
           "model.fc2.weight": _rn(gen, (Da, D), std, device), "model.fc2.bias": _rn(gen, (Da,), std, device)}
     for i in range(cfg.num_blocks):
         p = f"model.mlp_resnet_blocks.{i}."
-        for n in ("q_proj", "k_self", "v_self", "k_adapter", "v_adapter", "k_task", "v_task", "o_proj", "ffn.1"):
+        names = ("q_proj", "k_self", "v_self", "k_adapter", "v_adapter", "k_task", "v_task", "o_proj", "ffn.1") if cfg.pro else (
+            "q_proj", "k_proj", "v_proj", "o_proj", "ffn.1")           # MLPResNetBlock_Pro (:287-335) / MLPResNetBlock (:195-214)
+        for n in names:
             sd[p + n + ".weight"], sd[p + n + ".bias"] = _rn(gen, (D, D), std, device), _rn(gen, (D,), std, device)
         sd[p + "ffn.0.weight"] = (1 + _rn(gen, (D,), 0.05, device).float()).to(torch.bfloat16)
         sd[p + "ffn.0.bias"] = _rn(gen, (D,), 0.02, device)
         sd[p + "gating_factor"] = torch.full((1,), 0.1, device=device, dtype=torch.bfloat16)
-        sd[p + "film_gen.0.weight"], sd[p + "film_gen.0.bias"] = _rn(gen, (2 * D, D), std, device), _rn(gen, (2 * D,), std, device)
+        if cfg.pro:
+            sd[p + "film_gen.0.weight"], sd[p + "film_gen.0.bias"] = _rn(gen, (2 * D, D), std, device), _rn(gen, (2 * D,), std, device)
     pp = {"fc1.weight": _rn(gen, (D, cfg.proprio_dim), 0.2, device), "fc1.bias": _rn(gen, (D,), std, device),
           "fc2.weight": _rn(gen, (D, D), std, device), "fc2.bias": _rn(gen, (D,), std, device)}
     return sd, pp
