@@ -38,7 +38,7 @@ class L1RegressionActionHead:
         phase == "Training" draws the N(0, 0.02^2) input perturbation of action_heads.py:14-17, 69-72 unless ``noise``
         ([chunk, action_dim*D]) is given."""
         assert proprio is not None and proprio_projector is not None, "the reference head dereferences both (action_heads.py:53-54)"
-        B, n, KA, D = actions_hidden_states.shape
+        B, _, KA, D = actions_hidden_states.shape
         K = self.num_task_tokens
         assert KA == K + E.NUM_TOKENS, f"expected {K}+64 rows per layer, got {KA}"
         if proprio_projector is not None and hasattr(proprio_projector, "params"):

@@ -572,7 +572,7 @@ class Head:
     def fwd_begin(self, HS, pos1, proprio, Np, noise=None):
         """Everything that does not depend on the LLM's output: buffers, proprio projector, input stage
         (zeros/noise -> LN -> fc1 -> ReLU, action_heads.py:60-72, 113-115)."""
-        cfg, P, D = self.cfg, self.P, self.D
+        cfg, P = self.cfg, self.P
         B, S = HS.shape[1], HS.shape[2]
         T = cfg.chunk
         self._alloc(B, Np)
@@ -689,7 +689,7 @@ class Head:
     def bwd_layer(self, i: int, dHS: torch.Tensor):
         """Backward of block i: the x-chain (critical path), then this layer's hidden-state gradients
         dHS[i+1] (task rows written in place, action rows scattered) - all the LLM backward of layer i waits for."""
-        P, D, H = self.P, self.D, self.H
+        P, D = self.P, self.D
         B, S, Kt, Ka = self.B, self.S, self.Kt, self.Ka
         dff = self.dFF[i]
         ops.N.check(ops._lib().vla_relu_bwd(ops._st(), ops._p(self.dx), ops._p(self.X[i + 1]), ops._p(dff), self.dx.numel()), "relu_bwd")
@@ -710,7 +710,7 @@ class Head:
     def bwd_end(self):
         """Off the critical path: input stage, proprio projector, and every dW as batched NT GEMMs on transposed operands."""
         cfg, P, D, nb = self.cfg, self.P, self.D, self.nb
-        B, Ka, Kt = self.B, self.Ka, self.Kt
+        B, Ka = self.B, self.Ka
         G = P.g
         # input stage: relu -> fc1 -> layer_norm1 (input is noise/zeros: only parameter gradients)
         dy1 = ops.relu_bwd(self.dx, self.X[0])
@@ -847,7 +847,6 @@ class VLAEngine:
         Np, D = cfg.n_patches, cfg.llm.d
         S = L + Np
         llm._alloc(B, S)
-        X0 = llm.HS[0]
         # vision: per image, per backbone (modeling_prismatic.py:196-237) -> fused feature buffer
         px = batch["pixel_values"]
         nbk, npi = len(cfg.vit), cfg.vit[0].n_patches

@@ -125,7 +125,7 @@ def finetune(cfg: FinetuneConfig) -> dict:
     mcfg = E.tiny_config() if cfg.tiny else E.config2()
     mcfg.n_img = cfg.num_images_in_input
     W = S.make_weights(mcfg, dev, seed=cfg.seed)                  # identical on all ranks == DDP's initial broadcast
-    for path, key in ((cfg.resum_vla_path, None),):
+    for path in (cfg.resum_vla_path,):
         if cfg.resume and path and os.path.isdir(path):           # resume head / proprio only (finetune.py:275-278)
             step = cfg.resume_step
             W["head"] = torch.load(os.path.join(path, f"action_head--{step}_checkpoint.pt"), weights_only=True)
