@@ -132,6 +132,17 @@ int vla_rope_half(void* stream, void* x, const float* cos_t, const float* sin_t,
 int vla_rope_interleaved(void* stream, void* x, const float* cos_t, const float* sin_t, int rows, int T, int nheads,
                          int dh, int ldx, int mode);
 
+/* ---------------------------------------------------------------- input stage */
+/* ToTensor + Normalize of PrismaticImageProcessor.apply_transform (processing_prismatic.py:128-145) for images already at
+ * the model's input size: img u8 [B, H, W, 3] -> out[b, c0 + c, y, x] = ((img / 255) - mean[c]) / std[c]  (f32 math in
+ * torchvision's order; stored bf16, or f32 if out_f32) inside a channel-stacked [B, Ctot, H, W] tensor.  mean3 / std3: host. */
+int vla_image_normalize_u8(void* stream, const void* img, void* out, int B, int H, int W, int Ctot, int c0,
+                           const float* mean3 /* host */, const float* std3 /* host */, int out_f32);
+/* ActionTokenizer.__call__ (prismatic/vla/action_tokenizer.py:60-74, use_minivlm): ids[i] = tokenizer_len -
+ * digitize(clip(actions[i], lo, hi), bins) with numpy semantics (bins: device f64 [nbins], increasing). */
+int vla_action_tokenize(void* stream, const float* actions, const double* bins, long long* ids, long long n, int nbins,
+                        float lo, float hi, long long tokenizer_len);
+
 /* ---------------------------------------------------------------- glue */
 /* timm PatchEmbed conv PxP/P as im2col: pixels [B, Ctot, H, W] (f32 if px_f32 else bf16), channels c0..c0+2 ->
  * cols bf16 [B*(H/P)*(W/P), ldo] with (c, py, px) ordering, zero-filled up to ldo.  (modeling_prismatic.py:229-230) */

@@ -324,6 +324,42 @@ __global__ void adamw_kernel(bf16_t* __restrict__ p, const void* __restrict__ g,
 
 #define GRID1D(n, per) dim3(min(nblk((n), (per)), 8192u))
 
+// ---- input stage --------------------------------------------------------------------------------------
+// ToTensor + Normalize of processing_prismatic.py:128-145 for images that already have the model's input size:
+// u8 HWC -> (x / 255 - mean) / std in f32 (same operation order as torchvision) -> bf16 (finetune.py:339) or f32, CHW,
+// written at channel offset c0 of a channel-stacked pixel tensor (fused backbones / wrist images share one tensor).
+__global__ void image_normalize_kernel(const unsigned char* __restrict__ img, void* __restrict__ out, int B, int H, int W, int Ctot,
+                                       int c0, float m0, float m1, float m2, float s0, float s1, float s2, int out_f32) {
+  const long long total = (long long)B * 3 * H * W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W);
+    const int y = (int)((i / W) % H);
+    const int c = (int)((i / ((long long)W * H)) % 3);
+    const long long b = i / ((long long)3 * W * H);
+    const float t = (float)img[((b * H + y) * W + x) * 3 + c] / 255.0f;
+    const float v = (t - (c == 0 ? m0 : c == 1 ? m1 : m2)) / (c == 0 ? s0 : c == 1 ? s1 : s2);
+    const long long o = ((b * Ctot + c0 + c) * H + y) * W + x;
+    if (out_f32) reinterpret_cast<float*>(out)[o] = v;
+    else reinterpret_cast<bf16_t*>(out)[o] = f2bf(v);
+  }
+}
+
+// ActionTokenizer.__call__ (action_tokenizer.py:60-74, use_minivlm branch): clip to [lo, hi], np.digitize against the
+// caller's bin edges (count of edges <= x, compared in f64 like numpy), token id = tokenizer_len - bin index.
+__global__ void action_tokenize_kernel(const float* __restrict__ act, const double* __restrict__ bins, long long* __restrict__ ids,
+                                       long long n, int nbins, float lo, float hi, long long tokenizer_len) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double x = (double)fminf(fmaxf(act[i], lo), hi);
+  int a = 0, b = nbins;                       // first edge index with bins[idx] > x  (== np.digitize(x, bins), bins increasing)
+  while (a < b) {
+    const int mid = (a + b) >> 1;
+    if (bins[mid] <= x) a = mid + 1;
+    else b = mid;
+  }
+  ids[i] = tokenizer_len - a;
+}
+
 extern "C" int vla_im2col_patch(void* stream, const void* pixels, void* cols, int B, int Ctot, int c0, int H, int W, int P,
                                 int ldo, int px_f32) {
   VLA_REQUIRE(pixels && cols && B > 0 && P > 0 && H % P == 0 && W % P == 0, "im2col: bad shape");
@@ -479,5 +515,25 @@ extern "C" int vla_adamw_bf16(void* stream, void* p, const void* g, void* m, voi
   hipLaunchKernelGGL(adamw_kernel, GRID1D(n, 256), dim3(256), 0, (hipStream_t)stream, (bf16_t*)p, g, (bf16_t*)m, (bf16_t*)v, n,
                      decay, omb1, (float)beta2, omb2, (float)sqrt(bc2), (float)eps, neg_step, g_f32, gscale == 0.f ? 1.f : gscale);
   VLA_CHECK_LAUNCH("adamw");
+  return VLA_OK;
+}
+
+extern "C" int vla_image_normalize_u8(void* stream, const void* img, void* out, int B, int H, int W, int Ctot, int c0,
+                                      const float* mean3, const float* std3, int out_f32) {
+  VLA_REQUIRE(img && out && mean3 && std3 && B > 0 && H > 0 && W > 0 && c0 >= 0 && c0 + 3 <= Ctot, "image_normalize: bad args");
+  VLA_REQUIRE(std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, "image_normalize: zero std");
+  const long long total = (long long)B * 3 * H * W;
+  hipLaunchKernelGGL(image_normalize_kernel, GRID1D(total, 256), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)img, out, B,
+                     H, W, Ctot, c0, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], out_f32);
+  VLA_CHECK_LAUNCH("image_normalize");
+  return VLA_OK;
+}
+
+extern "C" int vla_action_tokenize(void* stream, const float* actions, const double* bins, long long* ids, long long n, int nbins,
+                                   float lo, float hi, long long tokenizer_len) {
+  VLA_REQUIRE(actions && bins && ids && n > 0 && nbins > 1 && lo < hi, "action_tokenize: bad args");
+  hipLaunchKernelGGL(action_tokenize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, actions, bins, ids, n,
+                     nbins, lo, hi, tokenizer_len);
+  VLA_CHECK_LAUNCH("action_tokenize");
   return VLA_OK;
 }

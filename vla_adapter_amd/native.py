@@ -71,6 +71,8 @@ _PROTOS = {
     "vla_rope_half": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I], _I),
     "vla_rope_interleaved": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I], _I),
     "vla_im2col_patch": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I], _I),
+    "vla_image_normalize_u8": ([_P, _P, _P, _I, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _I], _I),
+    "vla_action_tokenize": ([_P, _P, _P, _P, _L, _I, _F, _F, _L], _I),
     "vla_action_mask": ([_P, _P, _P, _P, _P, _I, _I, _I], _I),
     "vla_embed_splice": ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I], _I),
     "vla_action_query_grad": ([_P, _P, _P, _P, _I, _I, _I, _I, _I], _I),

@@ -434,3 +434,24 @@ def adamw_(p, g, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, w
     assert p.numel() == g.numel() == m.numel() == v.numel()
     N.check(_lib().vla_adamw_bf16(_st(), _p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, wd, step,
                                   int(g.dtype == torch.float32), gscale), "adamw")
+
+
+# ---- input stage ------------------------------------------------------------------------------------
+def image_normalize_u8_(img_u8: torch.Tensor, out: torch.Tensor, c0: int, mean, std):
+    """img_u8 [B, H, W, 3] uint8 -> out[:, c0:c0+3] = ((img / 255) - mean) / std  (out [B, Ctot, H, W] bf16 or f32)."""
+    assert img_u8.dtype == torch.uint8 and img_u8.is_contiguous() and img_u8.dim() == 4 and img_u8.shape[-1] == 3
+    B, H, W, _ = img_u8.shape
+    assert out.is_contiguous() and out.shape[0] == B and tuple(out.shape[2:]) == (H, W) and out.dtype in (BF16, torch.float32)
+    m3, s3 = (C.c_float * 3)(*[float(x) for x in mean]), (C.c_float * 3)(*[float(x) for x in std])
+    N.check(_lib().vla_image_normalize_u8(_st(), _p(img_u8), _p(out), B, H, W, out.shape[1], c0, m3, s3,
+                                          int(out.dtype == torch.float32)), "image_normalize_u8")
+    return out
+
+
+def action_tokenize(actions_f32: torch.Tensor, bins_f64: torch.Tensor, tokenizer_len: int, lo: float = -1.0, hi: float = 1.0):
+    """ActionTokenizer (use_minivlm): int64 ids of the same shape = tokenizer_len - np.digitize(np.clip(a, lo, hi), bins)."""
+    assert actions_f32.dtype == torch.float32 and actions_f32.is_contiguous() and bins_f64.dtype == torch.float64 and bins_f64.is_contiguous()
+    ids = torch.empty(actions_f32.shape, device=actions_f32.device, dtype=torch.int64)
+    N.check(_lib().vla_action_tokenize(_st(), _p(actions_f32), _p(bins_f64), _p(ids), actions_f32.numel(), bins_f64.numel(), lo, hi,
+                                       tokenizer_len), "action_tokenize")
+    return ids
