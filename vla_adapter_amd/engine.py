@@ -816,7 +816,7 @@ class VLAEngine:
                 self.forward(static, None)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 out = self.forward(static, None)
             cache[key] = (g, static, out)
         g, static, out = cache[key]
@@ -1120,7 +1120,8 @@ class VLAEngine:
         self._next_px = batch["pixel_values"].clone()
         self._px_stage = batch["pixel_values"].clone()
         self._g_vis = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_vis, pool=pools["V"], stream=self.vis_stream):
+        # thread_local: other host threads (the RCCL watchdog of a multi-rank job) may touch the HIP runtime meanwhile
+        with torch.cuda.graph(self._g_vis, pool=pools["V"], stream=self.vis_stream, capture_error_mode="thread_local"):
             self._vision(dict(batch, pixel_values=self._px_stage))
         self._vis_ev = None
         self._segs = self._segments(batch, noise)
@@ -1130,7 +1131,7 @@ class VLAEngine:
                 self._graphs.append(None)
                 continue
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pools[st], stream=cap[st]):
+            with torch.cuda.graph(g, pool=pools[st], stream=cap[st], capture_error_mode="thread_local"):
                 fn()
             self._graphs.append(g)
         torch.cuda.synchronize()
