@@ -1,0 +1,59 @@
+"""Checkpoint interop: key maps between the reference's state-dict layouts and the engine's weight dict."""
+import torch
+
+from vla_adapter_amd import checkpoints as C
+
+
+class _V:          # minimal stand-ins for engine.VLACfg on a CPU-only box (no GPU needed for key handling)
+    def __init__(self, fused):
+        self.fused = fused
+
+
+def _hf_sd(fused):
+    sd = {"vision_backbone.featurizer.blocks.0.attn.qkv.weight": torch.ones(2), "vision_backbone.featurizer.pos_embed": torch.zeros(3),
+          "vision_backbone.featurizer.blocks.0.ls1.scale_factor": torch.ones(1),
+          "projector.fc1.weight": torch.ones(4), "projector.fc2.bias": torch.ones(5),
+          "language_model.model.embed_tokens.weight": torch.ones(6), "language_model.model.norm.weight": torch.ones(7),
+          "language_model.model.layers.0.self_attn.q_proj.bias": torch.ones(8), "language_model.lm_head.weight": torch.ones(9),
+          "action_queries.weight": torch.ones(10)}
+    if fused:
+        sd["vision_backbone.fused_featurizer.blocks.0.mlp.fc1.weight"] = torch.ones(11)
+    return sd
+
+
+def test_split_and_merge_roundtrip():
+    for fused in (False, True):
+        sd = _hf_sd(fused)
+        W = C.split_reference_state_dict(sd, _V(fused))
+        assert len(W["vit"]) == (2 if fused else 1)
+        assert set(W["vit"][0]) == {"blocks.0.attn.qkv.weight", "pos_embed", "blocks.0.ls1.scale_factor"}
+        assert set(W["proj"]) == {"fc1.weight", "fc2.bias"}
+        assert set(W["llm"]) == {"embed_tokens.weight", "norm.weight", "layers.0.self_attn.q_proj.bias"}      # lm_head is not part of the path
+        assert W["action_queries"].numel() == 10
+        back = C.merge_reference_state_dict(W, _V(fused))
+        assert set(back) == set(sd) - {"language_model.lm_head.weight"}
+        assert all(torch.equal(back[k], sd[k]) for k in back)
+
+
+def test_native_prismatic_keys_follow_the_reference_rename_map():
+    native = {"vision_backbone.dino_featurizer.blocks.1.ls2.gamma": torch.ones(1), "vision_backbone.siglip_featurizer.pos_embed": torch.ones(2),
+              "llm_backbone.llm.model.norm.weight": torch.ones(3), "llm_backbone.llm.model.embed_tokens.weight": torch.ones(3),
+              "projector.projector.0.weight": torch.ones(4), "projector.projector.2.bias": torch.ones(5), "projector.projector.4.weight": torch.ones(6)}
+    r = C.rename_prismatic_keys(native)
+    assert set(r) == {"vision_backbone.featurizer.blocks.1.ls2.scale_factor", "vision_backbone.fused_featurizer.pos_embed",
+                      "language_model.model.norm.weight", "language_model.model.embed_tokens.weight",
+                      "projector.fc1.weight", "projector.fc2.bias", "projector.fc3.weight"}
+    W = C.split_reference_state_dict({"module." + k: v for k, v in native.items()}, _V(True))     # DDP prefix + native names
+    assert "blocks.1.ls2.scale_factor" in W["vit"][0] and "pos_embed" in W["vit"][1] and "fc3.weight" in W["proj"]
+
+
+def test_run_dir_files_roundtrip(tmp_path):
+    head = {"module.model.fc1.weight": torch.ones(3), "module.model.mlp_resnet_blocks.0.q_proj.bias": torch.zeros(2)}
+    pp = {"fc1.weight": torch.ones(4)}
+    torch.save(head, tmp_path / "action_head--150_checkpoint.pt")
+    torch.save(pp, tmp_path / "proprio_projector--150_checkpoint.pt")
+    h, p = C.load_run_dir(str(tmp_path), 150)
+    assert set(h) == {"model.fc1.weight", "model.mlp_resnet_blocks.0.q_proj.bias"} and set(p) == {"fc1.weight"}
+    from safetensors.torch import save_file
+    save_file({"a.b": torch.arange(3.0)}, str(tmp_path / "m.safetensors"))
+    assert torch.equal(C.load_file(str(tmp_path / "m.safetensors"))["a.b"], torch.arange(3.0))

@@ -122,3 +122,20 @@ def test_predict_action_batch1_inference_matches_oracle():
     assert not np.allclose(act3, act) and len(vla.engine._predict_graphs) == 1
     with pytest.raises(NotImplementedError):
         vla.predict_action(input_ids=ids, action_head=None, pixel_values=px, attention_mask=torch.ones_like(ids))
+
+
+def test_engine_from_reference_layout_state_dict(tmp_path):
+    """A VLM state dict in the reference's HF key layout (saved as .safetensors) loads into the engine and gives the
+    forward of the original weights (checkpoints.split_reference_state_dict / merge_reference_state_dict)."""
+    from safetensors.torch import save_file
+    from vla_adapter_amd import checkpoints as CK, engine as E, synthetic as S
+    cfg = E.tiny_config()
+    W = S.make_weights(cfg, DEV, seed=21, std=0.05)
+    batch = S.make_batch(cfg, 2, DEV, seed=22, P=24)
+    ref = E.VLAEngine(cfg, W, DEV).forward(batch, None).clone()
+    hf = {k: v.cpu().contiguous() for k, v in CK.merge_reference_state_dict(W, cfg).items()}
+    assert "language_model.model.layers.0.self_attn.q_proj.weight" in hf and "vision_backbone.featurizer.pos_embed" in hf
+    save_file(hf, str(tmp_path / "vla.safetensors"))
+    W2 = CK.split_reference_state_dict(CK.load_file(str(tmp_path / "vla.safetensors")), cfg, head=W["head"], proprio=W["proprio"])
+    got = E.VLAEngine(cfg, W2, DEV).forward(batch, None)
+    assert torch.equal(got, ref)

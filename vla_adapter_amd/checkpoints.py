@@ -1,0 +1,99 @@
+"""Checkpoint interop with the reference's file / key layout.
+
+* VLM weights: the HF-style state dict of ``OpenVLAForActionPrediction`` (modeling_prismatic.py) -
+  ``vision_backbone.featurizer.*`` (DINOv2 in the fused setup, the only backbone otherwise),
+  ``vision_backbone.fused_featurizer.*`` (SigLIP), ``projector.fc{1,2,3}.*``, ``language_model.model.*``,
+  ``action_queries.weight`` - or a native Prismatic checkpoint, whose keys the reference renames with the map at
+  vla-scripts/finetune.py:792-800 before loading.  ``split_reference_state_dict`` turns either into the weight dict
+  ``engine.VLAEngine`` takes; ``merge_reference_state_dict`` is its inverse (what ``vla.state_dict()`` would hold).
+* Trainable parts: ``action_head--{step}_checkpoint.pt`` / ``proprio_projector--{step}_checkpoint.pt`` with the reference's
+  key names (finetune.py:527-572) are written by ``finetune.save_training_checkpoint`` and read back through
+  ``Head.load_state_dicts``; DDP's ``module.`` prefix is stripped on load (finetune.py:132-154).
+Only loaders that execute nothing from the file are used (torch.load(weights_only=True) / safetensors).
+LoRA adapters (``lora_adapter/``, merge_lora_weights_and_save.py) are not handled: LoRA itself is not built yet.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Optional
+
+import torch
+
+from .engine import VLACfg
+
+# vla-scripts/finetune.py:792-800 (native Prismatic checkpoint -> HF module names)
+PRISMATIC_TO_HF = [("vision_backbone.dino_featurizer", "vision_backbone.featurizer"),
+                   ("vision_backbone.siglip_featurizer", "vision_backbone.fused_featurizer"),
+                   ("llm_backbone.llm", "language_model"),
+                   ("projector.projector.0", "projector.fc1"), ("projector.projector.2", "projector.fc2"),
+                   ("projector.projector.4", "projector.fc3"), ("gamma", "scale_factor")]
+
+
+def rename_prismatic_keys(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """rename_state_dict_keys of finetune.py:802-810: every matching substring is replaced, in map order."""
+    out = {}
+    for k, v in sd.items():
+        nk = k
+        for old, new in PRISMATIC_TO_HF:
+            if old in nk:
+                nk = nk.replace(old, new)
+        out[nk] = v
+    return out
+
+
+def strip_ddp_prefix(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """remove_ddp_in_checkpoint (finetune.py:132-154)."""
+    return {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+
+
+def load_file(path: str) -> Dict[str, torch.Tensor]:
+    """.safetensors or a torch checkpoint (tensors only; weights_only=True refuses anything that would unpickle code)."""
+    if path.endswith(".safetensors"):
+        from safetensors.torch import load_file as _lf
+        return _lf(path)
+    obj = torch.load(path, map_location="cpu", weights_only=True)
+    return obj.get("model", obj) if isinstance(obj, dict) and "model" in obj and isinstance(obj["model"], dict) else obj
+
+
+def split_reference_state_dict(sd: Dict[str, torch.Tensor], cfg: VLACfg, head: Optional[Dict[str, torch.Tensor]] = None,
+                               proprio: Optional[Dict[str, torch.Tensor]] = None) -> Dict:
+    """HF-style (or native Prismatic) VLM state dict -> {"vit": [sd...], "proj": sd, "llm": sd, "action_queries": t,
+    "head": sd, "proprio": sd} with the per-module key names engine.ViT / engine.LLM read."""
+    sd = strip_ddp_prefix(rename_prismatic_keys(sd))
+    sub = lambda pre: {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+    feats = [sub("vision_backbone.featurizer.")]
+    if cfg.fused:
+        feats.append(sub("vision_backbone.fused_featurizer."))
+    assert all(feats), "state dict holds no vision_backbone.(fused_)featurizer.* weights"
+    for i, f in enumerate(feats):                 # LayerScale may still be called gamma in an un-renamed timm checkpoint
+        feats[i] = {k.replace(".gamma", ".scale_factor"): v for k, v in f.items()}
+    llm = sub("language_model.model.")
+    assert "embed_tokens.weight" in llm and "norm.weight" in llm, "state dict holds no language_model.model.* weights"
+    W = dict(vit=feats, proj=sub("projector."), llm=llm)
+    if "action_queries.weight" in sd:
+        W["action_queries"] = sd["action_queries.weight"]
+    if head is not None:
+        W["head"] = strip_ddp_prefix(head)
+    if proprio is not None:
+        W["proprio"] = strip_ddp_prefix(proprio)
+    return W
+
+
+def merge_reference_state_dict(W: Dict, cfg: VLACfg) -> Dict[str, torch.Tensor]:
+    """Inverse of split_reference_state_dict for the VLM part (+ action_queries)."""
+    out = {}
+    names = ["vision_backbone.featurizer."] + (["vision_backbone.fused_featurizer."] if cfg.fused else [])
+    for pre, f in zip(names, W["vit"]):
+        out.update({pre + k: v for k, v in f.items()})
+    out.update({"projector." + k: v for k, v in W["proj"].items()})
+    out.update({"language_model.model." + k: v for k, v in W["llm"].items()})
+    if W.get("action_queries") is not None:
+        out["action_queries.weight"] = W["action_queries"]
+    return out
+
+
+def load_run_dir(run_dir: str, step, device="cpu"):
+    """(head state dict, proprio state dict) of a reference-layout run directory / ``--{step}_chkpt`` directory."""
+    suffix = "latest_checkpoint.pt" if step in (None, "latest") else f"{step}_checkpoint.pt"
+    ld = lambda n: strip_ddp_prefix(torch.load(os.path.join(run_dir, f"{n}--{suffix}"), map_location=device, weights_only=True))
+    return ld("action_head"), ld("proprio_projector")

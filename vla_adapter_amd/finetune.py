@@ -117,19 +117,19 @@ def finetune(cfg: FinetuneConfig) -> dict:
     from . import ddp, engine as E, synthetic as S
     if cfg.use_lora or cfg.use_film or cfg.use_diffusion or not cfg.use_l1_regression:
         raise NotImplementedError("native path: adapter-only L1-regression fine-tune (LoRA / FiLM / diffusion not accelerated yet)")
-    if not cfg.use_pro_version:
-        raise NotImplementedError("native head implements the Pro block (reference default use_pro_version=True)")
     rank, local, world = ddp.init_process_group_from_env()
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     mcfg = E.tiny_config() if cfg.tiny else E.config2()
     mcfg.n_img = cfg.num_images_in_input
+    mcfg.pro = bool(cfg.use_pro_version)
     W = S.make_weights(mcfg, dev, seed=cfg.seed)                  # identical on all ranks == DDP's initial broadcast
-    for path in (cfg.resum_vla_path,):
-        if cfg.resume and path and os.path.isdir(path):           # resume head / proprio only (finetune.py:275-278)
-            step = cfg.resume_step
-            W["head"] = torch.load(os.path.join(path, f"action_head--{step}_checkpoint.pt"), weights_only=True)
-            W["proprio"] = torch.load(os.path.join(path, f"proprio_projector--{step}_checkpoint.pt"), weights_only=True)
+    if cfg.vlm_path and os.path.isfile(cfg.vlm_path):             # local VLM state dict (HF-style or native Prismatic keys)
+        from . import checkpoints as CK
+        W.update(CK.split_reference_state_dict(CK.load_file(cfg.vlm_path), mcfg))
+    if cfg.resume and cfg.resum_vla_path and os.path.isdir(cfg.resum_vla_path):   # head / proprio only (finetune.py:275-278)
+        from . import checkpoints as CK
+        W["head"], W["proprio"] = CK.load_run_dir(cfg.resum_vla_path, cfg.resume_step)
     eng = E.VLAEngine(mcfg, W, dev)
     if world > 1:
         eng.reducer = ddp.FlatGradReducer()
