@@ -360,3 +360,37 @@ def test_original_head_block_end_to_end():
     losses = [e2.train_step_graphed(2e-3)[0].item() for _ in range(12)]
     e2.flush()
     assert losses[-1] < 0.8 * losses[0], losses
+
+
+def test_fused_two_backbone_two_image_config():
+    """The reference's default layout (modeling_prismatic.py:196-237): DINOv2-style (prefix tokens, LayerScale) + SigLIP-style
+    backbones on channel-stacked pixels, two images per sample (all images of a backbone go through it in ONE pass here),
+    fused 3-layer projector - forward parity with the oracle, backward parity of action_queries, captured step trains."""
+    from vla_adapter_amd import engine as E, synthetic as S, ops
+    cfg = E.tiny_fused_config()
+    W = S.make_weights(cfg, DEV, seed=17, std=0.05)
+    batch = S.make_batch(cfg, 2, DEV, seed=18, P=24, ragged=True)
+    assert batch["pixel_values"].shape[1] == 12 and cfg.n_patches == 32 and cfg.vis_dim == 320
+    eng = E.VLAEngine(cfg, W, DEV)
+    pred = eng.forward(batch, None)
+    eng.loss_and_backward(pred, batch["actions"])
+    torch.cuda.synchronize()
+    out, OW = _oracle_run(cfg, W, batch, None, True, cfg.num_blocks)
+    assert rel(eng.llm.HS[0][:, 1:cfg.n_patches + 1], out["patches"]) < 1.2e-2, rel(eng.llm.HS[0][:, 1:cfg.n_patches + 1], out["patches"])
+    assert rel(pred, out["pred"]) < 1.5e-2, rel(pred, out["pred"])
+    _, dpred = ops.l1_loss(pred, batch["actions"].to(BF), True)
+    out["pred"].backward(dpred.float().cpu())
+    # end-to-end gradient tolerance: see test_backward_and_step_parity (a ~1e-2 forward-state difference moves these
+    # gradients by 4-5e-2 on the single-backbone config; this deeper vision stack measures 7.6e-2); the structural check
+    # is the bit-identity with the full-sequence backward below
+    r = rel(eng.head.P.g("action_queries"), OW["action_queries"].grad)
+    assert r < 1e-1, r
+    ef = E.VLAEngine(cfg, W, DEV)
+    ef.full_llm_backward = True
+    ef.loss_and_backward(ef.forward(batch, None), batch["actions"])
+    assert torch.equal(ef.head.P.g("action_queries"), eng.head.P.g("action_queries"))
+    e2 = E.VLAEngine(cfg, W, DEV)
+    e2.capture(batch, None)
+    losses = [e2.train_step_graphed(2e-3)[0].item() for _ in range(10)]
+    e2.flush()
+    assert losses[-1] < 0.85 * losses[0], losses

@@ -118,6 +118,13 @@ def tiny_config() -> VLACfg:
                   llm=LLMCfg(256, 2, 4, 2, 64, 512, 1e-6, 1e6, 1024), num_blocks=2)
 
 
+def tiny_fused_config() -> VLACfg:
+    """Plumbing-size version of the reference's default setup: DINOv2-like backbone (cls + 4 register tokens,
+    LayerScale) + SigLIP-like backbone, fused 3-layer projector, two images per sample."""
+    return VLACfg(vit=[ViTCfg(192, 3, 3, 768, 14, 56, 5, True), ViTCfg(128, 3, 2, 512, 14, 56, 0, False)], n_img=2,
+                  llm=LLMCfg(256, 2, 4, 2, 64, 512, 1e-6, 1e6, 1024), num_blocks=2)
+
+
 # ------------------------------------------------------------------------------------------------ frozen ViT
 class ViT:
     """timm VisionTransformer forward up to block depth-2, no final norm (modeling_prismatic.py:120-144,196-237;
@@ -841,40 +848,54 @@ class VLAEngine:
     def _vision(self, batch: Dict[str, torch.Tensor]):
         """Frozen part that reads NO trainable tensor: ViT(s) + projector -> self.patches [B, Np, D] (its own buffer, so
         that the vision stage of the NEXT step can run while the current step is still using llm.HS)."""
-        cfg, llm = self.cfg, self.llm
-        ids = batch["input_ids"]
-        B, L = ids.shape
-        Np, D = cfg.n_patches, cfg.llm.d
-        S = L + Np
-        llm._alloc(B, S)
-        # vision: per image, per backbone (modeling_prismatic.py:196-237) -> fused feature buffer
-        px = batch["pixel_values"]
-        nbk, npi = len(cfg.vit), cfg.vit[0].n_patches
-        feats = torch.empty(B, Np, cfg.vis_dim, device=self.device, dtype=BF16)
-        single = nbk == 1 and cfg.n_img == 1
-        col = 0
-        for j, vit in enumerate(self.vits):
-            for im in range(cfg.n_img):
-                c0 = im * 3 * nbk + 3 * j
-                if single:
-                    vit.forward(px, c0, feats.view(B * Np, -1))
-                else:
-                    tmp = torch.empty(B * npi, vit.cfg.d, device=self.device, dtype=BF16)
-                    vit.forward(px, c0, tmp)
-                    feats[:, im * npi:(im + 1) * npi, col:col + vit.cfg.d] = tmp.view(B, npi, -1)
-            col += vit.cfg.d
-        # projector (modeling_prismatic.py:261-273); the last Linear writes straight into the multimodal sequence
-        f2 = feats.view(B * Np, -1)
+        self._vision_begin(batch)
+        for j in range(len(self.vits)):
+            self._vision_backbone(j, batch)
+        self._vision_project()
+
+    def _vision_begin(self, batch: Dict[str, torch.Tensor]):
+        cfg = self.cfg
+        B, L = batch["input_ids"].shape
+        Np = cfg.n_patches
+        self.llm._alloc(B, L + Np)
+        bufs = self.__dict__.setdefault("_vis_bufs", {})     # one pair per batch size: captured graphs keep their addresses
+        if (B, Np) not in bufs:
+            bufs[(B, Np)] = (torch.empty(B, Np, cfg.vis_dim, device=self.device, dtype=BF16),
+                             torch.empty(B, Np, cfg.llm.d, device=self.device, dtype=BF16))
+        self.feats, self.patches = bufs[(B, Np)]
+        self.B, self.S, self.Np = B, L + Np, Np
+
+    def _vision_backbone(self, j: int, batch: Dict[str, torch.Tensor]):
+        """Backbone j over ALL images of the batch in one pass (modeling_prismatic.py:196-237 runs them one by one): image
+        `im` uses channels 3*(im*n_backbones + j) .. +2 and fills feats[:, im*npi:(im+1)*npi, column block of backbone j]."""
+        cfg, vit, px = self.cfg, self.vits[j], batch["pixel_values"]
+        B, Np, nbk, npi = self.B, self.Np, len(cfg.vit), cfg.vit[0].n_patches
+        col = sum(v.cfg.d for v in self.vits[:j])
+        if nbk == 1 and cfg.n_img == 1:
+            vit.forward(px, 0, self.feats.view(B * Np, -1))
+            return
+        if cfg.n_img == 1:
+            stacked, c0 = px, 3 * j
+        else:          # [n_img * B, 3, H, W]: the images of one backbone stacked along the batch
+            stacked = torch.cat([px[:, 3 * (im * nbk + j):3 * (im * nbk + j) + 3] for im in range(cfg.n_img)], 0).contiguous()
+            c0 = 0
+        tmp = torch.empty(cfg.n_img * B * npi, vit.cfg.d, device=self.device, dtype=BF16)
+        vit.forward(stacked, c0, tmp)
+        t4 = tmp.view(cfg.n_img, B, npi, vit.cfg.d)
+        for im in range(cfg.n_img):
+            self.feats[:, im * npi:(im + 1) * npi, col:col + vit.cfg.d] = t4[im]
+
+    def _vision_project(self):
+        """PrismaticProjector (modeling_prismatic.py:261-273) -> self.patches."""
+        cfg, B, Np = self.cfg, self.B, self.Np
+        f2 = self.feats.view(B * Np, -1)
         h = ops.gemm_nt(f2, self.proj["fc1.weight"], bias=self.proj["fc1.bias"], act=ACT_GELU)
-        if getattr(self, "patches", None) is None or tuple(self.patches.shape) != (B, Np, D):
-            self.patches = torch.empty(B, Np, D, device=self.device, dtype=BF16)
-        dst = self.patches.view(B * Np, D)
+        dst = self.patches.view(B * Np, cfg.llm.d)
         if cfg.fused:
             h = ops.gemm_nt(h, self.proj["fc2.weight"], bias=self.proj["fc2.bias"], act=ACT_GELU)
             ops.gemm_nt(h, self.proj["fc3.weight"], bias=self.proj["fc3.bias"], out=dst)
         else:
             ops.gemm_nt(h, self.proj["fc2.weight"], bias=self.proj["fc2.bias"], out=dst)
-        self.B, self.S, self.Np = B, S, Np
 
     def _embed(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         """Action masks + embedding gather + action-query splice (train_utils.py:8-41; modeling_prismatic.py:601-636)
