@@ -167,6 +167,7 @@ def main():
     ap.add_argument("--cpu-samples", type=int, default=1)
     ap.add_argument("--no-full-backward", action="store_true", help="skip the extra timing of the reference-shaped full LLM backward")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
+    ap.add_argument("--ragged", action="store_true", help="prompt lengths in [24, 32], right-padded (exercises the mask path; SURVEY 8d)")
     args = ap.parse_args()
 
     from vla_adapter_amd import ddp, engine as E, flops, synthetic as S
@@ -179,7 +180,7 @@ def main():
     B, P = args.batch, 32
     W = S.make_weights(cfg, dev, seed=0)                    # identical on every rank (== DDP's initial broadcast)
     eng = E.VLAEngine(cfg, W, dev)
-    batch = S.make_batch(cfg, B, dev, seed=1000 + rank, P=P)  # every rank draws its own samples (finetune.py:988-994)
+    batch = S.make_batch(cfg, B, dev, seed=1000 + rank, P=P, ragged=args.ragged)  # every rank draws its own samples (finetune.py:988-994)
     batch["pixel_values"] = batch["pixel_values"].to(torch.bfloat16)   # finetune.py:339
     noise = (torch.randn(cfg.chunk, cfg.action_dim * cfg.llm.d, device=dev) * 0.02).to(torch.bfloat16)  # phase="Training"
     if world > 1:
@@ -249,6 +250,7 @@ def main():
                                    "1 image (256 patches) + 32-token prompt + 64 action queries (S=352)",
                        "global_batch": world * B, "per_gpu_batch": B, "seq_len": cfg.n_patches + P + 64,
                        "parallelism": f"dp{world}", "weights": "random-init", "launch": "eager" if args.eager else "hipGraph replay",
+                       "prompts": "ragged 24..32 tokens, right-padded" if args.ragged else "32 tokens",
                        "llm_backward": (f"live rows >= {row0} of {cfg.n_patches + P + 64} (gradient rows that only reach frozen inputs are "
                                         "not computed; parameter gradients identical)") if row0 else "all rows",
                        "final_loss": round(float(loss3[0]), 5)},

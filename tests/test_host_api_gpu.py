@@ -114,8 +114,7 @@ def test_predict_action_batch1_inference_matches_oracle():
     ref_un = np.where(mk, 0.5 * (ref + 1) * (hi - lo + 1e-8) + lo, ref)
     err = np.linalg.norm(act - ref_un) / np.linalg.norm(ref_un)
     assert err < 2e-2, err
-    assert np.allclose(act[:, 6], np.asarray(vla.engine.predict.__self__._predict_graphs[next(iter(vla.engine._predict_graphs))][2]
-                                             .float().cpu().numpy()[0, :, 6]))          # masked dim stays normalised
+    assert np.allclose(act[:, 6], vla.engine._pred_out.float().cpu().numpy()[0, :, 6])      # masked dim stays normalised
     # different inputs through the same captured graph
     ids2, px2 = torch.randint(3, 700, (1, 19), generator=g), torch.randn(1, 3, cfg.vit[0].img, cfg.vit[0].img, generator=g).clamp_(-3, 3)
     act3, _ = call(ids2, px2)

@@ -811,27 +811,64 @@ class VLAEngine:
     # ---- batch-1 inference (modeling_prismatic.py:892-972): forward only, captured per input shape ------------------
     def predict(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         """Forward pass in phase "Inference" (no input perturbation) -> normalised actions [B, chunk, action_dim] bf16.
-        The kernel sequence of one (B, L) shape is captured into a hipGraph on first use and replayed on static input
-        buffers afterwards: at batch 1 the ~700 launches of the forward are launch-bound otherwise."""
+        At batch 1 every kernel is a handful of workgroups and the ~1000 launches form dependent chains, so the forward is
+        cut into single-stream segments like the training step: one stream per vision backbone (they are independent),
+        the LLM on the caller's stream with the action head trailing it on the head stream; each segment is a linear
+        hipGraph captured on first use of an input shape and replayed on static input buffers afterwards."""
         key = (tuple(batch["input_ids"].shape), tuple(batch["pixel_values"].shape), batch["pixel_values"].dtype)
         cache = self.__dict__.setdefault("_predict_graphs", {})
         if os.environ.get("VLA_PREDICT_EAGER"):
             return self.forward(batch, None)
+        self._ensure_streams()
         if key not in cache:
             static = {k: v.clone() for k, v in batch.items()}
             for _ in range(2):                       # allocate buffers / set kernel attributes outside the capture
                 self.forward(static, None)
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                out = self.forward(static, None)
-            cache[key] = (g, static, out)
-        g, static, out = cache[key]
+            segs = self._predict_segments(static)
+            graphs = self._capture_segments(segs, {})
+            torch.cuda.synchronize()
+            cache[key] = (graphs, static, segs)
+        graphs, static, segs = cache[key]
         for k, v in batch.items():
             static[k].copy_(v)
         self.head.refresh_forward_operands()     # parameters may have changed since the capture (no-op when fresh)
-        g.replay()
-        return out
+        ev = self._run_segments(segs, graphs, getattr(self, "_timeline", None))
+        torch.cuda.current_stream().wait_event(ev[("end", 0)])
+        return self._pred_out
+
+    def _predict_segments(self, batch):
+        cfg, llm, head = self.cfg, self.llm, self.head
+        n, nb = cfg.llm.n_layers, cfg.num_blocks
+        self._vision_begin(batch)                                 # host-side bookkeeping only
+        segs = [(f"V{j}", (lambda j=j: self._vision_backbone(j, batch)), None, ("v", j)) for j in range(len(self.vits))]
+        ch = self._chunks(n, [6] * max(0, (n - 6) // 6) + [4, 2]) if n >= 12 else self._chunks(n, [1])   # few launches: the caller blocks on every call
+
+        def m_fwd(c, lo, hi):
+            def fn():
+                if c == 0:
+                    self._vision_project()
+                    llm.fwd_begin(self.B, self.S, self._embed(batch), 0)
+                for i in range(lo, hi):
+                    llm.fwd_layer(i)
+                if hi == n:
+                    llm.fwd_final()
+            return fn
+
+        def h_fwd(c, lo, hi, last):
+            def fn():
+                if c == 0:
+                    head.fwd_begin(llm.HS, self.pos1, batch["proprio"], self.Np, None)
+                for i in range(lo, min(hi, nb)):
+                    head.fwd_layer(i)
+                if last:
+                    self._pred_out = head.fwd_end()
+            return fn
+
+        for c, (lo, hi) in enumerate(ch):
+            segs.append(("M", m_fwd(c, lo, hi), [("v", j) for j in range(len(self.vits))] if c == 0 else None, ("f", c)))
+            segs.append(("H", h_fwd(c, lo, hi, c == len(ch) - 1), ("f", c), ("end", 0) if c == len(ch) - 1 else None))
+        return segs
 
     # modeling_prismatic.py:596-655 (multimodal forward): fills llm.HS with the n+1 hidden states
     def forward_vlm(self, batch: Dict[str, torch.Tensor], for_training: bool = False):
@@ -991,6 +1028,7 @@ class VLAEngine:
             self.side = torch.cuda.Stream(priority=-1)  # the head chain is latency-critical: high priority
             self._cap_main = torch.cuda.Stream()       # capture stream of the "M" graphs (replayed on the current stream)
             self.vis_stream = torch.cuda.Stream()      # vision stage of the NEXT step (fills the backward's idle CUs)
+            self._vstreams = [self.vis_stream] + [torch.cuda.Stream() for _ in range(max(0, len(self.vits) - 1))]   # one per backbone
 
     @staticmethod
     def _chunks(n: int, sizes) -> List[Tuple[int, int]]:
@@ -1074,17 +1112,23 @@ class VLAEngine:
         segs.append(("H", head.bwd_end, None, ("end", 0)))      # the caller joins on this event (head gradients final)
         return segs
 
+    def _stream_of(self, name: str, main):
+        return main if name == "M" else self.side if name == "H" else self._vstreams[int(name[1:])]
+
     def _run_segments(self, segs, graphs=None, timeline=None, hooks=None):
-        """timeline: optional list that receives (stream, index, start_event, end_event) per segment (timing events).
-        hooks: {segment index: fn(event)} called right after that segment was enqueued, with an event recorded behind it."""
-        main, side = torch.cuda.current_stream(), self.side
-        side.wait_stream(main)                                   # fork (inputs / previous AdamW are ordered before the head)
+        """Enqueue the segments [(stream 'M'|'H'|'V<j>', fn|None, wait key | [keys] | None, signal key | None)] in order.
+        timeline: optional list that receives (stream, index, start_event, end_event) per segment (timing events).
+        hooks: {segment index: fn(event)} called right after that segment was enqueued, with an event recorded behind it.
+        Returns the dict of recorded events."""
+        main = torch.cuda.current_stream()
+        for name in {sg[0] for sg in segs} - {"M"}:
+            self._stream_of(name, main).wait_stream(main)        # fork (inputs / previous AdamW are ordered before them)
         ev = {}
         for k, (st, fn, wait, signal) in enumerate(segs):
-            stream = main if st == "M" else side
+            stream = self._stream_of(st, main)
             with torch.cuda.stream(stream):
-                if wait is not None:
-                    stream.wait_event(ev[wait])
+                for w in ([] if wait is None else wait if isinstance(wait, list) else [wait]):
+                    stream.wait_event(ev[w])
                 if timeline is not None:
                     t0 = torch.cuda.Event(enable_timing=True)
                     t0.record(stream)
@@ -1106,13 +1150,29 @@ class VLAEngine:
                     if signal is None:
                         hev.record(stream)
                     hooks[k](hev)
-        return ev[("end", 0)]
+        return ev
+
+    def _capture_segments(self, segs, pools):
+        """One linear hipGraph per segment, captured on a stream of the segment's kind with that kind's memory pool (graphs
+        sharing a pool replay strictly in capture order on ONE stream, so the allocator's reuse of freed capture-time
+        temporaries stays race-free while the streams overlap)."""
+        graphs = []
+        for st, fn, _, _ in segs:
+            if fn is None:
+                graphs.append(None)
+                continue
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pools.setdefault(st, torch.cuda.graph_pool_handle()),
+                                  stream=self._cap_main if st == "M" else self._stream_of(st, None), capture_error_mode="thread_local"):
+                fn()
+            graphs.append(g)
+        return graphs
 
     def _fwd_bwd(self, batch, noise, vision: bool = True):
         """Eager run of the two-stream schedule (vision stage first unless the vision graph already ran)."""
         if vision:
             self._vision(batch)
-        torch.cuda.current_stream().wait_event(self._run_segments(self._segments(batch, noise)))   # join
+        torch.cuda.current_stream().wait_event(self._run_segments(self._segments(batch, noise))[("end", 0)])   # join
         return self._loss3
 
     # Data-parallel schedule of the captured step.  The gradient exchange of step k (one bucketed RCCL all-reduce of the
@@ -1135,8 +1195,7 @@ class VLAEngine:
         self.head.dirty = True
         # one memory pool per stream: graphs sharing a pool are replayed strictly in capture order on ONE stream, so the
         # allocator's reuse of freed capture-time temporaries stays race-free while the two streams overlap
-        pools = {"M": torch.cuda.graph_pool_handle(), "H": torch.cuda.graph_pool_handle(), "V": torch.cuda.graph_pool_handle()}
-        cap = {"M": self._cap_main, "H": self.side}
+        pools = {"V": torch.cuda.graph_pool_handle()}
         # vision stage: reads the staged pixels of the NEXT batch (stage_next_pixels), writes self.patches
         self._next_px = batch["pixel_values"].clone()
         self._px_stage = batch["pixel_values"].clone()
@@ -1146,15 +1205,7 @@ class VLAEngine:
             self._vision(dict(batch, pixel_values=self._px_stage))
         self._vis_ev = None
         self._segs = self._segments(batch, noise)
-        self._graphs = []
-        for st, fn, _, _ in self._segs:
-            if fn is None:
-                self._graphs.append(None)
-                continue
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pools[st], stream=cap[st], capture_error_mode="thread_local"):
-                fn()
-            self._graphs.append(g)
+        self._graphs = self._capture_segments(self._segs, pools)
         torch.cuda.synchronize()
         self._pending_lr = None
         # the vision stage of step k+1 starts behind this forward segment of step k (default: the last one, i.e. it runs
@@ -1207,7 +1258,7 @@ class VLAEngine:
         self.flush()
         cur.wait_event(self._vis_ev)           # patches of THIS step (computed during the previous call)
         self._h_end = self._run_segments(self._segs, self._graphs, getattr(self, "_timeline", None),
-                                         hooks={self._vis_after: lambda ev: self._launch_vision(ev)})
+                                         hooks={self._vis_after: lambda ev: self._launch_vision(ev)})[("end", 0)]
         cur.wait_event(self._px_copied)        # later writes to the staging source are ordered behind the vision copy
         if self.reducer is not None:
             aq_off = self.head.P.offsets["action_queries"][0]
