@@ -58,6 +58,11 @@ typedef struct vla_gemm_desc {
   /* optional: rows m of C with (m % c_live_mod) < c_live_from are NOT stored (c_live_mod 0 = store all).  Used for
    * tensors kept only for a live-row backward: the SwiGLU pre-activations of the rows the backward never visits. */
   int c_live_mod, c_live_from;
+  /* optional split-K (0/1 = off): the K range is cut into split_k slices that run as blockIdx.z, each parking its fp32
+   * accumulators in its own plane of `ws` (device, fp32 [split_k, M, N], no initialisation needed); a second small kernel
+   * sums the planes and applies bias / activation (none, GELU, ReLU) / residual.  For few-tile long-K problems (batch-1
+   * inference); batch == 1 and N % 4 == 0 only. */
+  int split_k; float* ws;
 } vla_gemm_desc;
 
 /* C = epilogue(A . B^T).  Replaces nn.Linear forward and, with pre-transposed operands, its dX / dW products:

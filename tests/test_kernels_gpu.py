@@ -625,3 +625,21 @@ def test_gemm_live_row_store_and_bias_paths(ops):
     ops.gemm_nt(a.to(DEV), w.to(DEV), bias=bias_buf[:N].contiguous(), out=out, c_live=(S, r0))
     o3, r3 = out.view(B, S, N), ref.view(B, S, N)
     assert torch.equal(o3[:, r0:], r3[:, r0:]) and bool((o3[:, :r0] == 7.0).all())
+
+
+@pytest.mark.parametrize("M,N,K,act,res", [(261, 1024, 4096, 0, True), (625, 896, 4864, 0, True), (512, 1152, 4352, 1, False), (256, 896, 2688, 2, True)])
+def test_gemm_split_k_matches_single_pass(ops, M, N, K, act, res, monkeypatch):
+    """Few-tile long-K problems run split-K (slices meet in an fp32 workspace, epilogue in a second kernel): same result as
+    the single-pass kernel up to the fp32 summation order."""
+    a, w, bias, r = gen(M, K, seed=190), gen(N, K, seed=191, scale=0.05), gen(N, seed=192), gen(M, N, seed=193)
+    kw = dict(bias=bias.to(DEV), act=act, residual=r.to(DEV) if res else None)
+    out = torch.empty(M, N, dtype=BF, device=DEV)
+    ops.gemm_nt(a.to(DEV), w.to(DEV), out=out, **kw)
+    assert (torch.cuda.current_stream().cuda_stream, str(out.device)) in ops._SPLITK_WS, "the split-K path must have run"
+    monkeypatch.setenv("VLA_NO_SPLITK", "1")
+    ref = torch.empty(M, N, dtype=BF, device=DEV)
+    ops.gemm_nt(a.to(DEV), w.to(DEV), out=ref, **kw)
+    check(out, f(ref), rel=2e-3, name="split-K vs single pass")
+    y = O.linear(a.float(), w.float(), bias.float(), emu=True)
+    y = {0: y, 1: O.rnd(O.gelu(y), True), 2: torch.relu(y)}[act]
+    check(out, O.rnd(y + r.float(), True) if res else y, name="split-K vs oracle")

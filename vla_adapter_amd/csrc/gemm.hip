@@ -39,6 +39,7 @@ struct GemmP {
   float alpha;
   int gA, gC, gR; long long sgA, sgC, sgR;  // row-group addressing: row r -> (r / g) * sg + (r % g) * ld
   int c_live_mod, c_live_from;              // C rows with (m % c_live_mod) < c_live_from are not stored
+  float* ws;                                // split-K: fp32 [M, N] accumulator (blockIdx.z = K slice), finalised by a second kernel
   int rope_mode, rope_T, rope_dh, rope_cols; const float* rope_cos; const float* rope_sin;
 };
 
@@ -213,6 +214,21 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
   asm volatile("" ::: "memory");
 
   // ---------------- epilogue ----------------
+  if (ROPE == 0 && p.ws != nullptr) {
+    // split-K slice z: park the raw accumulators in its own fp32 plane ws[z][M][N] (plain 16-B stores; fp32 atomics into one
+    // plane were throughput-bound: 4 M atomics per GEMM); the planes are summed and bias / activation / residual / bf16
+    // rounding applied once, in splitk_finalize_kernel.  (Few-tile long-K problems are otherwise one serial K loop.)
+    float* plane = p.ws + (long long)z * p.M * p.N;
+#pragma unroll
+    for (int ni = 0; ni < C::NT; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int m = wm0 + mi * 16 + lr, n = wn0 + ni * 16 + lq * 4;
+        if (m < p.M && n + 3 < p.N)
+          *reinterpret_cast<f32x4*>(plane + (long long)m * p.N + n) = acc[ni][mi];
+      }
+    return;
+  }
   char* reg = smem + wid * (C::EPI_ROWS * C::EPI_STRIDE);
 
   if (ROPE == 3) {
@@ -418,6 +434,24 @@ inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode, int
   return TileChoice{128, 128};
 }
 
+// split-K second pass: C = bf16(bf16(act(bf16(sum_z ws[z] * alpha + bias))) + R); 4 columns per thread
+__global__ void splitk_finalize_kernel(const float* __restrict__ ws, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ R,
+                                       bf16_t* __restrict__ C, int M, int N, int ldc, int ldr, int act, float alpha, int split) {
+  const long long total = (long long)M * N / 4, plane = (long long)M * N;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int m = (int)(i * 4 / N), n = (int)(i * 4 - (long long)m * N);
+    f32x4 a = *reinterpret_cast<const f32x4*>(ws + i * 4);
+    for (int z = 1; z < split; ++z) a += *reinterpret_cast<const f32x4*>(ws + z * plane + i * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = a[j] * alpha + (bias ? bf2f(bias[n + j]) : 0.f);
+      if (act != VLA_ACT_NONE) v = apply_act(rbf(v), act);
+      if (R) v = rbf(v) + bf2f(R[(long long)m * ldr + n + j]);
+      C[(long long)m * ldc + n + j] = f2bf(v);
+    }
+  }
+}
+
 template <int BM, int BN, int STAGES, int ROPE, int WN = 2>
 int launch(const GemmP& p0, int M, int N, int batch, hipStream_t st) {
   using C = Cfg<BM, BN, STAGES, WN>;
@@ -471,6 +505,19 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   p.gA = d->a_group; p.sgA = d->a_group_stride; p.gC = d->c_group; p.sgC = d->c_group_stride;
   p.gR = d->r_group; p.sgR = d->r_group_stride;
   p.c_live_mod = d->c_live_mod; p.c_live_from = d->c_live_from;
+  p.ws = nullptr;
+  const int split = d->split_k > 1 ? d->split_k : 1;
+  if (split > 1) {
+    VLA_REQUIRE(d->ws && d->batch == 1 && d->K % (BK * split) == 0 && d->rope_mode == 0 && d->c_group == 0 && d->r_group == 0 &&
+                    d->res_mod == 0 && d->c_live_mod == 0 && d->C &&
+                    (d->act == VLA_ACT_NONE || d->act == VLA_ACT_GELU || d->act == VLA_ACT_RELU || d->act == VLA_ACT_GELU_TANH),
+                "gemm: split_k needs an fp32 workspace [split_k, M, N], batch 1, K % (64 * split_k) == 0 and a plain epilogue");
+    VLA_REQUIRE(d->N % 4 == 0 && ((uintptr_t)d->ws & 15) == 0, "gemm: split_k needs N % 4 == 0 and a 16-B aligned workspace");
+    p.ws = d->ws;
+    p.K = d->K / split;            // every z slice owns K / split_k of the contraction
+    p.sA = p.sB = p.K;             // ... starting K / split_k elements further along the rows of A and B
+    p.bias = nullptr; p.R = nullptr;
+  }
   VLA_REQUIRE(d->c_live_mod >= 0 && d->c_live_from >= 0 && (d->c_live_mod == 0 || d->c_live_from < d->c_live_mod),
               "gemm: c_live_from must lie inside c_live_mod");
   VLA_REQUIRE(d->r_group >= 0 && d->r_group_stride % 8 == 0 && (d->r_group == 0 || d->res_mod == 0),
@@ -485,7 +532,7 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
     if (d->rope_mode == 1) VLA_REQUIRE(d->rope_dh == 64, "gemm: fused rotate_half RoPE needs head dim 64");
   }
   const char* e = getenv("VLA_GEMM_TILE");     // 0/unset auto, 1: 256x128, 2: 128x128, 3: 128x64  (benchmarking aid)
-  const TileChoice tc = choose_tile(d->M, d->N, d->K, e ? atoi(e) : 0, d->rope_mode, d->batch);
+  const TileChoice tc = choose_tile(d->M, d->N, d->K / split, e ? atoi(e) : 0, d->rope_mode, split > 1 ? split : d->batch);
   hipStream_t st = (hipStream_t)stream;
   if (d->act == VLA_ACT_SWIGLU_BWD) launch<128, 128, 2, 3, 4>(p, d->M, d->N, d->batch, st);
   else if (d->rope_mode == 1) launch<128, 128, 2, 1>(p, d->M, d->N, d->batch, st);
@@ -495,8 +542,15 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   } else if (tc.bm == 256 && tc.bn == 256) launch<256, 256, 2, 0>(p, d->M, d->N, d->batch, st);
   else if (tc.bm == 256) launch<256, 128, 3, 0, 4>(p, d->M, d->N, d->batch, st);   // 16 waves, loads two K-tiles ahead
   else if (tc.bn == 129) launch<128, 128, 2, 0>(p, d->M, d->N, d->batch, st);      // 4 waves of 64x64 (forced only)
-  else if (tc.bn == 128) launch<128, 128, 2, 0, 4>(p, d->M, d->N, d->batch, st);   // 8 waves (2x4) of 64x32
-  else launch<128, 64, 2, 0>(p, d->M, d->N, d->batch, st);
+  else if (tc.bn == 128) launch<128, 128, 2, 0, 4>(p, d->M, d->N, split > 1 ? split : d->batch, st);   // 8 waves (2x4) of 64x32
+  else launch<128, 64, 2, 0>(p, d->M, d->N, split > 1 ? split : d->batch, st);
   VLA_CHECK_LAUNCH("gemm_bf16_nt");
+  if (split > 1) {
+    const long long total = (long long)d->M * d->N / 4;
+    const unsigned nblk = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(splitk_finalize_kernel, dim3(nblk), dim3(256), 0, st, (const float*)d->ws, (const bf16_t*)d->bias,
+                       (const bf16_t*)d->R, (bf16_t*)d->C, d->M, d->N, d->ldc, d->ldr, d->act, d->alpha == 0.f ? 1.f : d->alpha, split);
+    VLA_CHECK_LAUNCH("gemm_splitk_finalize");
+  }
   return VLA_OK;
 }

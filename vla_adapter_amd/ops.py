@@ -6,6 +6,7 @@ Every function launches on ``torch.cuda.current_stream()`` and raises on failure
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from typing import Optional, Tuple
 
@@ -92,10 +93,31 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_m
         assert cos_t.shape[1] == (dh // 2 if mode == 1 else dh)
         d.rope_mode, d.rope_T, d.rope_dh, d.rope_cols = mode, T, dh, ncols
         d.rope_cos, d.rope_sin = cos_t.data_ptr(), sin_t.data_ptr()
+    # split-K for few-tile long-K problems (batch-1 inference: M <= 1024): the K loop of a tile is serial, so a problem
+    # with a handful of tiles runs at the latency of ONE long loop; slices meet in a per-stream fp32 workspace
+    if (not batched and M <= 1024 and K >= 2048 and act in (ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_TANH) and out is not None
+            and a_group is None and c_group is None and r_group is None and rope is None and c_live is None and res_mod == 0
+            and ((M + 127) // 128) * ((Nn + 127) // 128) <= 64 and Nn % 4 == 0 and not os.environ.get("VLA_NO_SPLITK")):
+        for sk in (8, 4, 2):
+            if K % (64 * sk) == 0 and K // sk >= 512:
+                d.split_k, d.ws = sk, _splitk_ws(sk * M * Nn, a.device).data_ptr()
+                break
     N.check(_lib().vla_gemm_bf16_nt(_st(), C.byref(d)), "gemm_bf16_nt")
     if act == ACT_SWIGLU:
         return out, out2
     return out
+
+
+_SPLITK_WS = {}
+
+
+def _splitk_ws(numel: int, device) -> torch.Tensor:
+    """fp32 workspace of the CURRENT stream (streams overlap, so each has its own)."""
+    key = (torch.cuda.current_stream().cuda_stream, str(device))
+    ws = _SPLITK_WS.get(key)
+    if ws is None or ws.numel() < numel:
+        ws = _SPLITK_WS[key] = torch.empty(max(numel, 8 << 20), device=device, dtype=torch.float32)
+    return ws
 
 
 def gemm_swiglu_bwd(d: torch.Tensor, w_downT: torch.Tensor, gu: torch.Tensor, out: Optional[torch.Tensor] = None,
