@@ -32,6 +32,26 @@ def gemm_flops_of_call(a, b, batched):
     return 2.0 * nb * M * N * K
 
 
+def gemm_bytes_of_call(a, b, batched, kw):
+    """Algorithmic HBM bytes of one launch: A and B read once, C written once (bf16), + residual read, + the second SwiGLU
+    output / the SwiGLU-backward pre-activations; rows skipped by c_live are not counted."""
+    M, K = a.shape[-2:]
+    N = b.shape[-2]
+    nb = a.shape[0] if batched else 1
+    c_rows = M
+    if kw.get("c_live") is not None:
+        period, first = kw["c_live"]
+        c_rows = M * (period - first) // period
+    by = 2.0 * nb * (M * K + N * K + c_rows * N)
+    if kw.get("residual") is not None:
+        by += 2.0 * nb * M * N
+    if kw.get("act", 0) == 4:            # SwiGLU forward: h = [M, N/2]
+        by += 2.0 * nb * M * (N // 2)
+    if "_swiglu_bwd" in kw:              # dGU [M, 2N] written, GU [M, 2N] read (C above counted [M, N] once)
+        by += 2.0 * nb * (3 * M * N)
+    return by
+
+
 def measure_gemm_roofline(eng, batch, noise, lr, reps=10):
     """Live HIP-event timing of the dominant kernel (gemm_nt_kernel) on the stream it is launched on (torch's current
     stream == the stream handed to the C ABI).  One eager step records every GEMM launch of a training step (operands,
@@ -49,7 +69,7 @@ def measure_gemm_roofline(eng, batch, noise, lr, reps=10):
             kw2 = dict(kw)
             if kw2.get("out") is None and kw2.get("act", 0) != 4:
                 kw2["out"] = r
-            calls[sig] = [0, gemm_flops_of_call(a, b, a.dim() == 3), a, b, kw2]
+            calls[sig] = [0, gemm_flops_of_call(a, b, a.dim() == 3), a, b, kw2, gemm_bytes_of_call(a, b, a.dim() == 3, kw2)]
         calls[sig][0] += 1
         return r
 
@@ -59,7 +79,8 @@ def measure_gemm_roofline(eng, batch, noise, lr, reps=10):
         r = orig_sw(d_, w_, gu_, out=out, gu_group=gu_group)
         sig = (tuple(d_.shape), tuple(w_.shape), d_.stride(-2), w_.stride(-2), 5, False, True)
         if sig not in calls:
-            calls[sig] = [0, gemm_flops_of_call(d_, w_, False), d_, w_, dict(_swiglu_bwd=(gu_, r, gu_group))]
+            kw_sw = dict(_swiglu_bwd=(gu_, r, gu_group))
+            calls[sig] = [0, gemm_flops_of_call(d_, w_, False), d_, w_, kw_sw, gemm_bytes_of_call(d_, w_, False, kw_sw)]
         calls[sig][0] += 1
         return r
 
@@ -77,10 +98,10 @@ def measure_gemm_roofline(eng, batch, noise, lr, reps=10):
     finally:
         ops.gemm_nt, ops.gemm_swiglu_bwd = orig, orig_sw
         eng.reducer = reducer
-    total_t = total_f = 0.0
+    total_t = total_f = total_b = 0.0
     n = 0
     per = []
-    for sig, (cnt, fl, a, b, kw) in calls.items():
+    for sig, (cnt, fl, a, b, kw, nbytes) in calls.items():
         for _ in range(2):
             replay(a, b, kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -92,11 +113,12 @@ def measure_gemm_roofline(eng, batch, noise, lr, reps=10):
         t = e0.elapsed_time(e1) * 1e-3 / reps
         total_t += cnt * t
         total_f += cnt * fl
+        total_b += cnt * nbytes
         n += cnt
         per.append((cnt * t, cnt, sig[0], sig[1], fl / t / 1e12))
     per.sort(reverse=True)
     top = [dict(ms_per_step=round(x[0] * 1e3, 3), count=x[1], A=list(x[2]), B=list(x[3]), tflops=round(x[4], 1)) for x in per[:8]]
-    return dict(launches=n, seconds=total_t, flops=total_f, tflops=total_f / total_t / 1e12, top=top)
+    return dict(launches=n, seconds=total_t, flops=total_f, tflops=total_f / total_t / 1e12, top=top, bytes=total_b)
 
 
 def pmc_traffic():
@@ -105,7 +127,9 @@ def pmc_traffic():
     f = os.path.join(ROOT, "profiles", "r01_gemm_traffic_pmc.json")
     try:
         d = json.load(open(f))
-        return {"bytes_per_launch": round(d["bytes_per_launch"]), "source": "profiles/r01_gemm_traffic_pmc.json"}
+        return {"bytes_per_launch": round(d["bytes_per_launch"]), "source": "profiles/r01_gemm_traffic_pmc.json",
+                "note": "TCC fetch/write sizes = traffic between the 8 private L2s and the fabric (Infinity Cache + HBM), not HBM alone: "
+                        "every XCD streams the weight operand into its own L2, so fills are ~2.5x the algorithmic bytes (DESIGN.md 4)"}
     except Exception:
         return None
 
@@ -263,6 +287,11 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 MFMA NT GEMM, all launches of one step)",
                          "achieved": round(roof["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(roof["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
+                         "algorithmic_bytes_per_launch": round(roof["bytes"] / roof["launches"]),
+                         "avg_launch_us": round(roof["seconds"] / roof["launches"] * 1e6, 1),
+                         "timing": "each distinct launch signature of one step replayed back-to-back between two HIP events on its "
+                                   "launch stream, weighted by its count; inside the two-stream step the same launches average "
+                                   "~25 % longer (rocprofv3: profiles/r01_final_kernel_stats.csv) because the streams share the CUs",
                          "launches_per_step": roof["launches"], "gemm_ms_per_step": round(roof["seconds"] * 1e3, 3),
                          "gemm_flops_per_step": roof["flops"], "top_launches": roof["top"]},
             "cpu_baseline": cpu,
