@@ -643,3 +643,97 @@ def test_gemm_split_k_matches_single_pass(ops, M, N, K, act, res, monkeypatch):
     y = O.linear(a.float(), w.float(), bias.float(), emu=True)
     y = {0: y, 1: O.rnd(O.gelu(y), True), 2: torch.relu(y)}[act]
     check(out, O.rnd(y + r.float(), True) if res else y, name="split-K vs oracle")
+
+
+def test_gemm_random_shapes_and_epilogues(ops):
+    """Seeded sweep over ragged M / N (not multiples of the tile, N odd included), short and long K, every plain epilogue
+    combination - result vs the oracle (edge handling: clamped loads, masked stores, scalar bias / store fallbacks)."""
+    rng = torch.Generator().manual_seed(1234)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=rng))
+    for case in range(16):
+        M, N, K = ri(1, 700), ri(1, 600), 64 * ri(1, 40)
+        act = [0, 1, 2, 3][ri(0, 3)]
+        use_bias, use_res = bool(ri(0, 1)), bool(ri(0, 1))
+        a, w = gen(M, K, seed=300 + case), gen(N, K, seed=400 + case, scale=0.05)
+        bias, r = gen(N, seed=500 + case), gen(M, N, seed=600 + case)
+        out = ops.gemm_nt(a.to(DEV), w.to(DEV), bias=bias.to(DEV) if use_bias else None, act=act,
+                          residual=r.to(DEV) if use_res else None)
+        y = O.linear(a.float(), w.float(), bias.float() if use_bias else None, emu=True)
+        y = {0: y, 1: O.rnd(O.gelu(y), True), 2: torch.relu(y), 3: O.rnd(O.gelu(y, tanh=True), True)}[act]
+        ref = O.rnd(y + r.float(), True) if use_res else y
+        check(out, ref, name=f"gemm case {case}: {M}x{N}x{K} act{act} bias{use_bias} res{use_res}")
+
+
+def test_attention_random_shapes(ops):
+    """Seeded sweep over ragged sequence lengths, GQA ratios, masks and live-row windows (forward + backward)."""
+    rng = torch.Generator().manual_seed(4321)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=rng))
+    for case in range(8):
+        B, Hkv, grp, S = ri(1, 3), ri(1, 2), [1, 2, 7][ri(0, 2)], ri(33, 300)
+        Hq, dh, causal, masked = Hkv * grp, 64, bool(ri(0, 1)), bool(ri(0, 1))
+        qkv, q, k, v = _attn_inputs(B, S, Hq, Hkv, dh, 700 + case)
+        km = torch.ones(B, S, dtype=torch.bool)
+        if masked:
+            km[0, S - ri(1, 20):] = False
+        d = qkv.to(DEV)
+        a, b = Hq * dh, (Hq + Hkv) * dh
+        kmd = km.to(torch.uint8).to(DEV) if masked else None
+        o, lse = ops.attn_fwd(d[:, :, :a], d[:, :, a:b], d[:, :, b:], Hq, Hkv, dh, causal, kmd, want_lse=True)
+        hd = lambda t, h: t.float().reshape(B, S, h, dh).transpose(1, 2)
+        qr, kr, vr = (hd(t, h).clone().requires_grad_(True) for t, h in ((q, Hq), (k, Hkv), (v, Hkv)))
+        ref = O.attention(qr, kr, vr, causal, km if masked else None)
+        check(o, ref.detach().transpose(1, 2).reshape(B, S, Hq * dh), rel=6e-3, mx=3e-2, name=f"attn fwd case {case}")
+        dout = gen(B, S, Hq * dh, seed=800 + case)
+        g = torch.zeros_like(d)
+        ops.attn_bwd(dout.to(DEV), d[:, :, :a], d[:, :, a:b], d[:, :, b:], o, lse, Hq, Hkv, dh, causal, kmd,
+                     dq=g[:, :, :a], dk=g[:, :, a:b], dv=g[:, :, b:])
+        (ref * hd(dout, Hq)).sum().backward()
+        un = lambda t, h: t.transpose(1, 2).reshape(B, S, h * dh)
+        for name, got, want in (("dq", g[:, :, :a], un(qr.grad, Hq)), ("dk", g[:, :, a:b], un(kr.grad, Hkv)), ("dv", g[:, :, b:], un(vr.grad, Hkv))):
+            check(got, want, rel=1.2e-2, mx=6e-2, name=f"attn {name} case {case} B{B} S{S} Hq{Hq} Hkv{Hkv} causal{causal} masked{masked}")
+        if causal and S > 64:
+            r0 = 32 * ri(1, (S - 1) // 32)
+            dl = dout.to(DEV).clone()
+            dl[:, :r0] = 0
+            full, win = torch.zeros_like(d), torch.zeros(B, S - r0, d.shape[-1], dtype=BF, device=DEV)
+            ops.attn_bwd(dl, d[:, :, :a], d[:, :, a:b], d[:, :, b:], o, lse, Hq, Hkv, dh, True, kmd, dq=full[:, :, :a], dk=full[:, :, a:b], dv=full[:, :, b:])
+            ops.attn_bwd(dl[:, r0:].contiguous(), d[:, r0:, :a], d[:, :, a:b], d[:, :, b:], o[:, r0:], lse, Hq, Hkv, dh, True, kmd,
+                         dq=win[:, :, :a], dk=win[:, :, a:b], dv=win[:, :, b:], row0=r0)
+            assert torch.equal(win, full[:, r0:]), f"live-row window case {case} S{S} r0{r0}"
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("masked_keys", [[31], [3], [28, 29, 30, 31], [3, 4, 5, 6], [0], [27], [5, 40, 63], list(range(30, 40))])
+def test_attention_fwd_sparse_key_masks(ops, causal, masked_keys):
+    """Key-padding masks that leave key rows 27 / 31 of a 32-key tile visible while the tile takes the masking path: an
+    earlier formulation of that path returned wrong weights for exactly those rows (accumulator register 15) - trailing
+    masks of >= 5 keys, the only kind the other tests used, hid it."""
+    B, S, Hq, Hkv, dh = 2, 72, 4, 2, 64
+    qkv, q, k, v = _attn_inputs(B, S, Hq, Hkv, dh, 900)
+    km = torch.ones(B, S, dtype=torch.bool)
+    km[0, masked_keys] = False
+    d = qkv.to(DEV)
+    a, b = Hq * dh, (Hq + Hkv) * dh
+    o, lse = ops.attn_fwd(d[:, :, :a], d[:, :, a:b], d[:, :, b:], Hq, Hkv, dh, causal, km.to(torch.uint8).to(DEV), want_lse=True)
+    hd = lambda t, h: t.float().reshape(B, S, h, dh).transpose(1, 2)
+    qr, kr, vr = (hd(t, h).clone().requires_grad_(True) for t, h in ((q, Hq), (k, Hkv), (v, Hkv)))
+    ref = O.attention(qr, kr, vr, causal, km)
+    valid = torch.ones(B, S, dtype=torch.bool)
+    if causal:                      # a query whose every visible key is masked has no defined output (all -inf row)
+        for bb in range(B):
+            for i in range(S):
+                valid[bb, i] = bool(km[bb, :i + 1].any())
+    got = o.float().cpu()[valid]
+    want = ref.detach().transpose(1, 2).reshape(B, S, Hq * dh)[valid]
+    check(got, want, rel=6e-3, mx=3e-2, name=f"attn fwd sparse mask {masked_keys} causal={causal}")
+    dout = gen(B, S, Hq * dh, seed=901)
+    dout[~valid] = 0
+    g = torch.zeros_like(d)
+    ops.attn_bwd(dout.to(DEV), d[:, :, :a], d[:, :, a:b], d[:, :, b:], o, lse, Hq, Hkv, dh, causal, km.to(torch.uint8).to(DEV),
+                 dq=g[:, :, :a], dk=g[:, :, a:b], dv=g[:, :, b:])
+    if bool(valid.all()):
+        (ref * hd(dout, Hq)).sum().backward()
+        un = lambda t, h: t.transpose(1, 2).reshape(B, S, h * dh)
+        check(g[:, :, :a], un(qr.grad, Hq), rel=1.2e-2, mx=6e-2, name="dq sparse mask")
+        check(g[:, :, a:b], un(kr.grad, Hkv), rel=1.2e-2, mx=6e-2, name="dk sparse mask")
+        check(g[:, :, b:], un(vr.grad, Hkv), rel=1.2e-2, mx=6e-2, name="dv sparse mask")

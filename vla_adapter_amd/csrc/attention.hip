@@ -122,22 +122,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
       const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (lane & 31) * G::LD + 16 * ks + 8 * h);
       S = mfma32(kf, qf[ks], S);
     }
-    float mt = -INFINITY;
-    if (km == 0xffffffffu && (!p.causal || k0 + 31 <= q0 + p.q_off)) {   // wave-uniform: whole tile visible to every query
+    // scale, then (only when the tile is not entirely visible to every query of the wave - a wave-uniform test) mask.
+    // The mask-only branch replaces an earlier if/else of two complete loops, for which the compiler produced wrong
+    // values for accumulator register 15 (key rows 27 / 31) whenever the masked arm ran with those rows unmasked
+    // (tests/test_kernels_gpu.py::test_attention_fwd_sparse_key_masks).
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        S[r] *= p.scale_log2;
-        mt = fmaxf(mt, S[r]);
-      }
-    } else {
+    for (int r = 0; r < 16; ++r) S[r] *= p.scale_log2;
+    if (!(km == 0xffffffffu && (!p.causal || k0 + 31 <= q0 + p.q_off))) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int kr = acc_row(r, h);
         const bool ok = ((km >> kr) & 1u) && (!p.causal || k0 + kr <= qi + p.q_off);
-        S[r] = ok ? S[r] * p.scale_log2 : -INFINITY;
-        mt = fmaxf(mt, S[r]);
+        S[r] = ok ? S[r] : -INFINITY;
       }
     }
+    float mt = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mt = fmaxf(mt, S[r]);
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     const float m_new = fmaxf(m_run, mt);
     const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
