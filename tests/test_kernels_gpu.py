@@ -737,3 +737,80 @@ def test_attention_fwd_sparse_key_masks(ops, causal, masked_keys):
         check(g[:, :, :a], un(qr.grad, Hq), rel=1.2e-2, mx=6e-2, name="dq sparse mask")
         check(g[:, :, a:b], un(kr.grad, Hkv), rel=1.2e-2, mx=6e-2, name="dk sparse mask")
         check(g[:, :, b:], un(vr.grad, Hkv), rel=1.2e-2, mx=6e-2, name="dv sparse mask")
+
+
+def test_head_attention_random_shapes(ops):
+    """Seeded sweep over (T, Ka, Kt, dh) of the action-head attention, ragged segment lengths included (segments that do
+    not end on a 32-key tile boundary; Kt smaller than a tile)."""
+    rng = torch.Generator().manual_seed(2468)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=rng))
+    for case in range(8):
+        B, T, Ka, Kt, H = ri(1, 3), [8, 5, 25, 8][ri(0, 3)], ri(2, 70), ri(3, 300), [8, 4][ri(0, 1)]
+        dh = [16, 32, 64, 112][ri(0, 3)]
+        if case == 0:
+            B, T, Ka, Kt, H, dh = 2, 8, 65, 256, 8, 112          # the production shape
+        tag = f"case {case}: B{B} T{T} Ka{Ka} Kt{Kt} H{H} dh{dh}"
+        D = H * dh
+        xs, xa, xt = gen(B, T, 3 * D, seed=1000 + case, scale=0.5), gen(B, Ka, 2 * D, seed=1100 + case, scale=0.5), gen(B, Kt, 2 * D, seed=1200 + case, scale=0.5)
+        gate = torch.tensor([0.3] + [0] * 7).to(BF)
+        args = [t.to(DEV) for t in (xs[:, :, :D], xs[:, :, D:2 * D], xs[:, :, 2 * D:], xa[:, :, :D], xa[:, :, D:], xt[:, :, :D], xt[:, :, D:])]
+        hd = lambda t, n: t.float().reshape(B, n, H, dh).transpose(1, 2)
+        leaves = [hd(xs[:, :, :D], T), hd(xs[:, :, D:2 * D], T), hd(xs[:, :, 2 * D:], T), hd(xa[:, :, :D], Ka), hd(xa[:, :, D:], Ka),
+                  hd(xt[:, :, :D], Kt), hd(xt[:, :, D:], Kt)]
+        leaves = [l.clone().requires_grad_(True) for l in leaves]
+        gr = gate[:1].float().clone().requires_grad_(True)
+        out, probs = ops.head_attn_fwd(*args, gate.to(DEV), H)
+        ref32 = O.head_attention_core(leaves[0], [(leaves[1], leaves[2]), (leaves[3], leaves[4]), (leaves[5], leaves[6])], torch.tanh(gr), False)
+        check(out, ref32.detach().transpose(1, 2).reshape(B, T, D), rel=8e-3, mx=4e-2, name="head fwd " + tag)
+        dout = gen(B, T, D, seed=1300 + case)
+        (ref32 * hd(dout, T)).sum().backward()
+        dgate = torch.zeros(1, dtype=torch.float32, device=DEV)
+        g3, ga, gt = torch.zeros_like(args[0].new_empty(B, T, 3 * D)), torch.zeros(B, Ka, 2 * D, dtype=BF, device=DEV), torch.zeros(B, Kt, 2 * D, dtype=BF, device=DEV)
+        d3, da, dt = xs.to(DEV), xa.to(DEV), xt.to(DEV)
+        a2 = (d3[:, :, :D], d3[:, :, D:2 * D], d3[:, :, 2 * D:], da[:, :, :D], da[:, :, D:], dt[:, :, :D], dt[:, :, D:])
+        out2, probs2 = ops.head_attn_fwd(*a2, gate.to(DEV), H)
+        ops.head_attn_bwd(dout.to(DEV), out2, *a2, gate.to(DEV), probs2, dgate, g3[:, :, :D], g3[:, :, D:2 * D], g3[:, :, 2 * D:],
+                          ga[:, :, :D], ga[:, :, D:], gt[:, :, :D], gt[:, :, D:], H)
+        un = lambda t, n: t.transpose(1, 2).reshape(B, n, D)
+        for name, got, want in (("dq", g3[:, :, :D], un(leaves[0].grad, T)), ("dks", g3[:, :, D:2 * D], un(leaves[1].grad, T)),
+                                ("dvs", g3[:, :, 2 * D:], un(leaves[2].grad, T)), ("dka", ga[:, :, :D], un(leaves[3].grad, Ka)),
+                                ("dva", ga[:, :, D:], un(leaves[4].grad, Ka)), ("dkt", gt[:, :, :D], un(leaves[5].grad, Kt)),
+                                ("dvt", gt[:, :, D:], un(leaves[6].grad, Kt))):
+            check(got, want, rel=2e-2, mx=8e-2, name=f"head {name} " + tag)
+        # the gate gradient is ONE scalar summed over every (sample, head, query, task key) with cancellation: looser bound
+        assert abs(dgate.item() - gr.grad.item()) <= 1e-1 * abs(gr.grad.item()) + 2e-3, (tag, dgate.item(), gr.grad.item())
+
+
+def test_norms_transpose_colsum_random_shapes(ops):
+    """Seeded sweep over row counts / widths of the HBM-bound kernels (every chunk-count instantiation of the norm kernels:
+    cols 8 .. 8192, rows not multiples of the 4 rows a block handles), transposes with padding, batched column sums."""
+    rng = torch.Generator().manual_seed(1357)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=rng))
+    for case in range(10):
+        rows, cols = ri(1, 300), 8 * ri(1, 1024)
+        if case < 6:
+            cols = [8, 64, 520, 1032, 2056, 4104][case]            # one per NCH instantiation boundary (512-wide chunks + 8)
+        x, w, b, dy = gen(rows, cols, seed=1400 + case), (1 + 0.1 * gen(cols, seed=1500 + case).float()).to(BF), gen(cols, seed=1600 + case, scale=0.1), gen(rows, cols, seed=1700 + case)
+        y, stats = ops.layernorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5, want_stats=True)
+        check(y, O.layer_norm(x.float(), w.float(), b.float(), 1e-5, True), name=f"layernorm fwd {rows}x{cols}")
+        xr, wr, br = x.float().requires_grad_(True), w.float().requires_grad_(True), b.float().requires_grad_(True)
+        (O.layer_norm(xr, wr, br, 1e-5) * dy.float()).sum().backward()
+        dw, db = torch.zeros(cols, device=DEV), torch.zeros(cols, device=DEV)
+        dx = ops.layernorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), stats, dw, db)
+        check(dx, xr.grad, rel=5e-3, name=f"layernorm dx {rows}x{cols}")
+        check(dw, wr.grad, rel=2e-3, mx=1e-2, name=f"layernorm dw {rows}x{cols}")
+        check(db, br.grad, rel=2e-3, mx=1e-2, name=f"layernorm db {rows}x{cols}")
+        yr, rstd = ops.rmsnorm_fwd(x.to(DEV), w.to(DEV), 1e-6, want_rstd=True)
+        check(yr, O.rms_norm(x.float(), w.float(), 1e-6, True), name=f"rmsnorm fwd {rows}x{cols}")
+        xr2 = x.float().requires_grad_(True)
+        (O.rms_norm(xr2, w.float(), 1e-6) * dy.float()).sum().backward()
+        check(ops.rmsnorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), rstd), xr2.grad, rel=5e-3, name=f"rmsnorm bwd {rows}x{cols}")
+    for case in range(6):
+        nb, R, Cc = ri(1, 4), ri(1, 200), 8 * ri(1, 40)
+        ld = (R + 63) // 64 * 64
+        x = gen(nb, R, Cc, seed=1800 + case)
+        t = ops.transpose(x.to(DEV), ld_out=ld)
+        assert torch.equal(f(t[:, :, :R]), x.float().transpose(1, 2)) and bool((f(t[:, :, R:]) == 0).all()), (nb, R, Cc)
+        cs = torch.zeros(nb, Cc, device=DEV)
+        ops.colsum_(x.to(DEV), cs)
+        check(cs, x.float().sum(1), rel=1e-5, mx=1e-5, name=f"colsum {nb}x{R}x{Cc}")
