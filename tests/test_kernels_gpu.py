@@ -814,3 +814,80 @@ def test_norms_transpose_colsum_random_shapes(ops):
         cs = torch.zeros(nb, Cc, device=DEV)
         ops.colsum_(x.to(DEV), cs)
         check(cs, x.float().sum(1), rel=1e-5, mx=1e-5, name=f"colsum {nb}x{R}x{Cc}")
+
+
+def test_glue_and_optimizer_random_sweep(ops):
+    """Seeded sweep over the integer / index kernels (bit-exact), the fused epilogue GEMMs and AdamW:
+    random label layouts for the action masks and the splice, random (B, S, heads) for the RoPE-in-GEMM epilogues,
+    random (M, I) for SwiGLU forward and its fused backward, AdamW on odd lengths over several steps."""
+    rng = torch.Generator().manual_seed(97531)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=rng))
+    # --- masks + splice + action-query gradient
+    for case in range(6):
+        B, P, extra, Np, D, V = ri(1, 5), ri(1, 40), ri(0, 9), 8 * ri(1, 6), 64 * ri(1, 3), 151936
+        L = P + 64 + extra
+        labels = torch.full((B, L), -100, dtype=torch.int64)
+        ids = torch.randint(0, 151000, (B, L), generator=rng)
+        for b in range(B):
+            p = ri(1, P)
+            labels[b, p - 1] = ri(0, 151000)                              # last prompt id: below ACTION_TOKEN_BEGIN_IDX
+            labels[b, p:p + 64] = torch.randint(151387, 151643, (64,), generator=rng)
+            ids[b, p:p + 64] = labels[b, p:p + 64]
+            ids[b, p + 64:] = 151643                                       # right padding
+        for shift in (0, 1):
+            qidx, pos, cnt = ops.action_mask(labels.to(DEV), shift)
+            m = O.all_actions_mask(labels[:, shift:])
+            assert torch.equal(qidx.cpu() >= 0, m) and cnt.cpu().tolist() == [64] * B, (case, shift)
+        am = ids != 151643
+        table, aq, patches = gen(V, D, seed=2000 + case), gen(64, D, seed=2100 + case), gen(B, Np, D, seed=2200 + case)
+        out = torch.zeros(B, L + Np, D, dtype=BF, device=DEV)
+        out[:, 1:Np + 1] = patches.to(DEV)
+        mm = torch.zeros(B, L + Np, dtype=torch.uint8, device=DEV)
+        qidx, pos, cnt = ops.action_mask(labels.to(DEV), 0)
+        ops.embed_splice(ids.to(DEV), am.to(torch.uint8).to(DEV), qidx, table.to(DEV), aq.to(DEV), out, mm, Np)
+        ref, refm = O.embed_splice(ids, labels, am, table.float(), aq.float(), patches.float())
+        assert torch.equal(f(out), ref) and torch.equal(mm.cpu().bool(), refm), f"splice case {case}"
+    # --- RoPE epilogues
+    for case in range(4):
+        B, S, H, KV, K = ri(1, 3), ri(3, 90), 2 * ri(1, 4), ri(1, 2), 64 * ri(1, 4)
+        dh = 64
+        N = (H + 2 * KV) * dh
+        x, w, bias = gen(B * S, K, seed=2300 + case), gen(N, K, seed=2400 + case, scale=0.1), gen(N, seed=2500 + case)
+        cos, sin = ops.rope_half_tables(S, dh, 1e6, DEV)
+        out = ops.gemm_nt(x.to(DEV), w.to(DEV), bias=bias.to(DEV), rope=(1, cos, sin, S, dh, (H + KV) * dh))
+        y = O.linear(x.float(), w.float(), bias.float(), True)
+        c, s = O.rope_half_tables(S, dh, 1e6, True)
+        q = O.rope_half(y[:, :H * dh].view(B, S, H, dh).transpose(1, 2), c, s, True).transpose(1, 2).reshape(B * S, H * dh)
+        k = O.rope_half(y[:, H * dh:(H + KV) * dh].view(B, S, KV, dh).transpose(1, 2), c, s, True).transpose(1, 2).reshape(B * S, KV * dh)
+        check(out, torch.cat([q, k, y[:, (H + KV) * dh:]], 1), name=f"gemm + rope_half B{B} S{S} H{H} KV{KV} K{K}")
+        T, Hh, dhh = ri(2, 40), 8, [16, 32, 112][ri(0, 2)]
+        Dd = Hh * dhh
+        x2, w2, b2 = gen(B * T, K, seed=2600 + case), gen(2 * Dd, K, seed=2700 + case, scale=0.1), gen(2 * Dd, seed=2800 + case)
+        c2, s2 = ops.rope_inter_tables(T + 3, dhh, DEV)
+        out2 = ops.gemm_nt(x2.to(DEV), w2.to(DEV), bias=b2.to(DEV), rope=(2, c2, s2, T, dhh, Dd))
+        y2 = O.linear(x2.float(), w2.float(), b2.float(), True)
+        cc, ss = O.head_rope_tables(T, dhh, True)
+        k2 = O.head_rope(y2[:, :Dd].view(B, T, Hh, dhh).transpose(1, 2), cc, ss, True).transpose(1, 2).reshape(B * T, Dd)
+        check(out2, torch.cat([k2, y2[:, Dd:]], 1), name=f"gemm + interleaved rope B{B} T{T} dh{dhh}")
+    # --- SwiGLU forward + fused backward
+    for case in range(4):
+        M, Dd, I = ri(1, 500), 64 * ri(1, 4), 64 * ri(1, 6)
+        x, wg, wu = gen(M, Dd, seed=2900 + case), gen(I, Dd, seed=3000 + case, scale=0.1), gen(I, Dd, seed=3100 + case, scale=0.1)
+        w = torch.stack([wg.view(I // 16, 16, Dd), wu.view(I // 16, 16, Dd)], dim=1).reshape(2 * I, Dd)
+        pre, h = ops.gemm_nt(x.to(DEV), w.to(DEV), act=ops.ACT_SWIGLU)
+        g_, u_ = O.linear(x.float(), wg.float(), None, True), O.linear(x.float(), wu.float(), None, True)
+        check(h, O.rnd(O.rnd(g_ * torch.sigmoid(g_), True) * u_, True), name=f"swiglu h {M}x{I}x{Dd}")
+        d, wdT = gen(M, Dd, seed=3200 + case), gen(I, Dd, seed=3300 + case, scale=0.1)
+        fused = ops.gemm_swiglu_bwd(d.to(DEV), wdT.to(DEV), pre)
+        check(fused, f(ops.swiglu_bwd(ops.gemm_nt(d.to(DEV), wdT.to(DEV)), pre)), rel=3e-3, name=f"fused swiglu bwd {M}x{I}x{Dd}")
+    # --- AdamW, odd lengths, several steps, bit-exact against the oracle's torch-emulating restatement
+    for case in range(3):
+        n = 8 * ri(1, 5000)
+        p0, m0, v0 = gen(n, seed=3400 + case, scale=0.05), torch.zeros(n), torch.zeros(n)
+        p, m, v = p0.to(DEV).clone(), torch.zeros(n, dtype=BF, device=DEV), torch.zeros(n, dtype=BF, device=DEV)
+        pr, mr, vr = p0.float(), m0, v0
+        for step in range(1, 4):
+            gg = gen(n, seed=3500 + 10 * case + step, scale=0.01)
+            ops.adamw_(p, gg.to(DEV), m, v, step, 3e-4, 0.9, 0.999, 1e-8, 0.01)
+            pr, mr, vr = O.adamw_step(pr, gg.float(), mr, vr, step, 3e-4, emu=True)
+            assert torch.equal(f(p), pr) and torch.equal(f(m), mr) and torch.equal(f(v), vr), f"adamw n={n} step {step}"
