@@ -394,3 +394,34 @@ def test_fused_two_backbone_two_image_config():
     losses = [e2.train_step_graphed(2e-3)[0].item() for _ in range(10)]
     e2.flush()
     assert losses[-1] < 0.85 * losses[0], losses
+
+
+def test_engine_forward_backward_random_batches():
+    """Seeded sweep over batch size, prompt length and ragged right-padding (key-padding masks of 0-8 trailing keys that cut
+    attention tiles at arbitrary rows) on both plumbing configs: forward parity with the oracle, live-row backward
+    bit-identical to the full backward."""
+    from vla_adapter_amd import engine as E, synthetic as S
+    rng = torch.Generator().manual_seed(8642)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=rng))
+    for case in range(6):
+        cfg = E.tiny_fused_config() if case % 2 else E.tiny_config()
+        W = S.make_weights(cfg, DEV, seed=40 + case, std=0.05)
+        B, P = ri(1, 4), ri(10, 60)
+        batch = S.make_batch(cfg, B, DEV, seed=50 + case, P=P, ragged=True)
+        eng = E.VLAEngine(cfg, W, DEV)
+        pred = eng.forward(batch, None)
+        out, _ = _oracle_run(cfg, W, batch, None, True, cfg.num_blocks)
+        n = cfg.llm.n_layers
+        valid = batch["attention_mask"].cpu()
+        Np = cfg.n_patches
+        full_valid = torch.cat([torch.ones(B, 1, dtype=torch.bool), torch.ones(B, Np, dtype=torch.bool), valid[:, 1:]], 1)
+        for i in range(n + 1):      # rows of padded positions hold don't-care values in both implementations
+            a, b = eng.llm.HS[i].float().cpu()[full_valid], out["hidden_states"][i].detach()[full_valid]
+            r = ((a - b).norm() / b.norm()).item()
+            assert r < 1.5e-2, f"case {case} (B{B} P{P} fused={cfg.fused}) hidden_states[{i}] rel-L2 {r:.3e}"
+        assert rel(pred, out["pred"]) < 1.5e-2, f"case {case}: pred {rel(pred, out['pred']):.3e}"
+        eng.loss_and_backward(pred, batch["actions"])
+        ef = E.VLAEngine(cfg, W, DEV)
+        ef.full_llm_backward = True
+        ef.loss_and_backward(ef.forward(batch, None), batch["actions"])
+        assert torch.equal(ef.head.P.g("action_queries"), eng.head.P.g("action_queries")), f"case {case}: live vs full backward"
