@@ -425,3 +425,35 @@ def test_engine_forward_backward_random_batches():
         ef.full_llm_backward = True
         ef.loss_and_backward(ef.forward(batch, None), batch["actions"])
         assert torch.equal(ef.head.P.g("action_queries"), eng.head.P.g("action_queries")), f"case {case}: live vs full backward"
+
+
+def test_full_size_forward_parity_config2():
+    """BASELINE configs[1] at FULL size (SigLIP so400m 27 blocks, Qwen2.5-0.5B 24 layers, Pro head 24 blocks), batch 2 with a
+    ragged prompt: ViT features, every hidden state and the predicted actions against the oracle (bf16-emulating, ~10 s of
+    host time).  Depth accumulates independent bf16 rounding realisations - measured: 1.5e-2 on the projected patches
+    (26 ViT blocks), 1.5e-2 -> 2.1e-2 over the 24 LLM layers, 1.1e-2 on the actions, 6e-4 on the loss; bounds are ~1.6x that."""
+    from vla_adapter_amd import engine as E, synthetic as S, ops
+    cfg = E.config2()
+    W = S.make_weights(cfg, DEV, seed=0)
+    batch = S.make_batch(cfg, 2, DEV, seed=77, P=32, ragged=True)
+    eng = E.VLAEngine(cfg, W, DEV)
+    pred = eng.forward(batch, None)
+    torch.cuda.synchronize()
+    torch.set_num_threads(min(16, torch.get_num_threads() or 16))
+    out, _ = _oracle_run(cfg, W, batch, None, True, cfg.num_blocks)
+    Np, n, B = cfg.n_patches, cfg.llm.n_layers, 2
+    r = rel(eng.llm.HS[0][:, 1:Np + 1], out["patches"])
+    assert r < 2.5e-2, f"projected patches {r:.3e}"
+    valid = batch["attention_mask"].cpu()
+    fv = torch.cat([torch.ones(B, 1 + Np, dtype=torch.bool), valid[:, 1:]], 1)
+    worst = 0.0
+    for i in range(n + 1):
+        a, b = eng.llm.HS[i].float().cpu()[fv], out["hidden_states"][i].detach()[fv]
+        ri_ = ((a - b).norm() / b.norm()).item()
+        worst = max(worst, ri_)
+        assert ri_ < 3.5e-2, f"hidden_states[{i}] rel-L2 {ri_:.3e}"
+    rp = rel(pred, out["pred"])
+    l_native, _ = ops.l1_loss(pred, batch["actions"].to(BF), False)
+    assert rp < 3e-2, f"pred rel-L2 {rp:.3e} (worst hidden state {worst:.3e})"
+    assert abs(l_native[0].item() - out["loss"].item()) <= 5e-3 * abs(out["loss"].item())
+    print(f"full-size parity: patches {r:.2e}, worst hidden state {worst:.2e}, pred {rp:.2e}")
