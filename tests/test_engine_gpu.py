@@ -457,3 +457,40 @@ def test_full_size_forward_parity_config2():
     assert rp < 3e-2, f"pred rel-L2 {rp:.3e} (worst hidden state {worst:.3e})"
     assert abs(l_native[0].item() - out["loss"].item()) <= 5e-3 * abs(out["loss"].item())
     print(f"full-size parity: patches {r:.2e}, worst hidden state {worst:.2e}, pred {rp:.2e}")
+
+
+def test_full_size_backward_config2():
+    """Full-size backward: action_queries gradient of the live-row backward bit-identical to the full-sequence backward,
+    and within the end-to-end gradient tolerance of the oracle's autograd (driven by the engine's own dpred)."""
+    from vla_adapter_amd import engine as E, synthetic as S, ops
+    cfg = E.config2()
+    W = S.make_weights(cfg, DEV, seed=0)
+    batch = S.make_batch(cfg, 2, DEV, seed=78, P=32, ragged=True)
+    eng = E.VLAEngine(cfg, W, DEV)
+    pred = eng.forward(batch, None)
+    eng.loss_and_backward(pred, batch["actions"])
+    g_live = eng.head.P.grad.clone()
+    assert eng.live_row0() == 256                     # ragged prompts 24..32: first action query >= row 280 -> window from 256
+    eng.full_llm_backward = True
+    eng.loss_and_backward(eng.forward(batch, None), batch["actions"])
+    aq = eng.head.P.offsets["action_queries"][0]
+    assert torch.equal(g_live[aq:], eng.head.P.grad[aq:]), "full-size: action_queries gradient must not depend on the dead rows"
+    assert (g_live[:aq].float() - eng.head.P.grad[:aq].float()).norm() <= 2e-3 * eng.head.P.grad[:aq].float().norm()
+    out, OW = _oracle_run(cfg, W, batch, None, True, cfg.num_blocks)
+    _, dpred = ops.l1_loss(eng.head.pred.view(2, cfg.chunk, cfg.action_dim), batch["actions"].to(BF), True)
+    out["pred"].backward(dpred.float().cpu())
+    r = rel(g_live[aq:].view(64, -1), OW["action_queries"].grad)
+    assert r < 1.5e-1, f"action_queries grad through 24 frozen layers vs oracle autograd: {r:.3e}"
+    # Head gradients.  Backpropagating through 24 ReLU / LayerNorm / softmax blocks amplifies the bf16-level difference of
+    # the forward states; measured on the oracle ITSELF (bf16-emulating vs fp32 evaluation, same weights, same upstream
+    # gradient, tools-free CPU run): fc2 7e-3, block 23 o_proj 3.5e-2, block 12 v_task 1.4e-1, block 0 k_task 3.7e-1,
+    # block 0 ffn 2.7e-1.  The engine-vs-oracle differences sit at or below those (6.8e-3 / 3.5e-2 / 1.1e-1 / 1.8e-1 /
+    # 1.8e-1); the bounds are the oracle's own sensitivity x 1.5.
+    for k, bound in (("model.fc2.weight", 1.5e-2), ("model.mlp_resnet_blocks.23.o_proj.weight", 5.5e-2),
+                     ("model.mlp_resnet_blocks.12.v_task.weight", 2.1e-1), ("model.mlp_resnet_blocks.0.k_task.weight", 5.5e-1),
+                     ("model.mlp_resnet_blocks.0.ffn.1.weight", 4e-1)):
+        got, ref = eng.head.named_views(g_live)[k], OW["head"][k].grad
+        rr = rel(got, ref.reshape(got.shape))
+        print(f"full-size grad {k}: rel {rr:.3e} (bound {bound})")
+        assert rr < bound, f"{k}: rel {rr:.3e}"
+    print(f"full-size grad action_queries: rel {r:.3e}")
