@@ -39,6 +39,7 @@ struct GemmP {
   float alpha;
   int gA, gC, gR; long long sgA, sgC, sgR;  // row-group addressing: row r -> (r / g) * sg + (r % g) * ld
   int c_live_mod, c_live_from;              // C rows with (m % c_live_mod) < c_live_from are not stored
+  int gm;                                   // group-M override (0 = default)
   float* ws;                                // split-K: fp32 [M, N] accumulator (blockIdx.z = K slice), finalised by a second kernel
   int rope_mode, rope_T, rope_dh, rope_cols; const float* rope_cos; const float* rope_sin;
 };
@@ -89,7 +90,10 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
   // group-M order inside the XCD's run: GM row-panels x all column tiles, row index fastest, so the ~32-64 tiles an
   // XCD has in flight form a GM x (32/GM) patch whose A panels stay in that XCD's 4 MiB L2 while B tiles stream once
   // (row-major order re-streamed every B tile from beyond L2 for every row panel: 44 x 17 MB for the gate/up GEMM).
-  constexpr int GM = BM == 256 ? 4 : 8;   // A panels kept L2-resident per XCD
+  // 6 for the 128-row tiles: in the two/three-stream step the XCD's L2 is shared with the other streams' kernels and the
+  // smaller patch wins (same-box sweep: 8 -> 31.55 ms/step, 6 -> 30.85, 5 -> 30.8, 4 -> 31.0, 3 -> 30.85, 12 -> 32.3;
+  // isolated launches are indifferent between 4 and 8).  VLA_GEMM_GM overrides.
+  const int GM = p.gm > 0 ? p.gm : (BM == 256 ? 4 : 6);   // A panels kept L2-resident per XCD
   const int tiles_m = p.ntiles / p.tiles_n, per_group = GM * p.tiles_n;
   const int grp = swz / per_group, rem = swz - grp * per_group;
   const int gm = min(GM, tiles_m - grp * GM);
@@ -505,6 +509,7 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   p.gA = d->a_group; p.sgA = d->a_group_stride; p.gC = d->c_group; p.sgC = d->c_group_stride;
   p.gR = d->r_group; p.sgR = d->r_group_stride;
   p.c_live_mod = d->c_live_mod; p.c_live_from = d->c_live_from;
+  { const char* ge = getenv("VLA_GEMM_GM"); p.gm = ge ? atoi(ge) : 0; }
   p.ws = nullptr;
   const int split = d->split_k > 1 ? d->split_k : 1;
   if (split > 1) {
