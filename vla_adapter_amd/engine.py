@@ -1025,7 +1025,7 @@ class VLAEngine:
     # forward->backward turn-around (little pipeline fill/drain) and longer elsewhere (fewer graph launches).
     def _ensure_streams(self):
         if getattr(self, "side", None) is None:
-            self.side = torch.cuda.Stream(priority=-1)  # the head chain is latency-critical: high priority
+            self.side = torch.cuda.Stream()            # head stream (a high-priority stream measured 0.7 % slower on the step)
             self._cap_main = torch.cuda.Stream()       # capture stream of the "M" graphs (replayed on the current stream)
             self.vis_stream = torch.cuda.Stream()      # vision stage of the NEXT step (fills the backward's idle CUs)
             self._vstreams = [self.vis_stream] + [torch.cuda.Stream() for _ in range(max(0, len(self.vits) - 1))]   # one per backbone
