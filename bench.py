@@ -211,9 +211,15 @@ def main():
         eng.reducer = ddp.FlatGradReducer()
     lr = 5e-4
 
+    def barrier():
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[local])        # pin the device: RCCL otherwise guesses it from the rank
+        else:
+            dist.barrier()
+
     def sync():
         if world > 1:
-            dist.barrier()
+            barrier()
         torch.cuda.synchronize()
 
     if args.eager:
@@ -298,7 +304,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
 
 
