@@ -292,7 +292,8 @@ def main():
             "full_backward_variant": full_bwd,
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 MFMA NT GEMM, all launches of one step)",
                          "achieved": round(roof["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(roof["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": pmc_traffic(),
+                         "frac": round(roof["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
+                         "traffic": (pmc_traffic() or {}).get("bytes_per_launch"), "traffic_detail": pmc_traffic(),
                          "algorithmic_bytes_per_launch": round(roof["bytes"] / roof["launches"]),
                          "avg_launch_us": round(roof["seconds"] / roof["launches"] * 1e6, 1),
                          "timing": "each distinct launch signature of one step replayed back-to-back between two HIP events on its "
