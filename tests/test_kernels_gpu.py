@@ -627,7 +627,8 @@ def test_gemm_live_row_store_and_bias_paths(ops):
     assert torch.equal(o3[:, r0:], r3[:, r0:]) and bool((o3[:, :r0] == 7.0).all())
 
 
-@pytest.mark.parametrize("M,N,K,act,res", [(261, 1024, 4096, 0, True), (625, 896, 4864, 0, True), (512, 1152, 4352, 1, False), (256, 896, 2688, 2, True)])
+@pytest.mark.parametrize("M,N,K,act,res", [(261, 1024, 4096, 0, True), (625, 896, 4864, 0, True), (512, 1152, 4352, 1, False), (256, 896, 2688, 2, True),
+                                            (2048, 896, 9728, 0, False), (3000, 896, 4864, 0, True)])
 def test_gemm_split_k_matches_single_pass(ops, M, N, K, act, res, monkeypatch):
     """Few-tile long-K problems run split-K (slices meet in an fp32 workspace, epilogue in a second kernel): same result as
     the single-pass kernel up to the fp32 summation order."""
@@ -643,6 +644,15 @@ def test_gemm_split_k_matches_single_pass(ops, M, N, K, act, res, monkeypatch):
     y = O.linear(a.float(), w.float(), bias.float(), emu=True)
     y = {0: y, 1: O.rnd(O.gelu(y), True), 2: torch.relu(y)}[act]
     check(out, O.rnd(y + r.float(), True) if res else y, name="split-K vs oracle")
+    for sk in (2, 4, 8):          # forced factors agree with the automatic choice
+        if K % (64 * sk) == 0:
+            forced = torch.empty(M, N, dtype=BF, device=DEV)
+            ops.gemm_nt(a.to(DEV), w.to(DEV), out=forced, split_k=sk, **kw)
+            check(forced, f(ref), rel=2e-3, name=f"split-K {sk} vs single pass")
+    off = torch.empty(M, N, dtype=BF, device=DEV)
+    monkeypatch.delenv("VLA_NO_SPLITK")
+    ops.gemm_nt(a.to(DEV), w.to(DEV), out=off, split_k=0, **kw)
+    assert torch.equal(off, ref), "split_k=0 is the single-pass kernel"
 
 
 def test_gemm_random_shapes_and_epilogues(ops):

@@ -38,9 +38,10 @@ def _chk_bf16(*ts):
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_mod: int = 0, act: int = ACT_NONE,
             out: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, alpha: float = 1.0,
-            want_pre: bool = True, a_group=None, c_group=None, r_group=None, rope=None, c_live=None) -> torch.Tensor:
+            want_pre: bool = True, a_group=None, c_group=None, r_group=None, rope=None, c_live=None,
+            split_k: Optional[int] = None) -> torch.Tensor:
     """C = epilogue(A @ B^T).  a: [M,K] or [batch,M,K] (row stride = a.stride(-2)); b: [N,K] or [batch,N,K].
-    SwiGLU: returns (pre [.., N] or None, h [.., N/2])."""
+    SwiGLU: returns (pre [.., N] or None, h [.., N/2]).  split_k: None = automatic, 0/1 = off, k = forced."""
     _chk_bf16(a, b, bias, residual, out, out2)
     assert a.stride(-1) == 1 and b.stride(-1) == 1
     batched = a.dim() == 3
@@ -93,15 +94,23 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_m
         assert cos_t.shape[1] == (dh // 2 if mode == 1 else dh)
         d.rope_mode, d.rope_T, d.rope_dh, d.rope_cols = mode, T, dh, ncols
         d.rope_cos, d.rope_sin = cos_t.data_ptr(), sin_t.data_ptr()
-    # split-K for few-tile long-K problems (batch-1 inference: M <= 1024): the K loop of a tile is serial, so a problem
-    # with a handful of tiles runs at the latency of ONE long loop; slices meet in a per-stream fp32 workspace
-    if (not batched and M <= 1024 and K >= 2048 and act in (ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_TANH) and out is not None
-            and a_group is None and c_group is None and r_group is None and rope is None and c_live is None and res_mod == 0
-            and ((M + 127) // 128) * ((Nn + 127) // 128) <= 64 and Nn % 4 == 0 and not os.environ.get("VLA_NO_SPLITK")):
-        for sk in (8, 4, 2):
-            if K % (64 * sk) == 0 and K // sk >= 512:
-                d.split_k, d.ws = sk, _splitk_ws(sk * M * Nn, a.device).data_ptr()
-                break
+    # split-K for few-tile long-K problems (batch-1 inference, and the live-row backward's M = B*64 GEMM over K = 2I): the
+    # K loop of a tile is serial, so a problem with fewer tiles than the chip has workgroup slots (2 x 256) runs at the
+    # latency of ONE long loop on part of the CUs; K slices meet in a per-stream fp32 workspace and are summed by
+    # splitk_finalize_kernel
+    plain = (not batched and act in (ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_TANH) and out is not None and a_group is None
+             and c_group is None and r_group is None and rope is None and c_live is None and res_mod == 0 and Nn % 4 == 0)
+    if split_k is None:
+        split_k = 0
+        tiles = ((M + 127) // 128) * ((Nn + 127) // 128)
+        if plain and K >= 2048 and tiles <= 256 and not os.environ.get("VLA_NO_SPLITK"):
+            for sk in (8, 4, 2):
+                if tiles * sk <= 512 and K % (64 * sk) == 0 and K // sk >= 512:
+                    split_k = sk
+                    break
+    if split_k > 1:
+        assert plain and K % (64 * split_k) == 0, "split-K needs a plain epilogue and K divisible by 64 * split_k"
+        d.split_k, d.ws = split_k, _splitk_ws(split_k * M * Nn, a.device).data_ptr()
     N.check(_lib().vla_gemm_bf16_nt(_st(), C.byref(d)), "gemm_bf16_nt")
     if act == ACT_SWIGLU:
         return out, out2
