@@ -39,8 +39,11 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return __builtin_bit_cast(unsigned short, b);
 }
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }  // bf16 rounding point
-__device__ __forceinline__ unsigned pack2(float lo, float hi) {
-  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {   // ONE v_cvt_pk_bf16_f32 (two RNE conversions, lo in bits 0..15)
+  typedef float f32x2_v __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_v __attribute__((ext_vector_type(2)));
+  const bf16x2_v b = __builtin_convertvector(f32x2_v{lo, hi}, bf16x2_v);
+  return __builtin_bit_cast(unsigned, b);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -63,14 +66,25 @@ __device__ __forceinline__ float fast_erf(float x) {
   const float r = 1.0f - poly * __expf(-ax * ax);
   return copysignf(r, x);
 }
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
+// gelu(x) = x * Phi(x) with Phi through the same A&S erf, folded: for z = |x|/sqrt2, t = 1/(1 + p z),
+// erf(z) = 1 - poly(t) exp(-z^2)  =>  gelu(x) = max(x, 0) - |x| * (poly(t)/2) * exp(-x^2/2)   (both signs of x; no
+// 1 - (1 - eps) cancellation on the negative side).  11 VALU + v_rcp + v_exp per element - the fc1 epilogue of the ViT
+// evaluates it 32x per thread per tile, right on the tile's tail.
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(ax, 0.3275911f * 0.70710678118654752440f, 1.0f));
+  const float poly = t * (0.127414796f + t * (-0.142248368f + t * (0.7107068705f + t * (-0.7265760135f + t * 0.5307027145f))));
+  const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);       // exp(-x^2/2)
+  return __builtin_fmaf(-ax * poly, e, fmaxf(x, 0.f));
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float c = 0.3989422804014327f;  // 1/sqrt(2 pi)
   return 0.5f * (1.0f + fast_erf(x * 0.70710678118654752440f)) + x * c * __expf(-0.5f * x * x);
 }
+// 0.5 x (1 + tanh u) = x * sigmoid(2u), u = k (x + 0.044715 x^3): one v_exp + one v_rcp instead of libm tanhf
 __device__ __forceinline__ float gelu_tanh(float x) {
-  const float k = 0.7978845608028654f;
-  return 0.5f * x * (1.0f + tanhf(k * (x + 0.044715f * x * x * x)));
+  const float u2 = x * __builtin_fmaf(x * x, 0.044715f * 1.5957691216057308f, 1.5957691216057308f);   // 2u
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u2 * -1.4426950408889634f));
 }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
