@@ -2,7 +2,13 @@
 // queries of one (sample, head) against three key/value segments [self | adapter | task]; third segment's scores
 // scaled by tanh(gating_factor); softmax over all T+Ka+Kt keys.
 //
-// One WAVE per (sample, head) - 4 independent waves per workgroup, wave-private LDS tiles, no workgroup barrier.
+// Forward: one WORKGROUP per (sample, head); its 4 waves take the 32-key tiles round-robin (wave w: tiles w, w+4, ...)
+// on wave-private LDS tiles and meet once at the end (flash-style merge of (m, l, O) through LDS): the key loop of one
+// (sample, head) is a serial chain of dependent global loads, and with one wave per (sample, head) a launch was 256 such
+// chains of 11 tiles on a quarter of the CUs (37 us); split four ways it is 3 tiles (18 us).
+// Backward: one WAVE per (sample, head) for dQ and per (sample, head, key tile) for dK/dV - 4 independent waves per
+// workgroup, wave-private LDS tiles, no workgroup barrier (the same four-way split of the dQ loop measured 81 vs 85 us
+// isolated but +60 us per layer inside the step: four times the workgroups queue for LDS behind the ViT's GEMMs).
 // Same operand tricks as attention.hip: forward and dQ use the S^T[key x q] orientation (query on the lane, softmax
 // statistics lane-local, P^T feeds O^T = V^T.P^T directly, V^T from ds_read_b64_tr_b16); dK/dV use S[q x key] (key on
 // the lane) with the single 32-row query tile parked in LDS and K/V fragments loaded straight from global memory,
@@ -13,6 +19,8 @@
 #include "head_attn_params.h"
 
 namespace {
+
+constexpr int HEAD_KV_WAVES = 4;   // waves of a forward workgroup that share the key tiles of one (sample, head)
 
 template <int D>
 struct HG {
@@ -95,8 +103,7 @@ __global__ __launch_bounds__(256) void head_fwd_mfma(HP p) {
   using G = HG<D>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = lane >> 5;
-  const int gid = blockIdx.x * 4 + w;
-  if (gid >= p.B * p.H) return;
+  const int gid = blockIdx.x;                          // grid = B * H exactly
   const int b = gid / p.H, hd = gid - b * p.H, hoff = hd * D, N = p.T + p.Ka + p.Kt;
   bf16_t* sK = reinterpret_cast<bf16_t*>(smem + w * G::WAVE_BYTES);
   bf16_t* sV = sK + G::TILE;
@@ -112,14 +119,14 @@ __global__ __launch_bounds__(256) void head_fwd_mfma(HP p) {
   for (int t = 0; t < G::DT; ++t) O[t] = zero16();
   float m_run = -INFINITY, l_run = 0.f;
   u32x4 rk[G::NCH], rv[G::NCH];
-  seg_prefetch<D>(rk, p.ks, p.ka, p.kt, p, b, hoff, 0, N, lane);
-  seg_prefetch<D>(rv, p.vs, p.va, p.vt, p, b, hoff, 0, N, lane);
-  for (int n0 = 0; n0 < N; n0 += 32) {
+  seg_prefetch<D>(rk, p.ks, p.ka, p.kt, p, b, hoff, 32 * w, N, lane);
+  seg_prefetch<D>(rv, p.vs, p.va, p.vt, p, b, hoff, 32 * w, N, lane);
+  for (int n0 = 32 * w; n0 < N; n0 += 32 * HEAD_KV_WAVES) {
     tile_put<D>(rk, sK, lane);
     tile_put<D>(rv, sV, lane);
-    if (n0 + 32 < N) {
-      seg_prefetch<D>(rk, p.ks, p.ka, p.kt, p, b, hoff, n0 + 32, N, lane);
-      seg_prefetch<D>(rv, p.vs, p.va, p.vt, p, b, hoff, n0 + 32, N, lane);
+    if (n0 + 32 * HEAD_KV_WAVES < N) {
+      seg_prefetch<D>(rk, p.ks, p.ka, p.kt, p, b, hoff, n0 + 32 * HEAD_KV_WAVES, N, lane);
+      seg_prefetch<D>(rv, p.vs, p.va, p.vt, p, b, hoff, n0 + 32 * HEAD_KV_WAVES, N, lane);
     }
     wave_lds_sync();
     f32x16 S = zero16();
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(256) void head_fwd_mfma(HP p) {
     }
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     const float m_new = fmaxf(m_run, mt);
-    const float alpha = fexp2(m_run - m_new);       // first tile always holds valid keys: m_new is finite
+    const float alpha = fexp2(m_run - m_new);       // every tile a wave visits holds a valid key: m_new is finite
     float rsum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -156,6 +163,42 @@ __global__ __launch_bounds__(256) void head_fwd_mfma(HP p) {
       for (int t = 0; t < G::DT; ++t) O[t] = mfma32(tr_frag(sV, G::LD, s, 32 * t, lane), pf, O[t]);
     }
     wave_lds_sync();
+  }
+  // merge the waves' partial softmax states in wave 0 (a wave without tiles carries m = -inf, l = 0, O = 0)
+  {
+    float* myO = reinterpret_cast<float*>(smem + w * G::WAVE_BYTES);
+    float* myml = reinterpret_cast<float*>(smem + w * G::WAVE_BYTES + 2 * G::TILE * 2);
+    if (w > 0) {
+#pragma unroll
+      for (int t = 0; t < G::DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) myO[(t * 16 + r) * 64 + lane] = O[t][r];
+      if (lane < 32) { myml[lane] = m_run; myml[32 + lane] = l_run; }
+    }
+    __syncthreads();
+    if (w > 0) return;
+    float M = m_run;
+#pragma unroll
+    for (int ww = 1; ww < HEAD_KV_WAVES; ++ww)
+      M = fmaxf(M, reinterpret_cast<const float*>(smem + ww * G::WAVE_BYTES + 2 * G::TILE * 2)[qi]);
+    const float a0 = fexp2(m_run - M);
+    l_run *= a0;
+#pragma unroll
+    for (int t = 0; t < G::DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[t][r] *= a0;
+#pragma unroll
+    for (int ww = 1; ww < HEAD_KV_WAVES; ++ww) {
+      const float* oO = reinterpret_cast<const float*>(smem + ww * G::WAVE_BYTES);
+      const float* oml = reinterpret_cast<const float*>(smem + ww * G::WAVE_BYTES + 2 * G::TILE * 2);
+      const float a = fexp2(oml[qi] - M);
+      l_run += oml[32 + qi] * a;
+#pragma unroll
+      for (int t = 0; t < G::DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[t][r] += oO[(t * 16 + r) * 64 + lane] * a;
+    }
+    m_run = M;
   }
   if (qi < p.T) {
     const float inv = 1.f / l_run;
@@ -384,7 +427,7 @@ __global__ __launch_bounds__(256) void head_bwd_mfma(HP p, int ndq) {
 template <int D>
 void launch_fwd(const HP& p, hipStream_t st) {
   const size_t lds = 4 * HG<D>::WAVE_BYTES;
-  hipLaunchKernelGGL(head_fwd_mfma<D>, dim3((p.B * p.H + 3) / 4), dim3(256), lds, st, p);
+  hipLaunchKernelGGL(head_fwd_mfma<D>, dim3(p.B * p.H), dim3(256), lds, st, p);
 }
 template <int D>
 void launch_bwd(const HP& p, hipStream_t st) {
