@@ -75,10 +75,11 @@ class FlatGradReducer:
             for a, b in ranges:
                 dist.all_reduce(view[a:b], op=dist.ReduceOp.SUM, group=self.group)
 
-    def wait(self):
-        """Make the current stream wait for the side-stream collectives (no host sync)."""
+    def wait(self, *streams):
+        """Make the given streams (default: the current one) wait for the side-stream collectives (no host sync)."""
         if self._pending:
-            torch.cuda.current_stream().wait_stream(self.stream)
+            for s in (streams or (torch.cuda.current_stream(),)):
+                s.wait_stream(self.stream)
             self._pending = False
 
     @property

@@ -1257,7 +1257,7 @@ class VLAEngine:
         """Replay of the captured step on the static buffers.  The parameter update of THIS step (RCCL exchange +
         AdamW) is left pending and applied inside the next call, after that step's vision graph - or by flush()."""
         cur = torch.cuda.current_stream()
-        self.flush()
+        self.flush(join=False)
         cur.wait_event(self._vis_ev)           # patches of THIS step (computed during the previous call)
         self._h_end = self._run_segments(self._segs, self._graphs, getattr(self, "_timeline", None),
                                          hooks={self._vis_after: lambda ev: self._launch_vision(ev)})[("end", 0)]
@@ -1271,9 +1271,32 @@ class VLAEngine:
         self._pending_lr = lr
         return self._loss3
 
-    def flush(self):
-        """Apply the pending parameter update of the last train_step_graphed (no-op if none)."""
-        if getattr(self, "_pending_lr", None) is not None:
-            torch.cuda.current_stream().wait_event(self._h_end)   # join the head stream of the pending step
-            self.optimizer_step(self._pending_lr)
-            self._pending_lr = None
+    def flush(self, join: bool = True):
+        """Apply the pending parameter update of the last train_step_graphed (no-op if none).  The update is two AdamW
+        launches: the action queries (64 x D, the only trainable tensor the LLM stream reads, in _embed) on the current
+        stream, everything else (head + proprio projector, 99.97 % of the bytes) on the head stream, behind that stream's
+        last backward kernel and ahead of its first forward kernel of the next step - the 0.5 ms of optimiser traffic
+        runs beside the first LLM forward segment instead of in front of it.  ``join`` (default) makes the current stream
+        wait for the head-stream half too, so that callers may read any parameter afterwards (checkpoints, evaluation);
+        the captured step passes False: its head segments run on the head stream anyway."""
+        if getattr(self, "_pending_lr", None) is None:
+            return
+        lr, self._pending_lr = self._pending_lr, None
+        cur, P = torch.cuda.current_stream(), self.head.P
+        aq_off = P.offsets["action_queries"][0]
+        assert aq_off + rup(math.prod(P.offsets["action_queries"][1]), 8) == P.numel, "action_queries must close the flat buffer"
+        self.step_count += 1
+        gscale = 1.0
+        if self.reducer is not None:
+            self.reducer.wait(cur, self.side)
+            gscale = self.reducer.grad_scale
+        if os.environ.get("VLA_UPDATE_ON_MAIN"):       # A/B knob: the whole update in front of the step, on the current stream
+            cur.wait_event(self._h_end)
+        with torch.cuda.stream(cur if os.environ.get("VLA_UPDATE_ON_MAIN") else self.side):
+            ops.adamw_(P.data[:aq_off], P.grad[:aq_off], P.m[:aq_off], P.v[:aq_off], self.step_count, lr, gscale=gscale)
+            side_done = torch.cuda.Event()
+            side_done.record()
+        ops.adamw_(P.data[aq_off:], P.grad[aq_off:], P.m[aq_off:], P.v[aq_off:], self.step_count, lr, gscale=gscale)
+        if join:
+            cur.wait_event(side_done)
+        self.head.dirty = True
