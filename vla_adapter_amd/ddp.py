@@ -8,8 +8,10 @@ the head's gradients; this build all-reduces them (mathematically correct DP).
 MI355X-first design: all trainable parameters live in ONE flat bf16 buffer (engine.FlatParams), so the exchange is
 a handful of large collectives instead of thousands of small ones.  In the captured step the head/proprio gradients
 (437 MB) are final when the head stream ends - before the LLM backward and the next step's vision stage have
-finished: their all-reduce is launched from that event on its own stream and runs underneath them; only the 64x896
-action-query gradient is reduced at the very end.  The update itself is applied at the start of the next step.
+finished: their all-reduce is launched from that event on its own stream and runs underneath them.  The 64x896
+action-query gradient (final when the LLM backward ends, which is earlier) is reduced FIRST: it is all the next step's
+LLM stream waits for, while the big exchange keeps running beside that step's first forward segment and is joined by the
+head stream only.  The update itself is applied at the start of the next step.
 Bucket size defaults to 64 MiB (xGMI is point-to-point, 7 links x ~153 GB/s: large messages amortise the per-
 collective latency; ring all-reduce is per-link bound).  The 1/N scale is folded into the AdamW kernel.
 """
@@ -58,7 +60,7 @@ class FlatGradReducer:
         """Launch the all-reduce of flat[start:end] after everything already enqueued on the current stream - or, with
         ``after_event``, as soon as that event fires (the slice was produced on another stream and is final there)."""
         if self.world == 1:
-            return
+            return None
         end = flat.numel() if end is None else end
         view = flat[start:end]
         ranges = bucket_ranges(view.numel(), self.bucket_bytes // view.element_size())
@@ -70,10 +72,13 @@ class FlatGradReducer:
             with torch.cuda.stream(self.stream):
                 for a, b in ranges:
                     dist.all_reduce(view[a:b], op=dist.ReduceOp.SUM, group=self.group)
+                done = torch.cuda.Event()
+                done.record()
             self._pending = True
-        else:
-            for a, b in ranges:
-                dist.all_reduce(view[a:b], op=dist.ReduceOp.SUM, group=self.group)
+            return done        # fires when THIS slice is reduced (later slices queue behind it on the same stream)
+        for a, b in ranges:
+            dist.all_reduce(view[a:b], op=dist.ReduceOp.SUM, group=self.group)
+        return None
 
     def wait(self, *streams):
         """Make the given streams (default: the current one) wait for the side-stream collectives (no host sync)."""

@@ -1266,8 +1266,11 @@ class VLAEngine:
             aq_off = self.head.P.offsets["action_queries"][0]
             # head / proprio gradients are final when the head stream ends: their exchange starts there, underneath the
             # rest of the LLM backward and the next step's vision stage; the action-query gradient follows the LLM backward
-            self.reducer.reduce_async(self.head.P.grad, 0, aq_off, after_event=self._h_end)
-            self.reducer.reduce_async(self.head.P.grad, aq_off, None)
+            # (the action queries go first on the exchange stream: the LLM backward ends before the head's tail does, and
+            # the next step's LLM stream only waits for them - flush())
+            ev_aq = self.reducer.reduce_async(self.head.P.grad, aq_off, None)
+            ev_head = self.reducer.reduce_async(self.head.P.grad, 0, aq_off, after_event=self._h_end)
+            self._reduced = (ev_aq, ev_head)
         self._pending_lr = lr
         return self._loss3
 
@@ -1288,7 +1291,14 @@ class VLAEngine:
         self.step_count += 1
         gscale = 1.0
         if self.reducer is not None:
-            self.reducer.wait(cur, self.side)
+            ev_aq, ev_head = getattr(self, "_reduced", None) or (None, None)
+            if ev_aq is not None and ev_head is not None:
+                cur.wait_event(ev_aq)                 # the LLM stream needs the action queries only ...
+                self.side.wait_event(ev_head)         # ... the 437 MB head exchange is joined by the head stream
+                self.reducer._pending = False
+            else:
+                self.reducer.wait(cur, self.side)
+            self._reduced = None
             gscale = self.reducer.grad_scale
         if os.environ.get("VLA_UPDATE_ON_MAIN"):       # A/B knob: the whole update in front of the step, on the current stream
             cur.wait_event(self._h_end)
