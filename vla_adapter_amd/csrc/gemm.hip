@@ -141,13 +141,18 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
   // epilogue it cost a dependent global load per element right on every tile's tail.
   const int wm0 = m0 + wr * 64, wn0 = n0 + wc * C::WTN;
   const int lq = lane >> 4, lr = lane & 15;
+  // Tile-local first column of this wave's 16-wide n tile ni.  Plain: WTN consecutive columns.  Fused rotate_half on the
+  // 8-wave geometry (32 columns per wave, head dim 64): the wave owns 16 columns of EACH half of one head, so that the
+  // rotation partners d <-> d + 32 are n tiles 0 and 1 of the same lane (no exchange between waves).
+  constexpr bool PERM = ROPE == 1 && C::NT == 2;
+  auto cbase = [&](int ni) { return PERM ? (wc >> 1) * 64 + ni * 32 + (wc & 1) * 16 : wc * C::WTN + ni * 16; };
   const bf16_t* bias = p.bias ? p.bias + (long long)z * p.sBias : nullptr;
   float bv[C::NT][4];
   {
     const bool bvec = bias && (((size_t)bias & 7) == 0);
 #pragma unroll
     for (int ni = 0; ni < C::NT; ++ni) {
-      const int n = wn0 + ni * 16 + lq * 4;
+      const int n = n0 + cbase(ni) + lq * 4;
       if (bvec && n + 3 < p.N) {
         const uint2 b2 = *reinterpret_cast<const uint2*>(bias + n);
         bv[ni][0] = bf2f((bf16_t)(b2.x & 0xffff)); bv[ni][1] = bf2f((bf16_t)(b2.x >> 16));
@@ -176,7 +181,7 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
       stage(nb, (t + STAGES - 1) * BK);
     }
     const char* sa = smem + buf * C::STAGE_BYTES + wr * 64 * 128;
-    const char* sb = smem + buf * C::STAGE_BYTES + C::A_BYTES + wc * C::WTN * 128;
+    const char* sb = smem + buf * C::STAGE_BYTES + C::A_BYTES;     // B tile; n tile i of this wave starts at row cbase(i)
     if constexpr (C::NT <= 4) {
       // all fragment reads of the K-tile (both 32-deep k-steps) are issued up front: the second k-step's LDS latency
       // hides under the first k-step's MFMAs instead of stalling between them
@@ -186,7 +191,7 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) fm[s][i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + foff[s]);
 #pragma unroll
-        for (int i = 0; i < C::NT; ++i) fn[s][i] = *reinterpret_cast<const bf16x8*>(sb + i * 16 * 128 + foff[s]);
+        for (int i = 0; i < C::NT; ++i) fn[s][i] = *reinterpret_cast<const bf16x8*>(sb + cbase(i) * 128 + foff[s]);
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s)
@@ -203,7 +208,7 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) fm[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + foff[s]);
 #pragma unroll
-        for (int i = 0; i < C::NT; ++i) fn[i] = *reinterpret_cast<const bf16x8*>(sb + i * 16 * 128 + foff[s]);
+        for (int i = 0; i < C::NT; ++i) fn[i] = *reinterpret_cast<const bf16x8*>(sb + cbase(i) * 128 + foff[s]);
 #pragma unroll
         for (int ni = 0; ni < C::NT; ++ni)
 #pragma unroll
@@ -324,7 +329,7 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
     else if (p.act == VLA_ACT_GELU_TANH) finish([](float v) { return gelu_tanh(rbf(v)); });
     else finish([](float v) { return v; });
     // ---- fused rotary embedding on the projected q/k columns (saves a full read+write pass per projection)
-    if (ROPE != 0 && wn0 < p.rope_cols) {
+    if (ROPE != 0 && n0 + cbase(0) < p.rope_cols) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
         const int pos = min(wm0 + mi * 16 + lr, p.M - 1) % p.rope_T;
@@ -357,6 +362,18 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
               acc[ni + 2][mi][j] = rbf(b * cc[j]) + rbf(a * ss[j]);
             }
           }
+        } else if (ROPE == 1 && C::NT == 2) {
+          // same rotation on the permuted 8-wave layout: n tile 0 holds head columns d = 16 (wc & 1) + 4 lq + j, tile 1 d + 32
+          const int half = p.rope_dh >> 1, d = (wc & 1) * 16 + lq * 4;
+          const float4 c = *reinterpret_cast<const float4*>(p.rope_cos + (long long)pos * half + d);
+          const float4 sn = *reinterpret_cast<const float4*>(p.rope_sin + (long long)pos * half + d);
+          const float cc[4] = {c.x, c.y, c.z, c.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float a = rbf(acc[0][mi][j]), b = rbf(acc[1][mi][j]);
+            acc[0][mi][j] = rbf(a * cc[j]) + rbf(-b * ss[j]);
+            acc[1][mi][j] = rbf(b * cc[j]) + rbf(a * ss[j]);
+          }
         }
       }
     }
@@ -382,7 +399,7 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
 #pragma unroll
     for (int it = 0; it < C::EPI_ROWS / RPP; ++it) {
       const int row = it * RPP + lane / CH, ch = lane % CH;
-      const int m = wm0 + half * C::EPI_ROWS + row, n = wn0 + ch * 8;
+      const int m = wm0 + half * C::EPI_ROWS + row, n = n0 + cbase(ch >> 1) + (ch & 1) * 8;
       uint4 v = *reinterpret_cast<const uint4*>(reg + row * C::EPI_STRIDE + ch * 16);
       if (m >= p.M || n >= p.N) continue;
       if (p.c_live_mod > 0 && (m % p.c_live_mod) < p.c_live_from) continue;   // row never read again (live-row backward)
@@ -426,7 +443,7 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
 //  * 128x64 (4 waves, 3 blocks/CU) only for problems smaller than one round of tiles (the M=256 head GEMMs).
 struct TileChoice { int bm, bn; };
 inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode, int batch = 1) {
-  if (rope_mode == 1) return {128, 128};   // rotate_half pairs live in one wave's 64-column tile
+  if (rope_mode == 1) return {128, 128};   // rotate_half: 8 waves, each owning 16 columns of both halves of one head
   if (force == 1 && rope_mode == 0) return {256, 128};
   if (force == 2) return {128, 128};
   if (force == 3) return {128, 64};
@@ -545,7 +562,7 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   const TileChoice tc = choose_tile(d->M, d->N, d->K / split, e ? atoi(e) : 0, d->rope_mode, split > 1 ? split : d->batch);
   hipStream_t st = (hipStream_t)stream;
   if (d->act == VLA_ACT_SWIGLU_BWD) launch<128, 128, 2, 3, 4>(p, d->M, d->N, d->batch, st);
-  else if (d->rope_mode == 1) launch<128, 128, 2, 1>(p, d->M, d->N, d->batch, st);
+  else if (d->rope_mode == 1) launch<128, 128, 2, 1, 4>(p, d->M, d->N, d->batch, st);   // 8 waves, rotation pairs inside a lane
   else if (d->rope_mode == 2) {
     if (tc.bn == 128) launch<128, 128, 2, 2, 4>(p, d->M, d->N, d->batch, st);
     else launch<128, 64, 2, 2>(p, d->M, d->N, d->batch, st);
