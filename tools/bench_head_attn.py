@@ -23,7 +23,7 @@ def timeit(fn, iters=50, warm=5):
 
 
 def main():
-    B, T, Ka, Kt, H, D = 32, 8, 65, 256, 8, 896
+    B, T, Ka, Kt, H, D = 32, 8, 65, int(sys.argv[1]) if len(sys.argv) > 1 else 256, 8, 896
     g = lambda *s: (torch.randn(*s, device="cuda") * 0.3).to(torch.bfloat16)
     x3, a2, t2 = g(B, T, 3 * D), g(B, Ka, 2 * D), g(B, Kt, 2 * D)
     gate, dout = torch.tensor([0.7], device="cuda").to(torch.bfloat16), g(B, T, D)
