@@ -320,6 +320,56 @@ __global__ void adamw_kernel(bf16_t* __restrict__ p, const void* __restrict__ g,
   }
 }
 
+// 8 parameters per thread, 16-B accesses (the scalar kernel above stays for tails and unaligned slices): same arithmetic
+__device__ __forceinline__ void adamw_one(float& pf, float gr, float& mf, float& vf, float decay, float omb1, float beta2, float omb2,
+                                          float bc2_sqrt, float eps, float neg_step) {
+  pf = rbf(pf * decay);
+  mf = rbf(__builtin_fmaf(omb1, gr - mf, mf));
+  vf = rbf(__builtin_fmaf(omb2 * gr, gr, rbf(vf * beta2)));
+  const float den = rbf(rbf(rbf(sqrtf(vf)) / bc2_sqrt) + eps);
+  pf = rbf(__builtin_fmaf(neg_step, mf / den, pf));
+}
+__global__ void adamw_vec8_kernel(uint4* __restrict__ p, const void* __restrict__ g, uint4* __restrict__ m, uint4* __restrict__ v,
+                                  long long n8, float decay, float omb1, float beta2, float omb2, float bc2_sqrt, float eps,
+                                  float neg_step, int g_f32, float gscale) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    const uint4 pv = p[i], mv = m[i], vv = v[i];
+    float gr[8];
+    if (g_f32) {
+      const float4 g0 = ((const float4*)g)[2 * i], g1 = ((const float4*)g)[2 * i + 1];
+      const float t[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) gr[k] = rbf(t[k] * gscale);
+    } else {
+      const uint4 gv = ((const uint4*)g)[i];
+      const unsigned t[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        gr[2 * k] = bf2f((bf16_t)(t[k] & 0xffff));
+        gr[2 * k + 1] = bf2f((bf16_t)(t[k] >> 16));
+      }
+      if (gscale != 1.f) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gr[k] = rbf(gr[k] * gscale);
+      }
+    }
+    const unsigned pw[4] = {pv.x, pv.y, pv.z, pv.w}, mw[4] = {mv.x, mv.y, mv.z, mv.w}, vw[4] = {vv.x, vv.y, vv.z, vv.w};
+    unsigned po[4], mo[4], vo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float p0 = bf2f((bf16_t)(pw[k] & 0xffff)), p1 = bf2f((bf16_t)(pw[k] >> 16));
+      float m0 = bf2f((bf16_t)(mw[k] & 0xffff)), m1 = bf2f((bf16_t)(mw[k] >> 16));
+      float v0 = bf2f((bf16_t)(vw[k] & 0xffff)), v1 = bf2f((bf16_t)(vw[k] >> 16));
+      adamw_one(p0, gr[2 * k], m0, v0, decay, omb1, beta2, omb2, bc2_sqrt, eps, neg_step);
+      adamw_one(p1, gr[2 * k + 1], m1, v1, decay, omb1, beta2, omb2, bc2_sqrt, eps, neg_step);
+      po[k] = pack2(p0, p1); mo[k] = pack2(m0, m1); vo[k] = pack2(v0, v1);
+    }
+    p[i] = uint4{po[0], po[1], po[2], po[3]};
+    m[i] = uint4{mo[0], mo[1], mo[2], mo[3]};
+    v[i] = uint4{vo[0], vo[1], vo[2], vo[3]};
+  }
+}
+
 }  // namespace
 
 #define GRID1D(n, per) dim3(min(nblk((n), (per)), 8192u))
@@ -512,8 +562,16 @@ extern "C" int vla_adamw_bf16(void* stream, void* p, const void* g, void* m, voi
   const float decay = (float)(1.0 - lr * wd);
   const float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
   const float neg_step = (float)(-(lr / bc1));
-  hipLaunchKernelGGL(adamw_kernel, GRID1D(n, 256), dim3(256), 0, (hipStream_t)stream, (bf16_t*)p, g, (bf16_t*)m, (bf16_t*)v, n,
-                     decay, omb1, (float)beta2, omb2, (float)sqrt(bc2), (float)eps, neg_step, g_f32, gscale == 0.f ? 1.f : gscale);
+  const float gs = gscale == 0.f ? 1.f : gscale;
+  const bool aligned = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;
+  const long long n8 = aligned ? n / 8 : 0, done = n8 * 8;
+  if (n8 > 0)
+    hipLaunchKernelGGL(adamw_vec8_kernel, GRID1D(n8, 256), dim3(256), 0, (hipStream_t)stream, (uint4*)p, g, (uint4*)m, (uint4*)v, n8,
+                       decay, omb1, (float)beta2, omb2, (float)sqrt(bc2), (float)eps, neg_step, g_f32, gs);
+  if (done < n)          // tail (< 8 elements) or an unaligned slice: scalar kernel
+    hipLaunchKernelGGL(adamw_kernel, GRID1D(n - done, 256), dim3(256), 0, (hipStream_t)stream, (bf16_t*)p + done,
+                       g_f32 ? (const void*)((const float*)g + done) : (const void*)((const bf16_t*)g + done), (bf16_t*)m + done,
+                       (bf16_t*)v + done, n - done, decay, omb1, (float)beta2, omb2, (float)sqrt(bc2), (float)eps, neg_step, g_f32, gs);
   VLA_CHECK_LAUNCH("adamw");
   return VLA_OK;
 }
