@@ -187,6 +187,37 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
     if (c0 + c < cols && r0 + tx < rows) ob[(long long)(c0 + c) * ldo + r0 + tx] = t[tx][c];
 }
 
+// 16-B variant (cols % 8 == 0, rows % 8 == 0, ld % 8 == 0, 16-B aligned bases): a lane moves 8 elements per global access
+// and both sides run in full 128-B lines (8 lanes per input row on the way in, 8 lanes per output row on the way out).
+// LDS pitch 66 elements = 33 dwords (odd): the transposed 2-B gathers of a wave (8 row groups x 8 columns) fall on 32
+// distinct banks.
+__global__ __launch_bounds__(256) void transpose_vec_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int rows,
+                                                            int cols, int ldi, int ldo, long long s_in, long long s_out) {
+  __shared__ unsigned t32[64 * 33];
+  const bf16_t* ib = in + (long long)blockIdx.z * s_in;
+  bf16_t* ob = out + (long long)blockIdx.z * s_out;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 512; i += 256) {
+    const int r = i >> 3, ch = i & 7;
+    uint4 v = {0u, 0u, 0u, 0u};
+    if (r0 + r < rows && c0 + ch * 8 < cols) v = *reinterpret_cast<const uint4*>(ib + (long long)(r0 + r) * ldi + c0 + ch * 8);
+    unsigned* d = t32 + r * 33 + ch * 4;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  __syncthreads();
+  const bf16_t* t = reinterpret_cast<const bf16_t*>(t32);
+  for (int i = threadIdx.x; i < 512; i += 256) {
+    const int g = i & 7, c = i >> 3;                     // 8 consecutive lanes = one 128-B run of an output row
+    if (c0 + c < cols && r0 + g * 8 < rows) {
+      unsigned o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        o[k] = (unsigned)t[(g * 8 + 2 * k) * 66 + c] | ((unsigned)t[(g * 8 + 2 * k + 1) * 66 + c] << 16);
+      *reinterpret_cast<uint4*>(ob + (long long)(c0 + c) * ldo + r0 + g * 8) = uint4{o[0], o[1], o[2], o[3]};
+    }
+  }
+}
+
 __global__ void colsum_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int rows, int cols, int ldx, int rows_per,
                               long long s_x, long long s_out) {
   const int c = blockIdx.x * 256 + threadIdx.x;
@@ -493,7 +524,12 @@ extern "C" int vla_transpose_bf16(void* stream, const void* in, void* out, int r
                                   long long s_in, long long s_out) {
   VLA_REQUIRE(in && out && rows > 0 && cols > 0 && ldi >= cols && ldo >= rows && batch > 0, "transpose: bad args");
   dim3 grid((cols + 63) / 64, (rows + 63) / 64, batch);
-  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, (bf16_t*)out, rows, cols, ldi, ldo, s_in, s_out);
+  const bool vec = rows % 8 == 0 && cols % 8 == 0 && ldi % 8 == 0 && ldo % 8 == 0 && s_in % 8 == 0 && s_out % 8 == 0 &&
+                   ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL(transpose_vec_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, (bf16_t*)out, rows, cols, ldi, ldo, s_in, s_out);
+  else
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, (bf16_t*)out, rows, cols, ldi, ldo, s_in, s_out);
   VLA_CHECK_LAUNCH("transpose");
   return VLA_OK;
 }
