@@ -166,7 +166,7 @@ int vla_embed_splice(void* stream, const long long* ids, const unsigned char* at
 /* d action_queries[k] = sum_b dX[b, Np + pos[b,k]] (f32 [64, D]); backward of the splice. pos from shift=0 mask.
  * dx holds the rows >= row0 of every sequence: bf16 [B, S, D] with S = (sequence length - row0). */
 int vla_action_query_grad(void* stream, const void* dx, const int* pos, float* dq, int B, int S, int Np, int D, int row0);
-/* out[i, :] = in[idx[i], :] (idx<0 -> zeros); bf16 rows of D elements. */
+/* out[i, :] = in[idx[i], :] (idx == -2 -> row i is left untouched, any other idx < 0 -> zeros); bf16 rows of D elements. */
 int vla_gather_rows(void* stream, const void* in, const int* idx, void* out, int n, int D, int ldi, int ldo);
 /* out[idx[i], :] += in[i, :] (idx unique, idx<0 skipped). */
 int vla_scatter_add_rows(void* stream, const void* in, const int* idx, void* out, int n, int D, int ldi, int ldo);

@@ -106,6 +106,7 @@ __global__ void gather_rows_kernel(const bf16_t* __restrict__ in, const int* __r
   const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= n) return;
   const int s = idx[r];
+  if (s == -2) return;                                   // -2: leave the output row alone (-1: zero it)
   for (int e = lane * 8; e < D; e += 512) {
     uint4 v = s >= 0 ? *reinterpret_cast<const uint4*>(in + (long long)s * ldi + e) : uint4{0, 0, 0, 0};
     *reinterpret_cast<uint4*>(out + r * ldo + e) = v;

@@ -558,7 +558,6 @@ class Head:
         self.h_adpT, self.dKV_adpT = z(nb, D, self.AK), z(nb, 2 * D, self.AK)
         self.h_taskT, self.dKV_taskT = z(nb, D, self.TK), z(nb, 2 * D, self.TK)
         self.dh_adp = e(nb, B * Ka, D)
-        self.gtmp = e(B * NUM_TOKENS, D)
         self.dpad = z(R, 64)
         self.rope_tab = ops.rope_inter_tables(max(T, Ka, Kt), D // self.H, dev)
         self._key = (B, Kt)
@@ -592,6 +591,10 @@ class Head:
         self.pf = ops.gemm_nt(self.pp_act, P.view("p_fc2_w"), bias=P.view("p_fc2_b"))       # [B, D]
         # rows of the 64 action-query hidden states inside one [B*S, D] layer slab
         self.row_idx = (torch.arange(B, device=HS.device, dtype=torch.int32)[:, None] * S + Np + pos1).to(torch.int32).contiguous()
+        # the adapter segment of every block = [64 action-query hidden states | proprio token]: the gather writes straight
+        # into h_adp[i] (index -2 = leave the row alone), the proprio token is filled in once for all blocks
+        self.row_idx_ka = torch.cat([self.row_idx, torch.full((B, 1), -2, device=HS.device, dtype=torch.int32)], dim=1).contiguous()
+        self.h_adp[:, :, NUM_TOKENS] = self.pf
         if noise is not None:
             self.x_in.view(B, T, self.Din).copy_(noise.to(BF16)[None].expand(B, T, self.Din))
         else:
@@ -607,9 +610,7 @@ class Head:
         rc, rs_ = self.rope_tab
         hs2 = HS[i + 1].view(B * S, D)
         # adapter tokens: the 64 action-query hidden states + the proprio token (:347); K/V projections, RoPE on K
-        ops.gather_rows(hs2, self.row_idx.view(-1), self.gtmp)
-        self.h_adp[i, :, :NUM_TOKENS] = self.gtmp.view(B, NUM_TOKENS, D)
-        self.h_adp[i, :, NUM_TOKENS] = self.pf
+        ops.gather_rows(hs2, self.row_idx_ka.view(-1), self.h_adp[i].view(B * Ka, D))
         wa, ba, _ = self._kv("adp", i)
         ops.gemm_nt(self.h_adp[i].view(B * Ka, D), wa, bias=ba, out=self.KV_adp[i])
         # task tokens = HS[i+1][:, :Np] read in place (row-group addressing)
@@ -674,6 +675,8 @@ class Head:
         loc = Np + pos1.to(torch.int32) - row0                     # [B, 64] row inside the live window (or < 0: dead row)
         base = torch.arange(B, device=loc.device, dtype=torch.int32)[:, None] * (S - row0)
         self.row_idx_live = torch.where((loc >= 0) & (pos1 >= 0), base + loc, torch.full_like(loc, -1)).to(torch.int32).contiguous()
+        # same indices over the [B, Ka] adapter rows (the proprio token's row scatters nowhere: -1)
+        self.row_idx_live_ka = torch.cat([self.row_idx_live, torch.full((B, 1), -1, device=loc.device, dtype=torch.int32)], dim=1).contiguous()
         self._prep_key = (B, S, Np, row0)
 
     def bwd_begin(self, dpred: torch.Tensor, row0: int = 0):
@@ -708,9 +711,7 @@ class Head:
         self.dx = ops.gemm_nt(self.dQKVx[i], self.T["w_x"][i], residual=do2)
         # d h_adapter -> action rows of dHS[i+1] (+ the proprio token's gradient); d h_task -> dHS[i+1][:, :Np] in place
         ops.gemm_nt(self.dKV_adp[i], self._kv("adp", i)[2], out=self.dh_adp[i])
-        dha = self.dh_adp[i].view(B, Ka, D)
-        self.gtmp.view(B, NUM_TOKENS, D).copy_(dha[:, :NUM_TOKENS])
-        ops.scatter_add_rows(self.gtmp, self.row_idx_live.view(-1), dHS[i + 1].view(-1, D))
+        ops.scatter_add_rows(self.dh_adp[i], self.row_idx_live_ka.view(-1), dHS[i + 1].view(-1, D))
         if self.row0 == 0:
             ops.gemm_nt(self.dKV_task[i], self._kv("task", i)[2], out=dHS[i + 1].view(B * S, D)[:B * Kt], c_group=(Kt, S * D))
 
