@@ -311,6 +311,35 @@ __global__ void rope_inter_kernel(bf16_t* __restrict__ x, const float* __restric
   }
 }
 
+// 16-B variant: a thread owns 8 consecutive elements (4 rotation pairs) of one head; 32-bit index math
+__global__ void rope_inter_vec_kernel(bf16_t* __restrict__ x, const float* __restrict__ ct, const float* __restrict__ st,
+                                      int rows, int T, int nheads, int dh, int ldx, int mode) {
+  const int cpr = nheads * dh / 8;
+  const long long total = (long long)rows * cpr;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cpr), col = (int)(i - (long long)r * cpr) * 8;
+    const int d0 = col % dh, pos = r % T;
+    uint4* px = reinterpret_cast<uint4*>(x + (long long)r * ldx + col);
+    float f[8], o[8];
+    unpack8(*px, f);
+    const float4 c0 = *reinterpret_cast<const float4*>(ct + (long long)pos * dh + d0), c1 = *reinterpret_cast<const float4*>(ct + (long long)pos * dh + d0 + 4);
+    const float4 s0 = *reinterpret_cast<const float4*>(st + (long long)pos * dh + d0), s1 = *reinterpret_cast<const float4*>(st + (long long)pos * dh + d0 + 4);
+    const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, ss[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      const float a = f[k], b = f[k + 1];
+      if (mode == 0) {
+        o[k] = rbf(a * cc[k]) + rbf(-b * ss[k]);
+        o[k + 1] = rbf(b * cc[k + 1]) + rbf(a * ss[k + 1]);
+      } else {
+        o[k] = a * cc[k] + b * ss[k + 1];
+        o[k + 1] = b * cc[k + 1] - a * ss[k];
+      }
+    }
+    *px = pack8(o);
+  }
+}
+
 // ---------------------------------------------------------------- L1 loss (finetune.py:418-444)
 __global__ __launch_bounds__(256) void l1_loss_kernel(const bf16_t* __restrict__ pred, const bf16_t* __restrict__ tgt,
                                                       float* __restrict__ loss3, bf16_t* __restrict__ dpred, int B, int C,
@@ -578,6 +607,10 @@ extern "C" int vla_rope_interleaved(void* stream, void* x, const float* cos_t, c
                                     int dh, int ldx, int mode) {
   VLA_REQUIRE(x && cos_t && sin_t && rows > 0 && T > 0 && nheads > 0 && dh % 2 == 0 && ldx >= nheads * dh, "rope_interleaved: bad args");
   const long long total = (long long)rows * nheads * (dh / 2);
+  if (dh % 8 == 0 && ldx % 8 == 0 && (((uintptr_t)x | (uintptr_t)cos_t | (uintptr_t)sin_t) & 15) == 0) {
+    const long long tv = (long long)rows * (nheads * dh / 8);
+    hipLaunchKernelGGL(rope_inter_vec_kernel, GRID1D(tv, 256), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, cos_t, sin_t, (int)rows, T, nheads, dh, ldx, mode);
+  } else
   hipLaunchKernelGGL(rope_inter_kernel, GRID1D(total, 256), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, cos_t, sin_t, (long long)rows, T, nheads, dh, ldx, mode);
   VLA_CHECK_LAUNCH("rope_interleaved");
   return VLA_OK;
