@@ -35,21 +35,49 @@ struct HG {
 
 __device__ __forceinline__ const bf16_t* hrow(const bf16_t* s0, const bf16_t* s1, const bf16_t* s2, const HP& p, int b, int n,
                                               int hoff) {
-  if (n < p.T) return s0 + ((long long)b * p.T + n) * p.ld_self + hoff;
-  if (n < p.T + p.Ka) return s1 + ((long long)b * p.Ka + (n - p.T)) * p.ld_adp + hoff;
-  return s2 + ((long long)b * p.Kt + (n - p.T - p.Ka)) * p.ld_task + hoff;
+  // branch-free segment select (the three-way if/else became ~40 exec-mask regions per key tile in the prefetch loops)
+  const bool in0 = n < p.T, in1 = n < p.T + p.Ka;
+  const bf16_t* base = in0 ? s0 : (in1 ? s1 : s2);
+  const int len = in0 ? p.T : (in1 ? p.Ka : p.Kt);
+  const int ld = in0 ? p.ld_self : (in1 ? p.ld_adp : p.ld_task);
+  const int loc = in0 ? n : (in1 ? n - p.T : n - p.T - p.Ka);
+  return base + ((long long)b * len + loc) * ld + hoff;
 }
 
-// 32 consecutive keys n0.. (clamped to N-1) of the segmented K or V tensor -> registers -> wave-private LDS tile
-template <int D>
-__device__ __forceinline__ void seg_prefetch(u32x4* __restrict__ v, const bf16_t* s0, const bf16_t* s1, const bf16_t* s2,
-                                             const HP& p, int b, int hoff, int n0, int N, int lane) {
+// 32 consecutive keys n0.. (clamped to N-1) of the segmented K AND V tensors -> registers -> wave-private LDS tiles.
+// K and V of a segment share row count and row stride (checked by the host wrapper), so one element offset serves both.
+// SELECT: branch-free segment select (backward: the three-way if/else became ~40 exec-mask regions per key tile, 117 ->
+// 79 us for the launch) or plain branches (forward: 18 vs 23 us - its waves visit three tiles only).
+template <int D, bool SELECT>
+__device__ __forceinline__ void seg_prefetch_kv(u32x4* __restrict__ vk, u32x4* __restrict__ vv, const HP& p, int b, int hoff, int n0,
+                                                int N, int lane) {
   using G = HG<D>;
 #pragma unroll
   for (int i = 0; i < G::NCH; ++i) {
     const int c = min(lane + i * 64, 32 * G::CPR - 1);
     const int r = c / G::CPR, ch = c - r * G::CPR;
-    v[i] = *reinterpret_cast<const u32x4*>(hrow(s0, s1, s2, p, b, min(n0 + r, N - 1), hoff) + ch * 8);
+    const int n = min(n0 + r, N - 1);
+    if constexpr (SELECT) {
+      const bool in0 = n < p.T, in1 = n < p.T + p.Ka;
+      const int len = in0 ? p.T : (in1 ? p.Ka : p.Kt);
+      const int ld = in0 ? p.ld_self : (in1 ? p.ld_adp : p.ld_task);
+      const int loc = in0 ? n : (in1 ? n - p.T : n - p.T - p.Ka);
+      const long long off = ((long long)b * len + loc) * ld + hoff + ch * 8;
+      vk[i] = *reinterpret_cast<const u32x4*>((in0 ? p.ks : (in1 ? p.ka : p.kt)) + off);
+      vv[i] = *reinterpret_cast<const u32x4*>((in0 ? p.vs : (in1 ? p.va : p.vt)) + off);
+    } else if (n < p.T) {
+      const long long off = ((long long)b * p.T + n) * p.ld_self + hoff + ch * 8;
+      vk[i] = *reinterpret_cast<const u32x4*>(p.ks + off);
+      vv[i] = *reinterpret_cast<const u32x4*>(p.vs + off);
+    } else if (n < p.T + p.Ka) {
+      const long long off = ((long long)b * p.Ka + (n - p.T)) * p.ld_adp + hoff + ch * 8;
+      vk[i] = *reinterpret_cast<const u32x4*>(p.ka + off);
+      vv[i] = *reinterpret_cast<const u32x4*>(p.va + off);
+    } else {
+      const long long off = ((long long)b * p.Kt + (n - p.T - p.Ka)) * p.ld_task + hoff + ch * 8;
+      vk[i] = *reinterpret_cast<const u32x4*>(p.kt + off);
+      vv[i] = *reinterpret_cast<const u32x4*>(p.vt + off);
+    }
   }
 }
 template <int D>
@@ -119,14 +147,12 @@ __global__ __launch_bounds__(256) void head_fwd_mfma(HP p) {
   for (int t = 0; t < G::DT; ++t) O[t] = zero16();
   float m_run = -INFINITY, l_run = 0.f;
   u32x4 rk[G::NCH], rv[G::NCH];
-  seg_prefetch<D>(rk, p.ks, p.ka, p.kt, p, b, hoff, 32 * w, N, lane);
-  seg_prefetch<D>(rv, p.vs, p.va, p.vt, p, b, hoff, 32 * w, N, lane);
+  seg_prefetch_kv<D, false>(rk, rv, p, b, hoff, 32 * w, N, lane);
   for (int n0 = 32 * w; n0 < N; n0 += 32 * HEAD_KV_WAVES) {
     tile_put<D>(rk, sK, lane);
     tile_put<D>(rv, sV, lane);
     if (n0 + 32 * HEAD_KV_WAVES < N) {
-      seg_prefetch<D>(rk, p.ks, p.ka, p.kt, p, b, hoff, n0 + 32 * HEAD_KV_WAVES, N, lane);
-      seg_prefetch<D>(rv, p.vs, p.va, p.vt, p, b, hoff, n0 + 32 * HEAD_KV_WAVES, N, lane);
+      seg_prefetch_kv<D, false>(rk, rv, p, b, hoff, n0 + 32 * HEAD_KV_WAVES, N, lane);
     }
     wave_lds_sync();
     f32x16 S = zero16();
@@ -253,14 +279,12 @@ __device__ __forceinline__ void head_dq_body(const HP& p, const int blk, char* s
   for (int t = 0; t < G::DT; ++t) dQ[t] = zero16();
   float gpart = 0.f;
   u32x4 rk[G::NCH], rv[G::NCH];
-  seg_prefetch<D>(rk, p.ks, p.ka, p.kt, p, b, hoff, 0, N, lane);
-  seg_prefetch<D>(rv, p.vs, p.va, p.vt, p, b, hoff, 0, N, lane);
+  seg_prefetch_kv<D, true>(rk, rv, p, b, hoff, 0, N, lane);
   for (int n0 = 0; n0 < N; n0 += 32) {
     tile_put<D>(rk, sK, lane);
     tile_put<D>(rv, sV, lane);
     if (n0 + 32 < N) {
-      seg_prefetch<D>(rk, p.ks, p.ka, p.kt, p, b, hoff, n0 + 32, N, lane);
-      seg_prefetch<D>(rv, p.vs, p.va, p.vt, p, b, hoff, n0 + 32, N, lane);
+      seg_prefetch_kv<D, true>(rk, rv, p, b, hoff, n0 + 32, N, lane);
     }
     wave_lds_sync();
     f32x16 S = zero16(), dP = zero16();
