@@ -496,10 +496,11 @@ def test_full_size_backward_config2():
     print(f"full-size grad action_queries: rel {r:.3e}")
 
 
-@pytest.mark.parametrize("B,P,ragged", [(3, 37, True), (1, 12, False), (5, 64, True)])
+@pytest.mark.parametrize("B,P,ragged", [(3, 37, True), (1, 12, False), (5, 64, True), (9, 33, True), (8, 20, False)])
 def test_captured_step_odd_shapes_match_eager(B, P, ragged):
-    """Captured (segment graphs, vision lead, deferred update) vs eager sequential step over three steps at odd batch
-    sizes / prompt lengths: same losses (first step bit-equal, later steps within the bf16 drift of the updates)."""
+    """Captured (segment graphs, vision lead, deferred update; from batch 8 on the LLM forward as two half-batch pipelines
+    on two streams) vs eager sequential step over three steps at odd batch sizes / prompt lengths: same losses (first step
+    bit-equal, later steps within the bf16 drift of the updates)."""
     from vla_adapter_amd import engine as E, synthetic as S
     cfg = E.tiny_config()
     W = S.make_weights(cfg, DEV, seed=61, std=0.05)

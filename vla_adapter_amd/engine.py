@@ -264,32 +264,38 @@ class LLM:
         self.kmask, self.B, self.S = kmask_u8, B, S
         self.gu_row0 = keep_from_row
 
-    def fwd_layer(self, i: int):
-        c, B, S = self.cfg, self.B, self.S
+    def fwd_layer(self, i: int, b0: int = 0, b1: Optional[int] = None):
+        """Layer i on the samples [b0, b1) of the batch (default: all).  Every op is row- or sample-wise, so disjoint sample
+        ranges can run on different streams (the step schedule pipelines the two halves of the batch)."""
+        c, S = self.cfg, self.S
+        b1 = self.B if b1 is None else b1
+        B, r0, r1 = b1 - b0, b0 * S, b1 * S
         M, D, H, KV, dh = B * S, c.d, c.heads, c.kv_heads, c.dh
         L = self.layers[i]
-        x = self.HS[i].view(M, D)
-        self._rms(x, L["n1"], self.nbuf, self.R1[i])
-        qkv = self.QKV[i]
+        x = self.HS[i].view(-1, D)[r0:r1]
+        nbuf, hbuf = self.nbuf[r0:r1], self.hbuf[r0:r1]
+        self._rms(x, L["n1"], nbuf, self.R1[i][r0:r1])
+        qkv = self.QKV[i][r0:r1]
         if dh == 64:          # RoPE fused into the projection's epilogue
-            ops.gemm_nt(self.nbuf, L["wqkv"], bias=L["bqkv"], out=qkv, rope=(1, self.cos, self.sin, S, dh, (H + KV) * dh))
+            ops.gemm_nt(nbuf, L["wqkv"], bias=L["bqkv"], out=qkv, rope=(1, self.cos, self.sin, S, dh, (H + KV) * dh))
         else:
-            ops.gemm_nt(self.nbuf, L["wqkv"], bias=L["bqkv"], out=qkv)
+            ops.gemm_nt(nbuf, L["wqkv"], bias=L["bqkv"], out=qkv)
             ops.rope_half_(qkv[:, :H * dh], self.cos, self.sin, S, H, dh)
             ops.rope_half_(qkv[:, H * dh:(H + KV) * dh], self.cos, self.sin, S, KV, dh)
-        self._attn_fwd(qkv.view(B, S, -1), i, B, S)
-        x1 = self.X1[i]
-        ops.gemm_nt(self.AO[i], L["wo"], residual=x, out=x1)
-        self._rms(x1, L["n2"], self.nbuf, self.R2[i])
+        self._attn_fwd(qkv.view(B, S, -1), i, b0, b1, S)
+        x1 = self.X1[i][r0:r1]
+        ops.gemm_nt(self.AO[i][r0:r1], L["wo"], residual=x, out=x1)
+        self._rms(x1, L["n2"], nbuf, self.R2[i][r0:r1])
         # the pre-activations are kept for the backward only: rows below the live window are never read again
-        ops.gemm_nt(self.nbuf, L["wgu"], act=ACT_SWIGLU, out=self.GU[i], out2=self.hbuf,
+        ops.gemm_nt(nbuf, L["wgu"], act=ACT_SWIGLU, out=self.GU[i][r0:r1], out2=hbuf,
                     c_live=(S, self.gu_row0) if self.gu_row0 else None)
-        ops.gemm_nt(self.hbuf, L["wd"], residual=x1, out=self.HS[self.out_slot(i)].view(M, D))
+        ops.gemm_nt(hbuf, L["wd"], residual=x1, out=self.HS[self.out_slot(i)].view(-1, D)[r0:r1])
 
-    def fwd_final(self):
+    def fwd_final(self, b0: int = 0, b1: Optional[int] = None):
         """hidden_states[n] = final RMSNorm of the last layer's output (HF convention)."""
-        n, M, D = self.cfg.n_layers, self.B * self.S, self.cfg.d
-        self._rms(self.HS[n + 1].view(M, D), self.norm, self.HS[n].view(M, D), self.RF)
+        n, D, S = self.cfg.n_layers, self.cfg.d, self.S
+        r0, r1 = b0 * S, (self.B if b1 is None else b1) * S
+        self._rms(self.HS[n + 1].view(-1, D)[r0:r1], self.norm, self.HS[n].view(-1, D)[r0:r1], self.RF[r0:r1])
 
     def _rms(self, x, w, out, rstd):
         ops.N.check(ops._lib().vla_rmsnorm_fwd(ops._st(), ops._p(x), ops._p(w), ops._p(out), ops._p(rstd), x.shape[0],
@@ -300,12 +306,13 @@ class LLM:
         a, b = c.heads * c.dh, (c.heads + c.kv_heads) * c.dh
         return t3[:, :, :a], t3[:, :, a:b], t3[:, :, b:]
 
-    def _attn_fwd(self, q3, i, B, S):
+    def _attn_fwd(self, q3, i, b0, b1, S):
         import ctypes as C
         c = self.cfg
         q, k, v = self._attn_views(q3)
-        o = self.AO[i].view(B, S, -1)
-        d = ops._attn_desc(q, k, v, o, self.LSE[i], self.kmask, True, c.dh ** -0.5, c.heads, c.kv_heads, c.dh)
+        o = self.AO[i].view(self.B, S, -1)[b0:b1]
+        km = self.kmask[b0:b1] if self.kmask is not None else None
+        d = ops._attn_desc(q, k, v, o, self.LSE[i][b0:b1], km, True, c.dh ** -0.5, c.heads, c.kv_heads, c.dh)
         ops.N.check(ops._lib().vla_attn_fwd(ops._st(), C.byref(d)), "attn_fwd")
 
     # ---- backward: dX only (frozen weights), restricted to the LIVE rows ------------------------------------------
@@ -1028,6 +1035,7 @@ class VLAEngine:
         if getattr(self, "side", None) is None:
             self.side = torch.cuda.Stream()            # head stream (a high-priority stream measured 0.7 % slower on the step)
             self._cap_main = torch.cuda.Stream()       # capture stream of the "M" graphs (replayed on the current stream)
+            self.llm2 = torch.cuda.Stream()            # second LLM forward pipeline (the other half of the batch)
             self.vis_stream = torch.cuda.Stream()      # vision stage of the NEXT step (fills the backward's idle CUs)
             self._vstreams = [self.vis_stream] + [torch.cuda.Stream() for _ in range(max(0, len(self.vits) - 1))]   # one per backbone
 
@@ -1061,16 +1069,19 @@ class VLAEngine:
         fch = self._chunks(n, [4] * max(0, (n - 4) // 4) + [2, 1, 1]) if n >= 8 else self._chunks(n, [1])
         segs = []
 
-        def m_fwd(c, lo, hi):
+        def m_begin():
+            mm = self._embed(batch)
+            self._prep_backward(batch)
+            llm.fwd_begin(self.B, self.S, mm, self._row0_used)
+
+        def m_fwd(c, lo, hi, b0=0, b1=None, begin=False):
             def fn():
-                if c == 0:
-                    mm = self._embed(batch)
-                    self._prep_backward(batch)
-                    llm.fwd_begin(self.B, self.S, mm, self._row0_used)
+                if begin:
+                    m_begin()
                 for i in range(lo, hi):
-                    llm.fwd_layer(i)
+                    llm.fwd_layer(i, b0, b1)
                 if hi == n:
-                    llm.fwd_final()
+                    llm.fwd_final(b0, b1)
             return fn
 
         def h_fwd(c, lo, hi, last):
@@ -1104,9 +1115,21 @@ class VLAEngine:
                     ops.cast_f32_bf16(dq, out=head.P.g("action_queries"))
             return fn
 
-        for c, (lo, hi) in enumerate(fch):
-            segs.append(("M", m_fwd(c, lo, hi), None, ("f", c)))
-            segs.append(("H", h_fwd(c, lo, hi, c == len(fch) - 1), ("f", c), None))
+        # The LLM forward runs as TWO pipelines over the halves of the batch ("M" = current stream, "N" = a second LLM
+        # stream): every op is sample-wise, and with one stream the chain qkv -> attention -> o -> norm -> gate/up -> down
+        # leaves the chip idle in every kernel's tail and at every kernel boundary; two half-batch chains fill each other's
+        # gaps (the backward phase already has three streams and is bound by total GEMM throughput instead).
+        bh = self.B // 2
+        if self.B >= 8 and not os.environ.get("VLA_NO_LLM_SPLIT"):
+            segs.append(("M", m_begin, None, ("e", 0)))
+            for c, (lo, hi) in enumerate(fch):
+                segs.append(("M", m_fwd(c, lo, hi, 0, bh), None, ("f", c)))
+                segs.append(("N", m_fwd(c, lo, hi, bh, self.B), ("e", 0) if c == 0 else None, ("g", c)))
+                segs.append(("H", h_fwd(c, lo, hi, c == len(fch) - 1), [("f", c), ("g", c)], None))
+        else:
+            for c, (lo, hi) in enumerate(fch):
+                segs.append(("M", m_fwd(c, lo, hi, begin=c == 0), None, ("f", c)))
+                segs.append(("H", h_fwd(c, lo, hi, c == len(fch) - 1), ("f", c), None))
         for k, (lo, hi) in enumerate(reversed(fch)):
             segs.append(("H", h_bwd(lo, hi), None, ("b", k)))
             segs.append(("M", m_bwd(lo, hi, k == 0, k == len(fch) - 1), ("b", k), None))
@@ -1114,7 +1137,7 @@ class VLAEngine:
         return segs
 
     def _stream_of(self, name: str, main):
-        return main if name == "M" else self.side if name == "H" else self._vstreams[int(name[1:])]
+        return main if name == "M" else self.side if name == "H" else self.llm2 if name == "N" else self._vstreams[int(name[1:])]
 
     def _run_segments(self, segs, graphs=None, timeline=None, hooks=None):
         """Enqueue the segments [(stream 'M'|'H'|'V<j>', fn|None, wait key | [keys] | None, signal key | None)] in order.
