@@ -18,6 +18,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the captured step drives five streams once a gradient-exchange stream joins (LLM x 2, head, vision, RCCL): give each
+# its own hardware queue (the HIP default is 4; read when the runtime initialises; no effect on the one-GPU number)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
