@@ -300,7 +300,7 @@ def main():
                          "algorithmic_bytes_per_launch": round(roof["bytes"] / roof["launches"]),
                          "avg_launch_us": round(roof["seconds"] / roof["launches"] * 1e6, 1),
                          "timing": "each distinct launch signature of one step replayed back-to-back between two HIP events on its "
-                                   "launch stream, weighted by its count; inside the two-stream step the same launches average "
+                                   "launch stream, weighted by its count; inside the multi-stream step the same launches average "
                                    "~25 % longer (rocprofv3: profiles/r01_final_kernel_stats.csv) because the streams share the CUs",
                          "launches_per_step": roof["launches"], "gemm_ms_per_step": round(roof["seconds"] * 1e3, 3),
                          "gemm_flops_per_step": roof["flops"], "top_launches": roof["top"]},
