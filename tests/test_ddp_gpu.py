@@ -20,3 +20,14 @@ def test_two_rank_captured_step_keeps_ranks_in_sync():
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("ranks-in-sync-ok") == 2, r.stdout[-3000:]
+
+
+def test_single_rank_rccl_exchange_is_the_identity():
+    """The RCCL path itself on one GPU: a one-rank "nccl" group with the reducer forced to issue its collectives between
+    the captured segment graphs (tools/rccl_single_rank.py) - same losses and parameters as without the exchange."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join("tools", "rccl_single_rank.py")], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "rccl-single-rank-ok" in r.stdout, r.stdout[-3000:]
