@@ -18,9 +18,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# the captured step drives five streams once a gradient-exchange stream joins (LLM x 2, head, vision, RCCL): give each
-# its own hardware queue (the HIP default is 4; read when the runtime initialises; no effect on the one-GPU number)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (GPU_MAX_HW_QUEUES is left at the HIP default of 4 on purpose: with the exchange stream running, the rehearsed step
+#  measured 28.0 ms at 4 queues, 29.9 at 6 or 16 and 37.7 at 8 - same box, --rehearse-exchange)
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -194,6 +193,7 @@ def main():
     ap.add_argument("--cpu-samples", type=int, default=1)
     ap.add_argument("--no-full-backward", action="store_true", help="skip the extra timing of the reference-shaped full LLM backward")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
+    ap.add_argument("--rehearse-exchange", action="store_true", help="one GPU: run the step with a one-rank RCCL group and forced gradient collectives")
     ap.add_argument("--ragged", action="store_true", help="prompt lengths in [24, 32], right-padded (exercises the mask path; SURVEY 8d)")
     args = ap.parse_args()
 
@@ -212,6 +212,16 @@ def main():
     noise = (torch.randn(cfg.chunk, cfg.action_dim * cfg.llm.d, device=dev) * 0.02).to(torch.bfloat16)  # phase="Training"
     if world > 1:
         eng.reducer = ddp.FlatGradReducer()
+    elif args.rehearse_exchange:
+        # one-GPU rehearsal of the RCCL exchange: a ONE-rank "nccl" group and a reducer that issues its collectives as an
+        # N-rank job would (a one-rank all-reduce is the identity; grad scale stays 1).  Costs what the exchange machinery
+        # costs (streams, events, RCCL launches of the 437 MB buffer), not what the links cost.
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+        eng.reducer = ddp.FlatGradReducer()
+        eng.reducer.world = 2
+        type(eng.reducer).grad_scale = property(lambda self: 1.0)
     lr = 5e-4
 
     def barrier():

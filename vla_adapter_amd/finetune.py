@@ -19,9 +19,7 @@ from dataclasses import dataclass
 from pathlib import Path
 from typing import Optional
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # one hardware queue per stream of the captured step (HIP default: 4)
-
-import torch  # noqa: E402
+import torch
 
 
 @dataclass
