@@ -190,7 +190,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE config: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-samples", type=int, default=3, help="samples of the batch the CPU oracle is timed on (3 steps each: about 12 s of CPU work)")
+    ap.add_argument("--cpu-samples", type=int, default=4, help="samples of the batch the CPU oracle is timed on (3 steps each: about 12 s of CPU work)")
     ap.add_argument("--no-full-backward", action="store_true", help="skip the extra timing of the reference-shaped full LLM backward")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
     ap.add_argument("--rehearse-exchange", action="store_true", help="one GPU: run the step with a one-rank RCCL group and forced gradient collectives")
