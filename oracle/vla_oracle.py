@@ -404,9 +404,13 @@ def adamw_step(p, g, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-
 
 
 def lr_at(step: int, base_lr: float, warmup_steps: float = 0.1, decay_at: int = 100000, gamma: float = 0.1):
-    """finetune.py:1061-1065 warm-up (10%->100% over warmup_steps) then MultiStepLR(:917)."""
-    lr = base_lr * (gamma if step >= decay_at else 1.0)
-    return lr * (0.1 + 0.9 * min((step + 1) / warmup_steps, 1.0))
+    """Learning rate of optimizer step ``step`` (finetune.py:917, 1061-1065, 1078-1082).  With warmup_steps > 0 the warm-up
+    block rewrites param_group['lr'] = base * (0.1 + 0.9 * min((step+1)/warmup, 1)) on every iteration BEFORE
+    optimizer.step(), which also undoes MultiStepLR's decay from the previous scheduler.step(): the decay only exists with
+    warmup_steps <= 0 (pinned by tests/test_host_api_cpu.py against a torch AdamW + MultiStepLR loop)."""
+    if warmup_steps > 0:
+        return base_lr * (0.1 + 0.9 * min((step + 1) / warmup_steps, 1.0))
+    return base_lr * (gamma if step >= decay_at else 1.0)
 
 
 # ----------------------------------------------------------------------------------------------

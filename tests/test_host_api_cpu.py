@@ -24,10 +24,91 @@ def test_finetune_config_keeps_every_reference_flag():
     assert cfg.lr_warmup_steps == 0.1 and cfg.num_steps_before_decay == 100000      # reference defaults
 
 
-def test_lr_schedule_matches_oracle():
+def _reference_lr_trace(cfg, n_steps):
+    """The reference loop's optimizer / scheduler choreography (vla-scripts/finetune.py:903-921, 1061-1065, 1078-1082) on a
+    dummy parameter: AdamW + MultiStepLR, warm-up block overwriting param_group['lr'] before optimizer.step().
+    Returns the lr every optimizer.step() ran with."""
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=cfg.learning_rate)
+    original_lr = opt.param_groups[0]["lr"]
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[cfg.num_steps_before_decay], gamma=0.1)
+    used = []
+    for batch_idx in range(n_steps * cfg.grad_accumulation_steps):
+        g = batch_idx // cfg.grad_accumulation_steps
+        if cfg.lr_warmup_steps > 0:
+            lr_progress = min((g + 1) / cfg.lr_warmup_steps, 1.0)
+            for pg in opt.param_groups:
+                pg["lr"] = original_lr * (0.1 + 0.9 * lr_progress)
+        if (batch_idx + 1) % cfg.grad_accumulation_steps == 0:
+            used.append(opt.param_groups[0]["lr"])
+            p.grad = torch.ones(1)
+            opt.step()
+            sched.step()
+            opt.zero_grad()
+    return used
+
+
+def test_lr_schedule_pinned_by_torch_adamw_multisteplr_loop():
+    """with the default lr_warmup_steps=0.1 the warm-up block undoes the MultiStepLR decay every iteration (the lr
+    stays at 100 % for ever); the decay only exists with lr_warmup_steps <= 0, where there is also no division."""
+    import pytest
+    for kw in (dict(), dict(lr_warmup_steps=5.0), dict(lr_warmup_steps=0.0), dict(lr_warmup_steps=0.0, grad_accumulation_steps=2),
+               dict(lr_warmup_steps=3.0, grad_accumulation_steps=3)):
+        cfg = F.FinetuneConfig(num_steps_before_decay=7, learning_rate=5e-4, **kw)
+        ref = _reference_lr_trace(cfg, 12)
+        got = [F.lr_at(g, cfg) for g in range(12)]
+        assert got == pytest.approx(ref, rel=1e-12), (kw, got, ref)
     cfg = F.FinetuneConfig()
-    for step in (0, 1, 99999, 100000, 150000):
-        assert F.lr_at(step, cfg) == O.lr_at(step, cfg.learning_rate, cfg.lr_warmup_steps, cfg.num_steps_before_decay)
+    assert F.lr_at(100000, cfg) == cfg.learning_rate and F.lr_at(0, cfg) == cfg.learning_rate      # defaults: always 100 %
+    assert F.lr_at(100000, F.FinetuneConfig(lr_warmup_steps=0)) == pytest.approx(cfg.learning_rate * 0.1)
+    assert O.lr_at(100000, cfg.learning_rate) == F.lr_at(100000, cfg)                                   # oracle restatement agrees
+
+
+def test_loop_plan_follows_the_reference_bookkeeping():
+    """vla-scripts/finetune.py:1018-1122: gradient_step_idx = batch_idx // accumulation, log_step offset by resume_step,
+    checkpoint when gradient_step_idx > 0 and log_step % save_freq == 0, stop after the batch with log_step == max_steps."""
+    cfg = F.FinetuneConfig(max_steps=6, save_freq=3, grad_accumulation_steps=2)
+    plan = list(F.loop_plan(cfg))
+    assert len(plan) == 2 * 7                                             # gradient steps 0..6 inclusive, two micro-batches each
+    assert [x[3] for x in plan] == [False, True] * 7                      # optimizer step on every second micro-batch
+    assert [x[2] for x in plan if x[4]] == [3, 6]                         # checkpoints at log_step 3 and 6
+    assert plan[-1][5] and not any(x[5] for x in plan[:-1])
+    cfg = F.FinetuneConfig(max_steps=105, save_freq=100, resume=True, resume_step=100)
+    plan = list(F.loop_plan(cfg))
+    assert [x[2] for x in plan] == [100, 101, 102, 103, 104, 105]          # log_step continues from resume_step
+    assert [x[2] for x in plan if x[4]] == []                              # gradient_step_idx 0 never saves (:1085)
+    cfg = F.FinetuneConfig(max_steps=100, save_freq=10000)                 # README launch: nothing due on save_freq ...
+    assert not any(x[4] for x in F.loop_plan(cfg))                          # ... finetune() writes a final checkpoint itself
+
+
+def test_unsupported_reference_flags_raise_instead_of_being_ignored():
+    import pytest
+    ok = F.parse_args(["--use_proprio", "True", "--batch_size", "4"])
+    F.check_supported(ok, ok._explicit)
+    for argv, exc in ((["--use_proprio", "True", "--use_lora", "True"], NotImplementedError),
+                      (["--use_proprio", "True", "--use_val_set", "True"], NotImplementedError),
+                      (["--use_proprio", "True", "--image_aug", "True"], NotImplementedError),       # explicit out-of-path flag
+                      (["--use_proprio", "True", "--shuffle_buffer_size", "5"], NotImplementedError),
+                      (["--use_proprio", "True", "--use_film", "True"], NotImplementedError),
+                      (["--use_proprio", "False"], TypeError),                                         # the reference crashes there too
+                      (["--use_proprio", "True", "--resume", "True"], ValueError),
+                      (["--use_proprio", "True", "--grad_accumulation_steps", "0"], ValueError)):
+        cfg = F.parse_args(argv)
+        with pytest.raises(exc):
+            F.check_supported(cfg, cfg._explicit)
+
+
+def test_prismatic_vlm_forward_refuses_what_it_cannot_honour():
+    import pytest
+    from vla_adapter_amd import modeling_prismatic as M
+    vlm = M.PrismaticVLM(model=None)
+    ids, px = torch.zeros(2, 5, dtype=torch.long), torch.zeros(2, 3, 8, 8)
+    with pytest.raises(RuntimeError):
+        vlm.forward(input_ids=ids, pixel_values=None)
+    for kw in (dict(inputs_embeds=torch.zeros(1)), dict(past_key_values=[1]), dict(use_cache=True), dict(output_attentions=True),
+               dict(return_dict=False), dict(multimodal_indices=torch.tensor([0]))):
+        with pytest.raises(NotImplementedError):
+            vlm.forward(input_ids=ids, pixel_values=px, **kw)
 
 
 def test_constants_and_masks_match_reference_semantics():

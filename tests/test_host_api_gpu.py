@@ -51,20 +51,99 @@ def test_model_forward_and_head_predict_action_like_run_forward_pass():
     assert rel(pred2, pred) < 8e-3
 
 
+def _tiny_batches(n, B=4, seed0=300):
+    from vla_adapter_amd import engine as E, synthetic as S
+    return [S.make_batch(E.tiny_config(), B, "cuda", seed=seed0 + i, P=32, ragged=True) for i in range(n)]
+
+
 def test_finetune_entry_point_tiny(tmp_path):
+    """Reference loop bookkeeping on the native engine: batches cycle through an iterable (their pixels staged one step ahead
+    of the captured graphs), gradient steps 0..max_steps inclusive, checkpoints on save_freq multiples plus a final one."""
     from vla_adapter_amd import finetune as F
     cfg = F.parse_args(["--tiny", "true", "--batch_size", "4", "--max_steps", "16", "--learning_rate", "2e-3", "--wandb_log_freq", "5",
-                        "--save_freq", "10", "--run_root_dir", str(tmp_path), "--phase", "Inference"])
-    out = F.finetune(cfg)
+                        "--save_freq", "10", "--run_root_dir", str(tmp_path), "--phase", "Inference", "--use_proprio", "True"])
+    out = F.finetune(cfg, batches=_tiny_batches(2))
     log = out["log"]
+    assert out["steps"] == 17 and out["final_step"] == 16 and [l["step"] for l in log] == [0, 5, 10, 15, 16]
     assert set(log[0]) >= {"loss_value", "curr_action_l1_loss", "next_actions_l1_loss"}
     assert log[-1]["loss_value"] < log[0]["loss_value"]
     import glob, os
     files = glob.glob(os.path.join(str(tmp_path), "*", "*"))
     names = {os.path.basename(f) for f in files}
     assert "action_head--10_checkpoint.pt" in names and "proprio_projector--10_checkpoint.pt" in names
+    assert "action_head--16_checkpoint.pt" in names, "the run must not end without a checkpoint of its last step"
     sd = torch.load([f for f in files if f.endswith("action_head--10_checkpoint.pt")][0], weights_only=True)
     assert "model.mlp_resnet_blocks.0.q_proj.weight" in sd and "model.fc2.bias" in sd
+
+
+def test_finetune_graphed_loop_equals_eager_loop_on_a_batch_sequence(tmp_path):
+    """Three different batches through the captured path (static buffers refreshed every step, next pixels staged a step ahead)
+    give the same losses as the eager path on the same sequence."""
+    from vla_adapter_amd import finetune as F
+    bs = _tiny_batches(3, seed0=320)
+    base = ["--tiny", "true", "--batch_size", "4", "--max_steps", "5", "--learning_rate", "1e-3", "--wandb_log_freq", "1", "--save_freq", "1000",
+            "--phase", "Inference", "--use_proprio", "True"]
+    a = F.finetune(F.parse_args(base + ["--run_root_dir", str(tmp_path / "a"), "--use_graph", "true"]), batches=bs)
+    b = F.finetune(F.parse_args(base + ["--run_root_dir", str(tmp_path / "b"), "--use_graph", "false"]), batches=bs)
+    la, lb = [l["loss_value"] for l in a["log"]], [l["loss_value"] for l in b["log"]]
+    assert len(la) == 6 and abs(la[0] - lb[0]) < 1e-6
+    assert all(abs(x - y) <= 2e-2 * abs(y) for x, y in zip(la, lb)), (la, lb)
+    assert len({round(x, 5) for x in lb[:3]}) == 3, "the three batches must differ for the check to mean anything"
+
+
+def test_finetune_resume_restores_every_trainable_tensor_and_the_step_counter(tmp_path):
+    """resume used to restart the action queries from random init and the step counter from 0."""
+    from vla_adapter_amd import finetune as F, engine as E, synthetic as S, checkpoints as CK
+    bs = _tiny_batches(2, seed0=340)
+    base = ["--tiny", "true", "--batch_size", "4", "--learning_rate", "2e-3", "--wandb_log_freq", "1", "--phase", "Inference", "--use_proprio", "True",
+            "--run_root_dir", str(tmp_path), "--run_id_override", "r"]
+    F.finetune(F.parse_args(base + ["--max_steps", "4", "--save_freq", "4"]), batches=bs)
+    ck = str(tmp_path / "r--4_chkpt")
+    head, pp, aq = CK.load_run_dir(ck, 4, with_action_queries=True)
+    out = F.finetune(F.parse_args(base + ["--max_steps", "6", "--save_freq", "100", "--resume", "True", "--resume_step", "4", "--resum_vla_path", ck,
+                                          "--learning_rate", "0.0"]), batches=bs)
+    assert [l["step"] for l in out["log"]] == [4, 5, 6]                    # log_step = resume_step + gradient_step_idx (:1056)
+    h2, p2, aq2 = CK.load_run_dir(str(tmp_path / "r--6_chkpt"), 6, with_action_queries=True)
+    # lr 0 and weight decay x lr = 0: the resumed run must hand back exactly what it loaded
+    assert torch.equal(aq, aq2) and all(torch.equal(head[k], h2[k]) for k in head) and all(torch.equal(pp[k], p2[k]) for k in pp)
+    fresh = S.make_weights(E.tiny_config(), "cuda", seed=0)["action_queries"].cpu()
+    assert not torch.equal(aq, fresh), "the checkpoint must hold TRAINED action queries"
+
+
+def test_gradient_accumulation_matches_one_big_batch():
+    """finetune.py:1039-1042: two micro-batches of 2 with loss / 2 == one batch of 4 (mean L1 over twice the samples), eager
+    and captured; the optimizer steps once per two micro-steps."""
+    from vla_adapter_amd import engine as E, synthetic as S
+    cfg = E.tiny_config()
+    W = S.make_weights(cfg, "cuda", seed=3, std=0.05)
+    big = S.make_batch(cfg, 4, "cuda", seed=360, P=32)
+    halves = [{k: v[i:i + 2].contiguous() for k, v in big.items()} for i in (0, 2)]
+    e_big, e_acc, e_gr = E.VLAEngine(cfg, W, "cuda"), E.VLAEngine(cfg, W, "cuda"), E.VLAEngine(cfg, W, "cuda")
+    e_big.train_step(big, 1e-3)
+    e_acc.set_grad_accumulation(2)
+    p0 = e_acc.head.P.data.clone()
+    e_acc.train_step(halves[0], 1e-3)
+    assert torch.equal(p0, e_acc.head.P.data) and e_acc.step_count == 0, "no optimizer step on the first micro-batch"
+    e_acc.train_step(halves[1], 1e-3)
+    torch.cuda.synchronize()
+    assert e_acc.step_count == 1
+    g_big, g_acc = e_big.head.P.grad.float(), e_acc.head.P.grad.float()
+    assert (g_big - g_acc).norm() <= 1.5e-2 * g_big.norm(), ((g_big - g_acc).norm() / g_big.norm()).item()
+    # captured: same two micro-steps through the graphs
+    e_gr.set_grad_accumulation(2)
+    static = {k: v.clone() for k, v in halves[0].items()}
+    e_gr.capture(static, None)
+    e_gr.stage_next_pixels(halves[1]["pixel_values"])
+    e_gr.train_step_graphed(1e-3)
+    assert e_gr._pending_lr is None, "no update pending after the first micro-step"
+    for k in static:
+        static[k].copy_(halves[1][k])
+    e_gr.train_step_graphed(1e-3)
+    e_gr.flush()
+    torch.cuda.synchronize()
+    assert e_gr.step_count == 1
+    assert (e_gr.head.P.grad.float() - g_acc).norm() <= 2e-3 * g_acc.norm()
+    assert (e_gr.head.P.data.float() - e_acc.head.P.data.float()).norm() <= 1e-3 * e_acc.head.P.data.float().norm()
 
 
 def test_predict_action_batch1_inference_matches_oracle():

@@ -88,7 +88,7 @@ def test_gemm_plain_bias(ops, M, N, K):
     check(out, O.linear(a.float(), b.float(), bias.float(), emu=True), name=f"gemm {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("M,N,K", [(300, 200, 192), (1000, 896, 896), (512, 384, 64), (2080, 1792, 896), (64, 7, 128)])
 def test_gemm_every_tile_config(ops, tile, M, N, K, monkeypatch):
     """The three kernel instantiations (256x128x3-stage, 128x128x2, 128x64x3) must agree with the oracle on ragged
@@ -100,7 +100,7 @@ def test_gemm_every_tile_config(ops, tile, M, N, K, monkeypatch):
     check(out, O.rnd(y + r.float(), True), name=f"gemm tile{tile} {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("tile", [1, 3])
+@pytest.mark.parametrize("tile", [1, 3, 6])
 def test_gemm_swiglu_tile_configs(ops, tile, monkeypatch):
     monkeypatch.setenv("VLA_GEMM_TILE", str(tile))
     M, I, K = 330, 320, 256
@@ -901,3 +901,111 @@ def test_glue_and_optimizer_random_sweep(ops):
             ops.adamw_(p, gg.to(DEV), m, v, step, 3e-4, 0.9, 0.999, 1e-8, 0.01)
             pr, mr, vr = O.adamw_step(pr, gg.float(), mr, vr, step, 3e-4, emu=True)
             assert torch.equal(f(p), pr) and torch.equal(f(m), mr) and torch.equal(f(v), vr), f"adamw n={n} step {step}"
+
+
+# ------------------------------------------------------------------------------------------------ 256 x 256 8-phase kernel
+# gemm256.hip accumulates every output element over K in the same order, with the same MFMA, as the 128-row kernels (K-tiles of
+# 64 in ascending order, two 32-deep k-steps each), and its epilogue rounds at the same points: results must be BIT-IDENTICAL
+# to the 128 x 128 kernel on every shape and epilogue - a far sharper check of the staggered pipeline (stale or early LDS
+# reads, half-tile mix-ups, edge clamps) than any tolerance against the oracle.
+def _both_tiles(monkeypatch, fn):
+    monkeypatch.setenv("VLA_GEMM_TILE", "2")
+    ref = fn()
+    monkeypatch.setenv("VLA_GEMM_TILE", "6")
+    out = fn()
+    monkeypatch.setenv("VLA_GEMM_TILE", "0")
+    return out, ref
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (256, 256, 192), (512, 768, 320), (1300, 900, 896), (5632, 1152, 1152),
+                                   (2048, 1000, 4864), (300, 77, 448), (11264, 1792, 896)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_gemm256_bit_identical_to_128_tiles(ops, M, N, K, act, monkeypatch):
+    a, b, bias, r = gen(M, K, seed=201).to(DEV), gen(N, K, seed=202, scale=0.05).to(DEV), gen(N, seed=203).to(DEV), gen(M, N, seed=204).to(DEV)
+    out, ref = _both_tiles(monkeypatch, lambda: ops.gemm_nt(a, b, bias=bias, residual=r if act != 1 else None, act=act, split_k=0))
+    assert torch.equal(out, ref), f"gemm256 {M}x{N}x{K} act {act}: {(out.float() - ref.float()).abs().max().item()}"
+    if M * N * K <= 2 ** 31:
+        y = O.linear(f(a), f(b), f(bias), emu=True)
+        y = {0: y, 1: O.gelu(y, True), 2: torch.relu(y)}[act]
+        check(out, O.rnd(y + f(r), True) if act != 1 else y, name=f"gemm256 vs oracle {M}x{N}x{K}")
+
+
+def test_gemm256_swiglu_forward_and_backward_bit_identical(ops, monkeypatch):
+    M, D, I = 1100, 896, 1216
+    x, wg, wu = gen(M, D, seed=211), gen(I, D, seed=212, scale=0.05), gen(I, D, seed=213, scale=0.05)
+    w = torch.stack([wg.view(I // 16, 16, D), wu.view(I // 16, 16, D)], dim=1).reshape(2 * I, D).to(DEV)
+    xd = x.to(DEV)
+    (pre, h), (pre_r, h_r) = _both_tiles(monkeypatch, lambda: ops.gemm_nt(xd, w, act=ops.ACT_SWIGLU))
+    assert torch.equal(pre, pre_r) and torch.equal(h, h_r)
+    # live-row store of the pre-activations (rows below the window untouched), no pre-activation output at all
+    S, r0 = 100, 64
+    o1 = torch.full((M, 2 * I), 3.0, dtype=BF, device=DEV)
+    monkeypatch.setenv("VLA_GEMM_TILE", "6")
+    _, h2 = ops.gemm_nt(xd, w, act=ops.ACT_SWIGLU, out=o1, c_live=(S, r0))
+    _, h3 = ops.gemm_nt(xd, w, act=ops.ACT_SWIGLU, want_pre=False)
+    rows = torch.arange(M, device=DEV) % S >= r0
+    assert torch.equal(h2, h_r) and torch.equal(h3, h_r) and torch.equal(o1[rows], pre_r[rows]) and bool((o1[~rows] == 3.0).all())
+    # fused SwiGLU backward, plain and through a row window of the pre-activations
+    d, wdT = gen(M, D, seed=214).to(DEV), gen(I, D, seed=215, scale=0.05).to(DEV)
+    fused, fused_r = _both_tiles(monkeypatch, lambda: ops.gemm_swiglu_bwd(d, wdT, pre_r))
+    assert torch.equal(fused, fused_r)
+    B, Sx, r0x = 11, 100, 36
+    R = Sx - r0x
+    dd = gen(B * R, D, seed=216).to(DEV)
+    win, win_r = _both_tiles(monkeypatch, lambda: ops.gemm_swiglu_bwd(dd, wdT, pre_r[r0x:], gu_group=(R, Sx * 2 * I)))
+    assert torch.equal(win, win_r)
+
+
+def test_gemm256_row_groups_batched_and_res_mod(ops, monkeypatch):
+    # A read through a row-group window, C written through one, residual broadcast by res_mod, batched with per-batch B / bias
+    B, S, Kt, D, N = 6, 352, 256, 896, 1792
+    hs = gen(B * S, D, seed=221).to(DEV)
+    w, bias = gen(N, D, seed=222, scale=0.05).to(DEV), gen(N, seed=223).to(DEV)
+    out, ref = _both_tiles(monkeypatch, lambda: ops.gemm_nt(hs[:B * Kt], w, bias=bias, a_group=(Kt, S * D)))
+    assert torch.equal(out, ref)
+    big1, big2 = torch.zeros(B * S, N, dtype=BF, device=DEV), torch.zeros(B * S, N, dtype=BF, device=DEV)
+    a2 = gen(B * Kt, D, seed=224).to(DEV)
+    monkeypatch.setenv("VLA_GEMM_TILE", "2")
+    ops.gemm_nt(a2, w, out=big1[:B * Kt], c_group=(Kt, S * N))
+    monkeypatch.setenv("VLA_GEMM_TILE", "6")
+    ops.gemm_nt(a2, w, out=big2[:B * Kt], c_group=(Kt, S * N))
+    assert torch.equal(big1, big2) and bool((big2.view(B, S, N)[:, Kt:] == 0).all())
+    pos = gen(Kt, N, seed=225).to(DEV)
+    out, ref = _both_tiles(monkeypatch, lambda: ops.gemm_nt(a2, w, bias=bias, residual=pos, res_mod=Kt))
+    assert torch.equal(out, ref)
+    nb, M2 = 3, 1024
+    ab, bb, bias_b = gen(nb, M2, D, seed=226).to(DEV), gen(nb, N, D, seed=227, scale=0.05).to(DEV), gen(nb, N, seed=228).to(DEV)
+    out, ref = _both_tiles(monkeypatch, lambda: ops.gemm_nt(ab, bb, bias=bias_b))
+    assert torch.equal(out, ref)
+
+
+def test_gemm256_repeatable_under_load(ops, monkeypatch):
+    """Race screen: the same multi-round launch (more tiles than CUs, long K) repeated back to back on two streams at once
+    must reproduce its first result bit for bit every time (an early LDS read shows up as rare differing tiles)."""
+    monkeypatch.setenv("VLA_GEMM_TILE", "6")
+    M, N, K = 8192, 4352, 1152
+    a, b = gen(M, K, seed=231).to(DEV), gen(N, K, seed=232, scale=0.05).to(DEV)
+    a2, b2 = gen(4096, 4864, seed=233).to(DEV), gen(896, 4864, seed=234, scale=0.05).to(DEV)
+    first, first2 = ops.gemm_nt(a, b, act=1), ops.gemm_nt(a2, b2, split_k=0)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    outs, outs2 = [], []
+    for _ in range(12):
+        outs.append(ops.gemm_nt(a, b, act=1))
+        with torch.cuda.stream(side):
+            outs2.append(ops.gemm_nt(a2, b2, split_k=0))
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, first) for o in outs) and all(torch.equal(o, first2) for o in outs2)
+
+
+def test_gemm_forced_tile_with_split_k(ops, monkeypatch):
+    """Forced big tiles used to launch grid.z = batch instead of the K-slice count: every forced tile must agree
+    with the automatic split-K result."""
+    M, N, K = 512, 896, 4096
+    a, w, bias = gen(M, K, seed=241).to(DEV), gen(N, K, seed=242, scale=0.05).to(DEV), gen(N, seed=243).to(DEV)
+    ref = ops.gemm_nt(a, w, bias=bias, split_k=4)
+    for tile in (1, 4, 5, 6):
+        monkeypatch.setenv("VLA_GEMM_TILE", str(tile))
+        out = ops.gemm_nt(a, w, bias=bias, split_k=4)
+        check(out, f(ref), rel=2e-3, name=f"split-K 4 with forced tile {tile}")

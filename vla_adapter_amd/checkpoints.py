@@ -92,8 +92,17 @@ def merge_reference_state_dict(W: Dict, cfg: VLACfg) -> Dict[str, torch.Tensor]:
     return out
 
 
-def load_run_dir(run_dir: str, step, device="cpu"):
-    """(head state dict, proprio state dict) of a reference-layout run directory / ``--{step}_chkpt`` directory."""
+def load_run_dir(run_dir: str, step, device="cpu", with_action_queries: bool = False):
+    """(head state dict, proprio state dict[, action queries or None]) of a reference-layout run directory /
+    ``--{step}_chkpt`` directory.  ``action_queries--*.pt`` is this build's addition (the reference keeps the queries in its
+    LoRA / VLM checkpoint); a directory written by the reference has none, and one without a proprio projector file
+    (use_proprio was off) yields an empty dict for it."""
     suffix = "latest_checkpoint.pt" if step in (None, "latest") else f"{step}_checkpoint.pt"
-    ld = lambda n: strip_ddp_prefix(torch.load(os.path.join(run_dir, f"{n}--{suffix}"), map_location=device, weights_only=True))
-    return ld("action_head"), ld("proprio_projector")
+    path = lambda n: os.path.join(run_dir, f"{n}--{suffix}")
+    ld = lambda n: strip_ddp_prefix(torch.load(path(n), map_location=device, weights_only=True))
+    head = ld("action_head")
+    proprio = ld("proprio_projector") if os.path.exists(path("proprio_projector")) else {}
+    if not with_action_queries:
+        return head, proprio
+    aq = ld("action_queries")["weight"] if os.path.exists(path("action_queries")) else None
+    return head, proprio, aq

@@ -23,6 +23,7 @@
 //
 // Epilogue rounding points follow the reference under bf16 autocast: bf16(acc+bias) -> act -> bf16 -> (+residual) -> bf16.
 #include "common.h"
+#include "gemm_params.h"
 #include "../../include/vla_native.h"
 
 namespace {
@@ -30,19 +31,6 @@ namespace {
 constexpr int BK = 64;
 constexpr int EPI_PAD = 16;  // bytes of padding per staged epilogue row (keeps 16-B alignment, spreads banks)
 
-struct GemmP {
-  const bf16_t* A; const bf16_t* B; bf16_t* C;
-  const bf16_t* bias; const bf16_t* R; bf16_t* C2;
-  int M, N, K, lda, ldb, ldc, ldr, ldc2, res_mod, act;
-  long long sA, sB, sC, sR, sC2, sBias;
-  int tiles_n, ntiles;
-  float alpha;
-  int gA, gC, gR; long long sgA, sgC, sgR;  // row-group addressing: row r -> (r / g) * sg + (r % g) * ld
-  int c_live_mod, c_live_from;              // C rows with (m % c_live_mod) < c_live_from are not stored
-  int gm;                                   // group-M override (0 = default)
-  float* ws;                                // split-K: fp32 [M, N] accumulator (blockIdx.z = K slice), finalised by a second kernel
-  int rope_mode, rope_T, rope_dh, rope_cols; const float* rope_cos; const float* rope_sin;
-};
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
@@ -442,7 +430,19 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
 //    reuse per wave: +5..+40 % over the 4-wave 64x64 geometry on every hot shape;
 //  * 128x64 (4 waves, 3 blocks/CU) only for problems smaller than one round of tiles (the M=256 head GEMMs).
 struct TileChoice { int bm, bn; };
-inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode, int batch = 1) {
+// When the 256 x 256 8-phase kernel (one workgroup per CU) is chosen automatically: problems with at least a chip-full of
+// its tiles' worth of work in both dimensions.  VLA_GEMM_TILE=6 forces it, VLA_NO_GEMM256 disables it.
+inline bool use_256(int M, int N, int K, int batch) {
+  static const bool off = getenv("VLA_NO_GEMM256") != nullptr;
+  if (off) return false;
+  const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256) * batch;
+  return M >= 1024 && N >= 768 && K >= 256 && tiles >= 96;
+}
+inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode, int batch = 1, int split = 1) {
+  if (rope_mode == 0 && split == 1) {
+    if (force == 6) return {256, 257};                 // 256 x 256 staggered 8-phase kernel (gemm256.hip)
+    if (force == 0 && use_256(M, N, K, batch)) return {256, 257};
+  }
   if (rope_mode == 1) return {128, 128};   // rotate_half: 8 waves, each owning 16 columns of both halves of one head
   if (force == 1 && rope_mode == 0) return {256, 128};
   if (force == 2) return {128, 128};
@@ -559,16 +559,18 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
     if (d->rope_mode == 1) VLA_REQUIRE(d->rope_dh == 64, "gemm: fused rotate_half RoPE needs head dim 64");
   }
   const char* e = getenv("VLA_GEMM_TILE");     // 0/unset auto, 1: 256x128, 2: 128x128, 3: 128x64  (benchmarking aid)
-  const TileChoice tc = choose_tile(d->M, d->N, d->K / split, e ? atoi(e) : 0, d->rope_mode, split > 1 ? split : d->batch);
+  const TileChoice tc = choose_tile(d->M, d->N, d->K / split, e ? atoi(e) : 0, d->rope_mode, split > 1 ? split : d->batch, split);
   hipStream_t st = (hipStream_t)stream;
-  if (d->act == VLA_ACT_SWIGLU_BWD) launch<128, 128, 2, 3, 4>(p, d->M, d->N, d->batch, st);
+  if (tc.bm == 256 && tc.bn == 257) {          // 256 x 256 staggered 8-phase kernel (gemm256.hip)
+    vla_gemm256_launch(p, d->act == VLA_ACT_SWIGLU ? 1 : d->act == VLA_ACT_SWIGLU_BWD ? 2 : 0, d->batch, st);
+  } else if (d->act == VLA_ACT_SWIGLU_BWD) launch<128, 128, 2, 3, 4>(p, d->M, d->N, d->batch, st);
   else if (d->rope_mode == 1) launch<128, 128, 2, 1, 4>(p, d->M, d->N, d->batch, st);   // 8 waves, rotation pairs inside a lane
   else if (d->rope_mode == 2) {
     if (tc.bn == 128) launch<128, 128, 2, 2, 4>(p, d->M, d->N, d->batch, st);
     else launch<128, 64, 2, 2>(p, d->M, d->N, d->batch, st);
-  } else if (tc.bm == 256 && tc.bn == 256) launch<256, 256, 2, 0>(p, d->M, d->N, d->batch, st);
-  else if (tc.bm == 256) launch<256, 128, 3, 0, 4>(p, d->M, d->N, d->batch, st);   // 16 waves, loads two K-tiles ahead
-  else if (tc.bn == 129) launch<128, 128, 2, 0>(p, d->M, d->N, d->batch, st);      // 4 waves of 64x64 (forced only)
+  } else if (tc.bm == 256 && tc.bn == 256) launch<256, 256, 2, 0>(p, d->M, d->N, split > 1 ? split : d->batch, st);
+  else if (tc.bm == 256) launch<256, 128, 3, 0, 4>(p, d->M, d->N, split > 1 ? split : d->batch, st);   // 16 waves, loads two K-tiles ahead
+  else if (tc.bn == 129) launch<128, 128, 2, 0>(p, d->M, d->N, split > 1 ? split : d->batch, st);      // 4 waves of 64x64 (forced only)
   else if (tc.bn == 128) launch<128, 128, 2, 0, 4>(p, d->M, d->N, split > 1 ? split : d->batch, st);   // 8 waves (2x4) of 64x32
   else launch<128, 64, 2, 0>(p, d->M, d->N, split > 1 ? split : d->batch, st);
   VLA_CHECK_LAUNCH("gemm_bf16_nt");

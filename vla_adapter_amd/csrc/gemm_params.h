@@ -1,0 +1,21 @@
+// Kernel-side parameter block shared by the GEMM translation units (gemm.hip: 128-row tiles, gemm256.hip: the 256x256
+// 8-phase kernel).  Filled by vla_gemm_bf16_nt from the public vla_gemm_desc.
+#pragma once
+#include "common.h"
+
+struct GemmP {
+  const bf16_t* A; const bf16_t* B; bf16_t* C;
+  const bf16_t* bias; const bf16_t* R; bf16_t* C2;
+  int M, N, K, lda, ldb, ldc, ldr, ldc2, res_mod, act;
+  long long sA, sB, sC, sR, sC2, sBias;
+  int tiles_n, ntiles;
+  float alpha;
+  int gA, gC, gR; long long sgA, sgC, sgR;  // row-group addressing: row r -> (r / g) * sg + (r % g) * ld
+  int c_live_mod, c_live_from;              // C rows with (m % c_live_mod) < c_live_from are not stored
+  int gm;                                   // group-M override (0 = default)
+  float* ws;                                // split-K: fp32 [M, N] accumulator (blockIdx.z = K slice), finalised by a second kernel
+  int rope_mode, rope_T, rope_dh, rope_cols; const float* rope_cos; const float* rope_sin;
+};
+
+// gemm256.hip: 256x256x64 tile, 8 waves, staggered 8-phase schedule.  epi: 0 plain, 1 SwiGLU forward, 2 SwiGLU backward.
+int vla_gemm256_launch(const GemmP& p, int epi, int batch, hipStream_t st);

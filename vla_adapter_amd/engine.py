@@ -810,6 +810,32 @@ class VLAEngine:
         self.full_llm_backward = bool(int(os.environ.get("VLA_FULL_LLM_BWD", "0")))
         self._row0 = None          # frozen by capture(); None = derive from every batch (one host sync)
         self.reducer = None        # ddp.FlatGradReducer when world_size > 1
+        self.ga, self._micro, self._gacc = 1, 0, None     # gradient accumulation (set_grad_accumulation)
+
+    def set_grad_accumulation(self, n: int):
+        """finetune.py:1039-1042, 1078-1082: loss / n on every micro-batch, gradients summed over n micro-batches (in bf16, as
+        autograd accumulates ``.grad``), one optimizer step per n.  The data-parallel exchange runs on the boundary
+        micro-step only (the reference's DDP all-reduces on every one; same result, n-1 exchanges saved).  Call before
+        capture(): the captured loss kernel carries the 1/n."""
+        assert n >= 1 and getattr(self, "_graphs", None) is None, "set_grad_accumulation() before capture()"
+        self.ga, self._micro = int(n), 0
+        self._gacc = torch.zeros_like(self.head.P.grad) if n > 1 else None
+
+    def _accumulate(self) -> bool:
+        """Fold the micro-step's gradient into the accumulator; True on the boundary micro-step (P.grad then holds the sum)."""
+        if self.ga == 1:
+            return True
+        G = self.head.P.grad
+        if self._micro == 0:
+            self._gacc.copy_(G)
+        else:
+            ops.add_(self._gacc, G)
+        self._micro += 1
+        if self._micro < self.ga:
+            return False
+        self._micro = 0
+        G.copy_(self._gacc)
+        return True
 
     def forward(self, batch: Dict[str, torch.Tensor], noise: Optional[torch.Tensor] = None, for_training: bool = False):
         """VLM forward + action head (finetune.py:336-411) -> predicted actions [B, chunk, 7]."""
@@ -879,11 +905,19 @@ class VLAEngine:
         return segs
 
     # modeling_prismatic.py:596-655 (multimodal forward): fills llm.HS with the n+1 hidden states
-    def forward_vlm(self, batch: Dict[str, torch.Tensor], for_training: bool = False):
+    def forward_vlm(self, batch: Dict[str, torch.Tensor], for_training: bool = False, action_queries: bool = True):
         """for_training: a loss_and_backward() follows - backward-only tensors are kept for its live rows only
-        (reads the mask positions back: one host sync, eager path)."""
-        mm = self._vision_and_embed(batch)
-        self.llm.forward(self.B, self.S, mm, self.live_row0() if for_training else 0)
+        (reads the mask positions back: one host sync, eager path).  action_queries=False: the plain VLM forward of
+        prismatic/models/vlms/prismatic.py:312-481 (embedding gather + patch splice only; ``labels`` not needed)."""
+        self._vision(batch)
+        mm = self._embed(batch, action_queries)
+        self.llm.forward(self.B, self.S, mm, self.live_row0() if (for_training and action_queries) else 0)
+
+    def token_ce(self, labels: torch.Tensor):
+        """HF shifted token cross-entropy of the last forward_vlm (lm_head 896 -> 151 936 + CE).  Not built yet:
+        raises instead of returning a loss that was never computed."""
+        raise NotImplementedError("token-CE loss (lm_head + cross-entropy over the vocabulary, SURVEY 8f-4) is not built yet; "
+                                  "call forward() without labels for the hidden states")
 
     def _vision_and_embed(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         """ViT(s) -> projector -> action masks -> embedding/query splice into llm.HS[0]; returns the key mask [B,S] u8."""
@@ -942,19 +976,22 @@ class VLAEngine:
         else:
             ops.gemm_nt(h, self.proj["fc2.weight"], bias=self.proj["fc2.bias"], out=dst)
 
-    def _embed(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+    def _embed(self, batch: Dict[str, torch.Tensor], action_queries: bool = True) -> torch.Tensor:
         """Action masks + embedding gather + action-query splice (train_utils.py:8-41; modeling_prismatic.py:601-636)
         into rows 0 and Np+1.. of llm.HS[0] (reads the trainable `action_queries`); returns the key mask [B,S] u8."""
         cfg, llm = self.cfg, self.llm
-        ids, labels, am = batch["input_ids"], batch["labels"], batch["attention_mask"]
+        ids, labels, am = batch["input_ids"], batch.get("labels"), batch["attention_mask"]
         B, L = ids.shape
         Np = cfg.n_patches
         S = L + Np
         llm._alloc(B, S)
         X0 = llm.HS[0]
         X0[:, 1:Np + 1].copy_(self.patches)                      # projected patches: sequence rows 1..Np
-        self.qidx0, self.pos0, self.cnt0 = ops.action_mask(labels, 0)
-        _, self.pos1, self.cnt1 = ops.action_mask(labels, 1)
+        if action_queries:
+            self.qidx0, self.pos0, self.cnt0 = ops.action_mask(labels, 0)
+            _, self.pos1, self.cnt1 = ops.action_mask(labels, 1)
+        else:                                                     # plain VLM forward: no slot is overwritten
+            self.qidx0 = torch.full((B, L), -1, device=self.device, dtype=torch.int32)
         mm = torch.empty(B, S, device=self.device, dtype=torch.uint8)
         ops.embed_splice(ids, am.to(torch.uint8).contiguous(), self.qidx0, llm.embed, self.head.P.view("action_queries"), X0, mm, Np)
         self.B, self.S, self.Np = B, S, Np
@@ -983,8 +1020,9 @@ class VLAEngine:
         self._dHS.zero_()
         return self._dHS
 
-    def loss_and_backward(self, pred, actions, gscale: float = 1.0):
-        """L1 loss (finetune.py:418) + backward into the flat grad buffer."""
+    def loss_and_backward(self, pred, actions, gscale: float = 1.0, exchange: bool = True):
+        """L1 loss (finetune.py:418) + backward into the flat grad buffer.  gscale scales the gradient (loss / grad-accumulation
+        steps); exchange=False leaves the data-parallel exchange to the caller (non-boundary micro-steps)."""
         llm, head = self.llm, self.head
         B, S, Np = self.B, self.S, self.Np
         loss3, dpred = ops.l1_loss(pred, actions.to(BF16), True, gscale)
@@ -992,12 +1030,12 @@ class VLAEngine:
         dHS = self._dhs(row0)
         head.backward(dpred, dHS, row0)
         aq_off = head.P.offsets["action_queries"][0]
-        if self.reducer is not None:       # head/proprio grads are final: exchange them under the LLM backward
+        if self.reducer is not None and exchange:       # head/proprio grads are final: exchange them under the LLM backward
             self.reducer.reduce_async(head.P.grad, 0, aq_off)
         dX0 = llm.backward(dHS, B, S, row0)
         dq = ops.action_query_grad(dX0.contiguous(), self.pos0, Np, row0)
         ops.cast_f32_bf16(dq, out=head.P.g("action_queries"))
-        if self.reducer is not None:
+        if self.reducer is not None and exchange:
             self.reducer.reduce_async(head.P.grad, aq_off, None)
         return loss3
 
@@ -1013,9 +1051,13 @@ class VLAEngine:
         self.head.dirty = True
 
     def train_step(self, batch, lr: float, noise=None):
+        """One micro-batch; the optimizer steps on every ``ga``-th call (set_grad_accumulation)."""
         pred = self.forward(batch, noise, for_training=True)
-        loss3 = self.loss_and_backward(pred, batch["actions"])
-        self.optimizer_step(lr)
+        loss3 = self.loss_and_backward(pred, batch["actions"], 1.0 / self.ga, exchange=self.ga == 1)
+        if self._accumulate():
+            if self.ga > 1 and self.reducer is not None:
+                self.reducer.reduce_async(self.head.P.grad, 0, None)
+            self.optimizer_step(lr)
         return loss3
 
     # ---- pipelined two-stream schedule + hipGraph replay -----------------------------------------------------------
@@ -1092,7 +1134,7 @@ class VLAEngine:
                     head.fwd_layer(i)
                 if last:
                     pred = head.fwd_end()
-                    self._loss3, dpred = ops.l1_loss(pred, self._actions_bf, True, 1.0)
+                    self._loss3, dpred = ops.l1_loss(pred, self._actions_bf, True, 1.0 / self.ga)
                     if self._guard is not None:
                         self._loss3 += self._guard
                     head.bwd_begin(dpred, self._row0_used)
@@ -1212,13 +1254,19 @@ class VLAEngine:
     # applies AdamW and replays the rest.  Same arithmetic as synchronous DP (every use of a parameter sees the updated
     # value); the all-reduce is hidden under the next step's ViT instead of under a backward tail that the live-row
     # LLM backward has made too short to hide it.  `flush()` applies the last pending update.
-    def capture(self, batch: Dict[str, torch.Tensor], noise: Optional[torch.Tensor] = None, warmup: int = 2):
-        """``batch``/``noise`` become the static input buffers: copy new data INTO them before each replay."""
+    def capture(self, batch: Dict[str, torch.Tensor], noise: Optional[torch.Tensor] = None, warmup: int = 2,
+                conservative_rows: bool = False):
+        """``batch``/``noise`` become the static input buffers: copy new data INTO them before each replay.
+        The live-row window of the LLM backward is frozen here: from the capture batch's first action-query row, or - with
+        ``conservative_rows`` - from the first text row (valid for ANY later batch of the same shape: the action block
+        cannot start before tok0 + patches + one prompt token)."""
         self._ensure_streams()
         self._static_batch, self._static_noise = batch, noise
         self._row0 = None
         self._vision_and_embed(batch)                # masks of the capture batch -> the frozen live-row window
         self._row0 = self.live_row0()
+        if conservative_rows and not self.full_llm_backward:
+            self._row0 = min(self._row0, (self.cfg.n_patches + 1) // 32 * 32)
         for _ in range(warmup):                      # allocate every buffer / set kernel attributes outside capture
             self.head.dirty = True
             self._fwd_bwd(batch, noise)
@@ -1293,6 +1341,12 @@ class VLAEngine:
         self._h_end = self._run_segments(self._segs, self._graphs, getattr(self, "_timeline", None),
                                          hooks={self._vis_after: lambda ev: self._launch_vision(ev)})[("end", 0)]
         cur.wait_event(self._px_copied)        # later writes to the staging source are ordered behind the vision copy
+        if self.ga > 1:                        # gradient accumulation: join, fold, update only on the boundary micro-step
+            cur.wait_event(self._h_end)
+            if not self._accumulate():
+                return self._loss3
+            self._h_end = torch.cuda.Event()
+            self._h_end.record(cur)            # the summed gradient is final on the current stream
         if self.reducer is not None:
             aq_off = self.head.P.offsets["action_queries"][0]
             # head / proprio gradients are final when the head stream ends: their exchange starts there, underneath the
@@ -1331,6 +1385,8 @@ class VLAEngine:
                 self.reducer.wait(cur, self.side)
             self._reduced = None
             gscale = self.reducer.grad_scale
+        if self.ga > 1:                                # accumulated gradient was assembled on the current stream
+            self.side.wait_event(self._h_end)
         if os.environ.get("VLA_UPDATE_ON_MAIN"):       # A/B knob: the whole update in front of the step, on the current stream
             cur.wait_event(self._h_end)
         with torch.cuda.stream(cur if os.environ.get("VLA_UPDATE_ON_MAIN") else self.side):

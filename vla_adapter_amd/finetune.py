@@ -4,9 +4,9 @@ Keeps the reference's flat ``FinetuneConfig`` (finetune.py:66-128) and its ``--f
 absent here: parsed with argparse from the dataclass fields), the per-step metric names (finetune.py:421-444), the LR
 warm-up / MultiStepLR schedule (:903-921, 1061-1065) and the checkpoint file names (:527-572).  What is NOT here, on
 purpose: HF-hub / network loaders (:752-754), the RLDS/TensorFlow input pipeline (out of scope) -
-batches come from ``synthetic.make_batch`` (same collator contract) unless a ``--batch_file`` (.pt dict) is given,
-weights are random-init unless ``--vlm_path`` / ``--resum_vla_path`` point at local state-dict files - LoRA and
-full-unfreeze (config 4/5) raise NotImplementedError.
+batches come from an iterable / ``--batch_file`` (a .pt dict or a directory of them: the collator's contract) or
+``synthetic.make_batch``; weights are random-init unless ``--vlm_path`` / ``--resum_vla_path`` point at local state-dict
+files.  Every reference flag is either honoured or refused with an error (``check_supported``); none is silently dropped.
 """
 from __future__ import annotations
 
@@ -79,6 +79,9 @@ class FinetuneConfig:
     seed: int = 0
     batch_file: Optional[str] = None      # torch-saved dict with the collator's keys
     use_graph: bool = True                # replay the captured hipGraphs
+    max_seq_len: int = 0                  # static token length every batch is right-padded to (0: length of the first batch)
+    conservative_rows: bool = False       # captured live-row window starts at the first text row instead of the first batch's action block
+    dataset_statistics_file: Optional[str] = None   # JSON written next to every checkpoint (finetune.py:531)
     # fmt: on
 
 
@@ -93,30 +96,139 @@ def parse_args(argv=None) -> FinetuneConfig:
             ap.add_argument(f"--{f.name}", type=Path, default=default)
         else:
             ap.add_argument(f"--{f.name}", type=(int if f.name in ("resume_step",) else t), default=default)
-    return FinetuneConfig(**vars(ap.parse_args(argv)))
+    ns = ap.parse_args(argv)
+    cfg = FinetuneConfig(**vars(ns))
+    import sys
+    given = [a[2:].split("=")[0] for a in (sys.argv[1:] if argv is None else argv) if str(a).startswith("--")]
+    cfg._explicit = tuple(given)          # flags the user passed: out-of-path ones are refused, not ignored (check_supported)
+    return cfg
 
 
-def lr_at(step: int, cfg: FinetuneConfig) -> float:
-    """finetune.py:1061-1065 warm-up (10 % -> 100 % over lr_warmup_steps) on top of MultiStepLR(gamma 0.1) (:917)."""
-    lr = cfg.learning_rate * (0.1 if step >= cfg.num_steps_before_decay else 1.0)
-    return lr * (0.1 + 0.9 * min((step + 1) / cfg.lr_warmup_steps, 1.0))
+# Flags of the reference that only configure subsystems outside the accelerated path (RLDS/TensorFlow input pipeline,
+# W&B, HF hub): the native entry point consumes pre-collated batches, so their DEFAULT values are inert - but a value the
+# user passes explicitly cannot be honoured and is refused instead of ignored.
+OUT_OF_PATH_FLAGS = ("data_root_dir", "shuffle_buffer_size", "image_aug", "wandb_entity", "wandb_project", "run_id_note",
+                     "config_file_path", "phase1_path", "num_diffusion_steps", "diffusion_sample_freq", "val_freq", "val_time_limit",
+                     "merge_lora_during_training", "lora_dropout", "lora_rank", "use_minivlm", "use_fz")
 
 
-def save_training_checkpoint(cfg: FinetuneConfig, run_dir: Path, step: int, eng) -> None:
-    """File names / key layout of finetune.py:527-572 (rank 0)."""
+def check_supported(cfg: FinetuneConfig, explicit=()) -> None:
+    """Raise for every reference option this path does not implement (nothing is parsed and silently dropped)."""
+    if cfg.use_lora:
+        raise NotImplementedError("--use_lora: LoRA (finetune.py:832-844) is not accelerated yet")
+    if cfg.use_film or cfg.use_diffusion or not cfg.use_l1_regression:
+        raise NotImplementedError("native path = L1-regression action head; --use_film / --use_diffusion are not built")
+    if cfg.use_val_set:
+        raise NotImplementedError("--use_val_set: validation needs the RLDS val split (out of scope, SURVEY section 2 #16)")
+    if not cfg.use_proprio:
+        # the reference passes proprio_projector=None into predict_action, which calls it (action_heads.py:54): TypeError
+        raise TypeError("use_proprio=False: 'NoneType' object is not callable (the reference's predict_action requires the "
+                        "proprio projector, action_heads.py:53-55); pass --use_proprio True as every reference launch script does")
+    if cfg.grad_accumulation_steps < 1:
+        raise ValueError("grad_accumulation_steps must be >= 1")
+    if cfg.resume and cfg.resume_step is None:
+        raise ValueError("--resume needs --resume_step (finetune.py:1056 computes log_step = resume_step + gradient_step_idx)")
+    bad = [n for n in explicit if n in OUT_OF_PATH_FLAGS]
+    if bad:
+        raise NotImplementedError(f"flags {bad} configure parts of the reference outside the accelerated path (input pipeline / "
+                                  "logging services / hub loaders): the native entry point takes pre-collated batches "
+                                  "(--batch_file) and cannot honour them")
+
+
+def lr_at(gradient_step_idx: int, cfg: FinetuneConfig) -> float:
+    """Learning rate the optimizer step of gradient step g runs with (finetune.py:917, 1061-1065, 1078-1082).
+    lr_warmup_steps > 0 (the default 0.1): the warm-up block overwrites param_group['lr'] with
+    original_lr * (0.1 + 0.9 * min((g + 1) / warmup, 1)) on EVERY iteration before optimizer.step(), which also undoes the
+    MultiStepLR decay applied after the previous step - the decay never takes effect.  lr_warmup_steps <= 0: plain
+    MultiStepLR, factor 0.1 from optimizer step num_steps_before_decay on."""
+    if cfg.lr_warmup_steps > 0:
+        return cfg.learning_rate * (0.1 + 0.9 * min((gradient_step_idx + 1) / cfg.lr_warmup_steps, 1.0))
+    return cfg.learning_rate * (0.1 if gradient_step_idx >= cfg.num_steps_before_decay else 1.0)
+
+
+def loop_plan(cfg: FinetuneConfig):
+    """The reference loop's bookkeeping (finetune.py:1018-1122) as a generator of
+    (batch_idx, gradient_step_idx, log_step, optimizer_step?, save?, last?) - one item per micro-batch.  Runs until
+    log_step == max_steps INCLUSIVE (the reference breaks after processing that batch: max_steps + 1 gradient steps from a
+    fresh start); a checkpoint is due when gradient_step_idx > 0 and log_step % save_freq == 0 (taken once, after the
+    optimizer step that completes the gradient step)."""
+    ga = cfg.grad_accumulation_steps
+    base = cfg.resume_step if cfg.resume else 0
+    batch_idx = 0
+    while True:
+        g = batch_idx // ga
+        log_step = base + g
+        boundary = (batch_idx + 1) % ga == 0
+        save = boundary and g > 0 and log_step % cfg.save_freq == 0
+        last = log_step >= cfg.max_steps and boundary
+        yield batch_idx, g, log_step, boundary, save, last
+        if last:
+            return
+        batch_idx += 1
+
+
+def save_training_checkpoint(cfg: FinetuneConfig, run_dir: Path, step: int, eng, dataset_statistics: Optional[dict] = None) -> Path:
+    """File names / key layout of finetune.py:527-572 (rank 0).  The reference keeps the action queries inside the LoRA /
+    VLM checkpoint; the adapter-only path has neither, so they go to ``action_queries--{suffix}`` (native addition, read back
+    by checkpoints.load_run_dir)."""
     suffix = "latest_checkpoint.pt" if cfg.save_latest_checkpoint_only else f"{step}_checkpoint.pt"
     d = run_dir if cfg.save_latest_checkpoint_only else Path(str(run_dir) + f"--{step}_chkpt")
     os.makedirs(d, exist_ok=True)
     torch.save({k: v.cpu() for k, v in eng.head.head_state_dict().items()}, d / f"action_head--{suffix}")
     torch.save({k: v.clone().cpu() for k, v in eng.head.proprio_views().items()}, d / f"proprio_projector--{suffix}")
     torch.save({"weight": eng.head.P.view("action_queries").clone().cpu()}, d / f"action_queries--{suffix}")
-    json.dump({}, open(d / "dataset_statistics.json", "w"))
+    if dataset_statistics is not None:          # save_dataset_statistics (finetune.py:531): q01/q99 etc. used to un-normalise actions
+        json.dump(dataset_statistics, open(d / "dataset_statistics.json", "w"), indent=2)
+    return d
 
 
-def finetune(cfg: FinetuneConfig) -> dict:
+def _pad_to(batch: dict, L: int, pad_id: int) -> dict:
+    """Right-pad (collator semantics, data_utils.py:114-134) a batch to the static sequence length of the captured step."""
+    cur = batch["input_ids"].shape[1]
+    if cur == L:
+        return batch
+    if cur > L:
+        raise ValueError(f"batch with {cur} tokens exceeds the captured sequence length {L}: raise --max_seq_len")
+    out = dict(batch)
+    pad = lambda t, v: torch.nn.functional.pad(t, (0, L - cur), value=v)
+    out["input_ids"], out["labels"] = pad(batch["input_ids"], pad_id), pad(batch["labels"], -100)
+    out["attention_mask"] = pad(batch["attention_mask"].to(torch.bool), False)
+    return out
+
+
+def batch_stream(cfg: FinetuneConfig, mcfg, dev: str, rank: int, batches=None):
+    """Endless iterator over collated batches: an explicit iterable, ``--batch_file`` (one .pt dict, or a directory of them,
+    cycled in sorted order; every rank starts at its own offset - the reference's ranks draw independent shuffles,
+    finetune.py:988-994), or seeded synthetic batches (a new one every micro-step)."""
+    from . import synthetic as S
+    if batches is not None:
+        while True:
+            n = 0
+            for b in batches:
+                n += 1
+                yield {k: v.to(dev) for k, v in b.items()}
+            if n == 0:
+                raise ValueError("empty batch iterable")
+    elif cfg.batch_file:
+        files = sorted(str(p) for p in Path(cfg.batch_file).glob("*.pt")) if os.path.isdir(cfg.batch_file) else [cfg.batch_file]
+        if not files:
+            raise FileNotFoundError(f"no .pt batch files under {cfg.batch_file}")
+        i = rank % len(files)
+        while True:
+            yield {k: v.to(dev) for k, v in torch.load(files[i], weights_only=True).items()}
+            i = (i + 1) % len(files)
+    else:
+        i = 0
+        while True:
+            yield S.make_batch(mcfg, cfg.batch_size, dev, seed=1_000_003 * cfg.seed + 7919 * rank + i, P=32, ragged=True)
+            i += 1
+
+
+def finetune(cfg: FinetuneConfig, batches=None, explicit=()) -> dict:
+    """``batches``: optional iterable of collated batch dicts (util/data_utils.py:165-172 contract); ``explicit``: names of
+    the flags given on the command line (parse_args records them)."""
     from . import ddp, engine as E, synthetic as S
-    if cfg.use_lora or cfg.use_film or cfg.use_diffusion or not cfg.use_l1_regression:
-        raise NotImplementedError("native path: adapter-only L1-regression fine-tune (LoRA / FiLM / diffusion not accelerated yet)")
+    check_supported(cfg, explicit or getattr(cfg, "_explicit", ()))
     rank, local, world = ddp.init_process_group_from_env()
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
@@ -124,43 +236,67 @@ def finetune(cfg: FinetuneConfig) -> dict:
     mcfg.n_img = cfg.num_images_in_input
     mcfg.pro = bool(cfg.use_pro_version)
     W = S.make_weights(mcfg, dev, seed=cfg.seed)                  # identical on all ranks == DDP's initial broadcast
+    from . import checkpoints as CK
     if cfg.vlm_path and os.path.isfile(cfg.vlm_path):             # local VLM state dict (HF-style or native Prismatic keys)
-        from . import checkpoints as CK
         W.update(CK.split_reference_state_dict(CK.load_file(cfg.vlm_path), mcfg))
-    if cfg.resume and cfg.resum_vla_path and os.path.isdir(cfg.resum_vla_path):   # head / proprio only (finetune.py:275-278)
-        from . import checkpoints as CK
-        W["head"], W["proprio"] = CK.load_run_dir(cfg.resum_vla_path, cfg.resume_step)
+    if cfg.resume:                                                # head / proprio (finetune.py:275-278) + the action queries
+        if not (cfg.resum_vla_path and os.path.isdir(cfg.resum_vla_path)):
+            raise FileNotFoundError(f"--resume: --resum_vla_path {cfg.resum_vla_path!r} is not a checkpoint directory")
+        W["head"], W["proprio"], aq = CK.load_run_dir(cfg.resum_vla_path, cfg.resume_step, with_action_queries=True)
+        if aq is not None:
+            W["action_queries"] = aq
     eng = E.VLAEngine(mcfg, W, dev)
     if world > 1:
         eng.reducer = ddp.FlatGradReducer()
-    if cfg.batch_file:
-        batch = {k: v.to(dev) for k, v in torch.load(cfg.batch_file, weights_only=True).items()}
-    else:
-        batch = S.make_batch(mcfg, cfg.batch_size, dev, seed=1000 * cfg.seed + rank, P=32, ragged=True)
-    D = mcfg.llm.d
+    eng.set_grad_accumulation(cfg.grad_accumulation_steps)
+    stream = batch_stream(cfg, mcfg, dev, rank, batches)
+    pad_id = min(S.PAD_ID, mcfg.llm.vocab - 1)
+    cur = next(stream)
+    L = cfg.max_seq_len or cur["input_ids"].shape[1]
+    cur = _pad_to(cur, L, pad_id)
+    training = cfg.phase == "Training"
     gen = torch.Generator(device=dev).manual_seed(cfg.seed * 7919 + rank)
-    noise = torch.zeros(mcfg.chunk, mcfg.action_dim * D, device=dev, dtype=torch.bfloat16)
+    noise = torch.zeros(mcfg.chunk, mcfg.action_dim * mcfg.llm.d, device=dev, dtype=torch.bfloat16)
     run_dir = Path(cfg.run_root_dir) / (cfg.run_id_override or f"native+{cfg.dataset_name}+b{cfg.batch_size * world}+lr-{cfg.learning_rate}")
+    stats = json.load(open(cfg.dataset_statistics_file)) if cfg.dataset_statistics_file else None
+    static = None
     if cfg.use_graph:
-        eng.capture(batch, noise if cfg.phase == "Training" else None)
-    log, t0 = [], time.time()
-    for step in range(cfg.max_steps):
-        if cfg.phase == "Training":   # fresh N(0, 0.02^2) perturbation every call (action_heads.py:14-17, 69-72)
+        static = {k: v.clone() for k, v in cur.items()}
+        eng.capture(static, noise if training else None, conservative_rows=cfg.conservative_rows)
+    log, t0, saved_at, steps_done = [], time.time(), None, 0
+    for batch_idx, g, log_step, boundary, save, last in loop_plan(cfg):
+        nxt = _pad_to(next(stream), L, pad_id)                    # one batch of look-ahead: its vision stage runs inside this step
+        if training:   # fresh N(0, 0.02^2) perturbation every call (action_heads.py:14-17, 69-72)
             noise.copy_((torch.randn(noise.shape, device=dev, generator=gen) * 0.02).to(torch.bfloat16))
-        lr = lr_at(step, cfg)
+        lr = lr_at(g, cfg)
         if cfg.use_graph:
+            for k in static:
+                if k != "pixel_values" or batch_idx == 0:
+                    static[k].copy_(cur[k])
+            eng.stage_next_pixels(nxt["pixel_values"])
             loss3 = eng.train_step_graphed(lr)
         else:
-            loss3 = eng.train_step(batch, lr, noise if cfg.phase == "Training" else None)
-        if step % cfg.wandb_log_freq == 0 or step == cfg.max_steps - 1:       # the only host sync, every log_freq steps
+            loss3 = eng.train_step(cur, lr, noise if training else None)
+        steps_done += int(boundary)
+        if boundary and (log_step % cfg.wandb_log_freq == 0 or last):          # the only host sync, every log_freq gradient steps
             l = loss3.tolist()
-            log.append(dict(step=step, loss_value=l[0], curr_action_l1_loss=l[1], next_actions_l1_loss=l[2], lr=lr))
+            if not all(x == x for x in l):
+                raise FloatingPointError(f"non-finite loss at step {log_step}: {l} (a captured step replayed on a batch whose action "
+                                         "block starts before the frozen live-row window poisons the loss: --conservative_rows true)")
+            log.append(dict(step=log_step, loss_value=l[0], curr_action_l1_loss=l[1], next_actions_l1_loss=l[2], lr=lr))
             if rank == 0:
                 print(json.dumps(log[-1]), flush=True)
-        if step > 0 and step % cfg.save_freq == 0:
+        if save:
             eng.flush()                      # the graphed step leaves its parameter update pending (engine.capture)
             if rank == 0:
-                save_training_checkpoint(cfg, run_dir, step, eng)
+                save_training_checkpoint(cfg, run_dir, log_step, eng, stats)
+            saved_at = log_step
+            if world > 1:
+                torch.distributed.barrier()  # finetune.py:544, 575
+        cur = nxt
+        final_step = log_step
     eng.flush()
     torch.cuda.synchronize()
-    return dict(log=log, seconds=time.time() - t0, steps=cfg.max_steps, world=world)
+    if saved_at != final_step and rank == 0:     # never discard a run: the reference only saves on save_freq multiples
+        save_training_checkpoint(cfg, run_dir, final_step, eng, stats)
+    return dict(log=log, seconds=time.time() - t0, steps=steps_done, world=world, final_step=final_step, run_dir=str(run_dir))

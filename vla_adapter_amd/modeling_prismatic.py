@@ -163,8 +163,19 @@ class OpenVLAForActionPrediction:
         return self._unnormalize_actions(normalized, unnorm_key), hid
 
 
+@dataclass
+class CausalLMOutputWithPast:                     # transformers.modeling_outputs.CausalLMOutputWithPast (what the reference returns)
+    loss: Optional[torch.Tensor] = None
+    logits: Optional[torch.Tensor] = None
+    past_key_values: Any = None
+    hidden_states: Optional[Tuple[torch.Tensor, ...]] = None
+    attentions: Any = None
+
+
 class PrismaticVLM:
-    """Signature keeper for prismatic/models/vlms/prismatic.py:312-325 (native, non-HF API)."""
+    """prismatic/models/vlms/prismatic.py:312-481 on the native engine: the fully-multimodal branch of the plain VLM
+    forward - ViT(s) -> projector -> [tok0 | patches | tok1..] splice (NO action queries: they belong to
+    OpenVLAForActionPrediction) -> Qwen2 stack.  Every argument the native path cannot honour raises; nothing is dropped."""
 
     def __init__(self, model: OpenVLAForActionPrediction):
         self.model = model
@@ -172,13 +183,31 @@ class PrismaticVLM:
     def forward(self, input_ids=None, attention_mask=None, pixel_values=None, labels=None, inputs_embeds=None,
                 past_key_values=None, use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None,
                 multimodal_indices=None):
+        if input_ids is None or input_ids.shape[1] == 1 or pixel_values is None:
+            if past_key_values is not None:
+                raise NotImplementedError("cached single-token decoding (prismatic.py:328-342) is outside the accelerated path")
+            raise RuntimeError("Invalid `forward()` call!")                      # prismatic.py:344-345
+        if inputs_embeds is not None or past_key_values is not None or use_cache:
+            raise NotImplementedError("inputs_embeds / past_key_values / use_cache: only the uncached multimodal forward is built")
+        if output_attentions:
+            raise NotImplementedError("output_attentions: the flash-style attention kernel never materialises the probabilities")
+        if return_dict is False:
+            raise NotImplementedError("return_dict=False: a CausalLMOutputWithPast is always returned")
         if isinstance(pixel_values, dict):          # {"dino": .., "siglip": ..} (dinosiglip_vit.py:158-170)
             pixel_values = torch.cat([pixel_values["dino"], pixel_values["siglip"]], dim=1)
-        if multimodal_indices is not None and len(multimodal_indices) != input_ids.shape[0]:
-            raise NotImplementedError("mixed unimodal/multimodal batches are outside the accelerated path")
-        out = self.model.forward(input_ids=input_ids, attention_mask=attention_mask, pixel_values=pixel_values, labels=labels,
-                                 output_hidden_states=True)
-        # token-CE loss over the 151 936-way vocab (lm_head) is the 'next' row 8f-4; hidden states are returned.
-        return out
+        B = input_ids.shape[0]
+        if multimodal_indices is not None and sorted(int(i) for i in multimodal_indices) != list(range(B)):
+            raise NotImplementedError("mixed unimodal/multimodal batches (prismatic.py:424-467) are outside the accelerated path")
+        eng, dev = self.model.engine, self.model.device
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids, dtype=torch.bool)
+        batch = dict(input_ids=input_ids.to(dev), attention_mask=attention_mask.to(dev), pixel_values=pixel_values.to(dev).contiguous())
+        eng.forward_vlm(batch, action_queries=False)
+        n = self.model.cfg.llm.n_layers
+        loss = logits = None
+        if labels is not None:                      # HF shifted cross-entropy over the vocabulary
+            loss, logits = eng.token_ce(labels.to(dev))
+        hs = tuple(eng.llm.HS[i] for i in range(n + 1)) if output_hidden_states else None
+        return CausalLMOutputWithPast(loss=loss, logits=logits, hidden_states=hs)
 
     __call__ = forward
