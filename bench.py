@@ -54,7 +54,7 @@ def gemm_bytes_of_call(a, b, batched, kw):
     return by
 
 
-def measure_gemm_roofline(eng, batch, noise, lr, reps=10):
+def measure_gemm_roofline(eng, batch, noise, lr, reps=10, record_only=False):
     """Live HIP-event timing of the dominant kernel (gemm_nt_kernel) on the stream it is launched on (torch's current
     stream == the stream handed to the C ABI).  One eager step records every GEMM launch of a training step (operands,
     epilogue, algorithmic FLOPs); each DISTINCT launch signature is then replayed `reps` times back-to-back between two
@@ -100,6 +100,9 @@ def measure_gemm_roofline(eng, batch, noise, lr, reps=10):
     finally:
         ops.gemm_nt, ops.gemm_swiglu_bwd = orig, orig_sw
         eng.reducer = reducer
+    if record_only:
+        return dict(launches=sum(c[0] for c in calls.values()), flops=sum(c[0] * c[1] for c in calls.values()),
+                    bytes=sum(c[0] * c[5] for c in calls.values()))
     total_t = total_f = total_b = 0.0
     n = 0
     per = []
@@ -194,6 +197,7 @@ def main():
     ap.add_argument("--no-full-backward", action="store_true", help="skip the extra timing of the reference-shaped full LLM backward")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
     ap.add_argument("--rehearse-exchange", action="store_true", help="one GPU: run the step with a one-rank RCCL group and forced gradient collectives")
+    ap.add_argument("--no-probe", action="store_true", help="skip the isolated GEMM replays (profiling runs: the trace then holds training steps only)")
     ap.add_argument("--ragged", action="store_true", help="prompt lengths in [24, 32], right-padded (exercises the mask path; SURVEY 8d)")
     args = ap.parse_args()
 
@@ -279,7 +283,13 @@ def main():
                     "step_tflops": round(fl["step"] * B / dtf / 1e12, 1),
                     "frac_of_bf16_mfma_peak": round(fl["step"] * B / dtf / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
         eng.full_llm_backward = False
-    if rank == 0:
+    if rank == 0 and args.no_probe:
+        rec = measure_gemm_roofline(eng, batch, noise, lr, record_only=True)      # ONE more (eager) training step, no replays
+        print(json.dumps({"metric": "fine-tune samples/sec (profiling run, no probe)", "value": round(value, 2), "unit": "samples/s",
+                          "ms_per_step": round(ms, 3), "steps": args.steps, "warmup": args.warmup,
+                          "executed_steps": eng.executed_steps, "gemm_flops_per_step": rec["flops"],
+                          "gemm_launches_per_step": rec["launches"], "gemm_algorithmic_bytes_per_step": rec["bytes"]}), flush=True)
+    elif rank == 0:
         roof = measure_gemm_roofline(eng, batch, noise, lr)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:

@@ -43,11 +43,17 @@ def rnd(x: torch.Tensor, emu: bool) -> torch.Tensor:
     return x.to(torch.bfloat16).to(torch.float32) if emu else x
 
 
-def linear(x, w, b=None, emu=False):
-    """nn.Linear: y = x W^T + b, one rounding after bias (fp32 accumulate)."""
+def linear(x, w, b=None, emu=False, strided_input=False):
+    """nn.Linear: y = x W^T + b, one rounding after bias (fp32 accumulate).
+    strided_input (bf16 emulation only): torch's CPU nn.Linear on a NON-CONTIGUOUS 3-D bf16 input does not take the fused
+    addmm path - it runs matmul, rounds the product to bf16, then adds the bias and rounds again.  That is how the reference
+    run computes k_task / v_task (k_proj / v_proj in the original block): h_t is a strided slice of the [B, 25, K+64, D] tensor
+    (action_heads.py:57, 118) - for batch size > 1 only: with B = 1 the slice [1, K, D] counts as contiguous (size-1
+    dimensions are ignored) and the fused path is taken (batch-1 inference!).  Verified op by op against the reference module in this container and pinned by
+    tests/golden/head_bf16_*.npz; every other Linear of the head sees a contiguous input (cat / view outputs)."""
     y = x @ w.t()
     if b is not None:
-        y = y + b
+        y = (rnd(y, emu) if strided_input else y) + b
     return rnd(y, emu)
 
 
@@ -267,11 +273,21 @@ def proprio_projector(proprio, p: Dict[str, torch.Tensor], emu=False):
 # a8/a9  action head (prismatic/models/action_heads.py)
 # ----------------------------------------------------------------------------------------------
 def head_rope_tables(T: int, dh: int, emu=False, base: float = 10000.0):
-    """RotaryPositionEmbedding.forward (action_heads.py:150-164): cos/sin of cat([f, f])."""
+    """RotaryPositionEmbedding.forward (action_heads.py:150-164): cos/sin of cat([f, f]).
+    emu: the tables as the reference's bf16 run builds them.  finetune.py:280-281 casts the whole head with
+    ``.to(torch.bfloat16)``, which also casts the registered ``inv_freq`` BUFFER (:158): ``t = arange(seq_len, dtype=bf16)``
+    (positions above 256 are not representable and collapse onto even numbers), ``freqs = einsum(t, inv_freq)`` is rounded
+    to bf16 BEFORE cos / sin, and those round again.  Pinned by tests/golden/head_bf16_*.npz (reference run in bf16)."""
     inv = 1.0 / (base ** (torch.arange(0, dh, 2).float() / dh))
+    if emu:
+        inv_b = inv.to(torch.bfloat16)
+        t = torch.arange(T, dtype=torch.bfloat16)
+        f = torch.einsum("i,j->ij", t, inv_b)                      # bf16 product, rounded
+        e = torch.cat([f, f], dim=-1)
+        return e.cos().float(), e.sin().float()                    # bf16 cos/sin of the bf16 angle
     f = torch.arange(T, dtype=torch.float32)[:, None] * inv[None, :]
     e = torch.cat([f, f], dim=-1)
-    return rnd(e.cos(), emu), rnd(e.sin(), emu)
+    return e.cos(), e.sin()
 
 
 def head_rope(x, cos, sin, emu=False):
@@ -308,7 +324,8 @@ def head_block_pro(x, h_t, h_a, pp, p: Dict[str, torch.Tensor], pre: str, emu=Fa
     q = _heads(L("q_proj", x), B, T, H)
     ks, vs = _heads(L("k_self", x), B, T, H), _heads(L("v_self", x), B, T, H)
     ka, va = _heads(L("k_adapter", h_ad), B, Ka, H), _heads(L("v_adapter", h_ad), B, Ka, H)
-    kt, vt = _heads(L("k_task", h_t), B, Kt, H), _heads(L("v_task", h_t), B, Kt, H)
+    Ls = lambda n, t: linear(t, p[pre + n + ".weight"], p[pre + n + ".bias"], emu, strided_input=B > 1)
+    kt, vt = _heads(Ls("k_task", h_t), B, Kt, H), _heads(Ls("v_task", h_t), B, Kt, H)      # h_t: strided slice (see linear())
     cm, sm = head_rope_tables(T, dh, emu)                          # :383-388 positions restart per segment
     q, ks = head_rope(q, cm, sm, emu), head_rope(ks, cm, sm, emu)
     ca, sa = head_rope_tables(Ka, dh, emu)
@@ -333,7 +350,8 @@ def head_block_orig(x, h_t, h_a, pp, p: Dict[str, torch.Tensor], pre: str, emu=F
     q = _heads(L("q_proj", x), B, T, H)
     kx, vx = _heads(L("k_proj", x), B, T, H), _heads(L("v_proj", x), B, T, H)
     kh, vh = _heads(L("k_proj", h), B, h.shape[1], H), _heads(L("v_proj", h), B, h.shape[1], H)
-    kt, vt = _heads(L("k_proj", h_t), B, h_t.shape[1], H), _heads(L("v_proj", h_t), B, h_t.shape[1], H)
+    Ls = lambda n, t: linear(t, p[pre + n + ".weight"], p[pre + n + ".bias"], emu, strided_input=B > 1)
+    kt, vt = _heads(Ls("k_proj", h_t), B, h_t.shape[1], H), _heads(Ls("v_proj", h_t), B, h_t.shape[1], H)   # h_t: strided slice
     o = head_attention_core(q, [(kx, vx), (kh, vh), (kt, vt)], ratio_g, emu)     # :262-275
     o = L("o_proj", o.transpose(1, 2).reshape(B, T, C))
     y = layer_norm(rnd(o + x, emu), p[pre + "ffn.0.weight"], p[pre + "ffn.0.bias"], 1e-5, emu)
@@ -342,7 +360,7 @@ def head_block_orig(x, h_t, h_a, pp, p: Dict[str, torch.Tensor], pre: str, emu=F
 
 def head_predict_action(mlhs, proprio, head_p: Dict[str, torch.Tensor], proprio_p: Dict[str, torch.Tensor],
                         num_task_tokens: int, pro: bool = True, noise: Optional[torch.Tensor] = None,
-                        emu=False, num_blocks: int = 24) -> torch.Tensor:
+                        emu=False, num_blocks: int = 24, taps: Optional[dict] = None) -> torch.Tensor:
     """L1RegressionActionHead.predict_action + MLPResNet.forward (action_heads.py:43-81, 111-121).
 
     mlhs [B, n_states, num_task_tokens+64, D]; ``noise`` [8, 7*D] is the Training-phase perturbation
@@ -360,6 +378,8 @@ def head_predict_action(mlhs, proprio, head_p: Dict[str, torch.Tensor], proprio_
     blk = head_block_pro if pro else head_block_orig
     for i in range(num_blocks):                                                           # :117-118
         x = blk(x, h_t_all[:, i + 1], h_a_all[:, i + 1], pf, head_p, f"model.mlp_resnet_blocks.{i}.", emu)
+        if taps is not None:
+            taps[i] = x.detach()                                                              # block outputs (tests)
     x = layer_norm(x, head_p["model.layer_norm2.weight"], head_p["model.layer_norm2.bias"], 1e-5, emu)
     return linear(x, head_p["model.fc2.weight"], head_p["model.fc2.bias"], emu)
 

@@ -54,15 +54,81 @@ def seeded_init_(module: torch.nn.Module, seed: int, std: float = 0.05):
                 p.copy_(torch.randn(p.shape, generator=g) * std)
 
 
+def bf16_head_fixtures(args, ah, pj, C):
+    # ---------------- (ii-b) action head run the way finetune.py runs it: bf16 module, CPU ----------------
+    # finetune.py:280-281 casts the module with .to(torch.bfloat16); :411 calls action_head.module.predict_action(mlhs, proprio,
+    # proprio_projector, phase) OUTSIDE autocast on bf16 hidden states; :418 L1Loss against actions.to(bf16).  Same call here,
+    # at MFMA-capable widths (D = 128: head dim 16; D = 896: the real head, head dim 112, 256 / 512 task tokens).  Inputs and
+    # the 218 M parameters are regenerated from seeds on both sides (tests/golden_gen.py); the fixture keeps the outputs of the
+    # bf16 run, of an fp32 run of the same module (the "truth" the bf16 error budget is measured against), a few gradients,
+    # and a digest of every generated input.
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    import golden_gen as GG
+    for case in GG.CASES:
+        pro, Dh, Kt, B, phase, nb = GG.case_cfg(case)
+        inp = GG.case_inputs(case)
+        res = {}
+        for dt, tag in ((torch.bfloat16, "bf16"), (torch.float32, "fp32")):
+            head = ah.L1RegressionActionHead(input_dim=Dh, hidden_dim=Dh, action_dim=C.ACTION_DIM, num_task_tokens=Kt, use_pro_version=pro)
+            if nb != 24:                           # the reference hard-codes 24 blocks (:35); MLPResNet itself takes num_blocks (:87)
+                head.model = ah.MLPResNet(num_blocks=nb, input_dim=Dh * C.ACTION_DIM, hidden_dim=Dh, output_dim=C.ACTION_DIM, use_pro_version=pro)
+            ppm = pj.ProprioProjector(llm_dim=Dh, proprio_dim=C.PROPRIO_DIM)
+            missing = head.load_state_dict(inp["head"], strict=False)
+            assert all("film_gen" in k for k in missing.missing_keys) and not missing.unexpected_keys, missing
+            ppm.load_state_dict(inp["proprio"])
+            head, ppm = head.to(dt), ppm.to(dt)
+            if dt == torch.float32:            # predict_action casts proprio to bf16 (:53) whatever the module dtype: feed fp32 back in
+                class Up(torch.nn.Module):
+                    def __init__(s, m): super().__init__(); s.m = m
+                    def forward(s, x): return s.m(x.float())
+                ppc = Up(ppm)
+            else:
+                ppc = ppm
+            mlhs = inp["mlhs"].to(dt).requires_grad_(True)
+            blk_out = {}
+            hooks = [head.model.mlp_resnet_blocks[i].register_forward_hook(lambda m, a, o, i=i: blk_out.__setitem__(i, o.detach().float().numpy()))
+                     for i in GG.block_taps(case)]
+            orig = ah.learnable_random_perturbations
+            if phase == "Training":            # the reference draws fresh N(0, 0.02^2) noise (:14-17, 69-72): inject the seeded one
+                ah.learnable_random_perturbations = lambda seq_len, dim, device, dtype: inp["noise"].to(dtype)
+            try:
+                out = head.predict_action(mlhs, proprio=inp["prop"], proprio_projector=ppc, phase=phase)
+            finally:
+                ah.learnable_random_perturbations = orig
+            loss = torch.nn.L1Loss()(out, inp["target"].to(dt))          # finetune.py:418 (value only; kept for reference)
+            out.backward(inp["dpred"].to(dt))                            # fixed upstream gradient (golden_gen.case_inputs)
+            res[f"out_{tag}"], res[f"loss_{tag}"] = out.detach().float().numpy(), loss.detach().float().numpy()
+            res[f"xblk_{tag}"] = np.stack([blk_out[i] for i in GG.block_taps(case)])      # block outputs [taps, B, 8, D]
+            for h in hooks:
+                h.remove()
+            named = dict(head.named_parameters())
+            for k in GG.grad_keys(case):
+                res[f"g_{tag}.{k}"] = named[k].grad.float().numpy()
+            for k in GG.weight_grad_rows(case):
+                res[f"g_{tag}.{k}"] = named[k].grad[:16].float().numpy()
+            res[f"g_{tag}.proprio.fc2.bias"] = ppm.fc2.bias.grad.float().numpy()
+            if Dh <= 128 or nb == 1:
+                res[f"dx_{tag}"] = mlhs.grad[:, GG.dx_layers(case)][:, :, GG.dx_rows(case)].float().numpy()
+        np.savez_compressed(os.path.join(args.out, f"head_bf16_{case}.npz"), digest=np.array(GG.digest(inp)),
+                            meta=np.array([int(pro), Dh, Kt, B, int(phase == "Training"), nb]), **res)
+        print(f"  {case}: bf16-vs-fp32 of the REFERENCE itself: pred rel-L2 "
+              f"{np.linalg.norm(res['out_bf16'] - res['out_fp32']) / np.linalg.norm(res['out_fp32']):.3e}")
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    ap.add_argument("--only-bf16-head", action="store_true", help="regenerate just the head_bf16_* fixtures")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     R = import_reference(args.ref)
     tu, ah, pj, C = R["train_utils"], R["action_heads"], R["projectors"], R["constants"]
     torch.manual_seed(0)
+    if args.only_bf16_head:
+        bf16_head_fixtures(args, ah, pj, C)
+        return
     g = torch.Generator().manual_seed(1234)
 
     # ---------------- (i) mask KATs: train_utils.py:8-41 ----------------
@@ -138,6 +204,8 @@ def main():
             np.savez_compressed(os.path.join(args.out, f"head_{'pro' if pro else 'orig'}_kt{Kt}.npz"), **npd(fx),
                                 **{"w." + k: v for k, v in npd(sd).items()},
                                 **{"pw." + k: v for k, v in npd(pp.state_dict()).items()})
+
+    bf16_head_fixtures(args, ah, pj, C)
 
     # ---------------- (iv) Qwen2 tiny via installed transformers ----------------
     from transformers import Qwen2Config, Qwen2ForCausalLM

@@ -26,6 +26,7 @@
 //       WAR  slot of half-tile h is refilled in phase h + 1: B0 is last read in phase h (its 4 reads are retired by the
 //            lgkmcnt(8) BEFORE that phase's first barrier), A0/B1/A1 are refilled >= 2 phases after their last read.
 //   * epilogue through the (now free) operand LDS: per wave two 64 x 64 passes, 16-B stores of whole row segments.
+#include <type_traits>
 #include "gemm_params.h"
 #include "../../include/vla_native.h"
 
@@ -106,7 +107,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
     }
   }
 
+#ifdef G256_ABL
+#if G256_ABL == 3
+  const int nt = 1;                 // diagnostic build: prologue + one K-tile + epilogue only
+#else
   const int nt = p.K / BK;
+#endif
+#else
+  const int nt = p.K / BK;
+#endif
   // ---- prologue: K-tile 0 (half-tiles 0..3) and the first three half-tiles of K-tile 1
   stage_b(0, 0, 0); stage_a(1, 0, 0); stage_b(2, 1, 0); stage_a(3, 1, 0);
   if (nt > 1) {
@@ -243,6 +252,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
   if (wr == 0) VLA_BARRIER();      // pairs with the last barrier of the wr = 1 waves: every operand read is finished
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
+#if defined(G256_ABL) && G256_ABL == 1
+  {                                 // diagnostic build: no epilogue at all (accumulators kept alive)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) asm volatile("" ::"v"(acc[a][b][c][e]));
+    return;
+  }
+#endif
   // ---------------- epilogue: two 64 x 64 passes per wave through its private staging region ----------------
   char* reg = smem + wid * (64 * EPI_STRIDE);
   float bv[4][4];
@@ -311,13 +333,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
       continue;
     }
     if (EPI == 1) {
-      // SwiGLU forward: columns interleaved in 16s - even n tiles are gate, odd n tiles the matching up columns
+      // SwiGLU forward: columns interleaved in 16s - even n tiles are gate, odd n tiles the matching up columns.  The product
+      // h (64 rows x 32 columns per pass) is staged through LDS like C, so that it leaves as 16-B row segments (direct 8-B
+      // stores touched 16 cache lines per instruction: 4x the store instructions on every tile's tail).
       bf16_t* C2 = p.C2 + (long long)z * p.sC2;
+      constexpr int HSTR = 32 * 2 + 16;                       // staged h row: 32 bf16 + pad
+      char* regh = smem + 8 * (64 * EPI_STRIDE) + wid * (64 * HSTR);
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
-          const int m = wm0 + mi * 16 + lr;
           float h[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -327,13 +352,28 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
             A4(2 * pr + 1, mi)[j] = u;
             h[j] = rbf(g * __builtin_amdgcn_rcpf(1.0f + __expf(-g))) * u;
           }
-          const int hc = (wn0 >> 1) + pr * 16 + lq * 4;
-          if (m < p.M && hc + 3 < (p.N >> 1)) {
-            uint2 o = {pack2(h[0], h[1]), pack2(h[2], h[3])};
-            *reinterpret_cast<uint2*>(C2 + (long long)m * p.ldc2 + hc) = o;
-          }
+          *reinterpret_cast<uint2*>(regh + (mi * 16 + lr) * HSTR + (pr * 16 + lq * 4) * 2) = uint2{pack2(h[0], h[1]), pack2(h[2], h[3])};
         }
+      const bool hvec = ((p.ldc2 & 7) == 0) && (((size_t)C2 & 15) == 0);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {                        // 64 rows x 4 chunks of 16 B: 16 rows per pass
+        const int row = it * 16 + (lane >> 2), ch = lane & 3;
+        const int m = wm0 + row, hc = (wn0 >> 1) + ch * 8;
+        const uint4 v = *reinterpret_cast<const uint4*>(regh + row * HSTR + ch * 16);
+        if (m >= p.M || hc >= (p.N >> 1)) continue;
+        bf16_t* dst = C2 + (long long)m * p.ldc2 + hc;
+        if (hvec && hc + 8 <= (p.N >> 1)) {
+          *reinterpret_cast<uint4*>(dst) = v;
+        } else {
+          const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if (hc + k < (p.N >> 1)) dst[k] = (bf16_t)((k & 1) ? (wv[k >> 1] >> 16) : (wv[k >> 1] & 0xffffu));
+        }
+      }
       if (p.C == nullptr) continue;
+      // pre-activations kept for a live-row backward only (c_live): a 64-row block without a live row stores nothing
+      if (p.c_live_mod > 0 && (wm0 % p.c_live_mod) + 63 < p.c_live_from) continue;
     } else {
       auto finish = [&](auto fn) {
 #pragma unroll
@@ -360,41 +400,55 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
         uint2 o = {pack2(A4(t4, mi)[0], A4(t4, mi)[1]), pack2(A4(t4, mi)[2], A4(t4, mi)[3])};
         *reinterpret_cast<uint2*>(reg + (mi * 16 + lr) * EPI_STRIDE + (t4 * 16 + lq * 4) * 2) = o;
       }
+    // Row addressing: the plain case (no row groups, no broadcast residual, no live-row filter) must not pay the four integer
+    // divisions per output row of the general case - 128 divisions per wave sat on every tile's tail.
+    const bool plain_rows = (p.res_mod | p.gR | p.gC | p.c_live_mod) == 0;
+    auto store_rows = [&](auto fast_t) {
+      constexpr bool FAST = decltype(fast_t)::value;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {                       // 64 rows x 8 chunks of 16 B: 8 rows per pass
-      const int row = it * 8 + (lane >> 3), ch = lane & 7;
-      const int m = wm0 + row, n = wn0 + ch * 8;
-      uint4 v = *reinterpret_cast<const uint4*>(reg + row * EPI_STRIDE + ch * 16);
-      if (m >= p.M || n >= p.N) continue;
-      if (p.c_live_mod > 0 && (m % p.c_live_mod) < p.c_live_from) continue;
-      const long long roff = p.res_mod > 0 ? (long long)(m % p.res_mod) * p.ldr
-                             : p.gR > 0 ? (long long)(m / p.gR) * p.sgR + (long long)(m % p.gR) * p.ldr : (long long)m * p.ldr;
-      const long long crow = p.gC > 0 ? (long long)(m / p.gC) * p.sgC + (long long)(m % p.gC) * p.ldc : (long long)m * p.ldc;
-      if (vec_ok && n + 8 <= p.N) {
-        if (Rb) {
-          const uint4 rv = *reinterpret_cast<const uint4*>(Rb + roff + n);
-          const unsigned a[4] = {v.x, v.y, v.z, v.w};
-          const unsigned b[4] = {rv.x, rv.y, rv.z, rv.w};
-          unsigned o[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            o[k] = pack2(bf2f((bf16_t)(a[k] & 0xffff)) + bf2f((bf16_t)(b[k] & 0xffff)),
-                         bf2f((bf16_t)(a[k] >> 16)) + bf2f((bf16_t)(b[k] >> 16)));
-          v = uint4{o[0], o[1], o[2], o[3]};
+      for (int it = 0; it < 8; ++it) {                       // 64 rows x 8 chunks of 16 B: 8 rows per pass
+        const int row = it * 8 + (lane >> 3), ch = lane & 7;
+        const int m = wm0 + row, n = wn0 + ch * 8;
+        uint4 v = *reinterpret_cast<const uint4*>(reg + row * EPI_STRIDE + ch * 16);
+        if (m >= p.M || n >= p.N) continue;
+        long long roff, crow;
+        if constexpr (FAST) {
+          roff = (long long)m * p.ldr;
+          crow = (long long)m * p.ldc;
+        } else {
+          if (p.c_live_mod > 0 && (m % p.c_live_mod) < p.c_live_from) continue;
+          roff = p.res_mod > 0 ? (long long)(m % p.res_mod) * p.ldr
+                 : p.gR > 0 ? (long long)(m / p.gR) * p.sgR + (long long)(m % p.gR) * p.ldr : (long long)m * p.ldr;
+          crow = p.gC > 0 ? (long long)(m / p.gC) * p.sgC + (long long)(m % p.gC) * p.ldc : (long long)m * p.ldc;
         }
-        *reinterpret_cast<uint4*>(Cb + crow + n) = v;
-      } else {
-        const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+        if (vec_ok && n + 8 <= p.N) {
+          if (Rb) {
+            const uint4 rv = *reinterpret_cast<const uint4*>(Rb + roff + n);
+            const unsigned a[4] = {v.x, v.y, v.z, v.w};
+            const unsigned b[4] = {rv.x, rv.y, rv.z, rv.w};
+            unsigned o[4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          if (n + k < p.N) {
-            float f = bf2f((bf16_t)((k & 1) ? (wv[k >> 1] >> 16) : (wv[k >> 1] & 0xffffu)));
-            if (Rb) f += bf2f(Rb[roff + n + k]);
-            Cb[crow + n + k] = f2bf(f);
+            for (int k = 0; k < 4; ++k)
+              o[k] = pack2(bf2f((bf16_t)(a[k] & 0xffff)) + bf2f((bf16_t)(b[k] & 0xffff)),
+                           bf2f((bf16_t)(a[k] >> 16)) + bf2f((bf16_t)(b[k] >> 16)));
+            v = uint4{o[0], o[1], o[2], o[3]};
+          }
+          *reinterpret_cast<uint4*>(Cb + crow + n) = v;
+        } else {
+          const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            if (n + k < p.N) {
+              float f = bf2f((bf16_t)((k & 1) ? (wv[k >> 1] >> 16) : (wv[k >> 1] & 0xffffu)));
+              if (Rb) f += bf2f(Rb[roff + n + k]);
+              Cb[crow + n + k] = f2bf(f);
+            }
           }
         }
       }
-    }
+    };
+    if (plain_rows) store_rows(std::true_type{});
+    else store_rows(std::false_type{});
   }
 }
 

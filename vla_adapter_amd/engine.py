@@ -811,6 +811,7 @@ class VLAEngine:
         self._row0 = None          # frozen by capture(); None = derive from every batch (one host sync)
         self.reducer = None        # ddp.FlatGradReducer when world_size > 1
         self.ga, self._micro, self._gacc = 1, 0, None     # gradient accumulation (set_grad_accumulation)
+        self.executed_steps = 0    # forward+backward passes enqueued so far (eager, pipelined or replayed): profile bookkeeping
 
     def set_grad_accumulation(self, n: int):
         """finetune.py:1039-1042, 1078-1082: loss / n on every micro-batch, gradients summed over n micro-batches (in bf16, as
@@ -1052,6 +1053,7 @@ class VLAEngine:
 
     def train_step(self, batch, lr: float, noise=None):
         """One micro-batch; the optimizer steps on every ``ga``-th call (set_grad_accumulation)."""
+        self.executed_steps += 1
         pred = self.forward(batch, noise, for_training=True)
         loss3 = self.loss_and_backward(pred, batch["actions"], 1.0 / self.ga, exchange=self.ga == 1)
         if self._accumulate():
@@ -1243,6 +1245,7 @@ class VLAEngine:
 
     def _fwd_bwd(self, batch, noise, vision: bool = True):
         """Eager run of the two-stream schedule (vision stage first unless the vision graph already ran)."""
+        self.executed_steps += 1
         if vision:
             self._vision(batch)
         torch.cuda.current_stream().wait_event(self._run_segments(self._segments(batch, noise))[("end", 0)])   # join
@@ -1336,6 +1339,7 @@ class VLAEngine:
         """Replay of the captured step on the static buffers.  The parameter update of THIS step (RCCL exchange +
         AdamW) is left pending and applied inside the next call, after that step's vision graph - or by flush()."""
         cur = torch.cuda.current_stream()
+        self.executed_steps += 1
         self.flush(join=False)
         cur.wait_event(self._vis_ev)           # patches of THIS step (computed during the previous call)
         self._h_end = self._run_segments(self._segs, self._graphs, getattr(self, "_timeline", None),

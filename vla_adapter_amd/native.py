@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("VLA_NATIVE_LIB") or os.path.join(_HERE, "libvla_native.so")   # override: same-box A/B of two builds
+LIB_PATH = (os.environ.get("VLA_NATIVE_LIB") or None) or os.path.join(_HERE, "libvla_native.so")   # override: same-box A/B of two builds
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_TANH, ACT_SWIGLU, ACT_SWIGLU_BWD = 0, 1, 2, 3, 4, 5
 

@@ -292,11 +292,15 @@ def rope_half_(x2d: torch.Tensor, cos_t, sin_t, S: int, nheads: int, dh: int, si
 
 
 def rope_inter_tables(T: int, dh: int, device, base: float = 10000.0):
-    """action_heads.py:150-164: cos/sin of cat([f, f]) -> f32 [T, dh] (bf16-rounded values)."""
-    inv = 1.0 / (base ** (torch.arange(0, dh, 2).float() / dh))
-    f = torch.arange(T, dtype=torch.float32)[:, None] * inv[None, :]
+    """action_heads.py:150-164: cos/sin of cat([f, f]) -> f32 [T, dh] tables holding the bf16 values the reference's bf16
+    head computes.  finetune.py:280-281 casts the head with .to(torch.bfloat16), which casts the registered ``inv_freq``
+    buffer too: positions are a bf16 arange (above 256 they collapse onto representable even numbers), the angle
+    t * inv_freq is rounded to bf16 BEFORE cos / sin.  Host-side table construction (torch CPU as the array library),
+    pinned by the reference-run fixtures tests/golden/head_bf16_*.npz."""
+    inv = (1.0 / (base ** (torch.arange(0, dh, 2).float() / dh))).to(BF16)
+    f = torch.einsum("i,j->ij", torch.arange(T, dtype=BF16), inv)
     e = torch.cat([f, f], dim=-1)
-    return (e.cos().to(BF16).float().to(device).contiguous(), e.sin().to(BF16).float().to(device).contiguous())
+    return (e.cos().float().to(device).contiguous(), e.sin().float().to(device).contiguous())
 
 
 def rope_inter_(x2d: torch.Tensor, cos_t, sin_t, T: int, nheads: int, dh: int, mode: int = 0):
