@@ -63,6 +63,11 @@ typedef struct vla_gemm_desc {
    * sums the planes and applies bias / activation (none, GELU, ReLU) / residual.  For few-tile long-K problems (batch-1
    * inference); batch == 1 and N % 4 == 0 only. */
   int split_k; float* ws;
+  /* optional: 1 = round the product to bf16 BEFORE the bias is added, C = bf16(bf16(alpha A.B^T) + bias).  This is what
+   * torch's CPU nn.Linear computes for a non-contiguous bf16 input (matmul, then add_) - the reference's k_task / v_task
+   * projections of the strided h_t slice at batch size > 1 (action_heads.py:57, 118, 366-367); pinned by the reference-run
+   * fixtures tests/golden/head_bf16_*.npz.  0 = the fused single rounding bf16(alpha A.B^T + bias). */
+  int bias_post_round;
 } vla_gemm_desc;
 
 /* C = epilogue(A . B^T).  Replaces nn.Linear forward and, with pre-transposed operands, its dX / dW products:

@@ -43,14 +43,17 @@ CASES = {
     # name: (pro, D, Kt, B, phase[, num_blocks])   D = 128 -> head dim 16 (smallest MFMA-capable), D = 896 -> head dim 112 (the real head)
     "pro_d128_kt64": (True, 128, 64, 2, "Inference"),
     "pro_d128_kt64_train": (True, 128, 64, 2, "Training"),
-    "orig_d128_kt64": (False, 128, 64, 2, "Inference"),
+    # (the original block has no RoPE: in phase "Inference" the 8 chunk rows of a sample stay IDENTICAL through all 24 blocks, and a
+    #  single ReLU pre-activation within rounding of zero then flips for all rows at once - a degenerate input where one flip moves a
+    #  bias gradient by 9 %; the Training-phase perturbation makes the rows distinct)
+    "orig_d128_kt64": (False, 128, 64, 2, "Training"),
     "pro_d896_kt256": (True, 896, 256, 2, "Inference"),
     "pro_d896_kt256_train": (True, 896, 256, 2, "Training"),
     "pro_d896_kt512": (True, 896, 512, 1, "Inference"),
     # ONE-block heads (MLPResNet(num_blocks=1)): forward and backward rounding points without 24 blocks of accumulated drift -
     # two bf16 evaluations of these agree to a few 1e-3 on every gradient, so an implementation error cannot hide in noise
     "pro1_d128_kt64": (True, 128, 64, 2, "Training", 1),
-    "orig1_d128_kt64": (False, 128, 64, 2, "Inference", 1),
+    "orig1_d128_kt64": (False, 128, 64, 2, "Training", 1),
     "pro1_d896_kt256": (True, 896, 256, 2, "Training", 1),
 }
 SEED = 20260

@@ -1,10 +1,12 @@
 """End-to-end parity of the native engine (forward, backward, optimiser step) against the CPU oracle on the
 prismatic-tiny configuration (BASELINE.json configs[0]) with the same seeded weights and batch.
 
-Tolerances: the whole pipeline is bf16 with fp32 accumulation; against the oracle evaluated with the SAME bf16
-rounding points (emu=True) we require rel-L2 <= 1e-2 on hidden states / predictions and <= 3e-2 on gradients
-(each layer adds independent 2^-9 rounding flips from different fp32 summation orders); the 1e-3 target of the
-north star is checked on the loss value.
+Bar: the whole pipeline is bf16 with fp32 accumulation, and two valid bf16 evaluations of the same
+network drift apart (tests/test_oracle_golden.py measures it on the reference itself), so every end-to-end check is an
+ERROR BUDGET against the fp32 truth:   |native - oracle_fp32|  <=  1.25 x |oracle_emu - oracle_fp32|
+where oracle_emu is the bf16-emulating oracle (rounding points pinned op by op against the reference's bf16 run).  Both
+numbers are printed.  For families of small gradient tensors a single tensor's ratio fluctuates (one realisation of
+rounding noise each): each tensor gets 4 x its own budget plus a floor, the aggregate over the family 1.5 x.
 """
 import pytest
 import torch
@@ -35,6 +37,33 @@ def oracle_cfg(cfg):
 def rel(a, b):
     a, b = a.detach().float().cpu(), b.detach().float().cpu()
     return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def budget(native, emu, truth, what, factor=1.25, floor=0.0):
+    """|native - fp32| <= factor x |emu - fp32| + floor x |fp32|; returns (native distance, emu distance) relative to |fp32|."""
+    n, e, t = (x.detach().float().cpu().reshape(-1) for x in (native, emu, truth))
+    nt = t.norm().item() + 1e-30
+    dn, de = (n - t).norm().item() / nt, (e - t).norm().item() / nt
+    print(f"budget {what}: native-vs-fp32 {dn:.3e}   oracle(emu)-vs-fp32 {de:.3e}   ratio {dn / (de + 1e-30):.2f}")
+    assert dn <= factor * de + floor, f"{what}: native is {dn:.3e} from the fp32 truth, the bf16-emulating oracle {de:.3e} (x{factor} + {floor})"
+    return dn, de
+
+
+def budget_family(items, what, each=4.0, total=1.5, floor=2e-3, absfloor=0.0):
+    """items: [(name, native, emu, truth)].  Per tensor: native <= each x emu + floor (or |err| <= absfloor: tensors orders of
+    magnitude below the family's dominant ones sit on the absolute noise floor of the chain feeding them); aggregate
+    (root of summed squared relative distances) <= total x emu's + floor."""
+    sn = se = 0.0
+    for name, native, emu, truth in items:
+        n, e, t = (x.detach().float().cpu().reshape(-1) for x in (native, emu, truth))
+        nt = t.norm().item() + 1e-30
+        dn, de = (n - t).norm().item() / nt, (e - t).norm().item() / nt
+        if dn * nt <= absfloor:
+            continue
+        sn, se = sn + dn * dn, se + de * de
+        assert dn <= each * de + floor, f"{what} / {name}: native-vs-fp32 {dn:.3e}, oracle(emu)-vs-fp32 {de:.3e}"
+    print(f"budget {what}: rms over {len(items)} tensors  native-vs-fp32 {sn ** 0.5:.3e}   oracle(emu)-vs-fp32 {se ** 0.5:.3e}")
+    assert sn ** 0.5 <= total * se ** 0.5 + floor, f"{what}: aggregate {sn ** 0.5:.3e} vs {se ** 0.5:.3e}"
 
 
 @pytest.fixture(scope="module")
@@ -77,19 +106,15 @@ def test_forward_parity(setup, use_noise):
     pred = eng.forward(batch, noise.to(DEV) if use_noise else None)
     torch.cuda.synchronize()
     out, _ = _oracle_run(cfg, W, batch, noise, True, cfg.num_blocks)
+    tru, _ = _oracle_run(cfg, W, batch, noise, False, cfg.num_blocks)
     n = cfg.llm.n_layers
-    B, L = batch["input_ids"].shape
-    S = L + cfg.n_patches
-    # patches as spliced into the multimodal sequence
-    assert rel(eng.llm.HS[0][:, 1:cfg.n_patches + 1], out["patches"]) < 1e-2
-    valid = batch["attention_mask"].cpu()
+    Np = cfg.n_patches
+    budget(eng.llm.HS[0][:, 1:Np + 1], out["patches"], tru["patches"], "projected patches")
     for i in range(n + 1):
-        r = rel(eng.llm.HS[i], out["hidden_states"][i])
-        assert r < 1.5e-2, f"hidden_states[{i}] rel-L2 {r:.3e}"
-    r = rel(pred, out["pred"])
-    assert r < 1.5e-2, f"pred rel-L2 {r:.3e}"
+        budget(eng.llm.HS[i], out["hidden_states"][i], tru["hidden_states"][i], f"hidden_states[{i}]")
+    budget(pred, out["pred"], tru["pred"], "predicted actions")
     loss3, _ = __import__("vla_adapter_amd.ops", fromlist=["ops"]).l1_loss(pred, batch["actions"].to(BF), False)
-    assert abs(loss3[0].item() - out["loss"].item()) <= 1e-2 * abs(out["loss"].item())
+    assert abs(loss3[0].item() - tru["loss"].item()) <= 1.25 * abs(out["loss"].item() - tru["loss"].item()) + 1e-3 * abs(tru["loss"].item())
 
 
 def test_backward_and_step_parity(setup):
@@ -98,38 +123,21 @@ def test_backward_and_step_parity(setup):
     loss3 = eng.loss_and_backward(pred, batch["actions"])
     torch.cuda.synchronize()
     out, OW = _oracle_run(cfg, W, batch, None, True, cfg.num_blocks)
-    # L1's gradient is sign(pred - target)/n: a bf16-level difference in pred flips signs and changes the whole
-    # backward signal discretely (oracle bf16-vs-fp32 grads differ by ~5% for that reason alone), so the oracle's
-    # backward is driven by the SAME upstream gradient the engine used.
+    tru, TW = _oracle_run(cfg, W, batch, None, False, cfg.num_blocks)
+    # L1's gradient is sign(pred - target)/n: a bf16-level difference in pred flips signs and changes the whole backward signal
+    # discretely, so all three backward passes are driven by the SAME upstream gradient (the engine's); the L1 kernel itself
+    # is pinned in test_kernels_gpu.py.
     from vla_adapter_amd import ops
     _, dpred = ops.l1_loss(pred, batch["actions"].to(BF), True)
     out["pred"].backward(dpred.float().cpu())
-    assert abs(loss3[0].item() - out["loss"].item()) <= 1e-2 * abs(out["loss"].item())
+    tru["pred"].backward(dpred.float().cpu())
+    assert abs(loss3[0].item() - tru["loss"].item()) <= 1.25 * abs(out["loss"].item() - tru["loss"].item()) + 1e-3 * abs(tru["loss"].item())
     g_head = eng.head.named_views(eng.head.P.grad)
-    # Gradients are bf16 tensors in the reference too (the oracle's rnd() rounds them in its backward), so two
-    # implementations differ by independent rounding realisations.  For tensors whose gradient is orders of magnitude
-    # below the block's dominant ones (q/k projections behind a near-uniform softmax: |g| ~ 1e-3 x |g(o_proj)|) that
-    # absolute noise floor dominates: accept rel <= 6e-2 OR |err| <= 1e-3 x the largest gradient norm of the head.
-    # Why 6e-2 end-to-end: the engine's forward state differs from the oracle's by ~1e-2 (independent bf16 rounding
-    # realisations through ViT + LLM); measured on the oracle itself, a 0.9e-2 forward-state difference (bf16 vs fp32
-    # forward, SAME upstream gradient) moves these gradients by 3.6-4.7e-2 (ReLU-mask / softmax sensitivity), while
-    # bf16 rounding of the gradients alone moves them by only 2e-3.  The isolated tests below (identical inputs to
-    # the head / to the LLM) use tighter bounds.
-    gmax = max(v.grad.norm().item() for v in OW["head"].values() if v.grad is not None)
-    bad = []
-    for k, v in g_head.items():
-        ref = OW["head"][k].grad
-        if ref is None:
-            continue
-        err = (v.detach().float().cpu() - ref.reshape(v.shape)).norm().item()
-        if err > 6e-2 * ref.norm().item() and err > 1e-3 * gmax:
-            bad.append((k, err / (ref.norm().item() + 1e-12), err / gmax))
-    assert not bad, f"head grads off (rel, rel-to-largest): {bad[:8]}"
-    for k, v in eng.head.proprio_views(eng.head.P.grad).items():
-        r = rel(v, OW["proprio"][k].grad)
-        assert r < 6e-2, f"proprio grad {k}: {r:.3e}"
-    r = rel(eng.head.P.g("action_queries"), OW["action_queries"].grad)
-    assert r < 6e-2, f"action_queries grad (through the whole frozen LLM): {r:.3e}"
+    gmax = max(v.grad.norm().item() for v in TW["head"].values() if v.grad is not None)
+    fam = [(k, v, OW["head"][k].grad.reshape(v.shape), TW["head"][k].grad.reshape(v.shape)) for k, v in g_head.items() if TW["head"][k].grad is not None]
+    fam += [("proprio." + k, v, OW["proprio"][k].grad, TW["proprio"][k].grad) for k, v in eng.head.proprio_views(eng.head.P.grad).items()]
+    budget_family(fam, "head + proprio gradients (end to end)", absfloor=1e-3 * gmax)
+    budget(eng.head.P.g("action_queries"), OW["action_queries"].grad, TW["action_queries"].grad, "action_queries gradient (through the frozen LLM)")
     # optimiser step: bit-exact AdamW on the engine's own gradients
     P = eng.head.P
     p0, g0 = P.data.float().cpu().clone(), P.grad.float().cpu().clone()
@@ -197,27 +205,21 @@ def test_head_only_parity_identical_inputs(setup, pro):
     head.backward(dpred.to(DEV), dHS)
     torch.cuda.synchronize()
     f = lambda sd: {k: v.float().cpu().clone().requires_grad_(True) for k, v in sd.items()}
-    hp, pp = f(W["head"]), f(W["proprio"])
-    hs = HS.float().requires_grad_(True)
-    mlhs = O.regroup_hidden_states([hs[i] for i in range(nb + 1)], batch["labels"].cpu(), Np)
-    ref = O.head_predict_action(mlhs, batch["proprio"].cpu().to(BF).float(), hp, pp, Np, pro, None, True, nb)
-    assert rel(pred, ref) < 6e-3, f"head pred {rel(pred, ref):.3e}"
-    ref.backward(dpred.float())
-    gmax = max(v.grad.norm().item() for v in hp.values() if v.grad is not None)
-    bad = []
-    for k, v in head.named_views(head.P.grad).items():
-        r = hp[k].grad
-        if r is None:
-            continue
-        err = (v.float().cpu() - r.reshape(v.shape)).norm().item()
-        # first-block grads amplify bf16-level forward differences (tools/diag_head_attn.py: the MFMA attention is as close to
-        # fp32 truth as the bit-emulating VALU kernel, 2.2e-3, but a different bf16 realisation than the oracle's)
-        if err > 1e-1 * r.norm().item() and err > 1e-3 * gmax:
-            bad.append((k, err / (r.norm().item() + 1e-12)))
-    assert not bad, bad[:8]
-    for k, v in head.proprio_views(head.P.grad).items():
-        assert rel(v, pp[k].grad) < 1e-1, (k, rel(v, pp[k].grad))
-    assert rel(dHS[1:], hs.grad[1:]) < 6e-2, f"dHS {rel(dHS[1:], hs.grad[1:]):.3e}"
+    res = {}
+    for emu in (True, False):
+        hp, pp = f(W["head"]), f(W["proprio"])
+        hs = HS.float().requires_grad_(True)
+        mlhs = O.regroup_hidden_states([hs[i] for i in range(nb + 1)], batch["labels"].cpu(), Np)
+        ref = O.head_predict_action(mlhs, batch["proprio"].cpu().to(BF).float(), hp, pp, Np, pro, None, emu, nb)
+        ref.backward(dpred.float())
+        res[emu] = (ref.detach(), hp, pp, hs.grad)
+    (re_, hpe, ppe, dhe), (rt, hpt, ppt, dht) = res[True], res[False]
+    budget(pred, re_, rt, f"head-only actions (pro={pro})")
+    gmax = max(v.grad.norm().item() for v in hpt.values() if v.grad is not None)
+    fam = [(k, v, hpe[k].grad.reshape(v.shape), hpt[k].grad.reshape(v.shape)) for k, v in head.named_views(head.P.grad).items() if hpt[k].grad is not None]
+    fam += [("proprio." + k, v, ppe[k].grad, ppt[k].grad) for k, v in head.proprio_views(head.P.grad).items()]
+    budget_family(fam, f"head-only gradients, identical inputs (pro={pro})", absfloor=1e-3 * gmax)
+    budget(dHS[1:], dhe[1:], dht[1:], "head-only hidden-state gradients")
 
 
 def test_llm_only_backward_identical_inputs(setup):
@@ -236,12 +238,16 @@ def test_llm_only_backward_identical_inputs(setup):
     llm.forward(B, S, km.to(torch.uint8).to(DEV))
     dx = llm.backward(dH.to(DEV), B, S)
     torch.cuda.synchronize()
-    xr = x.float().requires_grad_(True)
-    hs = O.qwen2_forward(xr, km, {k: v.float().cpu() for k, v in W["llm"].items()}, c.as_oracle(), True)
+    res = {}
+    for emu in (True, False):
+        xr = x.float().requires_grad_(True)
+        hs = O.qwen2_forward(xr, km, {k: v.float().cpu() for k, v in W["llm"].items()}, c.as_oracle(), emu)
+        sum((hs[i] * dH[i].float()).sum() for i in range(1, n + 1)).backward()
+        res[emu] = ([h.detach() for h in hs], xr.grad)
+    valid = km[:, :, None].expand(B, S, D)          # padded positions hold don't-care values in every implementation
     for i in range(1, n + 1):
-        assert rel(llm.HS[i], hs[i]) < 8e-3, f"hs[{i}] {rel(llm.HS[i], hs[i]):.3e}"
-    sum((hs[i] * dH[i].float()).sum() for i in range(1, n + 1)).backward()
-    assert rel(dx, xr.grad) < 2.5e-2, f"dX {rel(dx, xr.grad):.3e}"
+        budget(llm.HS[i].float().cpu()[valid], res[True][0][i][valid], res[False][0][i][valid], f"LLM-only hidden_states[{i}]")
+    budget(dx.float().cpu()[valid], res[True][1][valid], res[False][1][valid], "LLM-only dX")
     llm._buf_key = None      # other tests use a different (B, S)
 
 
@@ -282,11 +288,13 @@ def test_live_row_backward_equals_full_backward():
     # head / proprio grads: identical computation except fp32 atomic orders of the bias / LayerNorm reductions
     assert (grads[0][:aq] - grads[1][:aq]).norm() <= 2e-3 * grads[1][:aq].norm()
     # and against the oracle's full autograd
-    out, OW = _oracle_run(cfg, W, batch, None, True, cfg.num_blocks)
     _, dpred = ops.l1_loss(e_live.head.pred.view(3, cfg.chunk, cfg.action_dim), batch["actions"].to(BF), True)
-    out["pred"].backward(dpred.float().cpu())
-    r = rel(e_live.head.P.g("action_queries"), OW["action_queries"].grad)
-    assert r < 6e-2, f"action_queries grad (live-row backward) vs oracle autograd: {r:.3e}"
+    g = {}
+    for emu in (True, False):
+        out, OW = _oracle_run(cfg, W, batch, None, emu, cfg.num_blocks)
+        out["pred"].backward(dpred.float().cpu())
+        g[emu] = OW["action_queries"].grad
+    budget(e_live.head.P.g("action_queries"), g[True], g[False], "action_queries gradient, live-row backward vs full autograd")
 
 
 def test_graph_replay_guards_frozen_row_window():
@@ -345,16 +353,16 @@ def test_original_head_block_end_to_end():
     eng.loss_and_backward(pred, batch["actions"])
     torch.cuda.synchronize()
     out, OW = _oracle_run(cfg, W, batch, None, True, cfg.num_blocks)
-    assert rel(pred, out["pred"]) < 1.5e-2, rel(pred, out["pred"])
+    tru, TW = _oracle_run(cfg, W, batch, None, False, cfg.num_blocks)
+    budget(pred, out["pred"], tru["pred"], "original-block head: actions")
     _, dpred = ops.l1_loss(pred, batch["actions"].to(BF), True)
     out["pred"].backward(dpred.float().cpu())
+    tru["pred"].backward(dpred.float().cpu())
     g = eng.head.named_views(eng.head.P.grad)
-    gmax = max(v.grad.norm().item() for v in OW["head"].values() if v.grad is not None)
-    for name in ("k_proj", "v_proj", "q_proj", "o_proj"):
-        k = f"model.mlp_resnet_blocks.1.{name}.weight"
-        ref = OW["head"][k].grad
-        err = (g[k].float().cpu() - ref).norm().item()
-        assert err <= 6e-2 * ref.norm().item() or err <= 1e-3 * gmax, (k, err / ref.norm().item())
+    gmax = max(v.grad.norm().item() for v in TW["head"].values() if v.grad is not None)
+    keys = [f"model.mlp_resnet_blocks.{b}.{n}.weight" for b in (0, 1) for n in ("k_proj", "v_proj", "q_proj", "o_proj")]
+    budget_family([(k, g[k], OW["head"][k].grad, TW["head"][k].grad) for k in keys], "original-block head: shared k/v gradients",
+                  absfloor=1e-3 * gmax)
     e2 = E.VLAEngine(cfg, W, DEV)
     e2.capture(batch, None)
     losses = [e2.train_step_graphed(2e-3)[0].item() for _ in range(12)]
@@ -376,15 +384,13 @@ def test_fused_two_backbone_two_image_config():
     eng.loss_and_backward(pred, batch["actions"])
     torch.cuda.synchronize()
     out, OW = _oracle_run(cfg, W, batch, None, True, cfg.num_blocks)
-    assert rel(eng.llm.HS[0][:, 1:cfg.n_patches + 1], out["patches"]) < 1.2e-2, rel(eng.llm.HS[0][:, 1:cfg.n_patches + 1], out["patches"])
-    assert rel(pred, out["pred"]) < 1.5e-2, rel(pred, out["pred"])
+    tru, TW = _oracle_run(cfg, W, batch, None, False, cfg.num_blocks)
+    budget(eng.llm.HS[0][:, 1:cfg.n_patches + 1], out["patches"], tru["patches"], "fused two-backbone patches")
+    budget(pred, out["pred"], tru["pred"], "fused config: actions")
     _, dpred = ops.l1_loss(pred, batch["actions"].to(BF), True)
     out["pred"].backward(dpred.float().cpu())
-    # end-to-end gradient tolerance: see test_backward_and_step_parity (a ~1e-2 forward-state difference moves these
-    # gradients by 4-5e-2 on the single-backbone config; this deeper vision stack measures 7.6e-2); the structural check
-    # is the bit-identity with the full-sequence backward below
-    r = rel(eng.head.P.g("action_queries"), OW["action_queries"].grad)
-    assert r < 1e-1, r
+    tru["pred"].backward(dpred.float().cpu())
+    budget(eng.head.P.g("action_queries"), OW["action_queries"].grad, TW["action_queries"].grad, "fused config: action_queries gradient")
     ef = E.VLAEngine(cfg, W, DEV)
     ef.full_llm_backward = True
     ef.loss_and_backward(ef.forward(batch, None), batch["actions"])
@@ -411,15 +417,15 @@ def test_engine_forward_backward_random_batches():
         eng = E.VLAEngine(cfg, W, DEV)
         pred = eng.forward(batch, None)
         out, _ = _oracle_run(cfg, W, batch, None, True, cfg.num_blocks)
+        tru, _ = _oracle_run(cfg, W, batch, None, False, cfg.num_blocks)
         n = cfg.llm.n_layers
         valid = batch["attention_mask"].cpu()
         Np = cfg.n_patches
         full_valid = torch.cat([torch.ones(B, 1, dtype=torch.bool), torch.ones(B, Np, dtype=torch.bool), valid[:, 1:]], 1)
         for i in range(n + 1):      # rows of padded positions hold don't-care values in both implementations
-            a, b = eng.llm.HS[i].float().cpu()[full_valid], out["hidden_states"][i].detach()[full_valid]
-            r = ((a - b).norm() / b.norm()).item()
-            assert r < 1.5e-2, f"case {case} (B{B} P{P} fused={cfg.fused}) hidden_states[{i}] rel-L2 {r:.3e}"
-        assert rel(pred, out["pred"]) < 1.5e-2, f"case {case}: pred {rel(pred, out['pred']):.3e}"
+            budget(eng.llm.HS[i].float().cpu()[full_valid], out["hidden_states"][i].detach()[full_valid], tru["hidden_states"][i].detach()[full_valid],
+                   f"case {case} (B{B} P{P} fused={cfg.fused}) hidden_states[{i}]")
+        budget(pred, out["pred"], tru["pred"], f"case {case}: actions")
         eng.loss_and_backward(pred, batch["actions"])
         ef = E.VLAEngine(cfg, W, DEV)
         ef.full_llm_backward = True
@@ -441,22 +447,16 @@ def test_full_size_forward_parity_config2():
     torch.cuda.synchronize()
     torch.set_num_threads(min(16, torch.get_num_threads() or 16))
     out, _ = _oracle_run(cfg, W, batch, None, True, cfg.num_blocks)
+    tru, _ = _oracle_run(cfg, W, batch, None, False, cfg.num_blocks)
     Np, n, B = cfg.n_patches, cfg.llm.n_layers, 2
-    r = rel(eng.llm.HS[0][:, 1:Np + 1], out["patches"])
-    assert r < 2.5e-2, f"projected patches {r:.3e}"
+    budget(eng.llm.HS[0][:, 1:Np + 1], out["patches"], tru["patches"], "full size: projected patches (26 ViT blocks)")
     valid = batch["attention_mask"].cpu()
     fv = torch.cat([torch.ones(B, 1 + Np, dtype=torch.bool), valid[:, 1:]], 1)
-    worst = 0.0
     for i in range(n + 1):
-        a, b = eng.llm.HS[i].float().cpu()[fv], out["hidden_states"][i].detach()[fv]
-        ri_ = ((a - b).norm() / b.norm()).item()
-        worst = max(worst, ri_)
-        assert ri_ < 3.5e-2, f"hidden_states[{i}] rel-L2 {ri_:.3e}"
-    rp = rel(pred, out["pred"])
+        budget(eng.llm.HS[i].float().cpu()[fv], out["hidden_states"][i].detach()[fv], tru["hidden_states"][i].detach()[fv], f"full size: hidden_states[{i}]")
+    budget(pred, out["pred"], tru["pred"], "full size: actions")
     l_native, _ = ops.l1_loss(pred, batch["actions"].to(BF), False)
-    assert rp < 3e-2, f"pred rel-L2 {rp:.3e} (worst hidden state {worst:.3e})"
-    assert abs(l_native[0].item() - out["loss"].item()) <= 5e-3 * abs(out["loss"].item())
-    print(f"full-size parity: patches {r:.2e}, worst hidden state {worst:.2e}, pred {rp:.2e}")
+    assert abs(l_native[0].item() - tru["loss"].item()) <= 1.25 * abs(out["loss"].item() - tru["loss"].item()) + 1e-3 * abs(tru["loss"].item())
 
 
 def test_full_size_backward_config2():
@@ -476,24 +476,18 @@ def test_full_size_backward_config2():
     aq = eng.head.P.offsets["action_queries"][0]
     assert torch.equal(g_live[aq:], eng.head.P.grad[aq:]), "full-size: action_queries gradient must not depend on the dead rows"
     assert (g_live[:aq].float() - eng.head.P.grad[:aq].float()).norm() <= 2e-3 * eng.head.P.grad[:aq].float().norm()
-    out, OW = _oracle_run(cfg, W, batch, None, True, cfg.num_blocks)
     _, dpred = ops.l1_loss(eng.head.pred.view(2, cfg.chunk, cfg.action_dim), batch["actions"].to(BF), True)
-    out["pred"].backward(dpred.float().cpu())
-    r = rel(g_live[aq:].view(64, -1), OW["action_queries"].grad)
-    assert r < 1.5e-1, f"action_queries grad through 24 frozen layers vs oracle autograd: {r:.3e}"
-    # Head gradients.  Backpropagating through 24 ReLU / LayerNorm / softmax blocks amplifies the bf16-level difference of
-    # the forward states; measured on the oracle ITSELF (bf16-emulating vs fp32 evaluation, same weights, same upstream
-    # gradient, tools-free CPU run): fc2 7e-3, block 23 o_proj 3.5e-2, block 12 v_task 1.4e-1, block 0 k_task 3.7e-1,
-    # block 0 ffn 2.7e-1.  The engine-vs-oracle differences sit at or below those (6.8e-3 / 3.5e-2 / 1.1e-1 / 1.8e-1 /
-    # 1.8e-1); the bounds are the oracle's own sensitivity x 1.5.
-    for k, bound in (("model.fc2.weight", 1.5e-2), ("model.mlp_resnet_blocks.23.o_proj.weight", 5.5e-2),
-                     ("model.mlp_resnet_blocks.12.v_task.weight", 2.1e-1), ("model.mlp_resnet_blocks.0.k_task.weight", 5.5e-1),
-                     ("model.mlp_resnet_blocks.0.ffn.1.weight", 4e-1)):
-        got, ref = eng.head.named_views(g_live)[k], OW["head"][k].grad
-        rr = rel(got, ref.reshape(got.shape))
-        print(f"full-size grad {k}: rel {rr:.3e} (bound {bound})")
-        assert rr < bound, f"{k}: rel {rr:.3e}"
-    print(f"full-size grad action_queries: rel {r:.3e}")
+    G = {}
+    keys = ("model.fc2.weight", "model.mlp_resnet_blocks.23.o_proj.weight", "model.mlp_resnet_blocks.12.v_task.weight",
+            "model.mlp_resnet_blocks.0.k_task.weight", "model.mlp_resnet_blocks.0.ffn.1.weight", "model.mlp_resnet_blocks.12.ffn.0.weight",
+            "model.mlp_resnet_blocks.23.q_proj.bias")
+    for emu in (True, False):
+        out, OW = _oracle_run(cfg, W, batch, None, emu, cfg.num_blocks)
+        out["pred"].backward(dpred.float().cpu())
+        G[emu] = (OW["action_queries"].grad, {k: OW["head"][k].grad for k in keys})
+    budget(g_live[aq:].view(64, -1), G[True][0], G[False][0], "full size: action_queries gradient through 24 frozen layers")
+    nv = eng.head.named_views(g_live)
+    budget_family([(k, nv[k], G[True][1][k].reshape(nv[k].shape), G[False][1][k].reshape(nv[k].shape)) for k in keys], "full size: head gradients")
 
 
 @pytest.mark.parametrize("B,P,ragged", [(3, 37, True), (1, 12, False), (5, 64, True), (9, 33, True), (8, 20, False)])
@@ -515,3 +509,32 @@ def test_captured_step_odd_shapes_match_eager(B, P, ragged):
     for a, b in zip(eager[1:], graphed[1:]):
         assert abs(a - b) <= 2e-2 * abs(a), (eager, graphed)
     assert (e1.head.P.data.float() - e2.head.P.data.float()).norm() <= 3e-3 * e1.head.P.data.float().norm()
+
+
+def test_batch32_config2_matches_batch2_and_trains():
+    """BASELINE configs[1] at the METRIC's shape, batch 32 (two 16-sample LLM pipelines, the 5.3 GB pre-activation buffer, the
+    256x256 GEMM tiles): every op of the forward is sample-wise and every GEMM accumulates each output element over K in one
+    fixed order whatever the tile (tests/test_kernels_gpu.py::test_gemm256_bit_identical_to_128_tiles), so samples 0-1 of
+    the B = 32 forward must equal the B = 2 forward BIT FOR BIT; and three captured steps must keep a finite, falling loss."""
+    from vla_adapter_amd import engine as E, synthetic as S
+    cfg = E.config2()
+    W = S.make_weights(cfg, DEV, seed=0)
+    big = S.make_batch(cfg, 32, DEV, seed=91, P=32, ragged=True)
+    big["pixel_values"] = big["pixel_values"].to(BF)
+    two = {k: v[:2].contiguous() for k, v in big.items()}
+    e32, e2 = E.VLAEngine(cfg, W, DEV), E.VLAEngine(cfg, W, DEV)
+    p32 = e32.forward(big, None)
+    p2 = e2.forward(two, None)
+    torch.cuda.synchronize()
+    n = cfg.llm.n_layers
+    for i in range(n + 1):
+        assert torch.equal(e32.llm.HS[i][:2], e2.llm.HS[i]), f"hidden_states[{i}]: batch-32 rows differ from the batch-2 run"
+    assert torch.equal(p32[:2], p2), "actions of samples 0-1"
+    del e2
+    noise = (torch.randn(cfg.chunk, cfg.action_dim * cfg.llm.d, device=DEV) * 0.02).to(BF)
+    e32.capture({k: v.clone() for k, v in big.items()}, noise)
+    losses = [e32.train_step_graphed(5e-4)[0].item() for _ in range(3)]
+    e32.flush()
+    torch.cuda.synchronize()
+    assert all(l == l and abs(l) < 1e3 for l in losses), losses
+    assert losses[-1] < losses[0], losses

@@ -304,13 +304,23 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
     // alpha, bias, activation on the bf16-rounded linear output (the reference's Linear emits bf16 before the activation
     // module; the activation's own bf16 rounding is the pack into the staging tile below).  The activation is resolved
     // OUTSIDE the element loops: a per-element switch cost 5 us on the ViT fc1 GEMM even for ReLU.
+    float alpha = p.alpha;
+    if (p.bias_post) {                        // bf16(bf16(alpha acc) + bias): torch CPU Linear on a strided input
+#pragma unroll
+      for (int ni = 0; ni < C::NT; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[ni][mi][j] = rbf(acc[ni][mi][j] * alpha);
+      alpha = 1.f;
+    }
     auto finish = [&](auto fn) {
 #pragma unroll
       for (int ni = 0; ni < C::NT; ++ni)
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[ni][mi][j] = fn(acc[ni][mi][j] * p.alpha + bv[ni][j]);
+          for (int j = 0; j < 4; ++j) acc[ni][mi][j] = fn(acc[ni][mi][j] * alpha + bv[ni][j]);
     };
     if (p.act == VLA_ACT_GELU) finish([](float v) { return gelu_erf(rbf(v)); });
     else if (p.act == VLA_ACT_RELU) finish([](float v) { return fmaxf(v, 0.f); });
@@ -531,9 +541,13 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   p.gA = d->a_group; p.sgA = d->a_group_stride; p.gC = d->c_group; p.sgC = d->c_group_stride;
   p.gR = d->r_group; p.sgR = d->r_group_stride;
   p.c_live_mod = d->c_live_mod; p.c_live_from = d->c_live_from;
+  const int split = d->split_k > 1 ? d->split_k : 1;
+  p.bias_post = d->bias_post_round;
+  VLA_REQUIRE(d->bias_post_round == 0 || (d->bias_post_round == 1 && d->bias && d->rope_mode == 0 && split == 1 &&
+                                          d->act != VLA_ACT_SWIGLU && d->act != VLA_ACT_SWIGLU_BWD),
+              "gemm: bias_post_round needs a bias and a plain epilogue (no rope / split-K / SwiGLU)");
   { const char* ge = getenv("VLA_GEMM_GM"); p.gm = ge ? atoi(ge) : 0; }
   p.ws = nullptr;
-  const int split = d->split_k > 1 ? d->split_k : 1;
   if (split > 1) {
     VLA_REQUIRE(d->ws && d->batch == 1 && d->K % (BK * split) == 0 && d->rope_mode == 0 && d->c_group == 0 && d->r_group == 0 &&
                     d->res_mod == 0 && d->c_live_mod == 0 && d->C &&

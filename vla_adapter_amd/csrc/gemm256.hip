@@ -375,13 +375,23 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
       // pre-activations kept for a live-row backward only (c_live): a 64-row block without a live row stores nothing
       if (p.c_live_mod > 0 && (wm0 % p.c_live_mod) + 63 < p.c_live_from) continue;
     } else {
+      float alpha = p.alpha;
+      if (p.bias_post) {                      // bf16(bf16(alpha acc) + bias): torch CPU Linear on a strided input
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) A4(t4, mi)[j] = rbf(A4(t4, mi)[j] * alpha);
+        alpha = 1.f;
+      }
       auto finish = [&](auto fn) {
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
           for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) A4(t4, mi)[j] = fn(A4(t4, mi)[j] * p.alpha + bv[t4][j]);
+            for (int j = 0; j < 4; ++j) A4(t4, mi)[j] = fn(A4(t4, mi)[j] * alpha + bv[t4][j]);
       };
       if (p.act == VLA_ACT_GELU) finish([](float v) { return gelu_erf(rbf(v)); });
       else if (p.act == VLA_ACT_RELU) finish([](float v) { return fmaxf(v, 0.f); });

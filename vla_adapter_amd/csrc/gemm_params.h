@@ -14,6 +14,7 @@ struct GemmP {
   int c_live_mod, c_live_from;              // C rows with (m % c_live_mod) < c_live_from are not stored
   int gm;                                   // group-M override (0 = default)
   float* ws;                                // split-K: fp32 [M, N] accumulator (blockIdx.z = K slice), finalised by a second kernel
+  int bias_post;                            // 1: round alpha * acc to bf16 before adding the bias (torch CPU Linear on a strided input)
   int rope_mode, rope_T, rope_dh, rope_cols; const float* rope_cos; const float* rope_sin;
 };
 

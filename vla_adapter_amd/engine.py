@@ -622,7 +622,9 @@ class Head:
         ops.gemm_nt(self.h_adp[i].view(B * Ka, D), wa, bias=ba, out=self.KV_adp[i])
         # task tokens = HS[i+1][:, :Np] read in place (row-group addressing)
         wt, bt, _ = self._kv("task", i)
-        ops.gemm_nt(hs2[:B * Kt], wt, bias=bt, out=self.KV_task[i], a_group=(Kt, S * D))
+        # the reference feeds a STRIDED slice here: torch's CPU Linear then rounds the product before adding the bias, for B > 1
+        # only (oracle.linear, vla_native.h bias_post_round) - reproduced so that the head tracks the reference's bf16 run
+        ops.gemm_nt(hs2[:B * Kt], wt, bias=bt, out=self.KV_task[i], a_group=(Kt, S * D), bias_post_round=B > 1)
         x = self.X[i]
         if self.pro:      # RoPE (positions restart per segment) on q and on every segment's k; the original block has none
             ops.rope_inter_(self.KV_adp[i][:, :D], rc, rs_, Ka, H, dh, 0)

@@ -29,7 +29,7 @@ class GemmDesc(C.Structure):
                 ("rope_mode", C.c_int), ("rope_T", C.c_int), ("rope_dh", C.c_int), ("rope_cols", C.c_int),
                 ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
                 ("r_group", C.c_int), ("r_group_stride", C.c_longlong), ("c_live_mod", C.c_int), ("c_live_from", C.c_int),
-                ("split_k", C.c_int), ("ws", C.c_void_p)]
+                ("split_k", C.c_int), ("ws", C.c_void_p), ("bias_post_round", C.c_int)]
 
 
 class AttnDesc(C.Structure):

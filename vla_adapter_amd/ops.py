@@ -39,7 +39,7 @@ def _chk_bf16(*ts):
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_mod: int = 0, act: int = ACT_NONE,
             out: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, alpha: float = 1.0,
             want_pre: bool = True, a_group=None, c_group=None, r_group=None, rope=None, c_live=None,
-            split_k: Optional[int] = None) -> torch.Tensor:
+            split_k: Optional[int] = None, bias_post_round: bool = False) -> torch.Tensor:
     """C = epilogue(A @ B^T).  a: [M,K] or [batch,M,K] (row stride = a.stride(-2)); b: [N,K] or [batch,N,K].
     SwiGLU: returns (pre [.., N] or None, h [.., N/2]).  split_k: None = automatic, 0/1 = off, k = forced."""
     _chk_bf16(a, b, bias, residual, out, out2)
@@ -98,7 +98,10 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_m
     # K loop of a tile is serial, so a problem with fewer tiles than the chip has workgroup slots (2 x 256) runs at the
     # latency of ONE long loop on part of the CUs; K slices meet in a per-stream fp32 workspace and are summed by
     # splitk_finalize_kernel
-    plain = (not batched and act in (ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_TANH) and out is not None and a_group is None
+    if bias_post_round:          # C = bf16(bf16(A.B^T) + bias): torch CPU Linear on a strided bf16 input (vla_native.h)
+        assert bias is not None
+        d.bias_post_round = 1
+    plain = (not bias_post_round and not batched and act in (ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_TANH) and out is not None and a_group is None
              and c_group is None and r_group is None and rope is None and c_live is None and res_mod == 0 and Nn % 4 == 0)
     if split_k is None:
         split_k = 0
