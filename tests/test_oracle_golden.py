@@ -234,6 +234,6 @@ def test_oracle_modes_against_reference_bf16_and_fp32_runs(case):
     if not big:
         dx = mlhse.grad[:, GG.DX_LAYERS]
         e = (dx - z["dx_fp32"]).norm().item()
-        budget = max(1.5 * (z["dx_bf16"] - z["dx_fp32"]).norm().item(), 5e-2 * z["dx_fp32"].norm().item())
+        budget = max(1.5 * (z["dx_bf16"] - z["dx_fp32"]).norm().item(), 0.15 * z["dx_fp32"].norm().item())   # 0.15: ReLU-flip outliers, see above
         assert e <= budget, (e, budget)
         assert rel_l2(mlhs32.grad[:, GG.DX_LAYERS], z["dx_fp32"]) < 1e-4
