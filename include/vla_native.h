@@ -191,6 +191,23 @@ int vla_colsum_bf16(void* stream, const void* x, float* out, int rows, int cols,
 int vla_cast_f32_bf16(void* stream, const float* x, void* y, long long n);
 int vla_cast_bf16_f32(void* stream, const void* x, float* y, long long n);
 
+/* ---------------------------------------------------------------- host-glue replacements
+ * The reference's training step strings its ops together with dozens of small ATen index / cast / copy kernels
+ * (finetune.py:331-343, 396-409; action_heads.py:53-72; modeling_prismatic.py:499-508); these entry points do the same
+ * glue for the native step so that no framework kernel sits between the hand-written ones. */
+/* Strided 2-D copy with optional cast: dst[r, 0:cols] = src[r % src_mod (if src_mod > 0, else r), 0:cols]; dst row r lives at
+ * (r / d_group) * d_group_stride + (r % d_group) * ld_dst when d_group > 0.  dtype codes: 0 = bf16, 1 = f32. */
+int vla_copy2d(void* stream, const void* src, void* dst, long long rows, int cols, long long ld_src, long long ld_dst,
+               int src_dtype, int dst_dtype, int src_mod, int d_group, long long d_group_stride);
+/* Zero nbytes at ptr (16-B aligned) with a store kernel on the given stream (gradient accumulators, dHS); graph-capturable. */
+int vla_fill_zero(void* stream, void* ptr, long long nbytes);
+/* Gather / scatter row indices of the 64 action-query hidden states (+ the proprio slot) for engine.Head, and the NaN guard of a
+ * frozen live-row window: see the kernel comment in elementwise.hip (finetune.py:396-409 regroup, done by index). */
+int vla_head_index_prep(void* stream, const int* pos1, const int* pos0, const int* cnt0, int* gather, int* scatter,
+                        float* guard, int B, int S, int Np, int row0);
+/* x[0:n] += *s (device scalar). */
+int vla_add_scalar_f32(void* stream, float* x, const float* s, int n);
+
 /* ---------------------------------------------------------------- action head attention (action_heads.py:337-410) */
 typedef struct vla_head_attn_desc {
   const void* q;      /* [B, T, H*dh] bf16 (RoPE applied) */

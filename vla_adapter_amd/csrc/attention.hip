@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
 // the loop: 7-14 independent waves per CU hide each other's latency); the grp partial dK^T/dV^T accumulators of a key
 // tile are then summed through LDS (ds_add_f32) and written once - no global atomics, deterministic up to fp32 order.
 template <int D>
-__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int KT, int dbg) {
+__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int KT) {
   using G = Geo<D>;
   constexpr int TILE = 32 * G::LD;                       // elements per LDS tile
   constexpr int WAVE_BYTES = 2 * TILE * 2 + 256;         // Q tile, dO tile, lse[32], delta[32]
@@ -352,7 +352,6 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int
       delta_n = p.delta[sbase + qq];
     }
     for (int q0 = qstart; q0 < p.Sq; q0 += 32) {
-      if ((dbg & 4) && q0 > qstart) break;
       tile_store<D, 64, G::LD>(rq, sQ, lane);
       tile_store<D, 64, G::LD>(rdo, sdO, lane);
       if (lane < 32) {
@@ -370,7 +369,6 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // LDS tile written by this wave before it reads it
       __builtin_amdgcn_wave_barrier();
-      if (!(dbg & 2)) {
       f32x16 S = zero16(), dP = zero16();
 #pragma unroll
       for (int ks = 0; ks < G::KS; ++ks) {
@@ -397,14 +395,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int
           dK[t] = mfma32(tr_frag(sQ, G::LD, s, 32 * t, lane), dsf, dK[t]);  // dK^T[d x key] += Q^T . dS
         }
       }
-      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // reads of this tile done before the next store
       __builtin_amdgcn_wave_barrier();
     }
   }
   // ---- sum the grp heads of each key tile: every wave parks its partial tile in LDS (its own slab, no atomics -
   //      ds_add_f32 under 7-way contention cost 118 us here), then all threads add the grp slabs and store bf16.
-  if (grp > 1 && !(dbg & 1)) {
+  if (grp > 1) {
     float* part = reinterpret_cast<float*>(smem) + w * (32 * ACC_LD);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -538,14 +535,12 @@ extern "C" int vla_attn_bwd(void* stream, const vla_attn_desc* d) {
     attr_set = true;
   }
   VLA_REQUIRE(lds <= 160 * 1024, "attn_bwd: LDS budget exceeded");
-  const char* de = getenv("VLA_DKV_DBG");   // ablation aid (timing only, results invalid when set)
-  const int dbg = de ? atoi(de) : 0;
   if (p.dh == 64) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(256), 0, st, p);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gk, dim3(64 * grp * KT), lds, st, p, grp, KT, dbg);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gk, dim3(64 * grp * KT), lds, st, p, grp, KT);
   } else {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<72>, gq, dim3(256), 0, st, p);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<72>, gk, dim3(64 * grp * KT), lds, st, p, grp, KT, dbg);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<72>, gk, dim3(64 * grp * KT), lds, st, p, grp, KT);
   }
   VLA_CHECK_LAUNCH("attn_bwd");
   return VLA_OK;

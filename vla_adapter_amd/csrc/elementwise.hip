@@ -665,3 +665,104 @@ extern "C" int vla_action_tokenize(void* stream, const float* actions, const dou
   VLA_CHECK_LAUNCH("action_tokenize");
   return VLA_OK;
 }
+
+
+// ---------------------------------------------------------------- host-glue replacements (no ATen kernel on the step)
+// Strided 2-D copy with optional cast and row remapping: dst[row r] <- src[row r % src_mod (src_mod > 0)], dst row r lives at
+// (r / d_group) * d_group_stride + (r % d_group) * ld_dst when d_group > 0 (the GEMM's row-group rule).  dtype codes: 0 bf16, 1 f32.
+template <typename TS, typename TD>
+__global__ void copy2d_kernel(const TS* __restrict__ src, TD* __restrict__ dst, long long rows, int cols, long long ld_src, long long ld_dst,
+                              int src_mod, int d_group, long long d_group_stride) {
+  const long long total = rows * cols;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / cols;
+    const int c = (int)(i - r * cols);
+    const long long rs = src_mod > 0 ? r % src_mod : r;
+    const long long ro = d_group > 0 ? (r / d_group) * d_group_stride + (r % d_group) * ld_dst : r * ld_dst;
+    float v;
+    if constexpr (sizeof(TS) == 2) v = bf2f(src[rs * ld_src + c]); else v = src[rs * ld_src + c];
+    if constexpr (sizeof(TD) == 2) dst[ro + c] = f2bf(v); else dst[ro + c] = v;
+  }
+}
+
+extern "C" int vla_copy2d(void* stream, const void* src, void* dst, long long rows, int cols, long long ld_src, long long ld_dst,
+                          int src_dtype, int dst_dtype, int src_mod, int d_group, long long d_group_stride) {
+  VLA_REQUIRE(src && dst && rows > 0 && cols > 0 && src_mod >= 0 && d_group >= 0, "copy2d: bad args");
+  VLA_REQUIRE((src_dtype == 0 || src_dtype == 1) && (dst_dtype == 0 || dst_dtype == 1), "copy2d: dtype 0 (bf16) / 1 (f32)");
+  const dim3 g = GRID1D(rows * cols, 256);
+  hipStream_t st = (hipStream_t)stream;
+#define CP(TS, TD) hipLaunchKernelGGL((copy2d_kernel<TS, TD>), g, dim3(256), 0, st, (const TS*)src, (TD*)dst, rows, cols, ld_src, ld_dst, src_mod, d_group, d_group_stride)
+  if (src_dtype == 0 && dst_dtype == 0) CP(bf16_t, bf16_t);
+  else if (src_dtype == 1 && dst_dtype == 0) CP(float, bf16_t);
+  else if (src_dtype == 0 && dst_dtype == 1) CP(bf16_t, float);
+  else CP(float, float);
+#undef CP
+  VLA_CHECK_LAUNCH("copy2d");
+  return VLA_OK;
+}
+
+// A plain store kernel, not hipMemsetAsync: memset nodes recorded inside torch's stream capture were observed NOT to
+// clear the buffer on replay (ROCm 7.2; the fp32 gradient accumulators kept the previous step's sums).
+__global__ void fill_zero_kernel(uint4* __restrict__ p16, long long n16, unsigned char* __restrict__ tail, int ntail) {
+  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (long long i = i0; i < n16; i += (long long)gridDim.x * blockDim.x) p16[i] = uint4{0, 0, 0, 0};
+  if (i0 < ntail) tail[i0] = 0;
+}
+
+extern "C" int vla_fill_zero(void* stream, void* ptr, long long nbytes) {
+  VLA_REQUIRE(ptr && nbytes > 0 && ((uintptr_t)ptr & 15) == 0, "fill_zero: null / empty / not 16-B aligned");
+  const long long n16 = nbytes / 16;
+  hipLaunchKernelGGL(fill_zero_kernel, GRID1D(n16 > 0 ? n16 : 1, 256), dim3(256), 0, (hipStream_t)stream, (uint4*)ptr, n16,
+                     (unsigned char*)ptr + n16 * 16, (int)(nbytes - n16 * 16));
+  VLA_CHECK_LAUNCH("fill_zero");
+  return VLA_OK;
+}
+
+// Index arrays of the action head for one batch (engine.Head): pos1[B,64] = text-coordinate positions of the action-query
+// hidden states (-1: none).  gather[b, k] = b*S + Np + pos1 (k < 64), gather[b, 64] = -2 (proprio slot: leave the row alone);
+// scatter[b, k] = b*(S-row0) + Np + pos1 - row0 or -1 (dead row / none), scatter[b, 64] = -1;
+// guard = NaN if any sample's first action query (pos0[b,0] + Np, count > 0) lies before row0, else 0.
+__global__ void head_index_prep_kernel(const int* __restrict__ pos1, const int* __restrict__ pos0, const int* __restrict__ cnt0,
+                                       int* __restrict__ gather, int* __restrict__ scatter, float* __restrict__ guard,
+                                       int B, int S, int Np, int row0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * 65) {
+    const int b = i / 65, k = i - b * 65;
+    if (k == 64) {
+      gather[i] = -2;
+      scatter[i] = -1;
+    } else {
+      const int p = pos1[b * 64 + k];
+      gather[i] = b * S + Np + p;
+      const int loc = Np + p - row0;
+      scatter[i] = (loc >= 0 && p >= 0) ? b * (S - row0) + loc : -1;
+    }
+  }
+  if (i == 0 && guard) {
+    bool bad = false;
+    for (int b = 0; b < B; ++b) bad |= (row0 > 0) && ((cnt0[b] > 0 ? pos0[b * 64] + Np : 0) < row0);
+    *guard = bad ? __int_as_float(0x7fc00000) : 0.f;
+  }
+}
+
+extern "C" int vla_head_index_prep(void* stream, const int* pos1, const int* pos0, const int* cnt0, int* gather, int* scatter,
+                                   float* guard, int B, int S, int Np, int row0) {
+  VLA_REQUIRE(pos1 && pos0 && cnt0 && gather && scatter && B > 0 && S > row0 && row0 >= 0, "head_index_prep: bad args");
+  hipLaunchKernelGGL(head_index_prep_kernel, dim3(nblk((long long)B * 65, 256)), dim3(256), 0, (hipStream_t)stream, pos1, pos0, cnt0, gather,
+                     scatter, guard, B, S, Np, row0);
+  VLA_CHECK_LAUNCH("head_index_prep");
+  return VLA_OK;
+}
+
+// x[i] += *s  (the frozen live-row window's NaN guard folded into the reported loss without a host round trip)
+__global__ void add_scalar_f32_kernel(float* __restrict__ x, const float* __restrict__ s, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] += *s;
+}
+
+extern "C" int vla_add_scalar_f32(void* stream, float* x, const float* s, int n) {
+  VLA_REQUIRE(x && s && n > 0, "add_scalar_f32: bad args");
+  hipLaunchKernelGGL(add_scalar_f32_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, x, s, n);
+  VLA_CHECK_LAUNCH("add_scalar_f32");
+  return VLA_OK;
+}

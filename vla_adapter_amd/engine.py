@@ -547,7 +547,7 @@ class Head:
         # fp32 gradient accumulators (bias column sums, LayerNorm dw/db, gate): views of ONE buffer, zeroed by one fill
         bkeys = tuple(k for k in ("b_x", "b_adp", "b_task", "b_o", "b_ffn", "fc1_b", "fc2_b", "p_fc1_b", "p_fc2_b") if k in self.P.offsets)
         shapes = [("dgate", (nb,)), ("ln_dw", (nb, D)), ("ln_db", (nb, D)), ("ln1_dw", (self.Din,)), ("ln1_db", (self.Din,)),
-                  ("ln2_dw", (D,)), ("ln2_db", (D,))] + [("b:" + k, tuple(self.P.offsets[k][1])) for k in bkeys]
+                  ("ln2_dw", (D,)), ("ln2_db", (D,)), ("d_pf", (B, D))] + [("b:" + k, tuple(self.P.offsets[k][1])) for k in bkeys]
         self.acc32 = z(sum(rup(math.prod(sh), 4) for _, sh in shapes), dt=torch.float32)
         off, views = 0, {}
         for name, sh in shapes:
@@ -556,6 +556,13 @@ class Head:
         self.dgate, self.ln_dw, self.ln_db = views["dgate"], views["ln_dw"], views["ln_db"]
         self.ln1_dw, self.ln1_db, self.ln2_dw, self.ln2_db = views["ln1_dw"], views["ln1_db"], views["ln2_dw"], views["ln2_db"]
         self.b_f32 = {k: views["b:" + k] for k in bkeys}
+        self.d_pf32 = views["d_pf"]
+        # gather / scatter row indices of the action-query hidden states (+ proprio slot) and the live-row guard: static buffers
+        # filled by vla_head_index_prep (a captured step replays the kernel on the new batch's mask positions)
+        self.row_idx_ka = torch.empty(B, Ka, device=dev, dtype=torch.int32)
+        self.row_idx_live_ka = torch.empty(B, Ka, device=dev, dtype=torch.int32)
+        self._idx_scratch = torch.empty(B, Ka, device=dev, dtype=torch.int32)
+        self.guard = torch.zeros(1, device=dev, dtype=torch.float32)
         self.x_in = z(R, self.Din)
         self.pr_in = z(B, 64)
         # transposed operands for the batched dW products (K-dim = rows, zero-padded to a multiple of 64)
@@ -592,20 +599,21 @@ class Head:
         self.refresh_forward_operands()
         self.HSref, self.Np, self.S, self.B, self.pos1 = HS, Np, S, B, pos1
         # proprio projector (projectors.py:19-24); proprio rounded to bf16 first (action_heads.py:53)
-        self.pr_in[:, :cfg.proprio_dim] = proprio.to(BF16)
+        assert proprio.dim() == 2 and proprio.stride(1) == 1 and proprio.dtype in (BF16, torch.float32)
+        ops.copy2d(proprio, self.pr_in, B, cfg.proprio_dim, proprio.stride(0), 64)
         self.pp_pre = ops.gemm_nt(self.pr_in, self.pfc1_pad, bias=P.view("p_fc1_b"))
         self.pp_act = ops.gelu_fwd(self.pp_pre)
         self.pf = ops.gemm_nt(self.pp_act, P.view("p_fc2_w"), bias=P.view("p_fc2_b"))       # [B, D]
-        # rows of the 64 action-query hidden states inside one [B*S, D] layer slab
-        self.row_idx = (torch.arange(B, device=HS.device, dtype=torch.int32)[:, None] * S + Np + pos1).to(torch.int32).contiguous()
-        # the adapter segment of every block = [64 action-query hidden states | proprio token]: the gather writes straight
-        # into h_adp[i] (index -2 = leave the row alone), the proprio token is filled in once for all blocks
-        self.row_idx_ka = torch.cat([self.row_idx, torch.full((B, 1), -2, device=HS.device, dtype=torch.int32)], dim=1).contiguous()
-        self.h_adp[:, :, NUM_TOKENS] = self.pf
+        # rows of the 64 action-query hidden states inside one [B*S, D] layer slab.  The adapter segment of every block =
+        # [64 action-query hidden states | proprio token]: the gather writes straight into h_adp[i] (index -2 = leave the row
+        # alone), the proprio token is filled in once for all blocks
+        ops.head_index_prep(pos1, pos1, pos1, self.row_idx_ka, self._idx_scratch, None, B, S, Np, 0)
+        ops.copy2d(self.pf, self.h_adp[0, 0, NUM_TOKENS], self.nb * B, self.D, self.D, self.Ka * self.D, src_mod=B)
         if noise is not None:
-            self.x_in.view(B, T, self.Din).copy_(noise.to(BF16)[None].expand(B, T, self.Din))
+            assert tuple(noise.shape) == (T, self.Din) and noise.is_contiguous()
+            ops.copy2d(noise, self.x_in, B * T, self.Din, self.Din, self.Din, src_mod=T)
         else:
-            self.x_in.zero_()
+            ops.zero_(self.x_in)
         self.x_ln, self.st1 = ops.layernorm_fwd(self.x_in, P.view("ln1_w"), P.view("ln1_b"), 1e-5, want_stats=True)
         ops.gemm_nt(self.x_ln, P.view("fc1_w"), bias=P.view("fc1_b"), act=ACT_RELU, out=self.X[0])
 
@@ -678,14 +686,14 @@ class Head:
             self.bwd_layer(i, dHS)
         self.bwd_end()
 
-    def prep_backward(self, pos1: torch.Tensor, Np: int, B: int, S: int, row0: int):
-        """Scatter indices of the action-row gradients inside the live window [row0, S) of every sequence (-1: dead row).
+    def prep_backward(self, pos1: torch.Tensor, Np: int, B: int, S: int, row0: int, pos0=None, cnt0=None):
+        """Scatter indices of the action-row gradients inside the live window [row0, S) of every sequence (-1: dead row; the
+        proprio token's row scatters nowhere) and - given the unshifted mask positions - the NaN guard of a frozen window.
         Depends on the batch only, so the step schedule runs it long before the backward."""
-        loc = Np + pos1.to(torch.int32) - row0                     # [B, 64] row inside the live window (or < 0: dead row)
-        base = torch.arange(B, device=loc.device, dtype=torch.int32)[:, None] * (S - row0)
-        self.row_idx_live = torch.where((loc >= 0) & (pos1 >= 0), base + loc, torch.full_like(loc, -1)).to(torch.int32).contiguous()
-        # same indices over the [B, Ka] adapter rows (the proprio token's row scatters nowhere: -1)
-        self.row_idx_live_ka = torch.cat([self.row_idx_live, torch.full((B, 1), -1, device=loc.device, dtype=torch.int32)], dim=1).contiguous()
+        self._alloc(B, Np)
+        g = self.guard if pos0 is not None else None
+        ops.head_index_prep(pos1, pos0 if pos0 is not None else pos1, cnt0 if cnt0 is not None else pos1, self._idx_scratch,
+                            self.row_idx_live_ka, g, B, S, Np, row0)
         self._prep_key = (B, S, Np, row0)
 
     def bwd_begin(self, dpred: torch.Tensor, row0: int = 0):
@@ -696,12 +704,12 @@ class Head:
         self.row0 = row0
         assert getattr(self, "_prep_key", None) == (self.B, self.S, self.Np, row0), "prep_backward() first"
         self.refresh_transposes()                                  # W^T operands of the dX products (stale after AdamW)
-        self.acc32.zero_()                                         # every fp32 gradient accumulator in one fill
+        ops.zero_(self.acc32)                                      # every fp32 gradient accumulator in one fill
         dp = dpred.reshape(R, Da)
-        self.dpad.zero_()
-        self.dpad[:, :Da] = dp
+        ops.zero_(self.dpad)
+        ops.copy2d(dp, self.dpad, R, Da, Da, 64)
         ops.colsum_(dp, self.b_f32["fc2_b"])
-        P.g("fc2_w").copy_(self._dw(dp, self.xf_ln))
+        self._dw(dp, self.xf_ln, out=P.g("fc2_w"))
         d_ln2 = ops.gemm_nt(self.dpad, self.fc2T)                              # [R, D]
         self.dx = ops.layernorm_bwd(d_ln2, self.X[nb], P.view("ln2_w"), self.st2, self.ln2_dw, self.ln2_db)
 
@@ -732,17 +740,19 @@ class Head:
         # input stage: relu -> fc1 -> layer_norm1 (input is noise/zeros: only parameter gradients)
         dy1 = ops.relu_bwd(self.dx, self.X[0])
         ops.colsum_(dy1, self.b_f32["fc1_b"])
-        G("fc1_w").copy_(self._dw(dy1, self.x_ln))
+        self._dw(dy1, self.x_ln, out=G("fc1_w"))
         d_xln = ops.gemm_nt(dy1, self._t(P.view("fc1_w")))
         ops.layernorm_bwd(d_xln, self.x_in, P.view("ln1_w"), self.st1, self.ln1_dw, self.ln1_db, want_dx=False)
         # proprio projector backward (its token's gradient = sum over the blocks)
-        d_pf = self.dh_adp.view(nb, B, Ka, D)[:, :, NUM_TOKENS].float().sum(0).to(BF16)
+        ops.N.check(ops._lib().vla_colsum_bf16(ops._st(), ops._p(self.dh_adp[0, NUM_TOKENS]), ops._p(self.d_pf32), nb, D, B * Ka * D, B,
+                                                Ka * D, D), "colsum(d_pf)")             # [nb, B, D] strided -> sum over the blocks
+        d_pf = ops.cast_f32_bf16(self.d_pf32)
         ops.colsum_(d_pf, self.b_f32["p_fc2_b"])
-        G("p_fc2_w").copy_(self._dw(d_pf, self.pp_act))
+        self._dw(d_pf, self.pp_act, out=G("p_fc2_w"))
         d_act = ops.gemm_nt(d_pf, self.T["p_fc2_w"])
         d_pre = ops.gelu_bwd(d_act, self.pp_pre)
         ops.colsum_(d_pre, self.b_f32["p_fc1_b"])
-        G("p_fc1_w").copy_(self._dw(d_pre, self.pr_in)[:, :cfg.proprio_dim])
+        self._dw(d_pre, self.pr_in[:, :cfg.proprio_dim], out=G("p_fc1_w"))
         # batched dW products: dW = dY^T . X  as NT GEMMs on transposed operands
         bt = lambda src, dst: ops.transpose(src, out=dst)
         bt(self.X[:nb], self.XT); bt(self.dQKVx, self.dQKVxT); bt(self.AOx, self.AOxT); bt(self.dO2, self.dO2T)
@@ -769,15 +779,15 @@ class Head:
         ops.cast_f32_bf16(self.ln_dw, out=G("ln_w")); ops.cast_f32_bf16(self.ln_db, out=G("ln_b"))
         ops.cast_f32_bf16(self.ln1_dw, out=G("ln1_w")); ops.cast_f32_bf16(self.ln1_db, out=G("ln1_b"))
         ops.cast_f32_bf16(self.ln2_dw, out=G("ln2_w")); ops.cast_f32_bf16(self.ln2_db, out=G("ln2_b"))
-        G("gate")[:, 0] = self.dgate.to(BF16)
+        ops.copy2d(self.dgate, G("gate"), nb, 1, 1, 8)
 
     def _t(self, w2d):
         return ops.transpose(w2d.contiguous())
 
-    def _dw(self, dy, x):
+    def _dw(self, dy, x, out=None):
         """dW[N, K] = dY[R, N]^T . X[R, K] for the small one-off layers (R zero-padded to a multiple of 64)."""
         Rp = rup(dy.shape[0], 64)
-        return ops.gemm_nt(ops.transpose(dy.contiguous(), ld_out=Rp), ops.transpose(x.contiguous(), ld_out=Rp))
+        return ops.gemm_nt(ops.transpose(dy, ld_out=Rp), ops.transpose(x, ld_out=Rp), out=out)
 
     def _ln_bwd(self, dy, x, w, stats, dx, dw, db):
         ops.N.check(ops._lib().vla_layernorm_bwd(ops._st(), ops._p(dy), ops._p(x), ops._p(w), ops._p(stats), ops._p(dx), ops._p(dw),
@@ -989,14 +999,15 @@ class VLAEngine:
         S = L + Np
         llm._alloc(B, S)
         X0 = llm.HS[0]
-        X0[:, 1:Np + 1].copy_(self.patches)                      # projected patches: sequence rows 1..Np
+        ops.copy2d(self.patches, X0[0, 1], B * Np, cfg.llm.d, cfg.llm.d, cfg.llm.d, d_group=(Np, S * cfg.llm.d))   # patches: rows 1..Np
         if action_queries:
             self.qidx0, self.pos0, self.cnt0 = ops.action_mask(labels, 0)
             _, self.pos1, self.cnt1 = ops.action_mask(labels, 1)
         else:                                                     # plain VLM forward: no slot is overwritten
             self.qidx0 = torch.full((B, L), -1, device=self.device, dtype=torch.int32)
         mm = torch.empty(B, S, device=self.device, dtype=torch.uint8)
-        ops.embed_splice(ids, am.to(torch.uint8).contiguous(), self.qidx0, llm.embed, self.head.P.view("action_queries"), X0, mm, Np)
+        am8 = am.view(torch.uint8) if am.dtype == torch.bool and am.is_contiguous() else am.to(torch.uint8).contiguous()
+        ops.embed_splice(ids, am8, self.qidx0, llm.embed, self.head.P.view("action_queries"), X0, mm, Np)
         self.B, self.S, self.Np = B, S, Np
         return mm
 
@@ -1010,17 +1021,20 @@ class VLAEngine:
             return 0
         return (self.Np + int(first.min())) // 32 * 32
 
-    def _row0_guard(self, row0: int) -> torch.Tensor:
-        """NaN if a sample of the current batch has an action query before row0 (a captured graph is replayed with a
-        frozen row0), else 0 - added to the reported loss so that a violated assumption cannot pass silently."""
-        first = torch.where(self.cnt0 > 0, self.pos0[:, 0] + self.Np, torch.zeros_like(self.cnt0)).min()
-        return torch.where(first < row0, torch.full((), float("nan"), device=self.device), torch.zeros((), device=self.device))
+    def _to_bf16(self, t: torch.Tensor) -> torch.Tensor:
+        """bf16 copy of a small contiguous fp32 / bf16 tensor (targets) by the native cast-copy."""
+        if t.dtype == BF16:
+            return t
+        t = t.contiguous()
+        out = torch.empty(t.shape, device=t.device, dtype=BF16)
+        n = t.shape[-1]
+        return ops.copy2d(t, out, t.numel() // n, n, n, n)
 
     def _dhs(self, row0: int) -> torch.Tensor:
         B, S, D, n = self.B, self.S, self.cfg.llm.d, self.cfg.llm.n_layers
         if self._dHS is None or tuple(self._dHS.shape[1:3]) != (B, S - row0):
             self._dHS = torch.empty(n + 1, B, S - row0, D, device=self.device, dtype=BF16)
-        self._dHS.zero_()
+        ops.zero_(self._dHS)
         return self._dHS
 
     def loss_and_backward(self, pred, actions, gscale: float = 1.0, exchange: bool = True):
@@ -1028,7 +1042,7 @@ class VLAEngine:
         steps); exchange=False leaves the data-parallel exchange to the caller (non-boundary micro-steps)."""
         llm, head = self.llm, self.head
         B, S, Np = self.B, self.S, self.Np
-        loss3, dpred = ops.l1_loss(pred, actions.to(BF16), True, gscale)
+        loss3, dpred = ops.l1_loss(pred, self._to_bf16(actions), True, gscale)
         row0 = self.live_row0()
         dHS = self._dhs(row0)
         head.backward(dpred, dHS, row0)
@@ -1101,9 +1115,9 @@ class VLAEngine:
         row0 = self._row0 if self._row0 is not None else self.live_row0()
         self._row0_used = row0
         self._dhs(row0)
-        self._guard = self._row0_guard(row0) if row0 else None
-        self.head.prep_backward(self.pos1, self.Np, self.B, self.S, row0)
-        self._actions_bf = batch["actions"].to(BF16)
+        self.head.prep_backward(self.pos1, self.Np, self.B, self.S, row0, self.pos0, self.cnt0)
+        self._guard = self.head.guard if row0 else None          # NaN when a sample's action block starts before the frozen window
+        self._actions_bf = self._to_bf16(batch["actions"])
 
     def _segments(self, batch, noise):
         """[(stream 'M'|'H', fn, wait_key|None, signal_key|None)] for everything after the vision stage."""
@@ -1140,7 +1154,7 @@ class VLAEngine:
                     pred = head.fwd_end()
                     self._loss3, dpred = ops.l1_loss(pred, self._actions_bf, True, 1.0 / self.ga)
                     if self._guard is not None:
-                        self._loss3 += self._guard
+                        ops.add_scalar_f32_(self._loss3, self._guard)
                     head.bwd_begin(dpred, self._row0_used)
             return fn
 

@@ -87,6 +87,10 @@ _PROTOS = {
     "vla_colsum_bf16": ([_P, _P, _P, _I, _I, _I, _I, _L, _L], _I),
     "vla_cast_f32_bf16": ([_P, _P, _P, _L], _I),
     "vla_cast_bf16_f32": ([_P, _P, _P, _L], _I),
+    "vla_copy2d": ([_P, _P, _P, _L, _I, _L, _L, _I, _I, _I, _I, _L], _I),
+    "vla_fill_zero": ([_P, _P, _L], _I),
+    "vla_head_index_prep": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I], _I),
+    "vla_add_scalar_f32": ([_P, _P, _P, _I], _I),
     "vla_head_attn_fwd": ([_P, C.POINTER(HeadAttnDesc)], _I),
     "vla_head_attn_bwd": ([_P, C.POINTER(HeadAttnDesc)], _I),
     "vla_l1_loss": ([_P, _P, _P, _P, _P, _I, _I, _I, _F], _I),

@@ -474,6 +474,32 @@ def adamw_(p, g, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, w
                                   int(g.dtype == torch.float32), gscale), "adamw")
 
 
+# ---- host-glue replacements: no ATen kernel between the hand-written ones on the training step ---------------------------
+_DT = {BF16: 0, torch.float32: 1}
+
+
+def copy2d(src: torch.Tensor, dst: torch.Tensor, rows: int, cols: int, ld_src: int, ld_dst: int, src_mod: int = 0, d_group=None):
+    """dst[r, :cols] = cast(src[r % src_mod or r, :cols]) over raw row strides (elements); d_group=(rows per group, group stride)."""
+    g, gs = d_group if d_group is not None else (0, 0)
+    N.check(_lib().vla_copy2d(_st(), _p(src), _p(dst), rows, cols, ld_src, ld_dst, _DT[src.dtype], _DT[dst.dtype], src_mod, g, gs), "copy2d")
+    return dst
+
+
+def zero_(t: torch.Tensor):
+    assert t.is_contiguous()
+    N.check(_lib().vla_fill_zero(_st(), _p(t), t.numel() * t.element_size()), "fill_zero")
+    return t
+
+
+def head_index_prep(pos1, pos0, cnt0, gather, scatter, guard, B: int, S: int, Np: int, row0: int):
+    N.check(_lib().vla_head_index_prep(_st(), _p(pos1), _p(pos0), _p(cnt0), _p(gather), _p(scatter), _p(guard), B, S, Np, row0), "head_index_prep")
+
+
+def add_scalar_f32_(x: torch.Tensor, s: torch.Tensor):
+    N.check(_lib().vla_add_scalar_f32(_st(), _p(x), _p(s), x.numel()), "add_scalar_f32")
+    return x
+
+
 # ---- input stage (SURVEY 8f-2) ------------------------------------------------------------------------------------
 def image_normalize_u8_(img_u8: torch.Tensor, out: torch.Tensor, c0: int, mean, std):
     """img_u8 [B, H, W, 3] uint8 -> out[:, c0:c0+3] = ((img / 255) - mean) / std  (out [B, Ctot, H, W] bf16 or f32)."""
