@@ -102,6 +102,10 @@ int vla_rmsnorm_fwd(void* stream, const void* x, const void* w, void* y, float* 
 int vla_rmsnorm_bwd(void* stream, const void* dy, const void* x, const void* w, const float* rstd, const void* dres,
                     void* dx, int rows, int cols, int x_group, int x_group_rows, int x_row0);
 
+/* Qwen2RMSNorm weight gradient: dw[c] += sum_r dy[r, c] * bf16(x[r, c] * rstd[r]) (f32 accumulator).  Needed once the LLM
+ * trains (full fine-tune, vla-scripts/finetune.py:846-849; LoRA leaves the norms frozen). */
+int vla_rmsnorm_dw(void* stream, const void* dy, const void* x, const float* rstd, float* dw, int rows, int cols);
+
 /* ---------------------------------------------------------------- attention (MFMA, flash-style) */
 typedef struct vla_attn_desc {
   const void* q; const void* k; const void* v;   /* bf16; element (b, s, h, d) at b*sb + s*ss + h*dh + d */
@@ -190,6 +194,12 @@ int vla_colsum_bf16(void* stream, const void* x, float* out, int rows, int cols,
 /* f32 -> bf16 / bf16 -> f32 casts */
 int vla_cast_f32_bf16(void* stream, const float* x, void* y, long long n);
 int vla_cast_bf16_f32(void* stream, const void* x, float* y, long long n);
+
+/* Gradient of the embedding table (nn.Embedding backward, full fine-tune): grad_table[id] = sum of dx rows of the token
+ * positions holding id (positions overwritten by an action query excluded: qidx >= 0); rows of ids that do not occur are NOT
+ * touched (zero grad_table first).  dx [B, L + Np, D] = gradient w.r.t. inputs_embeds of the full sequence. */
+int vla_embed_grad(void* stream, const void* dx, const long long* ids, const int* qidx, void* grad_table, int B, int L,
+                   int Np, int D, int vocab);
 
 /* ---------------------------------------------------------------- host-glue replacements
  * The reference's training step strings its ops together with dozens of small ATen index / cast / copy kernels

@@ -1,0 +1,119 @@
+"""Full fine-tune (BASELINE configs[3]: every VLM parameter trains, vla-scripts/finetune.py:846-849, 903-910): gradients of
+one tensor of every kind against autograd through the CPU oracle, under the fp32-truth error budget of
+tests/test_engine_gpu.py (all three backward passes driven by the engine's own upstream gradient)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import vla_oracle as O  # noqa: E402
+import os, sys
+sys.path.insert(0, os.path.dirname(__file__))
+from test_engine_gpu import budget, budget_family, cpu_f32, oracle_cfg, rel  # noqa: E402
+
+DEV, BF = "cuda", torch.bfloat16
+
+
+def _oracle_full(cfg, W, batch, emu):
+    leaf = lambda d: {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in d.items()}
+    llm = leaf(W["llm"])
+    OW = dict(vit=[leaf(s) for s in W["vit"]], proj=leaf(W["proj"]), llm=llm, embed=llm["embed_tokens.weight"],
+              action_queries=W["action_queries"].float().cpu().clone().requires_grad_(True), head=leaf(W["head"]), proprio=leaf(W["proprio"]))
+    cb = {k: v.cpu() for k, v in batch.items()}
+    cb["pixel_values"], cb["proprio"] = cb["pixel_values"].float(), cb["proprio"].to(BF).float()
+    return O.vla_forward(cb, OW, oracle_cfg(cfg), emu=emu, noise=None), OW
+
+
+def _ref_grads(OW, cfg):
+    """Oracle gradients under the reference's state-dict names (what FullFinetune.reference_named_gradients returns)."""
+    out = {}
+    for k, v in OW["llm"].items():
+        if v.grad is not None:
+            out["language_model.model." + k] = v.grad
+    for k, v in OW["vit"][0].items():
+        if v.grad is not None:
+            out["vision_backbone.featurizer." + k] = v.grad
+    for k, v in OW["proj"].items():
+        out["projector." + k] = v.grad
+    return out
+
+
+def test_full_finetune_gradients_match_oracle_autograd():
+    from vla_adapter_amd import engine as E, synthetic as S, ops
+    from vla_adapter_amd.full_finetune import FullFinetune
+    cfg = E.tiny_config()
+    W = S.make_weights(cfg, DEV, seed=3, std=0.05)
+    batch = S.make_batch(cfg, 3, DEV, seed=4, P=20, ragged=True)
+    eng = E.VLAEngine(cfg, W, DEV)
+    ft = FullFinetune(eng)
+    pred = ft.forward(batch, None)
+    _, dpred = ops.l1_loss(pred, batch["actions"].to(BF), True)
+    ft.backward(pred, batch["actions"])
+    torch.cuda.synchronize()
+    G = {}
+    for emu in (True, False):
+        out, OW = _oracle_full(cfg, W, batch, emu)
+        if emu:
+            budget_pred = (pred, out["pred"])
+        out["pred"].backward(dpred.float().cpu())
+        G[emu] = (_ref_grads(OW, cfg), OW)
+        if not emu:
+            budget(budget_pred[0], budget_pred[1], out["pred"], "full fine-tune forward (unfused GELU, saved activations): actions")
+    got = ft.reference_named_gradients()
+    n, nbv = cfg.llm.n_layers, len(eng.vits[0].blocks)
+    fam = []
+    skipped = []
+    for k, g in got.items():
+        if k not in G[False][0]:
+            skipped.append(k)
+            continue
+        r_e, r_t = G[True][0][k], G[False][0][k]
+        fam.append((k, g, r_e.reshape(g.shape), r_t.reshape(g.shape)))
+    # the oracle computes the (dead) last ViT block too; the engine's parameter list stops at the last useful block
+    assert all("blocks.%d." % (cfg.vit[0].depth - 1) not in k for k in got), "last ViT block is never part of the path"
+    assert len(fam) >= 8 * nbv + 10 * n + 6, (len(fam), skipped[:5])
+    gmax = max(t[3].norm().item() for t in fam)
+    mats = [t for t in fam if t[1].dim() >= 2 and "embed_tokens" not in t[0]]
+    vecs = [t for t in fam if t[1].dim() < 2]
+    budget_family(mats, "full fine-tune: weight-matrix gradients (ViT, projector, LLM)", absfloor=1e-3 * gmax)
+    budget_family(vecs, "full fine-tune: bias / LayerNorm / RMSNorm gradients", absfloor=1e-3 * gmax)
+    emb = [t for t in fam if "embed_tokens" in t[0]][0]
+    budget(emb[1], emb[2], emb[3], "full fine-tune: embedding-table gradient", factor=1.5)
+    touched = (emb[3].abs().sum(1) > 0)
+    assert torch.equal((emb[1].float().cpu().abs().sum(1) > 0), touched), "exactly the rows of the tokens in the batch receive a gradient"
+    budget(eng.head.P.g("action_queries"), G[True][1]["action_queries"].grad, G[False][1]["action_queries"].grad, "full fine-tune: action_queries", factor=1.5)
+    hk = "model.mlp_resnet_blocks.0.k_task.weight"
+    budget(eng.head.named_views(eng.head.P.grad)[hk], G[True][1]["head"][hk].grad, G[False][1]["head"][hk].grad, "full fine-tune: head k_task", factor=1.5)
+
+
+def test_full_finetune_trains_and_updates_every_tensor():
+    from vla_adapter_amd import engine as E, synthetic as S
+    from vla_adapter_amd.full_finetune import FullFinetune
+    cfg = E.tiny_config()
+    W = S.make_weights(cfg, DEV, seed=5, std=0.05)
+    batch = S.make_batch(cfg, 4, DEV, seed=6, P=24, ragged=True)
+    ft = FullFinetune(E.VLAEngine(cfg, W, DEV))
+    p0 = ft.P.data.clone()
+    losses = [ft.train_step(batch, 3e-4)[0].item() for _ in range(10)]
+    torch.cuda.synchronize()
+    assert all(l == l for l in losses) and losses[-1] < 0.8 * losses[0], losses
+    # every tensor received a gradient (first AdamW moment non-zero) and every tensor that CAN move in bf16 did: LayerNorm / RMSNorm
+    # weights sit at ~1.0, where one bf16 ulp (7.8e-3) is far above lr = 3e-4 - they stay put in the reference's bf16 AdamW too
+    fed, moved = {}, {}
+    for s in ft.slots:
+        off, shape = ft.P.offsets[s.name]
+        n = 1
+        for d in shape:
+            n *= d
+        fed[s.name] = bool((ft.P.m[off:off + n] != 0).any())
+        moved[s.name] = bool((ft.P.data[off:off + n] != p0[off:off + n]).any())
+    assert all(fed.values()), [k for k, v in fed.items() if not v][:10]
+    still = [k for k, v in moved.items() if not v]
+    assert all(k.split(".")[-1] in ("n1w", "n2w", "n1", "n2", "norm") for k in still), still[:10]
+    # the fused operands the kernels read ARE the parameters: the engine's weight handles alias the flat buffer
+    assert ft.llm.layers[0]["wqkv"].data_ptr() == ft.P.view("llm.0.wqkv").data_ptr()
+    # zero-padded regions stay zero (zero weight, zero gradient under AdamW)
+    v = ft.vit
+    if v.mlp_pad != v.cfg.mlp:
+        assert bool((v.blocks[0]["w1"][v.cfg.mlp:] == 0).all()) and bool((v.blocks[0]["w2"][:, v.cfg.mlp:] == 0).all())
+    assert bool((v.wpe[:, 3 * v.cfg.patch ** 2:] == 0).all())

@@ -766,3 +766,51 @@ extern "C" int vla_add_scalar_f32(void* stream, float* x, const float* s, int n)
   VLA_CHECK_LAUNCH("add_scalar_f32");
   return VLA_OK;
 }
+
+
+// ---------------------------------------------------------------- embedding-table gradient (full fine-tune)
+// d table[id] = sum over the token positions (b, j) with input_ids[b, j] == id (and no action query spliced in there) of
+// dX0[b, row(j)], row(0) = 0, row(j) = Np + j - row0... here row0 = 0 (full backward): sequence row of token j is 0 for j = 0,
+// Np + j otherwise.  One workgroup per token position; the FIRST position holding an id sums every position of that id in
+// fp32, in position order, and writes the bf16 row once (deterministic, one rounding - torch's embedding_dense_backward also
+// accumulates a row in the accumulate type); all other positions do nothing.  n = B * L is ~1.5 k: the O(n) scans are free.
+__global__ void embed_grad_kernel(const bf16_t* __restrict__ dx, const long long* __restrict__ ids, const int* __restrict__ qidx,
+                                  bf16_t* __restrict__ gtable, int B, int L, int Np, int D, int vocab) {
+  const int t = blockIdx.x, n = B * L;
+  if (qidx[t] >= 0) return;                       // slot overwritten by an action query: its gradient goes to action_queries
+  long long id = ids[t];
+  if (id < 0 || id >= vocab) id = 0;              // same clamp as the forward gather
+  __shared__ int first;
+  if (threadIdx.x == 0) {
+    int f = 1;
+    for (int u = 0; u < t && f; ++u) {
+      long long iu = ids[u];
+      if (iu < 0 || iu >= vocab) iu = 0;
+      if (qidx[u] < 0 && iu == id) f = 0;
+    }
+    first = f;
+  }
+  __syncthreads();
+  if (!first) return;
+  const int S = L + Np;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    float a = 0.f;
+    for (int u = t; u < n; ++u) {
+      long long iu = ids[u];
+      if (iu < 0 || iu >= vocab) iu = 0;
+      if (qidx[u] >= 0 || iu != id) continue;
+      const int b = u / L, j = u - b * L;
+      a += bf2f(dx[((long long)b * S + (j == 0 ? 0 : Np + j)) * D + c]);
+    }
+    gtable[id * D + c] = f2bf(a);
+  }
+}
+
+extern "C" int vla_embed_grad(void* stream, const void* dx, const long long* ids, const int* qidx, void* grad_table, int B, int L,
+                              int Np, int D, int vocab) {
+  VLA_REQUIRE(dx && ids && qidx && grad_table && B > 0 && L > 0 && Np >= 0 && D > 0 && vocab > 0, "embed_grad: bad args");
+  hipLaunchKernelGGL(embed_grad_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dx, ids, qidx, (bf16_t*)grad_table,
+                     B, L, Np, D, vocab);
+  VLA_CHECK_LAUNCH("embed_grad");
+  return VLA_OK;
+}

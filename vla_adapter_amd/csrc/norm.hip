@@ -303,3 +303,28 @@ extern "C" int vla_rmsnorm_bwd(void* stream, const void* dy, const void* x, cons
   VLA_CHECK_LAUNCH("rmsnorm_bwd");
   return VLA_OK;
 }
+
+
+// ---------------------------------------------------------------- RMSNorm weight gradient (full fine-tune, BASELINE config 4)
+// Qwen2RMSNorm: y = w * bf16(x * rstd)  ->  dw[c] += sum_rows dy[r, c] * bf16(x[r, c] * rstd[r])   (fp32 accumulator, += ).
+// grid (ceil(cols / 256), row splits): same shape as layernorm_bwd_wb_kernel.
+__global__ __launch_bounds__(256) void rmsnorm_dw_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                         const float* __restrict__ rstd, float* __restrict__ dw, int rows, int cols,
+                                                         int rows_per) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+  float a = 0.f;
+#pragma unroll 4
+  for (int r = r0; r < r1; ++r) a += bf2f(dy[(long long)r * cols + c]) * rbf(bf2f(x[(long long)r * cols + c]) * rstd[r]);
+  atomicAdd(dw + c, a);
+}
+
+extern "C" int vla_rmsnorm_dw(void* stream, const void* dy, const void* x, const float* rstd, float* dw, int rows, int cols) {
+  VLA_REQUIRE(dy && x && rstd && dw && rows > 0 && cols > 0, "rmsnorm_dw: null/empty");
+  const int rows_per = 64;
+  dim3 grid((cols + 255) / 256, (rows + rows_per - 1) / rows_per);
+  hipLaunchKernelGGL(rmsnorm_dw_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, rstd, dw, rows, cols, rows_per);
+  VLA_CHECK_LAUNCH("rmsnorm_dw");
+  return VLA_OK;
+}
