@@ -186,12 +186,67 @@ def cpu_baseline(cfg, W, batch, noise, nsample, seconds_cap=60.0):
                 sample=f"{steps} step(s) x {nsample} sample(s) of the same synthetic batch, fp32 torch-CPU oracle fwd+bwd+AdamW, {el:.1f} s")
 
 
+def bench_full(args, cfg, W, eng, batch, noise, lr, rank, local, world, B, P):
+    """BASELINE configs[3]: full-backbone unfreeze (ViT + 0.5B LLM + adapter), bf16, batch 16 / GPU: forward + full backward
+    (dX and dW of every Linear, norms, embeddings) + AdamW over ~1.1 G parameters.  Not the headline metric (that is the
+    adapter-only configs[1]); same JSON contract."""
+    from vla_adapter_amd import flops
+    from vla_adapter_amd.full_finetune import FullFinetune
+    ft = FullFinetune(eng)
+
+    def sync():
+        if world > 1:
+            dist.barrier(device_ids=[local]) if dist.get_backend() == "nccl" else dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.eager:
+        step = lambda: ft.train_step(batch, lr, noise)
+    else:
+        ft.capture(batch, noise)
+        step = lambda: ft.train_step_graphed(lr)
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss3 = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=f"cuda:{local}", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    ms = dt / args.steps * 1e3
+    fl = flops.step_flops_per_sample(cfg, L=P + 64, row0=0)
+    full = 3.0 * fl["forward"]                               # SURVEY 8d: config 4 ~ 3 x forward (dX + dW for every op)
+    if rank == 0:
+        nparam = ft.P.numel + ft.head.P.numel
+        print(json.dumps({
+            "metric": "fine-tune samples/sec (224px img + 32-tok prompt), FULL unfreeze (ViT + LLM + adapter), fwd+bwd+AdamW",
+            "value": round(world * B * args.steps / dt, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[3]: Prismatic SigLIP-224 + Qwen2.5-0.5B + Pro action head, full-backbone unfreeze, "
+                                   "1 image (256 patches) + 32-token prompt + 64 action queries (S=352)",
+                       "global_batch": world * B, "per_gpu_batch": B, "seq_len": cfg.n_patches + P + 64, "parallelism": f"dp{world}",
+                       "weights": "random-init", "trainable_parameters": nparam, "launch": "eager" if args.eager else "hipGraph replay",
+                       "final_loss": round(float(loss3[0]), 5)},
+            "step_tflops_per_gpu": round(full * B / (ms * 1e-3) / 1e12, 1),
+            "step_frac_of_bf16_mfma_peak": round(full * B / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "gflop_per_sample": {"autograd_convention": round(full / 1e9, 1)},
+        }), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE config: 32)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (BASELINE configs[1]: 32; --mode full = configs[3]: 16)")
+    ap.add_argument("--mode", default="adapter", choices=["adapter", "full"],
+                    help="adapter: BASELINE configs[1]/[2] (the headline metric); full: configs[3], every VLM parameter trains")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=4, help="samples of the batch the CPU oracle is timed on (3 steps each: about 12 s of CPU work)")
     ap.add_argument("--no-full-backward", action="store_true", help="skip the extra timing of the reference-shaped full LLM backward")
@@ -208,7 +263,7 @@ def main():
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     cfg = E.config2()
-    B, P = args.batch, 32
+    B, P = (args.batch or (32 if args.mode == "adapter" else 16)), 32
     W = S.make_weights(cfg, dev, seed=0)                    # identical on every rank (== DDP's initial broadcast)
     eng = E.VLAEngine(cfg, W, dev)
     batch = S.make_batch(cfg, B, dev, seed=1000 + rank, P=P, ragged=args.ragged)  # every rank draws its own samples (finetune.py:988-994)
@@ -227,6 +282,8 @@ def main():
         eng.reducer.world = 2
         type(eng.reducer).grad_scale = property(lambda self: 1.0)
     lr = 5e-4
+    if args.mode == "full":
+        return bench_full(args, cfg, W, eng, batch, noise, lr, rank, local, world, B, P)
 
     def barrier():
         if dist.get_backend() == "nccl":

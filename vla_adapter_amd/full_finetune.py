@@ -376,7 +376,7 @@ class FullFinetune:
         return loss3
 
     # ------------------------------------------------------------------------------------------------ update
-    def optimizer_step(self, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, wd=0.01):
+    def optimizer_step(self, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, wd=0.01, refresh: bool = True):
         self.step_count += 1
         gscale = 1.0
         red = self.eng.reducer
@@ -389,10 +389,36 @@ class FullFinetune:
         ops.adamw_(P.data, P.grad, P.m, P.v, self.step_count, lr, beta1, beta2, eps, wd, gscale=gscale)
         ops.adamw_(HP.data, HP.grad, HP.m, HP.v, self.step_count, lr, beta1, beta2, eps, wd, gscale=gscale)
         self.head.dirty = True
-        self.refresh_transposes()
+        if refresh:
+            self.refresh_transposes()
 
     def train_step(self, batch, lr: float, noise=None):
         pred = self.forward(batch, noise)
         loss3 = self.backward(pred, batch["actions"])
         self.optimizer_step(lr)
         return loss3
+
+    # ---- hipGraph replay: the ~3000 launches of a step cost more host time than GPU time when issued from Python ------------
+    def capture(self, batch: Dict[str, torch.Tensor], noise: Optional[torch.Tensor] = None, warmup: int = 2):
+        """Forward + backward as ONE linear hipGraph on the static ``batch`` / ``noise`` buffers (copy new data into them before
+        each replay); AdamW stays outside (host-side bias corrections), the W^T rebuild is a second small graph."""
+        self._cap_stream = torch.cuda.Stream()
+        for _ in range(warmup):
+            self.head.dirty = True
+            self.backward(self.forward(batch, noise), batch["actions"])
+        torch.cuda.synchronize()
+        self.head.dirty = True                       # the head's own W^T / padded-operand refresh becomes part of the graph
+        pool = torch.cuda.graph_pool_handle()
+        self._g_step = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_step, pool=pool, stream=self._cap_stream, capture_error_mode="thread_local"):
+            self._loss3 = self.backward(self.forward(batch, noise), batch["actions"])
+        self._g_t = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_t, pool=pool, stream=self._cap_stream, capture_error_mode="thread_local"):
+            self.refresh_transposes()
+        torch.cuda.synchronize()
+
+    def train_step_graphed(self, lr: float):
+        self._g_step.replay()
+        self.optimizer_step(lr, refresh=False)
+        self._g_t.replay()
+        return self._loss3
