@@ -122,6 +122,10 @@ def measure_gemm_roofline(eng, batch, noise, lr, reps=10, record_only=False):
         n += cnt
         per.append((cnt * t, cnt, sig[0], sig[1], fl / t / 1e12))
     per.sort(reverse=True)
+    if os.environ.get("VLA_DUMP_GEMMS"):          # full per-signature table (tuning aid)
+        with open(os.environ["VLA_DUMP_GEMMS"], "w") as fdump:
+            for x in per:
+                fdump.write(f"{x[0] * 1e3:8.3f} ms/step  count {x[1]:4d}  A {list(x[2])}  B {list(x[3])}  {x[4]:7.1f} TF/s\n")
     top = [dict(ms_per_step=round(x[0] * 1e3, 3), count=x[1], A=list(x[2]), B=list(x[3]), tflops=round(x[4], 1)) for x in per[:8]]
     return dict(launches=n, seconds=total_t, flops=total_f, tflops=total_f / total_t / 1e12, top=top, bytes=total_b)
 

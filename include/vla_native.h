@@ -201,6 +201,13 @@ int vla_cast_bf16_f32(void* stream, const void* x, float* y, long long n);
 int vla_embed_grad(void* stream, const void* dx, const long long* ids, const int* qidx, void* grad_table, int B, int L,
                    int Np, int D, int vocab);
 
+/* Token cross-entropy of the native VLM path (prismatic/models/vlms/prismatic.py:469-481 -> HF shifted causal-LM loss):
+ * logits bf16 [rows, V] (row stride ld_logits), shifted_labels int64 [rows] (the target of each row, -100 = ignore);
+ * out[0] += sum over valid rows of (logsumexp(float(logits[row])) - logits[row, label]), out[1] += number of valid rows
+ * (zero `out` first; loss = out[0] / out[1]). */
+int vla_token_ce(void* stream, const void* logits, long long ld_logits, const long long* shifted_labels, int rows, int V,
+                 float* loss_sum_and_count);
+
 /* ---------------------------------------------------------------- host-glue replacements
  * The reference's training step strings its ops together with dozens of small ATen index / cast / copy kernels
  * (finetune.py:331-343, 396-409; action_heads.py:53-72; modeling_prismatic.py:499-508); these entry points do the same

@@ -398,6 +398,22 @@ def l1_metrics(pred, target):
 
 
 # ----------------------------------------------------------------------------------------------
+# 8f-4  token cross-entropy of the native VLM path (prismatic/models/vlms/prismatic.py:411-422, 469-481 -> HF causal-LM loss)
+# ----------------------------------------------------------------------------------------------
+def token_ce(hidden_last, lm_head, labels, num_patches: int, emu=False):
+    """hidden_last [B, S, D] = hidden_states[-1]; labels [B, L] (text positions); -> (loss, logits [B, S, V]).
+    multimodal labels = [labels[:, :1] | -100 x num_patches | labels[:, 1:]]; HF shifts by one and averages over labels != -100,
+    on the fp32 upcast of the (bf16) logits."""
+    B = hidden_last.shape[0]
+    logits = linear(hidden_last, lm_head, None, emu)
+    mm = torch.cat([labels[:, :1], torch.full((B, num_patches), IGNORE_INDEX, dtype=labels.dtype), labels[:, 1:]], dim=1)
+    lg, tg = logits[:, :-1].reshape(-1, logits.shape[-1]).float(), mm[:, 1:].reshape(-1)
+    valid = tg != IGNORE_INDEX
+    lse = torch.logsumexp(lg[valid], dim=-1)
+    return (lse - lg[valid].gather(1, tg[valid][:, None])[:, 0]).mean(), logits
+
+
+# ----------------------------------------------------------------------------------------------
 # a11  LoRA linear (peft LoraConfig r, alpha=2r; finetune.py:832-844).  PARITY UNPINNED (peft absent).
 # ----------------------------------------------------------------------------------------------
 def lora_linear(x, w, b, A, Bm, scale: float, emu=False):

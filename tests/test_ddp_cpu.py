@@ -20,13 +20,13 @@ def test_bucket_ranges_cover_exactly():
         assert all((s % 8 == 0) for s, _ in r)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, algo="allreduce"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     r, _, w = ddp.init_process_group_from_env("gloo")
     assert (r, w) == (rank, world)
     g = torch.Generator().manual_seed(100 + rank)
     flat = torch.randn(100_003, generator=g)
-    red = ddp.FlatGradReducer(bucket_bytes=64 * 1024)
+    red = ddp.FlatGradReducer(bucket_bytes=64 * 1024, algo=algo)
     red.reduce_async(flat, 0, 100_000)          # head region
     red.reduce_async(flat, 100_000, None)       # small tail (action queries)
     red.wait()
@@ -36,11 +36,14 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_flat_grad_allreduce_world2_gloo():
+@pytest.mark.parametrize("algo", ["allreduce", "rs_ag"])
+def test_flat_grad_allreduce_world2_gloo(algo):
+    """Both exchange algorithms (one all-reduce per bucket; reduce-scatter + all-gather per bucket with a ragged tail) leave the
+    mean of the two ranks' gradients on BOTH ranks."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, algo)) for r in range(2)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=120) for _ in range(2))

@@ -12,9 +12,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_rank_captured_step_keeps_ranks_in_sync():
+@pytest.mark.parametrize("algo", ["allreduce", "rs_ag"])
+def test_two_rank_captured_step_keeps_ranks_in_sync(algo):
+    """Ranks end bit-identical AND equal to a single-process run on the summed gradients (tools/ddp_rehearsal.py), with the
+    exchange as bucketed all-reduce or as reduce-scatter + all-gather."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, VLA_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, VLA_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", VLA_DDP_ALGO=algo)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", str(port), os.path.join("tools", "ddp_rehearsal.py")],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)

@@ -1,6 +1,10 @@
 """GPU checks of the reference-API mirrors (OpenVLAForActionPrediction.forward, L1RegressionActionHead.predict_action,
 the finetune entry point) on the prismatic-tiny configuration."""
+import os
+import sys
+
 import pytest
+sys.path.insert(0, os.path.dirname(__file__))
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -217,3 +221,41 @@ def test_engine_from_reference_layout_state_dict(tmp_path):
     W2 = CK.split_reference_state_dict(CK.load_file(str(tmp_path / "vla.safetensors")), cfg, head=W["head"], proprio=W["proprio"])
     got = E.VLAEngine(cfg, W2, DEV).forward(batch, None)
     assert torch.equal(got, ref)
+
+
+def test_prismatic_vlm_forward_token_ce_loss_and_logits():
+    """prismatic/models/vlms/prismatic.py:312-481 (the native, non-HF API): plain VLM forward - no action queries - with the HF
+    shifted cross-entropy over the vocabulary.  Hidden states, logits and loss against the oracle restatement."""
+    from oracle import vla_oracle as O
+    from vla_adapter_amd import engine as E, synthetic as S, modeling_prismatic as M
+    cfg = E.tiny_config()
+    W = S.make_weights(cfg, "cuda", seed=21, std=0.05)
+    batch = S.make_batch(cfg, 3, "cuda", seed=22, P=24, ragged=True)
+    vla = M.OpenVLAForActionPrediction(cfg, W, "cuda")
+    vlm = M.PrismaticVLM(vla)
+    labels = batch["labels"].clone()
+    labels[labels > cfg.llm.vocab - 1] = cfg.llm.vocab - 7            # tiny vocab: keep the targets inside the lm_head's range
+    out = vlm(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], pixel_values=batch["pixel_values"], labels=labels,
+              output_hidden_states=True)
+    torch.cuda.synchronize()
+    f = lambda sd: {k: v.float().cpu() for k, v in sd.items()}
+    res = {}
+    Np, n = cfg.n_patches, cfg.llm.n_layers
+    for emu in (True, False):
+        px = batch["pixel_values"].float().cpu()
+        patches = O.projector(O.vit_forward(px[:, :3], f(W["vit"][0]), cfg.vit[0].as_oracle(), emu), f(W["proj"]), cfg.fused, emu)
+        emb = f(W["llm"])["embed_tokens.weight"]
+        e = emb[batch["input_ids"].cpu()]
+        mm = torch.cat([e[:, :1], patches, e[:, 1:]], dim=1)
+        am = batch["attention_mask"].cpu().bool()
+        mask = torch.cat([am[:, :1], torch.ones(3, Np, dtype=torch.bool), am[:, 1:]], dim=1)
+        hs = O.qwen2_forward(mm, mask, f(W["llm"]), cfg.llm.as_oracle(), emu)
+        loss, logits = O.token_ce(hs[-1], emb, labels.cpu(), Np, emu)
+        res[emu] = (hs, loss, logits)
+    valid = torch.cat([am[:, :1], torch.ones(3, Np, dtype=torch.bool), am[:, 1:]], dim=1)
+    from test_engine_gpu import budget
+    budget(out.hidden_states[n].float().cpu()[valid], res[True][0][n][valid], res[False][0][n][valid], "PrismaticVLM hidden_states[-1]")
+    budget(out.logits.float().cpu()[valid], res[True][2][valid], res[False][2][valid], "PrismaticVLM logits")
+    le, lt = res[True][1].item(), res[False][1].item()
+    assert abs(out.loss.item() - lt) <= 1.25 * abs(le - lt) + 2e-3 * abs(lt), (out.loss.item(), le, lt)
+    assert out.logits.shape == (3, batch["input_ids"].shape[1] + Np, cfg.llm.vocab)

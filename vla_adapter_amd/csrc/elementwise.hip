@@ -814,3 +814,64 @@ extern "C" int vla_embed_grad(void* stream, const void* dx, const long long* ids
   VLA_CHECK_LAUNCH("embed_grad");
   return VLA_OK;
 }
+
+
+// ---------------------------------------------------------------- token cross-entropy
+// HF causal-LM loss (transformers' ForCausalLMLoss as the reference's PrismaticVLM.forward reaches it through the LLM backbone,
+// prismatic/models/vlms/prismatic.py:469-481): logits are bf16, upcast to fp32, shifted by one position, mean over the labels
+// != -100.  One workgroup per logits row: row_loss = logsumexp(logits[row]) - logits[row, label]; loss_sum += row_loss,
+// count += 1 (two f32 atomics per valid row); the caller divides.  labels = the SHIFTED targets, one per row (-100: ignore).
+__global__ __launch_bounds__(256) void token_ce_kernel(const bf16_t* __restrict__ logits, long long ldl, const long long* __restrict__ labels,
+                                                       int V, float* __restrict__ out2) {
+  const long long row = blockIdx.x;
+  const long long lab = labels[row];
+  if (lab < 0 || lab >= V) return;                 // IGNORE_INDEX (-100)
+  const bf16_t* x = logits + row * ldl;
+  __shared__ float red[8];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  float m = -3.0e38f;
+  for (int c = tid * 8; c < V; c += 256 * 8) {
+    if (c + 8 <= V) {
+      const uint4 v = *reinterpret_cast<const uint4*>(x + c);
+      const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m = fmaxf(m, fmaxf(bf2f((bf16_t)(u[k] & 0xffff)), bf2f((bf16_t)(u[k] >> 16))));
+    } else {
+      for (int k = c; k < V; ++k) m = fmaxf(m, bf2f(x[k]));
+    }
+  }
+  m = wave_max(m);
+  if (lane == 0) red[w] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int c = tid * 8; c < V; c += 256 * 8) {
+    if (c + 8 <= V) {
+      const uint4 v = *reinterpret_cast<const uint4*>(x + c);
+      const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s += __expf(bf2f((bf16_t)(u[k] & 0xffff)) - m) + __expf(bf2f((bf16_t)(u[k] >> 16)) - m);
+    } else {
+      for (int k = c; k < V; ++k) s += __expf(bf2f(x[k]) - m);
+    }
+  }
+  s = wave_sum(s);
+  if (lane == 0) red[w] = s;
+  __syncthreads();
+  if (tid == 0) {
+    const float lse = m + __logf(red[0] + red[1] + red[2] + red[3]);
+    atomicAdd(out2, lse - bf2f(x[lab]));
+    atomicAdd(out2 + 1, 1.0f);
+  }
+}
+
+extern "C" int vla_token_ce(void* stream, const void* logits, long long ld_logits, const long long* shifted_labels, int rows, int V,
+                            float* loss_sum_and_count) {
+  VLA_REQUIRE(logits && shifted_labels && loss_sum_and_count && rows > 0 && V > 0 && ld_logits % 8 == 0 && ((uintptr_t)logits & 15) == 0,
+              "token_ce: bad args (row stride % 8, 16-B aligned logits)");
+  hipLaunchKernelGGL(token_ce_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, ld_logits, shifted_labels, V,
+                     loss_sum_and_count);
+  VLA_CHECK_LAUNCH("token_ce");
+  return VLA_OK;
+}

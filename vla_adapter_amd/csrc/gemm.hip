@@ -442,16 +442,19 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
 struct TileChoice { int bm, bn; };
 // When the 256 x 256 8-phase kernel (one workgroup per CU) is chosen automatically: problems with at least a chip-full of
 // its tiles' worth of work in both dimensions.  VLA_GEMM_TILE=6 forces it, VLA_NO_GEMM256 disables it.
-inline bool use_256(int M, int N, int K, int batch) {
+inline bool use_256(int M, int N, int K, int batch, int act) {
   static const bool off = getenv("VLA_NO_GEMM256") != nullptr;
   if (off) return false;
   const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256) * batch;
+  // the SwiGLU-backward epilogue (gathers GU, writes 2N columns) is as long as a short K loop: below two rounds of tiles the
+  // 128-row kernel's second resident workgroup hides it better (live-row backward, M = 2048: 334 vs 650 TF/s)
+  if (act == VLA_ACT_SWIGLU_BWD && tiles < 512) return false;
   return M >= 1024 && N >= 768 && K >= 256 && tiles >= 96;
 }
-inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode, int batch = 1, int split = 1) {
+inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode, int batch = 1, int split = 1, int act = 0) {
   if (rope_mode == 0 && split == 1) {
     if (force == 6) return {256, 257};                 // 256 x 256 staggered 8-phase kernel (gemm256.hip)
-    if (force == 0 && use_256(M, N, K, batch)) return {256, 257};
+    if (force == 0 && use_256(M, N, K, batch, act)) return {256, 257};
   }
   if (rope_mode == 1) return {128, 128};   // rotate_half: 8 waves, each owning 16 columns of both halves of one head
   if (force == 1 && rope_mode == 0) return {256, 128};
@@ -573,7 +576,7 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
     if (d->rope_mode == 1) VLA_REQUIRE(d->rope_dh == 64, "gemm: fused rotate_half RoPE needs head dim 64");
   }
   const char* e = getenv("VLA_GEMM_TILE");     // 0/unset auto, 1: 256x128, 2: 128x128, 3: 128x64  (benchmarking aid)
-  const TileChoice tc = choose_tile(d->M, d->N, d->K / split, e ? atoi(e) : 0, d->rope_mode, split > 1 ? split : d->batch, split);
+  const TileChoice tc = choose_tile(d->M, d->N, d->K / split, e ? atoi(e) : 0, d->rope_mode, split > 1 ? split : d->batch, split, d->act);
   hipStream_t st = (hipStream_t)stream;
   if (tc.bm == 256 && tc.bn == 257) {          // 256 x 256 staggered 8-phase kernel (gemm256.hip)
     vla_gemm256_launch(p, d->act == VLA_ACT_SWIGLU ? 1 : d->act == VLA_ACT_SWIGLU_BWD ? 2 : 0, d->batch, st);

@@ -339,6 +339,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
       bf16_t* C2 = p.C2 + (long long)z * p.sC2;
       constexpr int HSTR = 32 * 2 + 16;                       // staged h row: 32 bf16 + pad
       char* regh = smem + 8 * (64 * EPI_STRIDE) + wid * (64 * HSTR);
+      const bool plain = bias == nullptr && p.alpha == 1.f;
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
@@ -346,8 +347,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
           float h[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float g = rbf(A4(2 * pr, mi)[j] * p.alpha + bv[2 * pr][j]);
-            const float u = rbf(A4(2 * pr + 1, mi)[j] * p.alpha + bv[2 * pr + 1][j]);
+            // (Qwen2's gate / up projections carry no bias and alpha is 1: the wave-uniform `plain` spares two FMAs per pair)
+            const float g = rbf(plain ? A4(2 * pr, mi)[j] : A4(2 * pr, mi)[j] * p.alpha + bv[2 * pr][j]);
+            const float u = rbf(plain ? A4(2 * pr + 1, mi)[j] : A4(2 * pr + 1, mi)[j] * p.alpha + bv[2 * pr + 1][j]);
             A4(2 * pr, mi)[j] = g;
             A4(2 * pr + 1, mi)[j] = u;
             h[j] = rbf(g * __builtin_amdgcn_rcpf(1.0f + __expf(-g))) * u;

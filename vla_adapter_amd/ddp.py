@@ -47,23 +47,51 @@ def bucket_ranges(numel: int, bucket_elems: int, align: int = 8) -> List[Tuple[i
 
 
 class FlatGradReducer:
-    """Sum-all-reduce of a flat gradient buffer in large buckets, optionally on a side stream (overlap)."""
+    """Sum-all-reduce of a flat gradient buffer in large buckets, optionally on a side stream (overlap).
 
-    def __init__(self, group=None, bucket_bytes: int = 64 << 20):
+    algo="allreduce" (default): one ``all_reduce`` per bucket, algorithm left to RCCL (a ring is bound by ONE xGMI link:
+    ~153 GB/s -> 437 MB x 2 x 7/8 / 153 GB/s ~ 5 ms at 8 GPUs).
+    algo="rs_ag": every bucket as ``reduce_scatter_tensor`` + ``all_gather_into_tensor`` - each rank sends 1/N of the bucket to
+    each of its N-1 peers directly, all 7 links of the fully connected xGMI node busy at once (~0.7 ms).  The
+    same sum in a different association order than a ring, so results may differ from "allreduce" in the last bf16 bit; bucket
+    bounds are aligned to N x 8 elements, the ragged tail of the buffer goes through a small all_reduce.  UNMEASURED on
+    hardware (no multi-GPU node in this round); covered functionally by tests/test_ddp_cpu.py on gloo."""
+
+    def __init__(self, group=None, bucket_bytes: int = 64 << 20, algo: str = "allreduce"):
+        assert algo in ("allreduce", "rs_ag")
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bucket_bytes = bucket_bytes
+        self.algo = algo
         self.stream = torch.cuda.Stream() if torch.cuda.is_available() else None
         self._pending = False
+        self._shards = {}
+
+    def _reduce_bucket(self, t: torch.Tensor):
+        """In-place sum over the ranks of the contiguous 1-D tensor ``t``."""
+        N = self.world
+        if self.algo == "allreduce" or N == 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        n = t.numel() // (8 * N) * (8 * N)              # equal 16-B aligned shards
+        if n:
+            key = (n // N, t.dtype, str(t.device))
+            shard = self._shards.get(key)
+            if shard is None:
+                shard = self._shards[key] = torch.empty(n // N, dtype=t.dtype, device=t.device)
+            dist.reduce_scatter_tensor(shard, t[:n], op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_gather_into_tensor(t[:n], shard, group=self.group)
+        if n < t.numel():
+            dist.all_reduce(t[n:], op=dist.ReduceOp.SUM, group=self.group)
 
     def reduce_async(self, flat: torch.Tensor, start: int = 0, end: Optional[int] = None, after_event=None):
-        """Launch the all-reduce of flat[start:end] after everything already enqueued on the current stream - or, with
+        """Launch the exchange of flat[start:end] after everything already enqueued on the current stream - or, with
         ``after_event``, as soon as that event fires (the slice was produced on another stream and is final there)."""
         if self.world == 1:
             return None
         end = flat.numel() if end is None else end
         view = flat[start:end]
-        ranges = bucket_ranges(view.numel(), self.bucket_bytes // view.element_size())
+        ranges = bucket_ranges(view.numel(), self.bucket_bytes // view.element_size(), align=8 * (self.world if self.algo == "rs_ag" else 1))
         if self.stream is not None and flat.is_cuda:
             if after_event is not None:
                 self.stream.wait_event(after_event)
@@ -71,13 +99,13 @@ class FlatGradReducer:
                 self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
                 for a, b in ranges:
-                    dist.all_reduce(view[a:b], op=dist.ReduceOp.SUM, group=self.group)
+                    self._reduce_bucket(view[a:b])
                 done = torch.cuda.Event()
                 done.record()
             self._pending = True
             return done        # fires when THIS slice is reduced (later slices queue behind it on the same stream)
         for a, b in ranges:
-            dist.all_reduce(view[a:b], op=dist.ReduceOp.SUM, group=self.group)
+            self._reduce_bucket(view[a:b])
         return None
 
     def wait(self, *streams):

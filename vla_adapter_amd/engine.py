@@ -927,10 +927,24 @@ class VLAEngine:
         self.llm.forward(self.B, self.S, mm, self.live_row0() if (for_training and action_queries) else 0)
 
     def token_ce(self, labels: torch.Tensor):
-        """HF shifted token cross-entropy of the last forward_vlm (lm_head 896 -> 151 936 + CE).  Not built yet:
-        raises instead of returning a loss that was never computed."""
-        raise NotImplementedError("token-CE loss (lm_head + cross-entropy over the vocabulary, SURVEY 8f-4) is not built yet; "
-                                  "call forward() without labels for the hidden states")
+        """HF shifted token cross-entropy of the last forward_vlm (prismatic/models/vlms/prismatic.py:469-481):
+        logits = lm_head(hidden_states[-1]) over ALL positions (bf16, returned like the reference does), multimodal labels =
+        [labels[:, :1] | IGNORE for the patches | labels[:, 1:]] (:411-422), loss = mean over the positions whose NEXT label is
+        valid of logsumexp(float(logits)) - logits[label].  lm_head = the checkpoint's ``lm_head.weight`` or, when tied
+        (Qwen2.5-0.5B: tie_word_embeddings), the embedding table.  Returns (loss f32 scalar tensor, logits [B, S, V])."""
+        llm, B, S, Np = self.llm, self.B, self.S, self.Np
+        n, D = self.cfg.llm.n_layers, self.cfg.llm.d
+        W = getattr(llm, "lm_head", None)
+        W = llm.embed if W is None else W
+        V = W.shape[0]
+        assert V % 8 == 0 and tuple(labels.shape) == (B, S - Np)
+        logits = ops.gemm_nt(llm.HS[n].view(B * S, D), W, split_k=0).view(B, S, V)
+        # target of sequence row s = multimodal label of row s + 1; the last row has none
+        tgt = torch.full((B, S), IGNORE_INDEX, device=self.device, dtype=torch.int64)
+        tgt[:, Np:S - 1] = labels[:, 1:]                  # rows Np .. S-2 predict text tokens 1 .. L-1 (row 0 predicts a patch: ignored)
+        out2 = torch.zeros(2, device=self.device, dtype=torch.float32)
+        ops.N.check(ops._lib().vla_token_ce(ops._st(), ops._p(logits), V, ops._p(tgt), B * S, V, ops._p(out2)), "token_ce")
+        return out2[0] / out2[1], logits
 
     def _vision_and_embed(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         """ViT(s) -> projector -> action masks -> embedding/query splice into llm.HS[0]; returns the key mask [B,S] u8."""
