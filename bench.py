@@ -133,12 +133,28 @@ def measure_gemm_roofline(eng, batch, noise, lr, reps=10, record_only=False):
 def pmc_traffic():
     """HBM-side bytes per GEMM launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate
     runs of this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if not collected."""
-    f = os.path.join(ROOT, "profiles", "r01_gemm_traffic_pmc.json")
+    for name in ("r02_gemm_traffic_pmc.json", "r01_gemm_traffic_pmc.json"):
+        f = os.path.join(ROOT, "profiles", name)
+        try:
+            d = json.load(open(f))
+            return {"bytes_per_launch": round(d["bytes_per_launch"]), "source": "profiles/" + name,
+                    "note": "TCC fetch/write sizes = traffic between the 8 private L2s and the fabric (Infinity Cache + HBM), not HBM alone: "
+                            "every XCD streams the weight operand into its own L2 (DESIGN.md 4)"}
+        except Exception:
+            continue
+    return None
+
+
+def in_situ_roofline(gemm_flops_per_step):
+    """GEMM FLOPs of one step / sum of the IN-SITU GEMM kernel time of one step (rocprofv3 --kernel-trace of the default step alone,
+    tools/profile_step.sh -> profiles/r02_gemm_in_situ.json; reproducible from profiles/r02_kernel_summary.csv with a calculator:
+    sum us_per_step over the gemm rows).  Kernels of concurrent streams share the CUs, so a launch's in-situ duration includes the
+    time it waits for CUs other streams hold: this is a LOWER bound on the kernel's own rate."""
     try:
-        d = json.load(open(f))
-        return {"bytes_per_launch": round(d["bytes_per_launch"]), "source": "profiles/r01_gemm_traffic_pmc.json",
-                "note": "TCC fetch/write sizes = traffic between the 8 private L2s and the fabric (Infinity Cache + HBM), not HBM alone: "
-                        "every XCD streams the weight operand into its own L2, so fills are ~2.5x the algorithmic bytes (DESIGN.md 4)"}
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02_gemm_in_situ.json")))
+        us = d["gemm_us_per_step_in_situ"]
+        return {"frac_in_situ": round(gemm_flops_per_step / us / 1e6 / MFMA_BF16_PEAK_TFLOPS, 4), "gemm_us_per_step_in_situ": us,
+                "gemm_launches_per_step": d["gemm_launches_per_step"], "source": "profiles/r02_gemm_in_situ.json (+ r02_kernel_summary.csv)"}
     except Exception:
         return None
 
@@ -374,15 +390,16 @@ def main():
             "step_frac_of_bf16_mfma_peak": round(fl["step_live"] * B / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
             "gflop_per_sample": {"executed": round(fl["step_live"] / 1e9, 1), "autograd_convention": round(fl["step"] / 1e9, 1)},
             "full_backward_variant": full_bwd,
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 MFMA NT GEMM, all launches of one step)",
+            "roofline": {"bound": "mfma", "kernel": "gemm256_kernel + gemm_nt_kernel (bf16 MFMA NT GEMMs, all launches of one step)",
                          "achieved": round(roof["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(roof["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
+                         "frac_in_situ": (in_situ_roofline(roof["flops"]) or {}).get("frac_in_situ"), "in_situ": in_situ_roofline(roof["flops"]),
                          "traffic": (pmc_traffic() or {}).get("bytes_per_launch"), "traffic_detail": pmc_traffic(),
                          "algorithmic_bytes_per_launch": round(roof["bytes"] / roof["launches"]),
                          "avg_launch_us": round(roof["seconds"] / roof["launches"] * 1e6, 1),
                          "timing": "each distinct launch signature of one step replayed back-to-back between two HIP events on its "
-                                   "launch stream, weighted by its count; inside the multi-stream step the same launches average "
-                                   "~25 % longer (rocprofv3: profiles/r01_final_kernel_stats.csv) because the streams share the CUs",
+                                   "launch stream, weighted by its count (`frac`); `frac_in_situ` divides the same FLOPs by the "
+                                   "summed GEMM kernel time of the profiled step (concurrent streams share the CUs)",
                          "launches_per_step": roof["launches"], "gemm_ms_per_step": round(roof["seconds"] * 1e3, 3),
                          "gemm_flops_per_step": roof["flops"], "top_launches": roof["top"]},
             "cpu_baseline": cpu,

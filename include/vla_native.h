@@ -188,6 +188,9 @@ int vla_gelu_bwd(void* stream, const void* dy, const void* x, void* dx, long lon
 int vla_relu_bwd(void* stream, const void* dy, const void* y, void* dx, long long n);
 /* SwiGLU backward: dH [M, I] and interleaved pre-activations GU [M, 2I] -> dGU [M, 2I] (same interleave). */
 int vla_swiglu_bwd(void* stream, const void* dh, const void* gu, void* dgu, int M, int I);
+/* h[M, I] = bf16(bf16(silu(gate)) * up) from the interleaved pre-activations gu[M, 2I] (same layout as VLA_ACT_SWIGLU): the
+ * stand-alone form of the fused epilogue, used when LoRA deltas are added to the pre-activations first (finetune.py:832-844). */
+int vla_swiglu_fwd(void* stream, const void* gu, void* h, int M, int I);
 /* column sums of bf16 matrices [batch][rows, cols] into f32 out[batch][cols] (+=): bias gradients. */
 int vla_colsum_bf16(void* stream, const void* x, float* out, int rows, int cols, int ldx, int batch, long long s_x,
                     long long s_out);

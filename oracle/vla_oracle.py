@@ -54,7 +54,17 @@ def linear(x, w, b=None, emu=False, strided_input=False):
     y = x @ w.t()
     if b is not None:
         y = (rnd(y, emu) if strided_input else y) + b
-    return rnd(y, emu)
+    y = rnd(y, emu)
+    l = LORA.get(id(w))
+    if l is not None:            # peft Linear.forward: result = base(x) + lora_B(lora_A(x)) * scaling, every step a bf16 tensor
+        A, Bm, scale = l
+        y = rnd(y + rnd(rnd(rnd(x @ A.t(), emu) @ Bm.t(), emu) * scale, emu), emu)
+    return y
+
+
+# LoRA registry (a11, parity unpinned: peft absent): id(base weight tensor) -> (A [r, in], B [out, r], alpha / r).  Tests fill it
+# to evaluate the LoRA-wrapped model (vla-scripts/finetune.py:832-844) through the unchanged restated forward.
+LORA: Dict[int, Tuple[torch.Tensor, torch.Tensor, float]] = {}
 
 
 def gelu(x, emu=False, tanh=False):

@@ -1,0 +1,137 @@
+"""LoRA fine-tune (vla-scripts/finetune.py:832-844) against autograd through the oracle with peft's Linear semantics
+(oracle.LORA registry): forward and the gradients of the A / B pairs of every kind of target, under the fp32-truth budget.
+PARITY UNPINNED (peft is not importable here)."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(__file__))
+
+from oracle import vla_oracle as O  # noqa: E402
+from test_engine_gpu import budget, budget_family, oracle_cfg  # noqa: E402
+
+DEV, BF = "cuda", torch.bfloat16
+
+
+def _oracle_lora(cfg, W, batch, lo, emu):
+    """lo: LoRAFinetune.  Builds oracle weights (frozen) + LoRA leaves registered on the matching base tensors."""
+    f = lambda d: {k: v.detach().float().cpu().clone() for k, v in d.items()}
+    llm = f(W["llm"])
+    leaf = lambda d: {k: v.requires_grad_(True) for k, v in d.items()}
+    OW = dict(vit=[f(s) for s in W["vit"]], proj=f(W["proj"]), llm=llm, embed=llm["embed_tokens.weight"],
+              action_queries=W["action_queries"].float().cpu().clone().requires_grad_(True), head=leaf(f(W["head"])), proprio=leaf(f(W["proprio"])))
+    sd = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in lo.lora_state_dict().items()}
+    O.LORA.clear()
+    pre = "base_model.model."
+
+    def reg(base, key):
+        O.LORA[id(base)] = (sd[pre + key + ".lora_A.weight"], sd[pre + key + ".lora_B.weight"], 2.0)
+    for i in range(len(lo.vit.blocks)):
+        for n in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2"):
+            reg(OW["vit"][0][f"blocks.{i}.{n}.weight"], f"vision_backbone.featurizer.blocks.{i}.{n}")
+    for k in OW["proj"]:
+        if k.endswith("weight"):
+            reg(OW["proj"][k], "projector." + k[:-7])
+    for i in range(cfg.llm.n_layers):
+        for n in ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj"):
+            reg(llm[f"layers.{i}.{n}.weight"], f"language_model.model.layers.{i}.{n}")
+    cb = {k: v.cpu() for k, v in batch.items()}
+    cb["pixel_values"], cb["proprio"] = cb["pixel_values"].float(), cb["proprio"].to(BF).float()
+    try:
+        out = O.vla_forward(cb, OW, oracle_cfg(cfg), emu=emu, noise=None)
+    finally:
+        O.LORA.clear()
+    return out, OW, sd
+
+
+def test_lora_forward_and_gradients_match_oracle_autograd():
+    from vla_adapter_amd import engine as E, synthetic as S, ops
+    from vla_adapter_amd.lora_finetune import LoRAFinetune
+    cfg = E.tiny_config()
+    W = S.make_weights(cfg, DEV, seed=3, std=0.05)
+    batch = S.make_batch(cfg, 3, DEV, seed=4, P=20, ragged=True)
+    eng = E.VLAEngine(cfg, W, DEV)
+    lo = LoRAFinetune(eng, rank=8, seed=1)
+    # peft starts with B = 0 (the wrapped model equals the base model): give B a value so that both branches carry signal
+    g = torch.Generator(device=DEV).manual_seed(2)
+    for l in lo.L.values():
+        for p, _ in l.projs:
+            Bv = lo.P.view(f"{l.name}.{p}.lora_B")
+            Bv[:, :l.r] = (torch.randn(Bv.shape[0], l.r, generator=g, device=DEV) * 0.05).to(BF)
+    # padded ViT MLP rows stay zero (no such rows in the reference)
+    v = lo.vit
+    if v.mlp_pad != v.cfg.mlp:
+        for i in range(len(v.blocks)):
+            lo.P.view(f"{lo.L[f'vit.{i}.fc1'].name}.fc1.lora_B")[v.cfg.mlp:] = 0
+    lo.refresh()
+    pred = lo.forward(batch, None)
+    n = cfg.llm.n_layers
+    hs_native = {i: eng.llm.HS[i].clone() for i in (0, n)}
+    _, dpred = ops.l1_loss(pred, batch["actions"].to(BF), True)
+    lo.backward(pred, batch["actions"])
+    torch.cuda.synchronize()
+    pred = pred.clone()
+    base_pred = eng.forward(batch, None)
+    assert (pred.float() - base_pred.float()).abs().max().item() > 1e-3, "the LoRA branches must change the output"
+    res = {}
+    for emu in (True, False):
+        out, OW, sd = _oracle_lora(cfg, W, batch, lo, emu)
+        out["pred"].backward(dpred.float().cpu())
+        res[emu] = (out, OW, sd)
+    budget(pred, res[True][0]["pred"], res[False][0]["pred"], "LoRA forward: actions")
+    for i in (0, n):
+        budget(hs_native[i], res[True][0]["hidden_states"][i], res[False][0]["hidden_states"][i], f"LoRA forward: hidden_states[{i}]")
+    got = {}
+    gsd = {}
+    for l in lo.L.values():
+        for p, _ in l.projs:
+            A, Bm = lo.P.g(f"{l.name}.{p}.lora_A")[:l.r], lo.P.g(f"{l.name}.{p}.lora_B")[:, :l.r]
+            if p == "fc1":
+                Bm = Bm[:v.cfg.mlp]
+            if p == "fc2":
+                A = A[:, :v.cfg.mlp]
+            gsd[f"{l.name}.{p}.lora_A.weight"], gsd[f"{l.name}.{p}.lora_B.weight"] = A, Bm
+    famA = [(k, t, res[True][2][k].grad, res[False][2][k].grad) for k, t in gsd.items() if "lora_A" in k]
+    famB = [(k, t, res[True][2][k].grad, res[False][2][k].grad) for k, t in gsd.items() if "lora_B" in k]
+    assert len(famA) == 4 * len(v.blocks) + 2 + 7 * n
+    gmax = max(t[3].norm().item() for t in famA + famB)
+    budget_family(famA, "LoRA A gradients (ViT / projector / LLM)", absfloor=1e-3 * gmax)
+    budget_family(famB, "LoRA B gradients (ViT / projector / LLM)", absfloor=1e-3 * gmax)
+    budget(eng.head.P.g("action_queries"), res[True][1]["action_queries"].grad, res[False][1]["action_queries"].grad, "LoRA: action_queries", factor=1.5)
+    # rank padding and block structure stay clean: padded rows / columns and off-block entries carry no gradient
+    l = lo.L["llm.0.gu"]
+    assert bool((lo.P.g(f"{l.name}.gate_proj.lora_A")[l.r:] == 0).all()) and bool((lo.P.g(f"{l.name}.gate_proj.lora_B")[:, l.r:] == 0).all())
+
+
+def test_lora_training_moves_only_the_adapters_and_merges():
+    from vla_adapter_amd import engine as E, synthetic as S
+    from vla_adapter_amd.lora_finetune import LoRAFinetune
+    cfg = E.tiny_config()
+    W = S.make_weights(cfg, DEV, seed=5, std=0.05)
+    batch = S.make_batch(cfg, 4, DEV, seed=6, P=24, ragged=True)
+    eng = E.VLAEngine(cfg, W, DEV)
+    lo = LoRAFinetune(eng, rank=8, seed=1)
+    w0 = eng.llm.layers[0]["wqkv"].clone()
+    pred0 = lo.forward(batch, None).clone()
+    base = eng.forward(batch, None)
+    assert torch.equal(pred0, base), "B = 0 at initialisation: the wrapped model IS the base model (peft init_lora_weights)"
+    losses = [lo.train_step(batch, 1e-3)[0].item() for _ in range(12)]
+    torch.cuda.synchronize()
+    assert losses[-1] < 0.8 * losses[0], losses
+    assert torch.equal(w0, eng.llm.layers[0]["wqkv"]), "base weights are frozen"
+    sd = lo.lora_state_dict()
+    assert any(v.abs().max().item() > 0 for k, v in sd.items() if "lora_B" in k), "the B matrices must have left zero"
+    k = "base_model.model.language_model.model.layers.0.self_attn.q_proj.lora_A.weight"
+    assert k in sd and tuple(sd[k].shape) == (8, cfg.llm.d)
+    # merging the adapter into the base (finetune.py:579-601) reproduces the adapted forward
+    merged = lo.merged_weights()
+    pred_l = lo.forward(batch, None).clone()
+    for key, wm in merged.items():
+        holder, wk = lo._base(key)
+        holder[wk].copy_(wm)
+    pred_m = eng.forward(batch, None)
+    from test_engine_gpu import rel
+    assert rel(pred_m, pred_l) < 2e-2, rel(pred_m, pred_l)

@@ -875,3 +875,35 @@ extern "C" int vla_token_ce(void* stream, const void* logits, long long ld_logit
   VLA_CHECK_LAUNCH("token_ce");
   return VLA_OK;
 }
+
+
+// ---------------------------------------------------------------- SwiGLU forward on interleaved pre-activations (LoRA path)
+// h[m, 16t + c] = bf16(bf16(silu(g)) * u), g = GU[m, 32t + c], u = GU[m, 32t + 16 + c]: the product the fused GEMM epilogue forms;
+// stand-alone because LoRA adds its low-rank deltas to the gate / up pre-activations BEFORE the activation (peft wraps each
+// nn.Linear: vla-scripts/finetune.py:832-844).  8 h columns per thread.
+__global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ h, long long nch, int I) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nch; i += (long long)gridDim.x * blockDim.x) {
+    const long long e = i * 8;                       // first h element of this chunk
+    const long long m = e / I;
+    const int c = (int)(e - m * I);                  // column in [0, I), multiple of 8
+    const bf16_t* row = gu + m * 2 * I + (c >> 4) * 32 + (c & 15);
+    const uint4 gv = *reinterpret_cast<const uint4*>(row), uv = *reinterpret_cast<const uint4*>(row + 16);
+    const unsigned ga[4] = {gv.x, gv.y, gv.z, gv.w}, ua[4] = {uv.x, uv.y, uv.z, uv.w};
+    unsigned o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float g0 = bf2f((bf16_t)(ga[k] & 0xffff)), g1 = bf2f((bf16_t)(ga[k] >> 16));
+      const float u0 = bf2f((bf16_t)(ua[k] & 0xffff)), u1 = bf2f((bf16_t)(ua[k] >> 16));
+      o[k] = pack2(rbf(g0 * __builtin_amdgcn_rcpf(1.0f + __expf(-g0))) * u0, rbf(g1 * __builtin_amdgcn_rcpf(1.0f + __expf(-g1))) * u1);
+    }
+    *reinterpret_cast<uint4*>(h + e) = uint4{o[0], o[1], o[2], o[3]};
+  }
+}
+
+extern "C" int vla_swiglu_fwd(void* stream, const void* gu, void* h, int M, int I) {
+  VLA_REQUIRE(gu && h && M > 0 && I > 0 && I % 16 == 0, "swiglu_fwd: I%16");
+  const long long nch = (long long)M * I / 8;
+  hipLaunchKernelGGL(swiglu_fwd_kernel, GRID1D(nch, 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gu, (bf16_t*)h, nch, I);
+  VLA_CHECK_LAUNCH("swiglu_fwd");
+  return VLA_OK;
+}

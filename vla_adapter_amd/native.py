@@ -84,6 +84,7 @@ _PROTOS = {
     "vla_gelu_bwd": ([_P, _P, _P, _P, _L], _I),
     "vla_relu_bwd": ([_P, _P, _P, _P, _L], _I),
     "vla_swiglu_bwd": ([_P, _P, _P, _P, _I, _I], _I),
+    "vla_swiglu_fwd": ([_P, _P, _P, _I, _I], _I),
     "vla_colsum_bf16": ([_P, _P, _P, _I, _I, _I, _I, _L, _L], _I),
     "vla_cast_f32_bf16": ([_P, _P, _P, _L], _I),
     "vla_cast_bf16_f32": ([_P, _P, _P, _L], _I),

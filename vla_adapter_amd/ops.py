@@ -396,6 +396,14 @@ def swiglu_bwd(dh, gu, out=None):
     return dgu
 
 
+def swiglu_fwd(gu, out=None):
+    M, I2 = gu.shape
+    assert gu.is_contiguous() and I2 % 32 == 0
+    h = torch.empty(M, I2 // 2, device=gu.device, dtype=BF16) if out is None else out
+    N.check(_lib().vla_swiglu_fwd(_st(), _p(gu), _p(h), M, I2 // 2), "swiglu_fwd")
+    return h
+
+
 def colsum_(x, out_f32):
     """x [rows, cols] or [batch, rows, cols] (bf16) -> out_f32 [cols] / [batch, cols] += column sums."""
     if x.dim() == 3:
