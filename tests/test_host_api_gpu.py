@@ -65,7 +65,7 @@ def test_finetune_entry_point_tiny(tmp_path):
     of the captured graphs), gradient steps 0..max_steps inclusive, checkpoints on save_freq multiples plus a final one."""
     from vla_adapter_amd import finetune as F
     cfg = F.parse_args(["--tiny", "true", "--batch_size", "4", "--max_steps", "16", "--learning_rate", "2e-3", "--wandb_log_freq", "5",
-                        "--save_freq", "10", "--run_root_dir", str(tmp_path), "--phase", "Inference", "--use_proprio", "True"])
+                        "--save_freq", "10", "--run_root_dir", str(tmp_path), "--phase", "Inference", "--use_proprio", "True", "--use_fz", "True"])
     out = F.finetune(cfg, batches=_tiny_batches(2))
     log = out["log"]
     assert out["steps"] == 17 and out["final_step"] == 16 and [l["step"] for l in log] == [0, 5, 10, 15, 16]
@@ -86,7 +86,7 @@ def test_finetune_graphed_loop_equals_eager_loop_on_a_batch_sequence(tmp_path):
     from vla_adapter_amd import finetune as F
     bs = _tiny_batches(3, seed0=320)
     base = ["--tiny", "true", "--batch_size", "4", "--max_steps", "5", "--learning_rate", "1e-3", "--wandb_log_freq", "1", "--save_freq", "1000",
-            "--phase", "Inference", "--use_proprio", "True"]
+            "--phase", "Inference", "--use_proprio", "True", "--use_fz", "True"]
     a = F.finetune(F.parse_args(base + ["--run_root_dir", str(tmp_path / "a"), "--use_graph", "true"]), batches=bs)
     b = F.finetune(F.parse_args(base + ["--run_root_dir", str(tmp_path / "b"), "--use_graph", "false"]), batches=bs)
     la, lb = [l["loss_value"] for l in a["log"]], [l["loss_value"] for l in b["log"]]
@@ -99,7 +99,7 @@ def test_finetune_resume_restores_every_trainable_tensor_and_the_step_counter(tm
     """resume used to restart the action queries from random init and the step counter from 0."""
     from vla_adapter_amd import finetune as F, engine as E, synthetic as S, checkpoints as CK
     bs = _tiny_batches(2, seed0=340)
-    base = ["--tiny", "true", "--batch_size", "4", "--learning_rate", "2e-3", "--wandb_log_freq", "1", "--phase", "Inference", "--use_proprio", "True",
+    base = ["--tiny", "true", "--batch_size", "4", "--learning_rate", "2e-3", "--wandb_log_freq", "1", "--phase", "Inference", "--use_proprio", "True", "--use_fz", "True",
             "--run_root_dir", str(tmp_path), "--run_id_override", "r"]
     F.finetune(F.parse_args(base + ["--max_steps", "4", "--save_freq", "4"]), batches=bs)
     ck = str(tmp_path / "r--4_chkpt")
@@ -259,3 +259,28 @@ def test_prismatic_vlm_forward_token_ce_loss_and_logits():
     le, lt = res[True][1].item(), res[False][1].item()
     assert abs(out.loss.item() - lt) <= 1.25 * abs(le - lt) + 2e-3 * abs(lt), (out.loss.item(), le, lt)
     assert out.logits.shape == (3, batch["input_ids"].shape[1] + Np, cfg.llm.vocab)
+
+
+@pytest.mark.parametrize("mode", ["lora", "full"])
+def test_finetune_entry_point_lora_and_full_modes(tmp_path, mode):
+    """--use_lora True (peft-style adapters on every Linear of the VLM, finetune.py:832-844) and the reference's default with
+    use_lora False (every VLM parameter trains, :846-849): loss falls, the checkpoints the reference writes exist with its key
+    names (lora_adapter/ for LoRA, optionally the merged VLM; the whole VLM for full fine-tune)."""
+    from vla_adapter_amd import finetune as F
+    from safetensors.torch import load_file
+    import glob
+    extra = ["--use_lora", "True", "--lora_rank", "8", "--merge_lora_during_training", "True"] if mode == "lora" else []
+    cfg = F.parse_args(["--tiny", "true", "--batch_size", "4", "--max_steps", "10", "--learning_rate", "1e-3" if mode == "lora" else "3e-4",
+                        "--wandb_log_freq", "5", "--save_freq", "10", "--run_root_dir", str(tmp_path), "--phase", "Inference", "--use_proprio", "True"] + extra)
+    out = F.finetune(cfg, batches=_tiny_batches(2, seed0=360))
+    assert out["mode"] == mode and out["log"][-1]["loss_value"] < out["log"][0]["loss_value"], out["log"]
+    d = glob.glob(os.path.join(str(tmp_path), "*--10_chkpt"))[0]
+    names = set(os.listdir(d))
+    assert {"action_head--10_checkpoint.pt", "proprio_projector--10_checkpoint.pt"} <= names
+    vlm = load_file(os.path.join(d, "model.safetensors"))
+    assert "language_model.model.layers.0.self_attn.q_proj.weight" in vlm and "vision_backbone.featurizer.blocks.0.mlp.fc1.weight" in vlm
+    assert "projector.fc1.weight" in vlm and "action_queries.weight" in vlm
+    if mode == "lora":
+        ad = load_file(os.path.join(d, "lora_adapter", "adapter_model.safetensors"))
+        k = "base_model.model.language_model.model.layers.1.mlp.gate_proj.lora_B.weight"
+        assert k in ad and ad[k].shape[1] == 8 and ad[k].abs().max() > 0

@@ -106,3 +106,44 @@ def load_run_dir(run_dir: str, step, device="cpu", with_action_queries: bool = F
         return head, proprio
     aq = ld("action_queries")["weight"] if os.path.exists(path("action_queries")) else None
     return head, proprio, aq
+
+
+def engine_vlm_state_dict(eng) -> Dict[str, torch.Tensor]:
+    """The VLM weights the engine holds (fused / padded layouts) under the reference's HF key names: q|k|v split, gate / up
+    de-interleaved, the ViT MLP's zero padding and the patch embedding's K padding removed.  Used for full-fine-tune and
+    LoRA-merged checkpoints (vla-scripts/finetune.py:556-601 saves the whole VLM with save_pretrained).  The last ViT block
+    (never computed here, dead in the reference too) is not part of the engine and therefore absent."""
+    cfg, out = eng.cfg, {}
+    c = cfg.llm
+    H, KV, dh, I, D = c.heads, c.kv_heads, c.dh, c.inter, c.d
+    cl = lambda t: t.detach().clone()
+    for i, L in enumerate(eng.llm.layers):
+        p = f"language_model.model.layers.{i}."
+        w, b = L["wqkv"], L["bqkv"]
+        for n, lo, hi in (("q_proj", 0, H * dh), ("k_proj", H * dh, (H + KV) * dh), ("v_proj", (H + KV) * dh, (H + 2 * KV) * dh)):
+            out[p + f"self_attn.{n}.weight"], out[p + f"self_attn.{n}.bias"] = cl(w[lo:hi]), cl(b[lo:hi])
+        out[p + "self_attn.o_proj.weight"] = cl(L["wo"])
+        gu = L["wgu"].view(I // 16, 2, 16, D)
+        out[p + "mlp.gate_proj.weight"], out[p + "mlp.up_proj.weight"] = gu[:, 0].reshape(I, D).clone(), gu[:, 1].reshape(I, D).clone()
+        out[p + "mlp.down_proj.weight"] = cl(L["wd"])
+        out[p + "input_layernorm.weight"], out[p + "post_attention_layernorm.weight"] = cl(L["n1"]), cl(L["n2"])
+    out["language_model.model.norm.weight"], out["language_model.model.embed_tokens.weight"] = cl(eng.llm.norm), cl(eng.llm.embed)
+    names = ["vision_backbone.featurizer."] + (["vision_backbone.fused_featurizer."] if cfg.fused else [])
+    for pre, v in zip(names, eng.vits):
+        vc = v.cfg
+        if vc.layerscale:
+            raise NotImplementedError("LayerScale is folded into the projections at load time: the original tensors cannot be recovered")
+        P_ = vc.patch
+        out[pre + "patch_embed.proj.weight"] = v.wpe[:, :3 * P_ * P_].reshape(vc.d, 3, P_, P_).clone()
+        out[pre + "patch_embed.proj.bias"], out[pre + "pos_embed"] = cl(v.bpe), v.pos.reshape(1, -1, vc.d).clone()
+        for i, b in enumerate(v.blocks):
+            q = f"{pre}blocks.{i}."
+            out[q + "norm1.weight"], out[q + "norm1.bias"], out[q + "norm2.weight"], out[q + "norm2.bias"] = cl(b["n1w"]), cl(b["n1b"]), cl(b["n2w"]), cl(b["n2b"])
+            out[q + "attn.qkv.weight"], out[q + "attn.qkv.bias"] = cl(b["wqkv"]), cl(b["bqkv"])
+            out[q + "attn.proj.weight"], out[q + "attn.proj.bias"] = cl(b["wproj"]), cl(b["bproj"])
+            out[q + "mlp.fc1.weight"], out[q + "mlp.fc1.bias"] = b["w1"][:vc.mlp].clone(), b["b1"][:vc.mlp].clone()
+            out[q + "mlp.fc2.weight"], out[q + "mlp.fc2.bias"] = b["w2"][:, :vc.mlp].clone(), cl(b["b2"])
+    for k, t in eng.proj.items():
+        out["projector." + k] = cl(t)
+    out["action_queries.weight"] = cl(eng.head.P.view("action_queries"))
+    return out

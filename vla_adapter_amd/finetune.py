@@ -109,13 +109,22 @@ def parse_args(argv=None) -> FinetuneConfig:
 # user passes explicitly cannot be honoured and is refused instead of ignored.
 OUT_OF_PATH_FLAGS = ("data_root_dir", "shuffle_buffer_size", "image_aug", "wandb_entity", "wandb_project", "run_id_note",
                      "config_file_path", "phase1_path", "num_diffusion_steps", "diffusion_sample_freq", "val_freq", "val_time_limit",
-                     "merge_lora_during_training", "lora_dropout", "lora_rank", "use_minivlm", "use_fz")
+                     "use_minivlm")
+
+
+def train_mode(cfg: FinetuneConfig) -> str:
+    """Which parameters train.  Reference: use_lora -> peft adapters on every Linear of the VLM + action_queries + head
+    (finetune.py:832-844); otherwise EVERY VLM parameter keeps requires_grad (:846-849) - ``use_fz`` only renames the run there
+    (:183-184), freezing the VLM is its evident intent and what BASELINE configs[1] ("adapter-only") means: implemented."""
+    return "lora" if cfg.use_lora else ("adapter" if cfg.use_fz else "full")
 
 
 def check_supported(cfg: FinetuneConfig, explicit=()) -> None:
     """Raise for every reference option this path does not implement (nothing is parsed and silently dropped)."""
-    if cfg.use_lora:
-        raise NotImplementedError("--use_lora: LoRA (finetune.py:832-844) is not accelerated yet")
+    if cfg.use_lora and cfg.lora_dropout != 0.0:
+        raise NotImplementedError("--lora_dropout > 0: the low-rank branch is built without dropout (every shipped script uses 0.0)")
+    if train_mode(cfg) != "adapter" and cfg.grad_accumulation_steps != 1:
+        raise NotImplementedError("grad_accumulation_steps > 1 is built for the adapter-only mode (--use_fz True) only")
     if cfg.use_film or cfg.use_diffusion or not cfg.use_l1_regression:
         raise NotImplementedError("native path = L1-regression action head; --use_film / --use_diffusion are not built")
     if cfg.use_val_set:
@@ -167,7 +176,8 @@ def loop_plan(cfg: FinetuneConfig):
         batch_idx += 1
 
 
-def save_training_checkpoint(cfg: FinetuneConfig, run_dir: Path, step: int, eng, dataset_statistics: Optional[dict] = None) -> Path:
+def save_training_checkpoint(cfg: FinetuneConfig, run_dir: Path, step: int, eng, dataset_statistics: Optional[dict] = None,
+                             trainer=None) -> Path:
     """File names / key layout of finetune.py:527-572 (rank 0).  The reference keeps the action queries inside the LoRA /
     VLM checkpoint; the adapter-only path has neither, so they go to ``action_queries--{suffix}`` (native addition, read back
     by checkpoints.load_run_dir)."""
@@ -177,6 +187,29 @@ def save_training_checkpoint(cfg: FinetuneConfig, run_dir: Path, step: int, eng,
     torch.save({k: v.cpu() for k, v in eng.head.head_state_dict().items()}, d / f"action_head--{suffix}")
     torch.save({k: v.clone().cpu() for k, v in eng.head.proprio_views().items()}, d / f"proprio_projector--{suffix}")
     torch.save({"weight": eng.head.P.view("action_queries").clone().cpu()}, d / f"action_queries--{suffix}")
+    from . import checkpoints as CK
+    from safetensors.torch import save_file
+    if cfg.use_lora and trainer is not None:    # peft's adapter directory (finetune.py:537-541: vla.module.save_pretrained(adapter_dir))
+        ad = d / "lora_adapter"
+        os.makedirs(ad, exist_ok=True)
+        save_file({k: v.contiguous().cpu() for k, v in trainer.lora_state_dict().items()}, str(ad / "adapter_model.safetensors"))
+        json.dump(dict(peft_type="LORA", r=cfg.lora_rank, lora_alpha=2 * cfg.lora_rank, lora_dropout=cfg.lora_dropout, target_modules="all-linear",
+                       init_lora_weights="gaussian"), open(ad / "adapter_config.json", "w"), indent=2)
+        if cfg.merge_lora_during_training:      # finetune.py:579-601: merge the adapter into a bf16 base and save the whole VLM
+            merged = trainer.merged_weights()
+            saved = {}
+            for key, wm in merged.items():
+                holder, wk = trainer._base(key)
+                saved[key] = holder[wk].clone()
+                holder[wk].copy_(wm)
+            try:
+                save_file({k: v.contiguous().cpu() for k, v in CK.engine_vlm_state_dict(eng).items()}, str(d / "model.safetensors"))
+            finally:
+                for key, w0 in saved.items():
+                    holder, wk = trainer._base(key)
+                    holder[wk].copy_(w0)
+    elif trainer is not None:                   # full fine-tune: the whole VLM (finetune.py:556-566 save_pretrained)
+        save_file({k: v.contiguous().cpu() for k, v in CK.engine_vlm_state_dict(eng).items()}, str(d / "model.safetensors"))
     if dataset_statistics is not None:          # save_dataset_statistics (finetune.py:531): q01/q99 etc. used to un-normalise actions
         json.dump(dataset_statistics, open(d / "dataset_statistics.json", "w"), indent=2)
     return d
@@ -248,6 +281,15 @@ def finetune(cfg: FinetuneConfig, batches=None, explicit=()) -> dict:
     eng = E.VLAEngine(mcfg, W, dev)
     if world > 1:
         eng.reducer = ddp.FlatGradReducer()
+    mode = train_mode(cfg)
+    trainer = None
+    if mode == "lora":
+        from .lora_finetune import LoRAFinetune
+        trainer = LoRAFinetune(eng, rank=cfg.lora_rank, seed=cfg.seed)
+    elif mode == "full":
+        from .full_finetune import FullFinetune
+        trainer = FullFinetune(eng)
+    use_graph = cfg.use_graph and trainer is None         # LoRA / full fine-tune: eager launches (GEMM-bound steps)
     eng.set_grad_accumulation(cfg.grad_accumulation_steps)
     stream = batch_stream(cfg, mcfg, dev, rank, batches)
     pad_id = min(S.PAD_ID, mcfg.llm.vocab - 1)
@@ -260,7 +302,7 @@ def finetune(cfg: FinetuneConfig, batches=None, explicit=()) -> dict:
     run_dir = Path(cfg.run_root_dir) / (cfg.run_id_override or f"native+{cfg.dataset_name}+b{cfg.batch_size * world}+lr-{cfg.learning_rate}")
     stats = json.load(open(cfg.dataset_statistics_file)) if cfg.dataset_statistics_file else None
     static = None
-    if cfg.use_graph:
+    if use_graph:
         static = {k: v.clone() for k, v in cur.items()}
         eng.capture(static, noise if training else None, conservative_rows=cfg.conservative_rows)
     log, t0, saved_at, steps_done = [], time.time(), None, 0
@@ -269,7 +311,9 @@ def finetune(cfg: FinetuneConfig, batches=None, explicit=()) -> dict:
         if training:   # fresh N(0, 0.02^2) perturbation every call (action_heads.py:14-17, 69-72)
             noise.copy_((torch.randn(noise.shape, device=dev, generator=gen) * 0.02).to(torch.bfloat16))
         lr = lr_at(g, cfg)
-        if cfg.use_graph:
+        if trainer is not None:
+            loss3 = trainer.train_step(cur, lr, noise if training else None)
+        elif use_graph:
             for k in static:
                 if k != "pixel_values" or batch_idx == 0:
                     static[k].copy_(cur[k])
@@ -289,7 +333,7 @@ def finetune(cfg: FinetuneConfig, batches=None, explicit=()) -> dict:
         if save:
             eng.flush()                      # the graphed step leaves its parameter update pending (engine.capture)
             if rank == 0:
-                save_training_checkpoint(cfg, run_dir, log_step, eng, stats)
+                save_training_checkpoint(cfg, run_dir, log_step, eng, stats, trainer)
             saved_at = log_step
             if world > 1:
                 torch.distributed.barrier()  # finetune.py:544, 575
@@ -298,5 +342,5 @@ def finetune(cfg: FinetuneConfig, batches=None, explicit=()) -> dict:
     eng.flush()
     torch.cuda.synchronize()
     if saved_at != final_step and rank == 0:     # never discard a run: the reference only saves on save_freq multiples
-        save_training_checkpoint(cfg, run_dir, final_step, eng, stats)
-    return dict(log=log, seconds=time.time() - t0, steps=steps_done, world=world, final_step=final_step, run_dir=str(run_dir))
+        save_training_checkpoint(cfg, run_dir, final_step, eng, stats, trainer)
+    return dict(log=log, seconds=time.time() - t0, steps=steps_done, world=world, final_step=final_step, run_dir=str(run_dir), mode=mode)
