@@ -121,6 +121,8 @@ def train_mode(cfg: FinetuneConfig) -> str:
 
 def check_supported(cfg: FinetuneConfig, explicit=()) -> None:
     """Raise for every reference option this path does not implement (nothing is parsed and silently dropped)."""
+    if cfg.grad_accumulation_steps < 1:
+        raise ValueError("grad_accumulation_steps must be >= 1")
     if cfg.use_lora and cfg.lora_dropout != 0.0:
         raise NotImplementedError("--lora_dropout > 0: the low-rank branch is built without dropout (every shipped script uses 0.0)")
     if train_mode(cfg) != "adapter" and cfg.grad_accumulation_steps != 1:
