@@ -204,6 +204,13 @@ int vla_cast_bf16_f32(void* stream, const void* x, float* y, long long n);
 int vla_embed_grad(void* stream, const void* dx, const long long* ids, const int* qidx, void* grad_table, int B, int L,
                    int Np, int D, int vocab);
 
+/* One pass of Pillow's 8-bit resampler along the middle axis of a uint8 [outer, in_len, inner] array (horizontal: outer = B*H,
+ * inner = 3; vertical: outer = B, inner = out_w*3): out = clip8((2^21 + sum_k in[lo+k] * coef[k]) >> 22).  bounds int32
+ * [out_len, 2] = (lo, count), coefs int32 [out_len, ksize] - Pillow's bicubic taps in 22-bit fixed point.  Two calls = the resize
+ * of PrismaticImageProcessor.apply_transform (processing_prismatic.py:128-145: TVF.resize(img, (224, 224), BICUBIC, antialias)). */
+int vla_resample_u8(void* stream, const void* src, void* dst, long long outer, int in_len, int out_len, int inner,
+                    const int* bounds, const int* coefs, int ksize);
+
 /* Token cross-entropy of the native VLM path (prismatic/models/vlms/prismatic.py:469-481 -> HF shifted causal-LM loss):
  * logits bf16 [rows, V] (row stride ld_logits), shifted_labels int64 [rows] (the target of each row, -100 = ignore);
  * out[0] += sum over valid rows of (logsumexp(float(logits[row])) - logits[row, label]), out[1] += number of valid rows

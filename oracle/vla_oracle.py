@@ -408,6 +408,82 @@ def l1_metrics(pred, target):
 
 
 # ----------------------------------------------------------------------------------------------
+# 8f-2  image resize of PrismaticImageProcessor.apply_transform (prismatic/extern/hf/processing_prismatic.py:128-145):
+#       TVF.resize(PIL image, (224, 224), BICUBIC, antialias=True) == PIL.Image.resize(..., resample=BICUBIC).
+#       The arithmetic lives in Pillow (third-party, pinned by the reference at pillow via torchvision; 12.2.0 installed here):
+#       restated below from its published algorithm (src/libImaging/Resample.c: precompute_coeffs, normalize_coeffs_8bpc,
+#       ImagingResampleHorizontal/Vertical_8bpc) and pinned BIT-EXACTLY against PIL.Image.resize in tests/test_oracle_golden.py.
+# ----------------------------------------------------------------------------------------------
+def _bicubic_filter(x: float) -> float:
+    a = -0.5
+    x = abs(x)
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def pil_bicubic_coeffs(in_size: int, out_size: int):
+    """-> (bounds int32 [out, 2] = (first source index, count), coefs int32 [out, ksize]): Pillow's 8-bit fixed-point bicubic
+    taps (22 fractional bits) with antialiasing (filter support scaled by the downscale factor)."""
+    import numpy as np
+    PREC = 32 - 8 - 2
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    coefs = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = [_bicubic_filter((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for v in w:
+            ww += v
+        if ww != 0.0:
+            w = [v / ww for v in w]
+        bounds[xx] = (xmin, xmax)
+        for x, v in enumerate(w):
+            coefs[xx, x] = int(-0.5 + v * (1 << PREC)) if v < 0 else int(0.5 + v * (1 << PREC))
+    return bounds, coefs
+
+
+def resize_bicubic_u8(img, out_h: int, out_w: int):
+    """img uint8 [H, W, C] (numpy) -> uint8 [out_h, out_w, C]: horizontal pass into an 8-bit intermediate, then vertical pass."""
+    import numpy as np
+    PREC = 32 - 8 - 2
+    H, W, Cc = img.shape
+
+    def one_pass(src, bounds, coefs, axis):
+        n_out = bounds.shape[0]
+        shape = list(src.shape)
+        shape[axis] = n_out
+        out = np.empty(shape, np.uint8)
+        s64 = src.astype(np.int64)
+        for o in range(n_out):
+            lo, cnt = int(bounds[o, 0]), int(bounds[o, 1])
+            k = coefs[o, :cnt].astype(np.int64)
+            seg = s64[:, lo:lo + cnt] if axis == 1 else s64[lo:lo + cnt]
+            acc = (1 << (PREC - 1)) + (np.tensordot(seg, k, axes=([1], [0])) if axis == 1 else np.tensordot(k, seg, axes=([0], [0])))
+            val = np.clip(acc >> PREC, 0, 255).astype(np.uint8)
+            if axis == 1:
+                out[:, o] = val
+            else:
+                out[o] = val
+        return out
+    cur = img
+    if W != out_w:
+        cur = one_pass(cur, *pil_bicubic_coeffs(W, out_w), axis=1)
+    if H != out_h:
+        cur = one_pass(cur, *pil_bicubic_coeffs(H, out_h), axis=0)
+    return cur
+
+
+# ----------------------------------------------------------------------------------------------
 # 8f-4  token cross-entropy of the native VLM path (prismatic/models/vlms/prismatic.py:411-422, 469-481 -> HF causal-LM loss)
 # ----------------------------------------------------------------------------------------------
 def token_ce(hidden_last, lm_head, labels, num_patches: int, emu=False):

@@ -71,3 +71,27 @@ def test_build_batch_follows_transform_and_collator():
     # and the batch runs through the native step
     cfg = E.config2()
     assert batch["pixel_values"].dtype == torch.bfloat16 and batch["input_ids"].max().item() < cfg.llm.vocab
+
+
+@pytest.mark.parametrize("H,W", [(256, 256), (300, 200), (128, 160), (480, 640)])
+def test_resize_is_bit_exact_against_pillow(H, W):
+    """PrismaticImageProcessor.apply_transform (processing_prismatic.py:128-145): TVF.resize(PIL image, (224, 224), BICUBIC,
+    antialias=True) = PIL.Image.resize.  The two device passes reproduce Pillow's uint8 output bit for bit, and the pixel tensor
+    built from the resized frames equals ToTensor + Normalize of Pillow's result."""
+    import numpy as np
+    from PIL import Image
+    from vla_adapter_amd.input_stage import GPUInputStage, pil_bicubic_coeffs
+    from oracle import vla_oracle as O
+    rng = np.random.default_rng(H + W)
+    imgs = rng.integers(0, 256, size=(3, H, W, 3), dtype=np.uint8)
+    imgs[0, : H // 2] = np.linspace(0, 255, W, dtype=np.uint8)[None, :, None]
+    st = GPUInputStage("cuda", backbones=("siglip",))
+    got = st.resize(torch.from_numpy(imgs)).cpu().numpy()
+    ref = np.stack([np.asarray(Image.fromarray(im).resize((224, 224), resample=Image.BICUBIC)) for im in imgs])
+    assert got.shape == ref.shape and np.array_equal(got, ref), f"max |diff| {np.abs(got.astype(int) - ref.astype(int)).max()}"
+    b1, c1 = pil_bicubic_coeffs(W, 224)
+    b2, c2 = O.pil_bicubic_coeffs(W, 224)
+    assert np.array_equal(b1, b2) and np.array_equal(c1, c2)              # product taps == oracle taps (pinned against Pillow on CPU)
+    px = st.pixels([torch.from_numpy(imgs)]).float().cpu()
+    want = ((torch.from_numpy(ref).permute(0, 3, 1, 2).float() / 255.0) - 0.5) / 0.5
+    assert (px - want.to(torch.bfloat16).float()).abs().max().item() == 0.0

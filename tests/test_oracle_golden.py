@@ -237,3 +237,19 @@ def test_oracle_modes_against_reference_bf16_and_fp32_runs(case):
         budget = max(1.5 * (z["dx_bf16"] - z["dx_fp32"]).norm().item(), 0.15 * z["dx_fp32"].norm().item())   # 0.15: ReLU-flip outliers, see above
         assert e <= budget, (e, budget)
         assert rel_l2(mlhs32.grad[:, GG.DX_LAYERS], z["dx_fp32"]) < 1e-4
+
+
+@pytest.mark.parametrize("H,W,oh,ow", [(256, 256, 224, 224), (300, 200, 224, 224), (128, 128, 224, 224), (224, 224, 224, 224), (480, 640, 224, 224),
+                                        (17, 23, 8, 9)])
+def test_resize_restatement_is_bit_exact_against_pillow(H, W, oh, ow):
+    """processing_prismatic.py:128-145 resizes with TVF.resize(PIL image, BICUBIC, antialias=True) = PIL.Image.resize: the
+    arithmetic is Pillow's.  The oracle restates its fixed-point two-pass resampler; pinned bit for bit against the installed
+    Pillow (down- and up-scaling, non-square, identity)."""
+    from PIL import Image
+    rng = np.random.default_rng(H * 1000 + W)
+    img = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+    img[: H // 3] = np.linspace(0, 255, W, dtype=np.uint8)[None, :, None]          # smooth ramps + noise + saturated corners
+    img[-2:, -2:] = 255
+    ref = np.asarray(Image.fromarray(img).resize((ow, oh), resample=Image.BICUBIC))
+    got = O.resize_bicubic_u8(img, oh, ow)
+    assert got.shape == ref.shape and np.array_equal(got, ref), f"max |diff| {np.abs(got.astype(int) - ref.astype(int)).max()}"

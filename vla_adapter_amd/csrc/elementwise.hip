@@ -907,3 +907,36 @@ extern "C" int vla_swiglu_fwd(void* stream, const void* gu, void* h, int M, int 
   VLA_CHECK_LAUNCH("swiglu_fwd");
   return VLA_OK;
 }
+
+
+// ---------------------------------------------------------------- image resize
+// One 1-D pass of Pillow's 8-bit resampler (what PrismaticImageProcessor.apply_transform reaches through torchvision's
+// TVF.resize(PIL image, BICUBIC, antialias=True), processing_prismatic.py:137): out[o, p, i] = clip8((2^21 + sum_k
+// in[o, lo_p + k, i] * coef[p, k]) >> 22) on a [outer, len, inner] uint8 layout - horizontal pass: outer = B*H, inner = 3;
+// vertical pass: outer = B, inner = out_w * 3.  Bounds / fixed-point taps come from the host (input_stage.pil_bicubic_coeffs,
+// the same double arithmetic as Pillow's precompute_coeffs).  Bit-exact against PIL.Image.resize (tests).
+__global__ void resample_u8_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, long long outer, int in_len,
+                                   int out_len, int inner, const int* __restrict__ bounds, const int* __restrict__ coefs, int ksize) {
+  const long long total = outer * out_len * inner;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(idx % inner);
+    const int p = (int)((idx / inner) % out_len);
+    const long long o = idx / ((long long)inner * out_len);
+    const int lo = bounds[2 * p], cnt = bounds[2 * p + 1];
+    const unsigned char* s = src + (o * in_len + lo) * inner + i;
+    const int* k = coefs + (long long)p * ksize;
+    int acc = 1 << 21;
+    for (int t = 0; t < cnt; ++t) acc += (int)s[(long long)t * inner] * k[t];
+    acc >>= 22;
+    dst[idx] = (unsigned char)(acc < 0 ? 0 : acc > 255 ? 255 : acc);
+  }
+}
+
+extern "C" int vla_resample_u8(void* stream, const void* src, void* dst, long long outer, int in_len, int out_len, int inner,
+                               const int* bounds, const int* coefs, int ksize) {
+  VLA_REQUIRE(src && dst && bounds && coefs && outer > 0 && in_len > 0 && out_len > 0 && inner > 0 && ksize > 0, "resample_u8: bad args");
+  hipLaunchKernelGGL(resample_u8_kernel, GRID1D(outer * out_len * inner, 256), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)src,
+                     (unsigned char*)dst, outer, in_len, out_len, inner, bounds, coefs, ksize);
+  VLA_CHECK_LAUNCH("resample_u8");
+  return VLA_OK;
+}

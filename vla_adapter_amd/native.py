@@ -90,6 +90,7 @@ _PROTOS = {
     "vla_cast_bf16_f32": ([_P, _P, _P, _L], _I),
     "vla_rmsnorm_dw": ([_P, _P, _P, _P, _P, _I, _I], _I),
     "vla_embed_grad": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I], _I),
+    "vla_resample_u8": ([_P, _P, _P, _L, _I, _I, _I, _P, _P, _I], _I),
     "vla_token_ce": ([_P, _P, _L, _P, _I, _I, _P], _I),
     "vla_copy2d": ([_P, _P, _P, _L, _I, _L, _L, _I, _I, _I, _I, _L], _I),
     "vla_fill_zero": ([_P, _P, _L], _I),
