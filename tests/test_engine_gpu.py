@@ -542,3 +542,58 @@ def test_batch32_config2_matches_batch2_and_trains(monkeypatch):
     e32.flush()
     torch.cuda.synchronize()
     assert all(l == l and abs(l) < 1e2 for l in losses), losses      # finite and bounded (AdamW's first unit-size steps overshoot on random data)
+
+
+def test_full_size_dinov2_backbone_forward_budget():
+    """The DINOv2-L/reg4 branch at FULL size (d 1024, 23 useful blocks, cls + 4 register tokens, LayerScale folded into the
+    projections) next to SigLIP so400m in the reference's default fused two-image layout, batch 1: projected patches within
+    the fp32-truth budget (this branch was parity-tested at plumbing size only)."""
+    from vla_adapter_amd import engine as E, synthetic as S
+    cfg = E.VLACfg(vit=[E.DINOV2_L_REG4, E.SIGLIP_SO400M], n_img=2)
+    W = S.make_weights(cfg, DEV, seed=2)
+    batch = S.make_batch(cfg, 1, DEV, seed=79, P=32)
+    eng = E.VLAEngine(cfg, W, DEV)
+    eng._vision(batch)
+    torch.cuda.synchronize()
+    torch.set_num_threads(min(16, torch.get_num_threads() or 16))
+    px = batch["pixel_values"].float().cpu()
+    res = {}
+    for emu in (True, False):
+        feats = []
+        for im in range(2):
+            ch = px[:, im * 6:(im + 1) * 6]
+            f = [O.vit_forward(ch[:, 3 * j:3 * j + 3], cpu_f32(W["vit"][j]), cfg.vit[j].as_oracle(), emu) for j in range(2)]
+            feats.append(torch.cat(f, dim=2))
+        res[emu] = (torch.cat(feats, dim=1), O.projector(torch.cat(feats, dim=1), cpu_f32(W["proj"]), True, emu))
+    d0 = cfg.vit[0].d
+    budget(eng.feats[:, :, :d0], res[True][0][:, :, :d0], res[False][0][:, :, :d0], "full size: DINOv2-L features (23 blocks, LayerScale folded)")
+    budget(eng.feats[:, :, d0:], res[True][0][:, :, d0:], res[False][0][:, :, d0:], "full size: SigLIP features in the fused layout")
+    budget(eng.patches, res[True][1], res[False][1], "full size: fused 3-layer projector output")
+
+
+def test_full_size_full_finetune_step_config4():
+    """BASELINE configs[3] at full size (SigLIP so400m + Qwen2.5-0.5B, every parameter trainable), batch 2: one eager step and two
+    captured steps - finite loss, every gradient region finite and non-zero, parameters move."""
+    from vla_adapter_amd import engine as E, synthetic as S
+    from vla_adapter_amd.full_finetune import FullFinetune
+    cfg = E.config2()
+    W = S.make_weights(cfg, DEV, seed=0)
+    batch = S.make_batch(cfg, 2, DEV, seed=80, P=32, ragged=True)
+    batch["pixel_values"] = batch["pixel_values"].to(BF)
+    ft = FullFinetune(E.VLAEngine(cfg, W, DEV))
+    p0 = ft.P.data[:4096].clone()
+    l0 = ft.train_step(batch, 1e-4)[0].item()
+    torch.cuda.synchronize()
+    g = ft.P.grad.float()
+    assert l0 == l0 and torch.isfinite(g).all()
+    for name in ("llm.0.wqkv", "llm.23.wd", "vit.0.wqkv", "vit.25.w2", "proj.fc1.weight", "llm.norm", "vit.pos", "llm.11.n2", "vit.12.b1"):
+        off, shape = ft.P.offsets[name]
+        n = 1
+        for d in shape:
+            n *= d
+        assert g[off:off + n].abs().max().item() > 0, name
+    assert not torch.equal(p0, ft.P.data[:4096])
+    ft.capture(batch, None)
+    ls = [ft.train_step_graphed(1e-4)[0].item() for _ in range(2)]
+    torch.cuda.synchronize()
+    assert all(l == l and abs(l) < 1e2 for l in ls), ls
