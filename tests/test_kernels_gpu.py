@@ -172,7 +172,8 @@ def test_transpose(ops):
 
 
 # ------------------------------------------------------------------ norms
-@pytest.mark.parametrize("rows,cols,eps", [(37, 1152, 1e-6), (256, 896, 1e-5), (16, 6272, 1e-5), (5, 64, 1e-5)])
+@pytest.mark.parametrize("rows,cols,eps", [(37, 1152, 1e-6), (256, 896, 1e-5), (16, 6272, 1e-5), (5, 64, 1e-5),
+                                           (9, 10752, 1e-5)])    # 7 x 1536: the 1.5B head's first LayerNorm
 def test_layernorm(ops, rows, cols, eps):
     x, w, b, dy = gen(rows, cols, seed=20), (1 + 0.1 * gen(cols, seed=21).float()).to(BF), gen(cols, seed=22, scale=0.1), gen(rows, cols, seed=23)
     y, stats = ops.layernorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), eps, want_stats=True)
@@ -269,7 +270,8 @@ def test_attention_fwd(ops, B, S, Hq, Hkv, dh, causal, masked):
 
 
 @pytest.mark.parametrize("B,S,Hq,Hkv,dh,causal,masked", [(2, 96, 2, 2, 64, False, False), (2, 77, 4, 2, 64, True, True),
-                                                       (1, 352, 14, 2, 64, True, True), (1, 100, 2, 2, 72, False, False)])
+                                                       (1, 352, 14, 2, 64, True, True), (1, 100, 2, 2, 72, False, False),
+                                                       (1, 352, 12, 2, 128, True, True)])     # Qwen2.5-1.5B head geometry
 def test_attention_bwd(ops, B, S, Hq, Hkv, dh, causal, masked):
     qkv, q, k, v = _attn_inputs(B, S, Hq, Hkv, dh, 41)
     dout = gen(B, S, Hq * dh, seed=42)
@@ -997,6 +999,36 @@ def test_gemm256_repeatable_under_load(ops, monkeypatch):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     assert all(torch.equal(o, first) for o in outs) and all(torch.equal(o, first2) for o in outs2)
+
+
+@pytest.mark.parametrize("grid", ["1", "3", "8", "37"])
+def test_gemm256_persistent_walk_small_grids(ops, grid, monkeypatch):
+    """The persistent walk proper: a forced grid of 1 / 3 / 8 / 37 workgroups makes each of them run many tiles back to back
+    (next tile's K-tile 0 in flight under the epilogue, staging region alternating between the K-tile buffers, bias slice and
+    sources re-derived per tile) - bit-identical to the 128-row kernel on ragged M / N, with residual, with an unaligned bias
+    (element path), with K = 64 (one K-tile: no second buffer in flight), batched, SwiGLU with live-row stores."""
+    monkeypatch.setenv("VLA_GEMM256_GRID", grid)
+    for (M, N, K, act, res) in [(1300, 900, 320, 0, True), (1100, 1152, 64, 1, False), (777, 520, 448, 2, True), (2048, 896, 896, 0, False)]:
+        a, b, bias, r = gen(M, K, seed=251).to(DEV), gen(N, K, seed=252, scale=0.05).to(DEV), gen(N + 1, seed=253).to(DEV), gen(M, N, seed=254).to(DEV)
+        for bb in (bias[:N], bias[1:]):                       # 8-B aligned / odd-element offset: vector and element bias paths
+            out, ref = _both_tiles(monkeypatch, lambda: ops.gemm_nt(a, b, bias=bb, residual=r if res else None, act=act, split_k=0))
+            assert torch.equal(out, ref), f"grid {grid} {M}x{N}x{K} act {act}"
+    nb, M2, D, N2 = 3, 600, 448, 700
+    ab, wb, bias_b = gen(nb, M2, D, seed=255).to(DEV), gen(nb, N2, D, seed=256, scale=0.05).to(DEV), gen(nb, N2, seed=257).to(DEV)
+    out, ref = _both_tiles(monkeypatch, lambda: ops.gemm_nt(ab, wb, bias=bias_b))
+    assert torch.equal(out, ref)
+    M, D, I, S, r0 = 1100, 448, 640, 100, 64
+    x, w = gen(M, D, seed=258).to(DEV), gen(2 * I, D, seed=259, scale=0.05).to(DEV)
+    o1, o2 = torch.full((M, 2 * I), 3.0, dtype=BF, device=DEV), torch.full((M, 2 * I), 3.0, dtype=BF, device=DEV)
+    monkeypatch.setenv("VLA_GEMM_TILE", "2")
+    _, h_r = ops.gemm_nt(x, w, act=ops.ACT_SWIGLU, out=o1, c_live=(S, r0))
+    monkeypatch.setenv("VLA_GEMM_TILE", "6")
+    _, h = ops.gemm_nt(x, w, act=ops.ACT_SWIGLU, out=o2, c_live=(S, r0))
+    assert torch.equal(h, h_r) and torch.equal(o1, o2)
+    d, wdT = gen(M, D, seed=260).to(DEV), gen(I, D, seed=261, scale=0.05).to(DEV)
+    pre = gen(M, 2 * I, seed=262).to(DEV)
+    fused, fused_r = _both_tiles(monkeypatch, lambda: ops.gemm_swiglu_bwd(d, wdT, pre))
+    assert torch.equal(fused, fused_r)
 
 
 def test_gemm_forced_tile_with_split_k(ops, monkeypatch):

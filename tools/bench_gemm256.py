@@ -26,10 +26,11 @@ def timeit(fn, iters=10):
 
 def main():
     B = 32
-    shapes = [("llm gate_up(swiglu)", B * 352, 9728, 896, 4), ("llm gate_up half", B * 176, 9728, 896, 4), ("llm down", B * 352, 896, 4864, 0),
+    shapes = [("llm gate_up(swiglu)", B * 352, 9728, 896, 4), ("llm gate_up live-rows", B * 352, 9728, 896, 5), ("llm gate_up half", B * 176, 9728, 896, 4), ("llm down", B * 352, 896, 4864, 0),
               ("llm down half", B * 176, 896, 4864, 0), ("llm qkv(norope)", B * 352, 1152, 896, 0), ("llm o", B * 352, 896, 896, 0),
               ("vit qkv", B * 256, 3456, 1152, 0), ("vit proj", B * 256, 1152, 1152, 0), ("vit fc1(gelu)", B * 256, 4352, 1152, 1),
-              ("vit fc2", B * 256, 1152, 4352, 0), ("head task kv", B * 256, 1792, 896, 0), ("llm d->dh", B * 352, 4864, 896, 0),
+              ("vit fc2", B * 256, 1152, 4352, 0), ("vit fc2 +res", B * 256, 1152, 4352, 10), ("llm down +res", B * 352, 896, 4864, 10),
+              ("llm o +res", B * 352, 896, 896, 10), ("head task kv", B * 256, 1792, 896, 0), ("llm d->dh", B * 352, 4864, 896, 0),
               ("llm dgu->dn", B * 352, 896, 9728, 0), ("live dgu->dn", 2048, 896, 9728, 0), ("live d->dh", 2048, 4864, 896, 0),
               ("square 4096", 4096, 4096, 4096, 0), ("square 8192", 8192, 8192, 8192, 0)]
     only = os.environ.get("SHAPES")
@@ -40,24 +41,34 @@ def main():
         w = (torch.randn(N, K, device=DEV) * 0.02).to(BF)
         bias = torch.randn(N, device=DEV).to(BF)
         out = torch.empty(M, N, device=DEV, dtype=BF)
-        if act == 4:
+        if act in (4, 5):
             out2 = torch.empty(M, N // 2, device=DEV, dtype=BF)
-            fn = lambda: ops.gemm_nt(a, w, act=4, out=out, out2=out2)
+            live = (352, 288) if act == 5 else None            # the step keeps pre-activations of the live rows only
+            fn = lambda: ops.gemm_nt(a, w, act=4, out=out, out2=out2, c_live=live)
+        elif act == 10:
+            res_t = torch.randn(M, N, device=DEV).to(BF)
+            fn = lambda: ops.gemm_nt(a, w, bias=bias, residual=res_t, out=out, split_k=0)
         else:
             fn = lambda: ops.gemm_nt(a, w, bias=bias, act=act, out=out, split_k=0)
-        variants = [("auto", "0"), ("128x128", "2"), ("256-8ph", "6")]
+        variants = [("auto", "0"), ("128x128", "2"), ("256-8ph", "6"), ("256 1wg/tile", "6:0")]
         res = {k: [] for k, _ in variants}
         res["vendor"] = []
         wt = w.t()
+        def setv(v):
+            os.environ["VLA_GEMM_TILE"] = v.split(":")[0]
+            if ":" in v:
+                os.environ["VLA_GEMM256_GRID"] = v.split(":")[1]
+            else:
+                os.environ.pop("VLA_GEMM256_GRID", None)
         for k, v in variants:
-            os.environ["VLA_GEMM_TILE"] = v
+            setv(v)
             fn()
         torch.matmul(a, wt)
         for _ in range(5):
             for k, v in variants:
-                os.environ["VLA_GEMM_TILE"] = v
+                setv(v)
                 res[k].append(timeit(fn))
-            if act != 4:
+            if act not in (4, 5):
                 res["vendor"].append(timeit(lambda: torch.matmul(a, wt)))
         os.environ["VLA_GEMM_TILE"] = "0"
         fl = 2.0 * M * N * K

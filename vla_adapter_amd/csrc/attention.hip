@@ -520,7 +520,8 @@ extern "C" int vla_attn_bwd(void* stream, const vla_attn_desc* d) {
   AttnP p{};
   int rc = fill(p, d, true);
   if (rc) return rc;
-  VLA_REQUIRE(p.dh == 64 || p.dh == 72, "attn_bwd: dh 64 or 72 only");
+  VLA_REQUIRE(p.dh == 64 || p.dh == 72 || p.dh == 128, "attn_bwd: dh 64, 72 or 128 only");
+  VLA_REQUIRE(p.dh == 64 || !p.rope_cos, "attn_bwd: the fused inverse RoPE needs head dim 64 (apply vla_rope_half with sign -1 otherwise)");
   hipStream_t st = (hipStream_t)stream;
   const int grp = p.Hq / p.Hkv;
   VLA_REQUIRE(grp <= 8, "attn_bwd: at most 8 query heads per kv head");
@@ -532,15 +533,19 @@ extern "C" int vla_attn_bwd(void* stream, const vla_attn_desc* d) {
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<72>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   VLA_REQUIRE(lds <= 160 * 1024, "attn_bwd: LDS budget exceeded");
   if (p.dh == 64) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(256), 0, st, p);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gk, dim3(64 * grp * KT), lds, st, p, grp, KT);
-  } else {
+  } else if (p.dh == 72) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<72>, gq, dim3(256), 0, st, p);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<72>, gk, dim3(64 * grp * KT), lds, st, p, grp, KT);
+  } else {                  // Qwen2.5-1.5B (BASELINE configs[4] backbone): 12 query / 2 kv heads x 128
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, gq, dim3(256), 0, st, p);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, gk, dim3(64 * grp * KT), lds, st, p, grp, KT);
   }
   VLA_CHECK_LAUNCH("attn_bwd");
   return VLA_OK;

@@ -539,16 +539,15 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr;
   p.ldc2 = d->ldc2; p.res_mod = d->res_mod; p.act = d->act;
   p.sA = d->sA; p.sB = d->sB; p.sC = d->sC; p.sR = d->sR; p.sC2 = d->sC2; p.sBias = d->sBias;
-  p.tiles_n = p.ntiles = 0;
+  p.tiles_n = p.ntiles = 0; p.batch = 1;
   p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
   p.gA = d->a_group; p.sgA = d->a_group_stride; p.gC = d->c_group; p.sgC = d->c_group_stride;
   p.gR = d->r_group; p.sgR = d->r_group_stride;
   p.c_live_mod = d->c_live_mod; p.c_live_from = d->c_live_from;
   const int split = d->split_k > 1 ? d->split_k : 1;
   p.bias_post = d->bias_post_round;
-  VLA_REQUIRE(d->bias_post_round == 0 || (d->bias_post_round == 1 && d->bias && d->rope_mode == 0 && split == 1 &&
-                                          d->act != VLA_ACT_SWIGLU && d->act != VLA_ACT_SWIGLU_BWD),
-              "gemm: bias_post_round needs a bias and a plain epilogue (no rope / split-K / SwiGLU)");
+  VLA_REQUIRE(d->bias_post_round == 0 || (d->bias_post_round == 1 && d->bias && d->rope_mode == 0 && split == 1 && d->act == VLA_ACT_NONE),
+              "gemm: bias_post_round needs a bias and a plain epilogue (no rope / split-K / activation)");
   { const char* ge = getenv("VLA_GEMM_GM"); p.gm = ge ? atoi(ge) : 0; }
   p.ws = nullptr;
   if (split > 1) {

@@ -26,6 +26,12 @@
 //       WAR  slot of half-tile h is refilled in phase h + 1: B0 is last read in phase h (its 4 reads are retired by the
 //            lgkmcnt(8) BEFORE that phase's first barrier), A0/B1/A1 are refilled >= 2 phases after their last read.
 //   * epilogue through the (now free) operand LDS: per wave two 64 x 64 passes, 16-B stores of whole row segments.
+//   * PERSISTENT over tiles: at most one workgroup per CU walks the tile list.  K-tile 0 of the NEXT tile is issued (LDS-DMA
+//     into the K-tile buffer the epilogue does not stage through) before the epilogue of the current one, so the pipeline
+//     fill of every tile but a workgroup's first hides behind an epilogue; the epilogue's stores drain behind the next fill.
+//     The walk is static (workgroup b takes the tiles of the virtual workgroups b, b + G, b + 2G ...): handing tiles out by
+//     atomic tickets fetched a tile ahead measured 0.5 - 1 % SLOWER on the whole step (26.03-26.14 vs 25.82-25.86 ms, one
+//     workgroup per tile 25.90-26.02) and needed device-side state; it is gone.
 #include <type_traits>
 #include "gemm_params.h"
 #include "../../include/vla_native.h"
@@ -34,8 +40,19 @@ namespace {
 
 constexpr int BK = 64;
 constexpr int HT = 16384;            // bytes per half-tile (128 rows x 64 k x 2 B)
-constexpr int LDS_BYTES = 8 * HT;    // 128 KiB: one workgroup per CU
-constexpr int EPI_STRIDE = 64 * 2 + 16;   // staged epilogue row: 64 bf16 + 16 B pad
+constexpr int LDS_BYTES = 8 * HT;    // 128 KiB of operands: one workgroup per CU
+constexpr int STG = 8192;            // epilogue staging per wave: 64 rows x 128 B, 16-B chunk c of row r at c ^ ((r >> 1) & 7)
+
+// LDS-DMA issued from inline asm: 16 B per lane from (wave-uniform base + per-lane 32-bit byte offset) to LDS address `dst`
+// (+ lane * 16).  Hidden from hipcc on purpose: beside a builtin global_load_lds it drains vmcnt(0) before every ordinary
+// load, every ds_write that might alias the DMA target and every reuse of a loaded register - i.e. all through an epilogue
+// that runs under the next tile's K-tile 0.  Its completion is counted by hand (the s_waitcnt statements below); M0 is
+// saved and restored in the same statement (it is compiler-reserved).
+__device__ __forceinline__ void glds16s(const char* base, unsigned voff, unsigned dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
+}
 
 #define VLA_BARRIER()                      \
   do {                                     \
@@ -48,64 +65,91 @@ constexpr int EPI_STRIDE = 64 * 2 + 16;   // staged epilogue row: 64 bf16 + 16 B
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool PRE = EPI != 2;      // next tile's K-tile 0 in flight during the epilogue (SwiGLU backward stages wider rows)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;
 
-  // XCD-aware bijective remap + group-M order (same scheme as gemm.hip)
-  const int nwg = p.ntiles, bid = blockIdx.x;
-  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  // ---- the tile list: `total` tiles (all batches) in eight contiguous XCD lists (bijective split, as gemm.hip); virtual
+  //      workgroup v owns entry v >> 3 of list v & 7, and workgroup b of a grid of G walks v = b, b + G, b + 2G ...
+  const int G = gridDim.x, bid = blockIdx.x;
+  const int total = p.ntiles * p.batch;
+  const int q8 = total >> 3, r8 = total & 7;
+  const int xcd = bid & 7;
+  auto rstart = [&](int x) { return x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8; };
+  int vt = bid;
+
+  // ---- tile identity + staging sources: this wave fills rows [16 wid, 16 wid + 16) of every half-tile (2 pieces of 8 rows)
   const int GM = p.gm > 0 ? p.gm : 4;
   const int tiles_m = p.ntiles / p.tiles_n, per_group = GM * p.tiles_n;
-  const int grp = swz / per_group, rem = swz - grp * per_group;
-  const int gmr = min(GM, tiles_m - grp * GM);
-  const int bm = grp * GM + rem % gmr, bn = rem / gmr;
-  const int m0 = bm * 256, n0 = bn * 256;
-  const int z = blockIdx.z;
-  const bf16_t* Ab = p.A + (long long)z * p.sA;
-  const bf16_t* Bb = p.B + (long long)z * p.sB;
-
-  // ---- staging sources: this wave fills rows [16 wid, 16 wid + 16) of every half-tile (2 pieces of 8 rows x 128 B)
-  const int kc = ((lane & 7) ^ ((lane >> 3) & 7)) * 8;   // LDS chunk lane&7 of row r holds global chunk (lane&7) ^ (r&7)
-  const int lrow = lane >> 3;
-  const bf16_t* pa[2][2];
-  const bf16_t* pb[2][2];
+  int m0, n0, z;
+  // sources as wave-uniform bases + 32-bit per-lane byte offsets (half the address registers of eight pointers)
+  const char* Ab; const char* Bb;
+  unsigned oa[2][2], ob[2][2];
+  auto setup = [&](int swz) {
+    int sl = lane;
+    asm volatile("" : "+v"(sl));       // per-tile address arithmetic stays here (hoisted out of the tile loop it costs registers
+    const int kc = ((sl & 7) ^ ((sl >> 3) & 7)) * 8;   // across the K loop); LDS chunk lane&7 of row r holds global chunk (lane&7)^(r&7)
+    const int lrow = sl >> 3;
+    int gA = p.gA;
+    asm volatile("" : "+s"(gA));       // (the same for the reciprocal of a divisor: recomputed per tile, not carried in VGPRs)
+    int ntl = p.ntiles, pg = per_group;
+    asm volatile("" : "+s"(ntl), "+s"(pg));
+    z = swz / ntl;
+    const int tl = swz - z * ntl;
+    const int grp = tl / pg, rem = tl - grp * pg;
+    const int gmr = min(GM, tiles_m - grp * GM);
+    m0 = (grp * GM + rem % gmr) * 256;
+    n0 = (rem / gmr) * 256;
+    Ab = reinterpret_cast<const char*>(p.A + (long long)z * p.sA);
+    Bb = reinterpret_cast<const char*>(p.B + (long long)z * p.sB);
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int ra = min(m0 + wr * 128 + h * 64 + (wid & 3) * 16 + j * 8 + lrow, p.M - 1);
-      pa[h][j] = Ab + (p.gA > 0 ? (long long)(ra / p.gA) * p.sgA + (long long)(ra % p.gA) * p.lda : (long long)ra * p.lda) + kc;
-      const int rb = min(n0 + (wid >> 1) * 64 + h * 32 + (wid & 1) * 16 + j * 8 + lrow, p.N - 1);
-      pb[h][j] = Bb + (long long)rb * p.ldb + kc;
-    }
-  char* const wdst = smem + wid * 2048;
+      for (int j = 0; j < 2; ++j) {
+        const int ra = min(m0 + wr * 128 + h * 64 + (wid & 3) * 16 + j * 8 + lrow, p.M - 1);
+        oa[h][j] = (unsigned)(((gA > 0 ? (long long)(ra / gA) * p.sgA + (long long)(ra % gA) * p.lda : (long long)ra * p.lda) + kc) * 2);
+        const int rb = min(n0 + (wid >> 1) * 64 + h * 32 + (wid & 1) * 16 + j * 8 + lrow, p.N - 1);
+        ob[h][j] = (unsigned)(((long long)rb * p.ldb + kc) * 2);
+      }
+  };
+  const unsigned wdst = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem) + wid * 2048;
   // half-tile kinds inside a K-tile buffer: 0 = B0, 1 = A0, 2 = B1, 3 = A1 (the order of first use)
   auto stage_a = [&](int slot, int h, int k0) {
-    glds16(pa[h][0] + k0, wdst + slot * HT);
-    glds16(pa[h][1] + k0, wdst + slot * HT + 1024);
+    glds16s(Ab + k0 * 2, oa[h][0], wdst + slot * HT);
+    glds16s(Ab + k0 * 2, oa[h][1], wdst + slot * HT + 1024);
   };
   auto stage_b = [&](int slot, int h, int k0) {
-    glds16(pb[h][0] + k0, wdst + slot * HT);
-    glds16(pb[h][1] + k0, wdst + slot * HT + 1024);
+    glds16s(Bb + k0 * 2, ob[h][0], wdst + slot * HT);
+    glds16s(Bb + k0 * 2, ob[h][1], wdst + slot * HT + 1024);
   };
-
-  // ---- bias slice of this wave's 64 columns (4 per lane and n tile), fetched ahead of everything else
-  const int lq = lane >> 4, lr = lane & 15;
-  const int wn0 = n0 + wc * 64;
+  auto stage_k0 = [&](int buf) {
+    stage_b(buf * 4 + 0, 0, 0); stage_a(buf * 4 + 1, 0, 0); stage_b(buf * 4 + 2, 1, 0); stage_a(buf * 4 + 3, 1, 0);
+  };
+  // bias slice of this wave's 64 columns (4 per lane and n tile): requested at the top of the tile BEHIND K-tile 1, as exactly
+  // four loads when the vector path applies (the top's counted wait leaves them in flight), none otherwise
   uint2 braw[4];
-  bool bok[4];
-  const bf16_t* bias = (EPI != 2 && p.bias) ? p.bias + (long long)z * p.sBias : nullptr;
-  {
-    const bool bvec = bias && (((size_t)bias & 7) == 0);
+  auto bias_vec = [&]() {
+    const bf16_t* bias = (EPI != 2 && p.bias) ? p.bias + (long long)z * p.sBias : nullptr;
+    return bias != nullptr && (((size_t)bias & 7) == 0) && p.N >= 4;
+  };
+  auto fetch_bias = [&](bool bvec) {
+    int sl = lane;
+    asm volatile("" : "+v"(sl));
+    const int lq = sl >> 4;
+    // always four loads, in one block (a conditional load would reach `braw` through a copy, and the copy waits for it): without
+    // a usable bias they read the head of B and are ignored
+    // (as an opaque byte distance from B, so that the address stays a global one and no copy of the loads is specialised per case)
+    long long dist = bvec ? (long long)((uintptr_t)(p.bias + (long long)z * p.sBias) - (uintptr_t)p.B) : 0;
+    int lim = bvec ? p.N : 0;
+    asm volatile("" : "+s"(dist), "+s"(lim));
+    const bf16_t* src = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(p.B) + dist);
 #pragma unroll
     for (int t4 = 0; t4 < 4; ++t4) {
-      const int n = wn0 + t4 * 16 + lq * 4;
-      bok[t4] = bvec && n + 3 < p.N;
-      braw[t4] = bok[t4] ? *reinterpret_cast<const uint2*>(bias + n) : uint2{0, 0};
+      const int n = n0 + wc * 64 + t4 * 16 + lq * 4;
+      braw[t4] = *reinterpret_cast<const uint2*>(src + (n + 3 < lim ? n : 0));
     }
-  }
+  };
 
 #ifdef G256_ABL
 #if G256_ABL == 3
@@ -116,144 +160,39 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
 #else
   const int nt = p.K / BK;
 #endif
-  // ---- prologue: K-tile 0 (half-tiles 0..3) and the first three half-tiles of K-tile 1
-  stage_b(0, 0, 0); stage_a(1, 0, 0); stage_b(2, 1, 0); stage_a(3, 1, 0);
-  if (nt > 1) {
-    stage_b(4, 0, BK); stage_a(5, 0, BK); stage_b(6, 1, BK);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  VLA_BARRIER();
-  if (wr == 1) VLA_BARRIER();      // stagger: the wr = 1 waves run one segment behind
 
-  f32x4 acc[2][2][2][4];           // [mh][nh][ni][mi]
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int d = 0; d < 4; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // fragment read offsets: row * 128 + ((4 s + lq) ^ (row & 7)) * 16, row & 7 == lane & 7
-  const int fo0 = lr * 128 + (((0 + lq) ^ (lane & 7)) << 4);
-  const int fo1 = lr * 128 + (((4 + lq) ^ (lane & 7)) << 4);
   const int aoff = wr * 64 * 128, boff = wc * 32 * 128;
 
-  bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+  int cur = rstart(xcd) + (bid >> 3);
+  setup(cur);
+  stage_k0(0);
   int d = 0;
-  for (int t = 0; t < nt; ++t) {
-    const char* kb = smem + d * 4 * HT;
-    const int so = d * 4, sn = (d ^ 1) * 4;
-    // ================= phase Q00: reads B0 (4, first) + A0 (8); issues A1 of K-tile t+1
-    {
-      const char* sb = kb + 0 * HT + boff;
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        fb0[ni][0] = *reinterpret_cast<const bf16x8*>(sb + ni * 2048 + fo0);
-        fb0[ni][1] = *reinterpret_cast<const bf16x8*>(sb + ni * 2048 + fo1);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      const char* sa = kb + 1 * HT + aoff;
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        fa[mi][0] = *reinterpret_cast<const bf16x8*>(sa + mi * 2048 + fo0);
-        fa[mi][1] = *reinterpret_cast<const bf16x8*>(sa + mi * 2048 + fo1);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < nt) stage_a(sn + 3, 1, (t + 1) * BK);
-      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");     // the B0 reads are done: its slot is refilled next phase
-      VLA_BARRIER();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
-            acc[0][0][ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[ni][s], fa[mi][s], acc[0][0][ni][mi], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-      VLA_BARRIER();
-    }
-    // ================= phase Q01: reads B1 (4); issues B0 of K-tile t+2
-    {
-      const char* sb = kb + 2 * HT + boff;
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        fb1[ni][0] = *reinterpret_cast<const bf16x8*>(sb + ni * 2048 + fo0);
-        fb1[ni][1] = *reinterpret_cast<const bf16x8*>(sb + ni * 2048 + fo1);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (t + 2 < nt) stage_b(so + 0, 0, (t + 2) * BK);
-      VLA_BARRIER();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
-            acc[0][1][ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[ni][s], fa[mi][s], acc[0][1][ni][mi], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-      VLA_BARRIER();
-    }
-    // ================= phase Q11: reads A1 (8); issues A0 of K-tile t+2
-    {
-      const char* sa = kb + 3 * HT + aoff;
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        fa[mi][0] = *reinterpret_cast<const bf16x8*>(sa + mi * 2048 + fo0);
-        fa[mi][1] = *reinterpret_cast<const bf16x8*>(sa + mi * 2048 + fo1);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (t + 2 < nt) stage_a(so + 1, 0, (t + 2) * BK);
-      VLA_BARRIER();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
-            acc[1][1][ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[ni][s], fa[mi][s], acc[1][1][ni][mi], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-      VLA_BARRIER();
-    }
-    // ================= phase Q10: no reads (B0 kept in registers); issues B1 of K-tile t+2; the K-tile's counted wait
-    {
-      if (t + 2 < nt) {
-        stage_b(so + 2, 1, (t + 2) * BK);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // K-tile t+1 has landed; three half-tiles of t+2 in flight
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      VLA_BARRIER();
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
-            acc[1][0][ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[ni][s], fa[mi][s], acc[1][0][ni][mi], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-      VLA_BARRIER();
-    }
-    d ^= 1;
-  }
-  if (wr == 0) VLA_BARRIER();      // pairs with the last barrier of the wr = 1 waves: every operand read is finished
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-#if defined(G256_ABL) && G256_ABL == 1
-  {                                 // diagnostic build: no epilogue at all (accumulators kept alive)
+  for (;;) {
+    // ================= top of a tile: its K-tile 0 is in flight in buffer d (behind it, the previous epilogue's stores)
+    vt += G;                           // the walk: virtual workgroup ids bid, bid + G, ... (same tile map as one workgroup per tile)
+    const int nxt = vt < total ? rstart(vt & 7) + (vt >> 3) : -1;
+    // Nothing but the walk position and the lane index is carried across an epilogue: the sources of this tile are derived again
+    // (its K-tile 0 was issued from the same values before the previous epilogue), the bias slice is requested now.
+    asm volatile("" : "+s"(cur));
+    setup(cur);
+    const bool bvec = bias_vec();
+    if (nt > 1) {
+      const int sn = (d ^ 1) * 4;
+      stage_b(sn + 0, 0, BK); stage_a(sn + 1, 0, BK); stage_b(sn + 2, 1, BK);
+    }
+    fetch_bias(bvec);
+    if (nt > 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");     // K-tile 0 is in; K-tile 1's three half-tiles and the bias stay in flight
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    VLA_BARRIER();
+    // fragment read offsets: row * 128 + ((4 s + lq) ^ (row & 7)) * 16, row & 7 == lane & 7
+    int fl = lane;
+    asm volatile("" : "+v"(fl));
+    const int fo0 = (fl & 15) * 128 + (((0 + (fl >> 4)) ^ (fl & 7)) << 4);
+    const int fo1 = (fl & 15) * 128 + (((4 + (fl >> 4)) ^ (fl & 7)) << 4);
+    if (wr == 1) VLA_BARRIER();      // stagger: the wr = 1 waves run one segment behind
+
+    f32x4 acc[2][2][2][4];           // [mh][nh][ni][mi]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -261,207 +200,455 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) asm volatile("" ::"v"(acc[a][b][c][e]));
-    return;
-  }
-#endif
-  // ---------------- epilogue: two 64 x 64 passes per wave through its private staging region ----------------
-  char* reg = smem + wid * (64 * EPI_STRIDE);
-  float bv[4][4];
-#pragma unroll
-  for (int t4 = 0; t4 < 4; ++t4) {
-    if (bok[t4]) {
-      bv[t4][0] = bf2f((bf16_t)(braw[t4].x & 0xffff)); bv[t4][1] = bf2f((bf16_t)(braw[t4].x >> 16));
-      bv[t4][2] = bf2f((bf16_t)(braw[t4].y & 0xffff)); bv[t4][3] = bf2f((bf16_t)(braw[t4].y >> 16));
-    } else {
-      const int n = wn0 + t4 * 16 + lq * 4;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bv[t4][j] = (bias && n + j < p.N) ? bf2f(bias[n + j]) : 0.f;
-    }
-  }
+          for (int e = 0; e < 4; ++e) acc[a][b][c][e] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+    for (int t = 0; t < nt; ++t) {
+      const char* kb = smem + d * 4 * HT;
+      const int so = d * 4, sn = (d ^ 1) * 4;
+      // ================= phase Q00: reads B0 (4, first) + A0 (8); issues A1 of K-tile t+1
+      {
+        const char* sb = kb + 0 * HT + boff;
 #pragma unroll
-  for (int mh = 0; mh < 2; ++mh) {
-    const int wm0 = m0 + wr * 128 + mh * 64;
-    // view of this half as [t4 = 2 nh + ni][mi]
-    auto A4 = [&](int t4, int mi) -> f32x4& { return acc[mh][t4 >> 1][t4 & 1][mi]; };
-
-    if (EPI == 2) {
-      // SwiGLU backward fused into dH = dY . W_down (accumulator = dH of this 64 x 64 patch): read the matching interleaved
-      // pre-activations GU[m, 2N], emit dGU in the same layout; dH itself is never stored.
-      const bf16_t* GU = p.R + (long long)z * p.sR;
-      bf16_t* Cb = p.C + (long long)z * p.sC;
-      constexpr int ROWB = 2 * 64 * 2 + 16;
-      char* reg2 = smem + wid * (32 * ROWB);
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-#pragma unroll
-        for (int mq = 0; mq < 2; ++mq) {
-          const int mi = 2 * half + mq;
-          const int m = min(wm0 + mi * 16 + lr, p.M - 1);
-#pragma unroll
-          for (int t4 = 0; t4 < 4; ++t4) {
-            const int hc = wn0 + t4 * 16 + lq * 4;
-            const long long go = (p.gR > 0 ? (long long)(m / p.gR) * p.sgR + (long long)(m % p.gR) * p.ldr : (long long)m * p.ldr) +
-                                 (hc >> 4) * 32 + (hc & 15);
-            const bool ok = hc + 3 < p.N;
-            const uint2 gv = ok ? *reinterpret_cast<const uint2*>(GU + go) : uint2{0, 0};
-            const uint2 uv = ok ? *reinterpret_cast<const uint2*>(GU + go + 16) : uint2{0, 0};
-            const float gg[4] = {bf2f((bf16_t)(gv.x & 0xffff)), bf2f((bf16_t)(gv.x >> 16)), bf2f((bf16_t)(gv.y & 0xffff)), bf2f((bf16_t)(gv.y >> 16))};
-            const float uu[4] = {bf2f((bf16_t)(uv.x & 0xffff)), bf2f((bf16_t)(uv.x >> 16)), bf2f((bf16_t)(uv.y & 0xffff)), bf2f((bf16_t)(uv.y >> 16))};
-            float dg[4], du[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float dd = rbf(A4(t4, mi)[j] * p.alpha);
-              const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-gg[j]));
-              du[j] = dd * gg[j] * sg;
-              dg[j] = dd * uu[j] * (sg * (1.0f + gg[j] * (1.0f - sg)));
-            }
-            char* rowp = reg2 + (mq * 16 + lr) * ROWB + (t4 * 32 + lq * 4) * 2;
-            *reinterpret_cast<uint2*>(rowp) = uint2{pack2(dg[0], dg[1]), pack2(dg[2], dg[3])};
-            *reinterpret_cast<uint2*>(rowp + 32) = uint2{pack2(du[0], du[1]), pack2(du[2], du[3])};
-          }
+        for (int ni = 0; ni < 2; ++ni) {
+          fb0[ni][0] = *reinterpret_cast<const bf16x8*>(sb + ni * 2048 + fo0);
+          fb0[ni][1] = *reinterpret_cast<const bf16x8*>(sb + ni * 2048 + fo1);
         }
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {                  // 32 rows x 16 chunks of 16 B: 4 rows per pass
-          const int row = it * 4 + (lane >> 4), ch = lane & 15;
-          const int m = wm0 + half * 32 + row, n2 = 2 * wn0 + ch * 8;
-          if (m < p.M && n2 + 8 <= 2 * p.N)
-            *reinterpret_cast<uint4*>(Cb + (long long)m * p.ldc + n2) = *reinterpret_cast<const uint4*>(reg2 + row * ROWB + ch * 16);
-        }
-      }
-      continue;
-    }
-    if (EPI == 1) {
-      // SwiGLU forward: columns interleaved in 16s - even n tiles are gate, odd n tiles the matching up columns.  The product
-      // h (64 rows x 32 columns per pass) is staged through LDS like C, so that it leaves as 16-B row segments (direct 8-B
-      // stores touched 16 cache lines per instruction: 4x the store instructions on every tile's tail).
-      bf16_t* C2 = p.C2 + (long long)z * p.sC2;
-      constexpr int HSTR = 32 * 2 + 16;                       // staged h row: 32 bf16 + pad
-      char* regh = smem + 8 * (64 * EPI_STRIDE) + wid * (64 * HSTR);
-      const bool plain = bias == nullptr && p.alpha == 1.f;
-#pragma unroll
-      for (int pr = 0; pr < 2; ++pr)
+        __builtin_amdgcn_sched_barrier(0);
+        const char* sa = kb + 1 * HT + aoff;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
-          float h[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            // (Qwen2's gate / up projections carry no bias and alpha is 1: the wave-uniform `plain` spares two FMAs per pair)
-            const float g = rbf(plain ? A4(2 * pr, mi)[j] : A4(2 * pr, mi)[j] * p.alpha + bv[2 * pr][j]);
-            const float u = rbf(plain ? A4(2 * pr + 1, mi)[j] : A4(2 * pr + 1, mi)[j] * p.alpha + bv[2 * pr + 1][j]);
-            A4(2 * pr, mi)[j] = g;
-            A4(2 * pr + 1, mi)[j] = u;
-            h[j] = rbf(g * __builtin_amdgcn_rcpf(1.0f + __expf(-g))) * u;
-          }
-          *reinterpret_cast<uint2*>(regh + (mi * 16 + lr) * HSTR + (pr * 16 + lq * 4) * 2) = uint2{pack2(h[0], h[1]), pack2(h[2], h[3])};
+          fa[mi][0] = *reinterpret_cast<const bf16x8*>(sa + mi * 2048 + fo0);
+          fa[mi][1] = *reinterpret_cast<const bf16x8*>(sa + mi * 2048 + fo1);
         }
-      const bool hvec = ((p.ldc2 & 7) == 0) && (((size_t)C2 & 15) == 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < nt) stage_a(sn + 3, 1, (t + 1) * BK);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");     // the B0 reads are done: its slot is refilled next phase
+        VLA_BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {                        // 64 rows x 4 chunks of 16 B: 16 rows per pass
-        const int row = it * 16 + (lane >> 2), ch = lane & 3;
-        const int m = wm0 + row, hc = (wn0 >> 1) + ch * 8;
-        const uint4 v = *reinterpret_cast<const uint4*>(regh + row * HSTR + ch * 16);
-        if (m >= p.M || hc >= (p.N >> 1)) continue;
-        bf16_t* dst = C2 + (long long)m * p.ldc2 + hc;
-        if (hvec && hc + 8 <= (p.N >> 1)) {
-          *reinterpret_cast<uint4*>(dst) = v;
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+              acc[0][0][ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[ni][s], fa[mi][s], acc[0][0][ni][mi], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        VLA_BARRIER();
+      }
+      // ================= phase Q01: reads B1 (4); issues B0 of K-tile t+2
+      {
+        const char* sb = kb + 2 * HT + boff;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          fb1[ni][0] = *reinterpret_cast<const bf16x8*>(sb + ni * 2048 + fo0);
+          fb1[ni][1] = *reinterpret_cast<const bf16x8*>(sb + ni * 2048 + fo1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 2 < nt) stage_b(so + 0, 0, (t + 2) * BK);
+        VLA_BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+              acc[0][1][ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[ni][s], fa[mi][s], acc[0][1][ni][mi], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        VLA_BARRIER();
+      }
+      // ================= phase Q11: reads A1 (8); issues A0 of K-tile t+2
+      {
+        const char* sa = kb + 3 * HT + aoff;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          fa[mi][0] = *reinterpret_cast<const bf16x8*>(sa + mi * 2048 + fo0);
+          fa[mi][1] = *reinterpret_cast<const bf16x8*>(sa + mi * 2048 + fo1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 2 < nt) stage_a(so + 1, 0, (t + 2) * BK);
+        VLA_BARRIER();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+              acc[1][1][ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[ni][s], fa[mi][s], acc[1][1][ni][mi], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        VLA_BARRIER();
+      }
+      // ================= phase Q10: no reads (B0 kept in registers); issues B1 of K-tile t+2; the K-tile's counted wait
+      {
+        if (t + 2 < nt) {
+          stage_b(so + 2, 1, (t + 2) * BK);
+          asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // K-tile t+1 has landed; three half-tiles of t+2 in flight
         } else {
-          const unsigned wv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (int k = 0; k < 8; ++k)
-            if (hc + k < (p.N >> 1)) dst[k] = (bf16_t)((k & 1) ? (wv[k >> 1] >> 16) : (wv[k >> 1] & 0xffffu));
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        VLA_BARRIER();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+              acc[1][0][ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[ni][s], fa[mi][s], acc[1][0][ni][mi], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        VLA_BARRIER();
       }
-      if (p.C == nullptr) continue;
-      // pre-activations kept for a live-row backward only (c_live): a 64-row block without a live row stores nothing
-      if (p.c_live_mod > 0 && (wm0 % p.c_live_mod) + 63 < p.c_live_from) continue;
-    } else {
-      float alpha = p.alpha;
-      if (p.bias_post) {                      // bf16(bf16(alpha acc) + bias): torch CPU Linear on a strided input
-#pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4)
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) A4(t4, mi)[j] = rbf(A4(t4, mi)[j] * alpha);
-        alpha = 1.f;
-      }
-      auto finish = [&](auto fn) {
-#pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4)
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) A4(t4, mi)[j] = fn(A4(t4, mi)[j] * alpha + bv[t4][j]);
-      };
-      if (p.act == VLA_ACT_GELU) finish([](float v) { return gelu_erf(rbf(v)); });
-      else if (p.act == VLA_ACT_RELU) finish([](float v) { return fmaxf(v, 0.f); });
-      else if (p.act == VLA_ACT_GELU_TANH) finish([](float v) { return gelu_tanh(rbf(v)); });
-      else finish([](float v) { return v; });
+      d ^= 1;
     }
+    if (wr == 0) VLA_BARRIER();      // pairs with the last barrier of the wr = 1 waves: every operand read is finished
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-    // stage the 64 x 64 half (bf16) through the wave's private LDS region, then 16-B stores of whole row segments
-    bf16_t* Cb = p.C + (long long)z * p.sC;
-    const bf16_t* Rb = p.R ? p.R + (long long)z * p.sR : nullptr;
-    const bool vec_ok = ((p.ldc & 7) == 0) && (!Rb || (p.ldr & 7) == 0);
+#if defined(G256_ABL) && G256_ABL == 1
+    {                                 // diagnostic build: no epilogue at all (accumulators kept alive)
 #pragma unroll
-    for (int t4 = 0; t4 < 4; ++t4)
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        uint2 o = {pack2(A4(t4, mi)[0], A4(t4, mi)[1]), pack2(A4(t4, mi)[2], A4(t4, mi)[3])};
-        *reinterpret_cast<uint2*>(reg + (mi * 16 + lr) * EPI_STRIDE + (t4 * 16 + lq * 4) * 2) = o;
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) asm volatile("" ::"v"(acc[a][b][c][e]));
+      if (nxt < 0) break;
+      VLA_BARRIER();
+      setup(nxt); stage_k0(d);
+      cur = nxt;
+      continue;
+    }
+#endif
+    // ---------------- epilogue of tile (em0, en0, ez): two 64 x 64 passes per wave through its private staging region,
+    //                  in the K-tile buffer that the next tile's K-tile 0 (issued first) does not occupy
+    const int em0 = m0, en0 = n0, ez = z;
+    int el = lane;
+    asm volatile("" : "+v"(el));       // (see setup: nothing of the epilogue's addressing may live across the K loop)
+    const int lq = el >> 4, lr = el & 15;
+    int gR = p.gR, gC = p.gC, res_mod = p.res_mod, c_live_mod = p.c_live_mod;
+    asm volatile("" : "+s"(gR), "+s"(gC), "+s"(res_mod), "+s"(c_live_mod));
+    const bf16_t* bias = (EPI != 2 && p.bias) ? p.bias + (long long)ez * p.sBias : nullptr;
+    const int wn0 = en0 + wc * 64;
+    float bv[4][4];
+    int ebvec = __builtin_amdgcn_readfirstlane(bias_vec() ? 1 : 0);
+    asm volatile("" : "+s"(ebvec));      // (opaque: the four loads of the top are read on every path, so that nothing stays pending)
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+      const int n = wn0 + t4 * 16 + lq * 4;
+      const bool ok = ebvec != 0 && n + 3 < p.N;
+      bv[t4][0] = ok ? bf2f((bf16_t)(braw[t4].x & 0xffff)) : 0.f; bv[t4][1] = ok ? bf2f((bf16_t)(braw[t4].x >> 16)) : 0.f;
+      bv[t4][2] = ok ? bf2f((bf16_t)(braw[t4].y & 0xffff)) : 0.f; bv[t4][3] = ok ? bf2f((bf16_t)(braw[t4].y >> 16)) : 0.f;
+      if (bias && !ok) {                   // unaligned bias / the ragged last columns: element loads
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (n + j < p.N) bv[t4][j] = bf2f(bias[n + j]);
       }
-    // Row addressing: the plain case (no row groups, no broadcast residual, no live-row filter) must not pay the four integer
-    // divisions per output row of the general case - 128 divisions per wave sat on every tile's tail.
-    const bool plain_rows = (p.res_mod | p.gR | p.gC | p.c_live_mod) == 0;
-    auto store_rows = [&](auto fast_t) {
-      constexpr bool FAST = decltype(fast_t)::value;
+    }
+    // the two 64 x 64 halves of this wave: outside C / entirely inside / on its edge
+    bf16_t* Cb = p.C + (long long)ez * p.sC;
+    const bf16_t* Rb = (EPI == 0 && p.R) ? p.R + (long long)ez * p.sR : nullptr;
+    const bool vec_ok = ((p.ldc & 7) == 0) && (!Rb || (p.ldr & 7) == 0);
+    const bool plain_rows = (res_mod | gR | gC | c_live_mod) == 0;
+    bool skip[2], inside[2], fastm[2];
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {                       // 64 rows x 8 chunks of 16 B: 8 rows per pass
-        const int row = it * 8 + (lane >> 3), ch = lane & 7;
-        const int m = wm0 + row, n = wn0 + ch * 8;
-        uint4 v = *reinterpret_cast<const uint4*>(reg + row * EPI_STRIDE + ch * 16);
-        if (m >= p.M || n >= p.N) continue;
-        long long roff, crow;
-        if constexpr (FAST) {
-          roff = (long long)m * p.ldr;
-          crow = (long long)m * p.ldc;
-        } else {
-          if (p.c_live_mod > 0 && (m % p.c_live_mod) < p.c_live_from) continue;
-          roff = p.res_mod > 0 ? (long long)(m % p.res_mod) * p.ldr
-                 : p.gR > 0 ? (long long)(m / p.gR) * p.sgR + (long long)(m % p.gR) * p.ldr : (long long)m * p.ldr;
-          crow = p.gC > 0 ? (long long)(m / p.gC) * p.sgC + (long long)(m % p.gC) * p.ldc : (long long)m * p.ldc;
-        }
-        if (vec_ok && n + 8 <= p.N) {
-          if (Rb) {
-            const uint4 rv = *reinterpret_cast<const uint4*>(Rb + roff + n);
-            const unsigned a[4] = {v.x, v.y, v.z, v.w};
-            const unsigned b[4] = {rv.x, rv.y, rv.z, rv.w};
-            unsigned o[4];
+    for (int mh = 0; mh < 2; ++mh) {
+      const int wm0 = em0 + wr * 128 + mh * 64;
+      skip[mh] = wm0 >= p.M || wn0 >= p.N;          // nothing of this half exists (N = 3.5 tiles: half the waves of the last column)
+      inside[mh] = wm0 + 64 <= p.M && wn0 + 64 <= p.N;
+      fastm[mh] = EPI != 2 && plain_rows && vec_ok && inside[mh] && !skip[mh];
+    }
+    // Residual segments (plain epilogue): ALWAYS sixteen loads per lane, in two straight-line groups, read on every path - a
+    // conditional load reaches its registers through a copy that waits for it, and a load that some path never reads leaves the
+    // compiler a pending register to protect with vmcnt(0) wherever it reuses it.  A half that takes the general path, or a
+    // GEMM without residual, reads the head of B instead and ignores it.
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 rv[2][8];
+    int fres0 = 0, fres1 = 0;
+    const char* rsrc = nullptr;
+    if constexpr (EPI == 0) {
+      long long rdist = Rb ? (long long)((uintptr_t)Rb - (uintptr_t)p.B) : 0;
+      fres0 = __builtin_amdgcn_readfirstlane((fastm[0] && Rb) ? 1 : 0);
+      fres1 = __builtin_amdgcn_readfirstlane((fastm[1] && Rb) ? 1 : 0);
+      asm volatile("" : "+s"(rdist), "+s"(fres0), "+s"(fres1));
+      rsrc = reinterpret_cast<const char*>(p.B) + rdist;
+    }
+    auto load_res = [&](int mh, int it0, int it1) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-              o[k] = pack2(bf2f((bf16_t)(a[k] & 0xffff)) + bf2f((bf16_t)(b[k] & 0xffff)),
-                           bf2f((bf16_t)(a[k] >> 16)) + bf2f((bf16_t)(b[k] >> 16)));
-            v = uint4{o[0], o[1], o[2], o[3]};
-          }
-          *reinterpret_cast<uint4*>(Cb + crow + n) = v;
-        } else {
-          const unsigned wv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            if (n + k < p.N) {
-              float f = bf2f((bf16_t)((k & 1) ? (wv[k >> 1] >> 16) : (wv[k >> 1] & 0xffffu)));
-              if (Rb) f += bf2f(Rb[roff + n + k]);
-              Cb[crow + n + k] = f2bf(f);
-            }
-          }
-        }
+      for (int it = it0; it < it1; ++it) {
+        const long long off = ((long long)(em0 + wr * 128 + mh * 64 + it * 8 + (el >> 3)) * p.ldr + wn0 + (el & 7) * 8) * 2;
+        rv[mh][it] = *reinterpret_cast<const u32x4*>(rsrc + ((mh == 0 ? fres0 : fres1) ? off : 0));
       }
     };
-    if (plain_rows) store_rows(std::true_type{});
-    else store_rows(std::false_type{});
+    auto drop_res = [&](int mh) {          // a path that does not add the residual still reads the registers (see above)
+      asm volatile("" ::"v"(rv[mh][0]), "v"(rv[mh][1]), "v"(rv[mh][2]), "v"(rv[mh][3]), "v"(rv[mh][4]), "v"(rv[mh][5]), "v"(rv[mh][6]),
+                   "v"(rv[mh][7]));
+    };
+    // next tile: its K-tile 0 goes out now
+    if (PRE && nxt >= 0) { setup(nxt); stage_k0(d); }
+    char* const reg = PRE ? smem + (d ^ 1) * 4 * HT + wid * STG : smem + wid * STG;
+    if constexpr (EPI == 0) load_res(0, 0, 4); // the first segments: in flight under the activation math (16 registers: all 32
+                                               // of the half do not fit beside 128 accumulators)
+
+    if constexpr (EPI == 2) {
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh) {
+        const int wm0 = em0 + wr * 128 + mh * 64;
+        auto A4 = [&](int t4, int mi) -> f32x4& { return acc[mh][t4 >> 1][t4 & 1][mi]; };
+        // SwiGLU backward fused into dH = dY . W_down (accumulator = dH of this 64 x 64 patch): read the matching interleaved
+          // pre-activations GU[m, 2N], emit dGU in the same layout; dH itself is never stored.
+          const bf16_t* GU = p.R + (long long)ez * p.sR;
+          bf16_t* Cb = p.C + (long long)ez * p.sC;
+          constexpr int ROWB = 2 * 64 * 2 + 16;
+          char* reg2 = smem + wid * (32 * ROWB);
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int mq = 0; mq < 2; ++mq) {
+              const int mi = 2 * half + mq;
+              const int m = min(wm0 + mi * 16 + lr, p.M - 1);
+#pragma unroll
+              for (int t4 = 0; t4 < 4; ++t4) {
+                const int hc = wn0 + t4 * 16 + lq * 4;
+                const long long go = (gR > 0 ? (long long)(m / gR) * p.sgR + (long long)(m % gR) * p.ldr : (long long)m * p.ldr) +
+                                     (hc >> 4) * 32 + (hc & 15);
+                const bool ok = hc + 3 < p.N;
+                const uint2 gv = ok ? *reinterpret_cast<const uint2*>(GU + go) : uint2{0, 0};
+                const uint2 uv = ok ? *reinterpret_cast<const uint2*>(GU + go + 16) : uint2{0, 0};
+                const float gg[4] = {bf2f((bf16_t)(gv.x & 0xffff)), bf2f((bf16_t)(gv.x >> 16)), bf2f((bf16_t)(gv.y & 0xffff)), bf2f((bf16_t)(gv.y >> 16))};
+                const float uu[4] = {bf2f((bf16_t)(uv.x & 0xffff)), bf2f((bf16_t)(uv.x >> 16)), bf2f((bf16_t)(uv.y & 0xffff)), bf2f((bf16_t)(uv.y >> 16))};
+                float dg[4], du[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  const float dd = rbf(A4(t4, mi)[j] * p.alpha);
+                  const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-gg[j]));
+                  du[j] = dd * gg[j] * sg;
+                  dg[j] = dd * uu[j] * (sg * (1.0f + gg[j] * (1.0f - sg)));
+                }
+                char* rowp = reg2 + (mq * 16 + lr) * ROWB + (t4 * 32 + lq * 4) * 2;
+                *reinterpret_cast<uint2*>(rowp) = uint2{pack2(dg[0], dg[1]), pack2(dg[2], dg[3])};
+                *reinterpret_cast<uint2*>(rowp + 32) = uint2{pack2(du[0], du[1]), pack2(du[2], du[3])};
+              }
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {                  // 32 rows x 16 chunks of 16 B: 4 rows per pass
+              const int row = it * 4 + (el >> 4), ch = el & 15;
+              const int m = wm0 + half * 32 + row, n2 = 2 * wn0 + ch * 8;
+              if (m < p.M && n2 + 8 <= 2 * p.N)
+                *reinterpret_cast<uint4*>(Cb + (long long)m * p.ldc + n2) = *reinterpret_cast<const uint4*>(reg2 + row * ROWB + ch * 16);
+            }
+          }
+      }
+    } else {
+      auto flo = [](unsigned v) { return __builtin_bit_cast(float, v << 16); };
+      auto fhi = [](unsigned v) { return __builtin_bit_cast(float, v & 0xffff0000u); };
+
+      // ---- phase A: alpha / bias / activation on all 128 values of the lane, rounded and packed.  The fp32 accumulators end
+      //      here: what the stores below carry is half the registers, and the residual segments fit beside it.
+      uint2 pk[2][4][4];          // [mh][t4 = 2 nh + ni][mi]: columns t4*16 + lq*4 .. +3 of row mi*16 + lr
+      uint2 hp[2][2][4];          // SwiGLU forward: the products h
+      if constexpr (EPI == 1) {
+        // columns interleaved in 16s - even n tiles are gate, odd n tiles the matching up columns
+        // (Qwen2's gate / up projections carry no bias and alpha is 1: the wave-uniform `plain` spares two FMAs per pair)
+        const bool plain = bias == nullptr && p.alpha == 1.f;
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+              f32x4 ga = acc[mh][pr][0][mi], ua = acc[mh][pr][1][mi];
+              if (!plain) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { ga[j] = ga[j] * p.alpha + bv[2 * pr][j]; ua[j] = ua[j] * p.alpha + bv[2 * pr + 1][j]; }
+              }
+              const uint2 gp = {pack2(ga[0], ga[1]), pack2(ga[2], ga[3])}, up = {pack2(ua[0], ua[1]), pack2(ua[2], ua[3])};
+              const float g[4] = {flo(gp.x), fhi(gp.x), flo(gp.y), fhi(gp.y)}, u[4] = {flo(up.x), fhi(up.x), flo(up.y), fhi(up.y)};
+              float h[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) h[j] = rbf(g[j] * __builtin_amdgcn_rcpf(1.0f + __expf(-g[j]))) * u[j];
+              pk[mh][2 * pr][mi] = gp;
+              pk[mh][2 * pr + 1][mi] = up;
+              hp[mh][pr][mi] = uint2{pack2(h[0], h[1]), pack2(h[2], h[3])};
+            }
+      } else {
+        auto phase_a = [&](auto fn, auto post_t) {
+          constexpr bool POST = decltype(post_t)::value;     // bf16(bf16(alpha acc) + bias): torch CPU Linear on a strided input
+          const float alpha = p.alpha;
+#pragma unroll
+          for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+              for (int mi = 0; mi < 4; ++mi) {
+                const f32x4 a = acc[mh][t4 >> 1][t4 & 1][mi];
+                float x[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] = fn(POST ? rbf(a[j] * alpha) + bv[t4][j] : a[j] * alpha + bv[t4][j]);
+                pk[mh][t4][mi] = uint2{pack2(x[0], x[1]), pack2(x[2], x[3])};
+              }
+        };
+        if (p.bias_post) phase_a([](float v) { return v; }, std::true_type{});       // (plain epilogue only: checked by the host)
+        else if (p.act == VLA_ACT_GELU) phase_a([](float v) { return gelu_erf(rbf(v)); }, std::false_type{});
+        else if (p.act == VLA_ACT_RELU) phase_a([](float v) { return fmaxf(v, 0.f); }, std::false_type{});
+        else if (p.act == VLA_ACT_GELU_TANH) phase_a([](float v) { return gelu_tanh(rbf(v)); }, std::false_type{});
+        else phase_a([](float v) { return v; }, std::false_type{});
+      }
+      // Phase A ends HERE, for the compiler too: every packed value is pinned, and the lane index that phase B computes its
+      // addresses from is only defined afterwards (left alone, the residual loads are hoisted above the packing and the
+      // second half's packing sunk below the first half's stores: 128 accumulators + 64 residual registers, and spills).
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4)
+          asm volatile("" : "+v"(pk[mh][t4][0].x), "+v"(pk[mh][t4][0].y), "+v"(pk[mh][t4][1].x), "+v"(pk[mh][t4][1].y),
+                            "+v"(pk[mh][t4][2].x), "+v"(pk[mh][t4][2].y), "+v"(pk[mh][t4][3].x), "+v"(pk[mh][t4][3].y));
+      asm volatile("" : "+v"(el));
+
+      // ---- phase B: per 64 x 64 half, through the wave's staging region, 16-B stores of whole row segments.  The common case
+      //      - the half entirely inside C, 16-B aligned rows, plain row addressing - runs without a branch and with all its
+      //      residual segments requested up front (in the general path every conditional load is followed by its own
+      //      vmcnt(0): 16 serial round trips per tile).
+      if constexpr (EPI == 0) { load_res(0, 4, 8); load_res(1, 0, 8); }     // the rest: behind the first stores
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh) {
+        const int wm0 = em0 + wr * 128 + mh * 64;
+        if (skip[mh]) {
+          if constexpr (EPI == 0) drop_res(mh);
+          continue;
+        }
+        if constexpr (EPI == 1) {
+          // the product h (64 rows x 32 columns per half) is staged through LDS like C, so that it leaves as 16-B row segments
+          bf16_t* C2 = p.C2 + (long long)ez * p.sC2;
+          constexpr int HSTR = 32 * 2 + 16;                       // staged h row: 32 bf16 + pad (64 rows: 5 KiB of the region)
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+              *reinterpret_cast<uint2*>(reg + (mi * 16 + lr) * HSTR + (pr * 16 + lq * 4) * 2) = hp[mh][pr][mi];
+          const bool hvec = ((p.ldc2 & 7) == 0) && (((size_t)C2 & 15) == 0);
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {                        // 64 rows x 4 chunks of 16 B: 16 rows per pass
+            const int row = it * 16 + (el >> 2), ch = el & 3;
+            const int m = wm0 + row, hc = (wn0 >> 1) + ch * 8;
+            const uint4 v = *reinterpret_cast<const uint4*>(reg + row * HSTR + ch * 16);
+            if (hvec && inside[mh]) {                             // (wave-uniform) whole half inside: no per-lane test
+              *reinterpret_cast<uint4*>(C2 + (long long)m * p.ldc2 + hc) = v;
+              continue;
+            }
+            if (m >= p.M || hc >= (p.N >> 1)) continue;
+            bf16_t* dst = C2 + (long long)m * p.ldc2 + hc;
+            if (hvec && hc + 8 <= (p.N >> 1)) {
+              *reinterpret_cast<uint4*>(dst) = v;
+            } else {
+              const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+              for (int k = 0; k < 8; ++k)
+                if (hc + k < (p.N >> 1)) dst[k] = (bf16_t)((k & 1) ? (wv[k >> 1] >> 16) : (wv[k >> 1] & 0xffffu));
+            }
+          }
+          if (p.C == nullptr) continue;
+          // pre-activations kept for a live-row backward only (c_live): a 64-row block without a live row stores nothing
+          if (c_live_mod > 0 && (wm0 % c_live_mod) + 63 < p.c_live_from) continue;
+        }
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) {
+            const int row = mi * 16 + lr;
+            *reinterpret_cast<uint2*>(reg + row * 128 + (((t4 * 2 + (lq >> 1)) ^ ((row >> 1) & 7)) << 4) + (lq & 1) * 8) = pk[mh][t4][mi];
+          }
+        if (fastm[mh]) {
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {                       // 64 rows x 8 chunks of 16 B: 8 rows per pass
+            const int row = it * 8 + (el >> 3), ch = el & 7;
+            uint4 v = *reinterpret_cast<const uint4*>(reg + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+            if constexpr (EPI == 0) {
+              const u32x4 r = rv[mh][it];
+              const unsigned a[4] = {v.x, v.y, v.z, v.w};
+              unsigned o[4];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) o[k] = (mh == 0 ? fres0 : fres1) ? pack2(flo(a[k]) + flo(r[k]), fhi(a[k]) + fhi(r[k])) : a[k];
+              v = uint4{o[0], o[1], o[2], o[3]};
+            }
+            *reinterpret_cast<uint4*>(Cb + (long long)(wm0 + row) * p.ldc + wn0 + ch * 8) = v;
+          }
+          continue;
+        }
+        // Row addressing: the plain case (no row groups, no broadcast residual, no live-row filter) must not pay the four integer
+        // divisions per output row of the general case - 128 divisions per wave sat on every tile's tail.
+        auto store_rows = [&](auto fast_t) {
+          constexpr bool FAST = decltype(fast_t)::value;
+#pragma nounroll
+          for (int it = 0; it < 8; ++it) {                       // 64 rows x 8 chunks of 16 B: 8 rows per pass (rare path: kept rolled)
+            const int row = it * 8 + (el >> 3), ch = el & 7;
+            const int m = wm0 + row, n = wn0 + ch * 8;
+            uint4 v = *reinterpret_cast<const uint4*>(reg + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+            if (m >= p.M || n >= p.N) continue;
+            long long roff, crow;
+            if constexpr (FAST) {
+              roff = (long long)m * p.ldr;
+              crow = (long long)m * p.ldc;
+            } else {
+              if (c_live_mod > 0 && (m % c_live_mod) < p.c_live_from) continue;
+              roff = res_mod > 0 ? (long long)(m % res_mod) * p.ldr
+                     : gR > 0 ? (long long)(m / gR) * p.sgR + (long long)(m % gR) * p.ldr : (long long)m * p.ldr;
+              crow = gC > 0 ? (long long)(m / gC) * p.sgC + (long long)(m % gC) * p.ldc : (long long)m * p.ldc;
+            }
+            if (vec_ok && n + 8 <= p.N) {
+              if (Rb) {
+                const uint4 rv = *reinterpret_cast<const uint4*>(Rb + roff + n);
+                const unsigned a[4] = {v.x, v.y, v.z, v.w};
+                const unsigned b[4] = {rv.x, rv.y, rv.z, rv.w};
+                unsigned o[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                  o[k] = pack2(bf2f((bf16_t)(a[k] & 0xffff)) + bf2f((bf16_t)(b[k] & 0xffff)),
+                               bf2f((bf16_t)(a[k] >> 16)) + bf2f((bf16_t)(b[k] >> 16)));
+                v = uint4{o[0], o[1], o[2], o[3]};
+              }
+              *reinterpret_cast<uint4*>(Cb + crow + n) = v;
+            } else {
+              const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                if (n + k < p.N) {
+                  float f = bf2f((bf16_t)((k & 1) ? (wv[k >> 1] >> 16) : (wv[k >> 1] & 0xffffu)));
+                  if (Rb) f += bf2f(Rb[roff + n + k]);
+                  Cb[crow + n + k] = f2bf(f);
+                }
+              }
+            }
+          }
+        };
+        if constexpr (EPI == 0) drop_res(mh);
+        if (plain_rows) store_rows(std::true_type{});
+        else store_rows(std::false_type{});
+      }
+    }
+
+    if (nxt < 0) break;
+    VLA_BARRIER();                   // every wave is done with its staging region: K-tile 1 may land there
+    if (!PRE) { setup(nxt); stage_k0(d); }
+    cur = nxt;
   }
+}
+
+int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  }
+  return n;
 }
 
 template <int EPI>
@@ -469,12 +656,18 @@ int launch256(const GemmP& p0, int batch, hipStream_t st) {
   GemmP p = p0;
   p.tiles_n = (p.N + 255) / 256;
   p.ntiles = ((p.M + 255) / 256) * p.tiles_n;
+  p.batch = batch;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(p.ntiles, 1, batch), dim3(512), LDS_BYTES, st, p);
+  // one workgroup per CU walks the tiles (VLA_GEMM256_GRID overrides the workgroup count: 0 = one workgroup per tile)
+  const char* ge = getenv("VLA_GEMM256_GRID");      // (read per launch: the A/B tool flips it in one process)
+  const long long total = (long long)p.ntiles * batch;
+  long long grid = ge ? atoll(ge) : num_cus();
+  if (grid <= 0 || grid > total) grid = total;
+  hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3((unsigned)grid), dim3(512), LDS_BYTES, st, p);
   return 0;
 }
 

@@ -9,6 +9,7 @@ struct GemmP {
   int M, N, K, lda, ldb, ldc, ldr, ldc2, res_mod, act;
   long long sA, sB, sC, sR, sC2, sBias;
   int tiles_n, ntiles;
+  int batch;                                // gemm256.hip: batches in the flattened tile list
   float alpha;
   int gA, gC, gR; long long sgA, sgC, sgR;  // row-group addressing: row r -> (r / g) * sg + (r % g) * ld
   int c_live_mod, c_live_from;              // C rows with (m % c_live_mod) < c_live_from are not stored

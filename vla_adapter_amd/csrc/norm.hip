@@ -228,14 +228,15 @@ inline int nch_for(int cols) { return (cols + 511) / 512; }
   else if (n <= 3) { CALL(3); }                  \
   else if (n <= 4) { CALL(4); }                  \
   else if (n <= 8) { CALL(8); }                  \
-  else { CALL(16); }
+  else if (n <= 16) { CALL(16); }                \
+  else { CALL(24); }
 
 }  // namespace
 
 extern "C" int vla_layernorm_fwd(void* stream, const void* x, const void* w, const void* b, void* y, float* stats,
                                  int rows, int cols, int ldx, int ldy, float eps) {
   VLA_REQUIRE(x && w && b && y && rows > 0 && cols > 0, "layernorm_fwd: null/empty");
-  VLA_REQUIRE(cols % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && cols <= 8192, "layernorm_fwd: cols%8, ld%8, cols<=8192");
+  VLA_REQUIRE(cols % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && cols <= 12288, "layernorm_fwd: cols%8, ld%8, cols<=12288");
   VLA_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)w | (uintptr_t)b) & 15) == 0, "layernorm_fwd: 16-B alignment");
   const int n = nch_for(cols);
   dim3 grid((rows + 3) / 4);
@@ -250,7 +251,7 @@ extern "C" int vla_layernorm_fwd(void* stream, const void* x, const void* w, con
 extern "C" int vla_layernorm_bwd(void* stream, const void* dy, const void* x, const void* w, const float* stats, void* dx,
                                  float* dw, float* db, int rows, int cols, int ldx, int lddy, int lddx) {
   VLA_REQUIRE(dy && x && w && stats && rows > 0 && cols > 0, "layernorm_bwd: null/empty");
-  VLA_REQUIRE(cols % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && cols <= 8192, "layernorm_bwd: cols%8, ld%8");
+  VLA_REQUIRE(cols % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && cols <= 12288, "layernorm_bwd: cols%8, ld%8");
   if (dx) {
     VLA_REQUIRE(lddx % 8 == 0, "layernorm_bwd: lddx%8");
     const int n = nch_for(cols);
@@ -276,7 +277,7 @@ extern "C" int vla_layernorm_bwd(void* stream, const void* dy, const void* x, co
 extern "C" int vla_rmsnorm_fwd(void* stream, const void* x, const void* w, void* y, float* rstd, int rows, int cols,
                                float eps) {
   VLA_REQUIRE(x && w && y && rows > 0 && cols > 0, "rmsnorm_fwd: null/empty");
-  VLA_REQUIRE(cols % 8 == 0 && cols <= 8192, "rmsnorm_fwd: cols%8==0, cols<=8192");
+  VLA_REQUIRE(cols % 8 == 0 && cols <= 12288, "rmsnorm_fwd: cols%8==0, cols<=12288");
   VLA_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)w) & 15) == 0, "rmsnorm_fwd: 16-B alignment");
   const int n = nch_for(cols);
   dim3 grid((rows + 3) / 4);
@@ -292,7 +293,7 @@ extern "C" int vla_rmsnorm_bwd(void* stream, const void* dy, const void* x, cons
                                const void* dres, void* dx, int rows, int cols, int x_group, int x_group_rows, int x_row0) {
   VLA_REQUIRE(dy && x && w && rstd && dx && rows > 0 && cols > 0, "rmsnorm_bwd: null/empty");
   VLA_REQUIRE(x_group >= 0 && (x_group == 0 || (x_row0 >= 0 && x_row0 + x_group <= x_group_rows)), "rmsnorm_bwd: bad row window");
-  VLA_REQUIRE(cols % 8 == 0 && cols <= 8192, "rmsnorm_bwd: cols%8==0");
+  VLA_REQUIRE(cols % 8 == 0 && cols <= 12288, "rmsnorm_bwd: cols%8==0");
   const int n = nch_for(cols);
   dim3 grid((rows + 3) / 4);
 #define CALL(N) hipLaunchKernelGGL(rmsnorm_bwd_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, \
