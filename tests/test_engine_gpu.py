@@ -597,3 +597,32 @@ def test_full_size_full_finetune_step_config4():
     ls = [ft.train_step_graphed(1e-4)[0].item() for _ in range(2)]
     torch.cuda.synchronize()
     assert all(l == l and abs(l) < 1e2 for l in ls), ls
+
+
+def test_qwen25_15b_layer_geometry_forward_backward():
+    """Qwen2.5-1.5B's layer geometry (BASELINE configs[4]: d 1536, 12 x 128 heads, 2 KV heads, MLP 8960) at two layers: head
+    dim 128 takes the unfused-RoPE projection, the 128-wide attention forward / backward kernels, and the head's first LayerNorm
+    spans 7 x 1536 columns.  Same error-budget criteria as the 0.5B tests."""
+    from vla_adapter_amd import engine as E, synthetic as S, ops
+    cfg = E.qwen15b_geometry_config(2)
+    W = S.make_weights(cfg, DEV, seed=31, std=0.03)
+    batch = S.make_batch(cfg, 2, DEV, seed=32, P=20, ragged=True)
+    eng = E.VLAEngine(cfg, W, DEV)
+    pred = eng.forward(batch, None)
+    loss3 = eng.loss_and_backward(pred, batch["actions"])
+    torch.cuda.synchronize()
+    out, OW = _oracle_run(cfg, W, batch, None, True, cfg.num_blocks)
+    tru, TW = _oracle_run(cfg, W, batch, None, False, cfg.num_blocks)
+    for i in range(cfg.llm.n_layers + 1):
+        budget(eng.llm.HS[i], out["hidden_states"][i], tru["hidden_states"][i], f"1.5B geometry hidden_states[{i}]")
+    budget(pred, out["pred"], tru["pred"], "1.5B geometry predicted actions")
+    assert torch.isfinite(loss3).all()
+    _, dpred = ops.l1_loss(pred, batch["actions"].to(BF), True)
+    out["pred"].backward(dpred.float().cpu())
+    tru["pred"].backward(dpred.float().cpu())
+    g_head = eng.head.named_views(eng.head.P.grad)
+    gmax = max(v.grad.norm().item() for v in TW["head"].values() if v.grad is not None)
+    fam = [(k, v, OW["head"][k].grad.reshape(v.shape), TW["head"][k].grad.reshape(v.shape)) for k, v in g_head.items() if TW["head"][k].grad is not None]
+    budget_family(fam, "1.5B geometry head gradients", absfloor=1e-3 * gmax)
+    budget(eng.head.P.g("action_queries"), OW["action_queries"].grad, TW["action_queries"].grad,
+           "1.5B geometry action_queries gradient (through the frozen LLM)", factor=1.5)

@@ -86,8 +86,8 @@ __global__ __launch_bounds__(256) void head_attn_fwd_kernel(HP p) {
   }
   __syncthreads();
   // out[t][d] = sum_n P[t][n] V[n][d]: thread -> column d, 4 rows
-  {
-    const int d = tid & 127, tg4 = (tid >> 7) * 4;
+  for (int d0 = 0; d0 < dh; d0 += 128) {         // (dh 112 at D = 896: one pass; 192 at D = 1536: two)
+    const int d = d0 + (tid & 127), tg4 = (tid >> 7) * 4;
     if (d < dh) {
       float acc[4] = {0.f, 0.f, 0.f, 0.f};
       for (int n = 0; n < N; ++n) {
@@ -200,8 +200,8 @@ __global__ __launch_bounds__(256) void head_attn_bwd_kernel(HP p) {
     }
   }
   // phase 5: dQ[t][d] = sum_n dDot[t][n] K[n][d]
-  {
-    const int d = tid & 127, tg4 = (tid >> 7) * 4;
+  for (int d0 = 0; d0 < dh; d0 += 128) {
+    const int d = d0 + (tid & 127), tg4 = (tid >> 7) * 4;
     if (d < dh) {
       float acc[4] = {0.f, 0.f, 0.f, 0.f};
       for (int n = 0; n < N; ++n) {
@@ -220,7 +220,7 @@ int fill(HP& p, const vla_head_attn_desc* d, bool bwd) {
   VLA_REQUIRE(d && d->q && d->k_self && d->v_self && d->k_adp && d->v_adp && d->k_task && d->v_task && d->gate && d->probs,
               "head_attn: null tensor");
   VLA_REQUIRE(d->T >= 1 && d->T <= 32, "head_attn: T must be in 1..32");
-  VLA_REQUIRE(d->B > 0 && d->Ka > 0 && d->Kt > 0 && d->H > 0 && d->dh > 0 && d->dh % 8 == 0 && d->dh <= 128, "head_attn: bad shape");
+  VLA_REQUIRE(d->B > 0 && d->Ka > 0 && d->Kt > 0 && d->H > 0 && d->dh > 0 && d->dh % 8 == 0 && d->dh <= 256, "head_attn: bad shape");
   VLA_REQUIRE(d->ld_q % 8 == 0 && d->ld_self % 8 == 0 && d->ld_adp % 8 == 0 && d->ld_task % 8 == 0 && d->ld_out % 8 == 0,
               "head_attn: row strides must be multiples of 8");
   VLA_REQUIRE(d->ld_q >= d->H * d->dh && d->ld_self >= d->H * d->dh && d->ld_adp >= d->H * d->dh && d->ld_task >= d->H * d->dh,

@@ -118,6 +118,14 @@ def tiny_config() -> VLACfg:
                   llm=LLMCfg(256, 2, 4, 2, 64, 512, 1e-6, 1e6, 1024), num_blocks=2)
 
 
+def qwen15b_geometry_config(n_layers: int = 2) -> VLACfg:
+    """BASELINE.json configs[4]'s language-model GEOMETRY at plumbing depth: Qwen2.5-1.5B's layer (d 1536, 12 heads of 128,
+    2 KV heads, MLP 8960) - head dim 128 (unfused RoPE, the 128-wide attention kernels) and a 7 x 1536-wide first head
+    LayerNorm - under a tiny ViT, `n_layers` layers and as many head blocks."""
+    return VLACfg(vit=[ViTCfg(192, 3, 3, 768, 14, 56, 0, False)],
+                  llm=LLMCfg(1536, n_layers, 12, 2, 128, 8960, 1e-6, 1e6, 1024), num_blocks=n_layers)
+
+
 def tiny_fused_config() -> VLACfg:
     """Plumbing-size version of the reference's default setup: DINOv2-like backbone (cls + 4 register tokens,
     LayerScale) + SigLIP-like backbone, fused 3-layer projector, two images per sample."""
