@@ -259,6 +259,9 @@ def bench_full(args, cfg, W, eng, batch, noise, lr, rank, local, world, B, P):
         dist.destroy_process_group()
 
 
+MARKER_BYTES = 16 * 256 * 4099      # 4099 workgroups of 256 threads x 16 B (tools/summarise_profiles.py looks for this grid)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -325,12 +328,23 @@ def main():
         step()
     eng.flush()
     sync()
+    # profiling runs bracket the timed region with a marker launch (a zero-fill of MARKER_BYTES: a grid no step kernel has), so
+    # that tools/summarise_profiles.py can cut the steady-state steps out of the kernel trace (weight init, capture warm-ups
+    # and the recording step stay outside)
+    marker = torch.empty(MARKER_BYTES, dtype=torch.uint8, device=dev) if args.no_probe else None
+    if marker is not None:
+        from vla_adapter_amd import ops as _ops
+        _ops.zero_(marker)
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss3 = step()
     eng.flush()          # the graphed step defers its RCCL exchange + AdamW into the next step: K steps = K updates
     sync()
     dt = time.perf_counter() - t0
+    if marker is not None:
+        _ops.zero_(marker)
+        torch.cuda.synchronize()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -364,7 +378,7 @@ def main():
         rec = measure_gemm_roofline(eng, batch, noise, lr, record_only=True)      # ONE more (eager) training step, no replays
         print(json.dumps({"metric": "fine-tune samples/sec (profiling run, no probe)", "value": round(value, 2), "unit": "samples/s",
                           "ms_per_step": round(ms, 3), "steps": args.steps, "warmup": args.warmup,
-                          "executed_steps": eng.executed_steps, "gemm_flops_per_step": rec["flops"],
+                          "executed_steps": eng.executed_steps, "marker_grid_x": MARKER_BYTES // 16, "gemm_flops_per_step": rec["flops"],
                           "gemm_launches_per_step": rec["launches"], "gemm_algorithmic_bytes_per_step": rec["bytes"]}), flush=True)
     elif rank == 0:
         roof = measure_gemm_roofline(eng, batch, noise, lr)

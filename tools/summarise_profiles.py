@@ -27,25 +27,50 @@ def short(name: str) -> str:
     return name.split("(")[0][:90]
 
 
-def stage_box():
-    f = glob.glob(os.path.join(SRC, "stats", "*", "*_kernel_trace.csv"))[0]
-    agg = defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(f)):
-        key = (short(r["Kernel_Name"]), r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Workgroup_Size_X", r.get("Workgroup_Size", "")))
-        a = agg[key]
-        a[0] += 1
-        a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-    steps = json.load(open(os.path.join(SRC, "bench_under_rocprof.json")))["executed_steps"]
+def _write_summary(path, agg, steps):
     rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
-    with open(os.path.join(SRC, "kernel_summary.csv"), "w", newline="") as fo:
+    with open(path, "w", newline="") as fo:
         w = csv.writer(fo)
         w.writerow(["kernel", "grid_x", "wg_x", "calls", "calls_per_step", "avg_us", "total_us", "us_per_step", "steps_in_trace"])
         for (k, g, wg), (n, us) in rows:
             w.writerow([k, g, wg, n, round(n / steps, 2), round(us / n, 2), round(us, 1), round(us / steps, 1), steps])
+    return rows
+
+
+def stage_box():
+    """Two summaries: the whole trace (weight init, capture warm-ups, the recording step included: per-step columns divide by
+    every executed step) and kernel_summary_steady.csv = ONLY the launches between bench.py's two marker launches, i.e. the K
+    timed graph replays - the step's own kernels and nothing else."""
+    f = glob.glob(os.path.join(SRC, "stats", "*", "*_kernel_trace.csv"))[0]
+    bench = json.load(open(os.path.join(SRC, "bench_under_rocprof.json")))
+    steps, timed, mgrid = bench["executed_steps"], bench["steps"], str(bench.get("marker_grid_x", -1))
+    rows = list(csv.DictReader(open(f)))
+    grid_of = lambda r: r.get("Grid_Size_X", r.get("Grid_Size", ""))
+    marks = sorted(int(r["Start_Timestamp"]) for r in rows if "fill_zero_kernel" in r["Kernel_Name"] and grid_of(r) == mgrid)
+    agg, steady = defaultdict(lambda: [0, 0.0]), defaultdict(lambda: [0, 0.0])
+    for r in rows:
+        key = (short(r["Kernel_Name"]), grid_of(r), r.get("Workgroup_Size_X", r.get("Workgroup_Size", "")))
+        us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        a = agg[key]
+        a[0] += 1
+        a[1] += us
+        if len(marks) == 2 and marks[0] < int(r["Start_Timestamp"]) < marks[1]:
+            a = steady[key]
+            a[0] += 1
+            a[1] += us
+    allrows = _write_summary(os.path.join(SRC, "kernel_summary.csv"), agg, steps)
     tot = sum(v[1] for v in agg.values())
-    print(f"{len(rows)} (kernel, grid) groups, {tot / steps / 1e3:.2f} ms of kernel time per step over {steps} steps")
-    for (k, g, wg), (n, us) in rows[:25]:
-        print(f"{k[:64]:64s} grid {g:>8s} calls/step {n / steps:7.1f} avg {us / n:8.1f} us  {us / steps / 1e3:6.2f} ms/step")
+    print(f"{len(allrows)} (kernel, grid) groups, {tot / steps / 1e3:.2f} ms of kernel time per step over {steps} steps (whole trace)")
+    if len(marks) == 2:
+        srows = _write_summary(os.path.join(SRC, "kernel_summary_steady.csv"), steady, timed)
+        tot = sum(v[1] for v in steady.values())
+        foreign = sorted({k for (k, _, _) in steady if "at::" in k or "rocclr" in k or "Cijk" in k})
+        print(f"timed region: {len(srows)} groups, {tot / timed / 1e3:.2f} ms of kernel time per step over {timed} steps; "
+              f"kernels that are not this library's: {foreign if foreign else 'none'}")
+        for (k, g, wg), (n, us) in srows[:25]:
+            print(f"{k[:64]:64s} grid {g:>8s} calls/step {n / timed:7.1f} avg {us / n:8.1f} us  {us / timed / 1e3:6.2f} ms/step")
+    else:
+        print(f"no marker pair found (grid {mgrid}): steady summary not written")
 
 
 def pmc_sum(sub, counter):
@@ -63,18 +88,25 @@ def pmc_sum(sub, counter):
 def stage_repo():
     os.makedirs(DST, exist_ok=True)
     shutil.copy(os.path.join(SRC, "kernel_summary.csv"), os.path.join(DST, "r02_kernel_summary.csv"))
+    steady = os.path.join(SRC, "kernel_summary_steady.csv")
+    if os.path.exists(steady):
+        shutil.copy(steady, os.path.join(DST, "r02_kernel_summary_steady.csv"))
     st = glob.glob(os.path.join(SRC, "stats", "*", "*_kernel_stats.csv"))
     if st:
         shutil.copy(st[0], os.path.join(DST, "r02_kernel_stats.csv"))
     for n in ("bench.json", "bench_under_rocprof.json"):
         if os.path.exists(os.path.join(SRC, n)):
             shutil.copy(os.path.join(SRC, n), os.path.join(DST, "r02_" + n))
-    rows = list(csv.DictReader(open(os.path.join(DST, "r02_kernel_summary.csv"))))
+    have_steady = os.path.exists(os.path.join(DST, "r02_kernel_summary_steady.csv"))
+    rows = list(csv.DictReader(open(os.path.join(DST, "r02_kernel_summary_steady.csv" if have_steady else "r02_kernel_summary.csv"))))
     gem = [r for r in rows if any(g in r["kernel"] for g in GEMM_KERNELS)]
     steps = int(rows[0]["steps_in_trace"])
     bench = json.load(open(os.path.join(DST, "r02_bench_under_rocprof.json")))
     out = {"source": "rocprofv3 --kernel-trace of `bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-full-backward --no-probe` "
-                     "(tools/profile_step.sh): every kernel in the trace belongs to a default training step",
+                     "(tools/profile_step.sh)" + (": the launches between the two marker launches that bracket the timed graph replays "
+                                                  "(profiles/r02_kernel_summary_steady.csv)" if have_steady else ": whole trace"),
+           "kernels_not_from_this_library_in_timed_region": (sorted({r["kernel"] for r in rows if "at::" in r["kernel"] or "rocclr" in r["kernel"]})
+                                                             if have_steady else None),
            "steps_in_trace": steps,
            "gemm_us_per_step_in_situ": round(sum(float(r["total_us"]) for r in gem) / steps, 1),
            "gemm_launches_per_step": round(sum(int(r["calls"]) for r in gem) / steps, 1),
