@@ -235,21 +235,40 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
     const bf16_t* GU = p.R + (long long)z * p.sR;          // aux input rides in the residual slot, row stride ldr
     bf16_t* Cb = p.C + (long long)z * p.sC;
     constexpr int ROWB = 2 * C::WTN * 2 + 16;              // staged row: 2*WTN bf16 (+16 B pad)
+    constexpr int CH2 = 2 * C::WTN / 8, RPP2 = 64 / CH2;   // 16-B chunks per staged row, rows per pass
+    constexpr int NIT = 32 / RPP2;                         // passes per 32-row half
     char* reg2 = smem + wid * (32 * ROWB);
+    if (wn0 >= p.N || wm0 >= p.M) return;                  // (N % 64 == 0: a wave's WTN h-columns are all inside or all outside)
+    // The pre-activations of the wave's patch arrive the way its results leave: whole 16-B row segments, ALL requested before
+    // the first is used (row clamped, no per-element condition), staged in the wave's LDS region and overwritten IN PLACE by dGU
+    // (same interleaved layout).  The former per-lane 8-B gathers (16 rows x 32 B per load instruction, each behind its own
+    // bounds branch and wait) made this epilogue as long as the K loop of the live-row backward's M = 2048 GEMM.
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 gin[2][NIT];
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int row = it * RPP2 + lane / CH2, ch = lane % CH2;
+        const int m = min(wm0 + half * 32 + row, p.M - 1);
+        const long long ro = p.gR > 0 ? (long long)(m / p.gR) * p.sgR + (long long)(m % p.gR) * p.ldr : (long long)m * p.ldr;
+        gin[half][it] = *reinterpret_cast<const u32x4*>(GU + ro + 2 * wn0 + ch * 8);
+      }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int row = it * RPP2 + lane / CH2, ch = lane % CH2;
+        *reinterpret_cast<u32x4*>(reg2 + row * ROWB + ch * 16) = gin[half][it];
+      }
+#pragma unroll
       for (int mh = 0; mh < 2; ++mh) {
         const int mi = 2 * half + mh;
-        const int m = min(wm0 + mi * 16 + lr, p.M - 1);
 #pragma unroll
         for (int ni = 0; ni < C::NT; ++ni) {
-          const int hc = wn0 + ni * 16 + lq * 4;            // first of this lane's 4 h-columns
-          const long long go = (p.gR > 0 ? (long long)(m / p.gR) * p.sgR + (long long)(m % p.gR) * p.ldr : (long long)m * p.ldr) +
-                               (hc >> 4) * 32 + (hc & 15);
-          const bool ok = hc + 3 < p.N;
-          const uint2 gv = ok ? *reinterpret_cast<const uint2*>(GU + go) : uint2{0, 0};
-          const uint2 uv = ok ? *reinterpret_cast<const uint2*>(GU + go + 16) : uint2{0, 0};
+          char* rowp = reg2 + (mh * 16 + lr) * ROWB + (ni * 32 + lq * 4) * 2;
+          const uint2 gv = *reinterpret_cast<const uint2*>(rowp);
+          const uint2 uv = *reinterpret_cast<const uint2*>(rowp + 32);
           const float gg[4] = {bf2f((bf16_t)(gv.x & 0xffff)), bf2f((bf16_t)(gv.x >> 16)), bf2f((bf16_t)(gv.y & 0xffff)), bf2f((bf16_t)(gv.y >> 16))};
           const float uu[4] = {bf2f((bf16_t)(uv.x & 0xffff)), bf2f((bf16_t)(uv.x >> 16)), bf2f((bf16_t)(uv.y & 0xffff)), bf2f((bf16_t)(uv.y >> 16))};
           float dg[4], du[4];
@@ -260,17 +279,15 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
             du[j] = d * gg[j] * sg;
             dg[j] = d * uu[j] * (sg * (1.0f + gg[j] * (1.0f - sg)));
           }
-          char* rowp = reg2 + (mh * 16 + lr) * ROWB + (ni * 32 + lq * 4) * 2;
           *reinterpret_cast<uint2*>(rowp) = uint2{pack2(dg[0], dg[1]), pack2(dg[2], dg[3])};
           *reinterpret_cast<uint2*>(rowp + 32) = uint2{pack2(du[0], du[1]), pack2(du[2], du[3])};
         }
       }
-      constexpr int CH2 = 2 * C::WTN / 8, RPP2 = 64 / CH2;   // 16-B chunks per staged row, rows per pass
 #pragma unroll
-      for (int it = 0; it < 32 / RPP2; ++it) {
+      for (int it = 0; it < NIT; ++it) {
         const int row = it * RPP2 + lane / CH2, ch = lane % CH2;
         const int m = wm0 + half * 32 + row, n2 = 2 * wn0 + ch * 8;
-        if (m < p.M && n2 + 8 <= 2 * p.N)
+        if (m < p.M)
           *reinterpret_cast<uint4*>(Cb + (long long)m * p.ldc + n2) = *reinterpret_cast<const uint4*>(reg2 + row * ROWB + ch * 16);
       }
     }
@@ -446,9 +463,10 @@ inline bool use_256(int M, int N, int K, int batch, int act) {
   static const bool off = getenv("VLA_NO_GEMM256") != nullptr;
   if (off) return false;
   const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256) * batch;
-  // the SwiGLU-backward epilogue (gathers GU, writes 2N columns) is as long as a short K loop: below two rounds of tiles the
-  // 128-row kernel's second resident workgroup hides it better (live-row backward, M = 2048: 334 vs 650 TF/s)
-  if (act == VLA_ACT_SWIGLU_BWD && tiles < 512) return false;
+  // the SwiGLU-backward epilogue streams GU in and dGU out (4 N bytes per row against 2 K of operands: as long as a short K
+  // loop, HBM-bound on the full sequence): the 128-row kernel's second resident workgroup overlaps it with the other one's
+  // K loop (live rows, M = 2048: 38 vs 44 us; full sequence, M = 11264: 166 vs 191 us)
+  if (act == VLA_ACT_SWIGLU_BWD) return false;
   return M >= 1024 && N >= 768 && K >= 256 && tiles >= 96;
 }
 inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode, int batch = 1, int split = 1, int act = 0) {
