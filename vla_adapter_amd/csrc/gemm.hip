@@ -411,6 +411,42 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
         uint2 o = {pack2(acc[ni][mi][0], acc[ni][mi][1]), pack2(acc[ni][mi][2], acc[ni][mi][3])};
         *reinterpret_cast<uint2*>(reg + (mh * 16 + lr) * C::EPI_STRIDE + (ni * 16 + lq * 4) * 2) = o;
       }
+    // The common case - the wave's rows and columns all inside C, 16-B aligned rows, plain row addressing - without a branch
+    // per row segment, the residual segments all requested before the first is added (as in gemm256.hip: in the general loop
+    // below every conditional residual load is followed by its own vmcnt(0)).
+    {
+      constexpr int NIT = C::EPI_ROWS / RPP;
+      const int wmh = wm0 + half * C::EPI_ROWS;
+      const bool plain_rows = (p.res_mod | p.gR | p.gC | p.c_live_mod) == 0;
+      if (plain_rows && vec_ok && wmh + C::EPI_ROWS <= p.M && n0 + cbase(C::NT - 1) + 16 <= p.N) {
+        const int row0 = lane / CH, ch = lane % CH;
+        const int n = n0 + cbase(ch >> 1) + (ch & 1) * 8;
+        if (Rb) {
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          u32x4 rv[NIT];
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) rv[it] = *reinterpret_cast<const u32x4*>(Rb + (long long)(wmh + it * RPP + row0) * p.ldr + n);
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            const int row = it * RPP + row0;
+            const uint4 v = *reinterpret_cast<const uint4*>(reg + row * C::EPI_STRIDE + ch * 16);
+            const unsigned a[4] = {v.x, v.y, v.z, v.w};
+            unsigned o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              o[k] = pack2(bf2f((bf16_t)(a[k] & 0xffff)) + bf2f((bf16_t)(rv[it][k] & 0xffff)), bf2f((bf16_t)(a[k] >> 16)) + bf2f((bf16_t)(rv[it][k] >> 16)));
+            *reinterpret_cast<uint4*>(Cb + (long long)(wmh + row) * p.ldc + n) = uint4{o[0], o[1], o[2], o[3]};
+          }
+        } else {
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            const int row = it * RPP + row0;
+            *reinterpret_cast<uint4*>(Cb + (long long)(wmh + row) * p.ldc + n) = *reinterpret_cast<const uint4*>(reg + row * C::EPI_STRIDE + ch * 16);
+          }
+        }
+        continue;
+      }
+    }
 #pragma unroll
     for (int it = 0; it < C::EPI_ROWS / RPP; ++it) {
       const int row = it * RPP + lane / CH, ch = lane % CH;
@@ -471,16 +507,14 @@ inline bool use_256(int M, int N, int K, int batch, int act) {
 }
 inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode, int batch = 1, int split = 1, int act = 0) {
   if (rope_mode == 0 && split == 1) {
-    if (force == 6) return {256, 257};                 // 256 x 256 staggered 8-phase kernel (gemm256.hip)
+    if (force == 6 || force == 4) return {256, 257};   // 256 x 256 staggered 8-phase kernel (gemm256.hip); 4 = its round-1 predecessor
     if (force == 0 && use_256(M, N, K, batch, act)) return {256, 257};
   }
   if (rope_mode == 1) return {128, 128};   // rotate_half: 8 waves, each owning 16 columns of both halves of one head
   if (force == 1 && rope_mode == 0) return {256, 128};
   if (force == 2) return {128, 128};
   if (force == 3) return {128, 64};
-  if (force == 4 && rope_mode == 0) return {256, 256};
   if (force == 5 && rope_mode == 0) return {128, 129};   // 128x128 with 4 waves of 64x64 (the round-1 v1 geometry)
-  if (M >= 8192 && N >= 8192 && K >= 8192) return {256, 256};   // 64x128 wave tiles: 12 LDS reads per 32 MFMAs (1201 vs 1093 TF/s)
   // In situ (whole training step, same-box A/B) the 8-wave 128x128 geometry beats the narrow tile on every shape of
   // the step, including the M=256 head GEMMs that overlap the LLM on the side stream (48.5 vs 49.5 vs 52.0 ms/step
   // for always-square / mixed / always-narrow); the narrow tile stays available through VLA_GEMM_TILE=3.
@@ -602,8 +636,7 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   else if (d->rope_mode == 2) {
     if (tc.bn == 128) launch<128, 128, 2, 2, 4>(p, d->M, d->N, d->batch, st);
     else launch<128, 64, 2, 2>(p, d->M, d->N, d->batch, st);
-  } else if (tc.bm == 256 && tc.bn == 256) launch<256, 256, 2, 0>(p, d->M, d->N, split > 1 ? split : d->batch, st);
-  else if (tc.bm == 256) launch<256, 128, 3, 0, 4>(p, d->M, d->N, split > 1 ? split : d->batch, st);   // 16 waves, loads two K-tiles ahead
+  } else if (tc.bm == 256) launch<256, 128, 3, 0, 4>(p, d->M, d->N, split > 1 ? split : d->batch, st);   // 16 waves, loads two K-tiles ahead
   else if (tc.bn == 129) launch<128, 128, 2, 0>(p, d->M, d->N, split > 1 ? split : d->batch, st);      // 4 waves of 64x64 (forced only)
   else if (tc.bn == 128) launch<128, 128, 2, 0, 4>(p, d->M, d->N, split > 1 ? split : d->batch, st);   // 8 waves (2x4) of 64x32
   else launch<128, 64, 2, 0>(p, d->M, d->N, split > 1 ? split : d->batch, st);
