@@ -685,12 +685,31 @@ __global__ void copy2d_kernel(const TS* __restrict__ src, TD* __restrict__ dst, 
   }
 }
 
+// same-type rows of whole 16-B chunks (the staged pixel tensor: one row of 9.6 MB): 16 B per lane
+__global__ void copy2d_vec_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long long rows, long long cols16, long long ld_src16,
+                                  long long ld_dst16) {
+  const long long total = rows * cols16;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / cols16, c = i - r * cols16;
+    dst[r * ld_dst16 + c] = src[r * ld_src16 + c];
+  }
+}
+
 extern "C" int vla_copy2d(void* stream, const void* src, void* dst, long long rows, int cols, long long ld_src, long long ld_dst,
                           int src_dtype, int dst_dtype, int src_mod, int d_group, long long d_group_stride) {
   VLA_REQUIRE(src && dst && rows > 0 && cols > 0 && src_mod >= 0 && d_group >= 0, "copy2d: bad args");
   VLA_REQUIRE((src_dtype == 0 || src_dtype == 1) && (dst_dtype == 0 || dst_dtype == 1), "copy2d: dtype 0 (bf16) / 1 (f32)");
-  const dim3 g = GRID1D(rows * cols, 256);
   hipStream_t st = (hipStream_t)stream;
+  const int esz = src_dtype == 0 ? 2 : 4, per16 = 16 / esz;
+  if (src_dtype == dst_dtype && src_mod == 0 && d_group == 0 && cols % per16 == 0 && ld_src % per16 == 0 && ld_dst % per16 == 0 &&
+      ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0) {
+    const long long c16 = cols / per16;
+    hipLaunchKernelGGL(copy2d_vec_kernel, GRID1D(rows * c16, 256), dim3(256), 0, st, (const uint4*)src, (uint4*)dst, rows, c16, ld_src / per16,
+                       ld_dst / per16);
+    VLA_CHECK_LAUNCH("copy2d");
+    return VLA_OK;
+  }
+  const dim3 g = GRID1D(rows * cols, 256);
 #define CP(TS, TD) hipLaunchKernelGGL((copy2d_kernel<TS, TD>), g, dim3(256), 0, st, (const TS*)src, (TD*)dst, rows, cols, ld_src, ld_dst, src_mod, d_group, d_group_stride)
   if (src_dtype == 0 && dst_dtype == 0) CP(bf16_t, bf16_t);
   else if (src_dtype == 1 && dst_dtype == 0) CP(float, bf16_t);

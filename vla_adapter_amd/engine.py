@@ -521,7 +521,8 @@ class Head:
 
     def refresh_forward_operands(self):
         if self._stale_fwd:
-            self.pfc1_pad[:, :self.cfg.proprio_dim] = self.P.view("p_fc1_w")
+            pd = self.cfg.proprio_dim                  # (native strided copy: a sliced assignment is an ATen kernel on the step)
+            ops.copy2d(self.P.view("p_fc1_w"), self.pfc1_pad, self.D, pd, pd, self.pfc1_pad.stride(0))
             self._stale_fwd = False
 
     def refresh_transposes(self):
@@ -531,7 +532,7 @@ class Head:
         for k in (("w_x", "w_adp", "w_task", "w_o", "w_ffn") if self.pro else ("w_x", "w_o", "w_ffn")):
             ops.transpose(P.view(k), out=self.T[k])
         ops.transpose(P.view("p_fc2_w"), out=self.T["p_fc2_w"])
-        self.fc2T[:, :self.cfg.action_dim] = P.view("fc2_w").t()
+        ops.transpose(P.view("fc2_w"), out=self.fc2T)             # [7, D] -> columns 0..6 of the zero-padded [D, 64]
         self._stale_bwd = False
 
     def _alloc(self, B: int, Kt: int):
@@ -1355,7 +1356,8 @@ class VLAEngine:
             if tl is not None:
                 t0 = torch.cuda.Event(enable_timing=True)
                 t0.record(V)
-            self._px_stage.copy_(self._next_px)
+            n = self._next_px.numel()
+            ops.copy2d(self._next_px, self._px_stage, 1, n, n, n)     # (native copy: no ATen / runtime copy kernel on the step)
             self._px_copied = torch.cuda.Event()
             self._px_copied.record(V)
             self._g_vis.replay()

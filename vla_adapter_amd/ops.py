@@ -165,7 +165,9 @@ def transpose(x: torch.Tensor, ld_out: Optional[int] = None, out: Optional[torch
     ld = ld_out or R
     if out is None:
         shape = (nb, Cc, ld) if batched else (Cc, ld)
-        out = torch.zeros(shape, device=x.device, dtype=BF16) if ld != R else torch.empty(shape, device=x.device, dtype=BF16)
+        out = torch.empty(shape, device=x.device, dtype=BF16)
+        if ld != R:
+            zero_(out)                 # (native fill: the padding columns; torch.zeros would put an ATen kernel on the step)
     N.check(_lib().vla_transpose_bf16(_st(), _p(x), _p(out), R, Cc, x.stride(-2), out.stride(-2), nb,
                                       x.stride(0) if batched else 0, out.stride(0) if batched else 0), "transpose")
     return out
