@@ -1031,6 +1031,22 @@ def test_gemm256_persistent_walk_small_grids(ops, grid, monkeypatch):
     assert torch.equal(fused, fused_r)
 
 
+@pytest.mark.parametrize("grid", [None, "5"])
+def test_gemm256_fused_rope_half_bit_identical(ops, grid, monkeypatch):
+    """The rotate_half RoPE epilogue of the 256-row kernel (the LLM's q|k|v projection: 14 + 2 rotated heads, v untouched) against
+    the 128-row kernel's, bit for bit - at the step's shape, on a ragged one (last rows / partial column tile) and walked by a
+    grid of five workgroups."""
+    if grid:
+        monkeypatch.setenv("VLA_GEMM256_GRID", grid)
+    for B, S, H, KV, K in [(16, 352, 14, 2, 896), (3, 100, 6, 2, 320)]:
+        dh = 64
+        N = (H + 2 * KV) * dh
+        x, w, bias = gen(B * S, K, seed=271).to(DEV), gen(N, K, seed=272, scale=0.05).to(DEV), gen(N, seed=273).to(DEV)
+        cos, sin = ops.rope_half_tables(S, dh, 1e6, DEV)
+        out, ref = _both_tiles(monkeypatch, lambda: ops.gemm_nt(x, w, bias=bias, rope=(1, cos, sin, S, dh, (H + KV) * dh)))
+        assert torch.equal(out, ref), f"gemm256 rope {B}x{S}: {(out.float() - ref.float()).abs().max().item()}"
+
+
 def test_gemm_forced_tile_with_split_k(ops, monkeypatch):
     """Forced big tiles used to launch grid.z = batch instead of the K-slice count: every forced tile must agree
     with the automatic split-K result."""

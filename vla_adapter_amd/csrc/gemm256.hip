@@ -496,7 +496,37 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
                 pk[mh][t4][mi] = uint2{pack2(x[0], x[1]), pack2(x[2], x[3])};
               }
         };
-        if (p.bias_post) phase_a([](float v) { return v; }, std::true_type{});       // (plain epilogue only: checked by the host)
+        // HF rotate_half RoPE on the projected q / k columns (rope_mode 1, head dim 64 == this wave's 64 columns: d <-> d + 32 are
+        // the n tiles t4 and t4 + 2 of the same lane), on the bf16-rounded projection, every product rounded - the arithmetic of
+        // gemm.hip's fused epilogue, value for value
+        auto phase_a_rope = [&]() {
+          const float alpha = p.alpha;
+#pragma unroll
+          for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+              const int pos = min(em0 + wr * 128 + mh * 64 + mi * 16 + lr, p.M - 1) % p.rope_T;
+#pragma unroll
+              for (int ni = 0; ni < 2; ++ni) {
+                const int d = ni * 16 + lq * 4;
+                const f32x4 c = *reinterpret_cast<const f32x4*>(p.rope_cos + (long long)pos * 32 + d);
+                const f32x4 sn = *reinterpret_cast<const f32x4*>(p.rope_sin + (long long)pos * 32 + d);
+                const f32x4 xa = acc[mh][0][ni][mi], xb = acc[mh][1][ni][mi];       // n tiles ni and ni + 2
+                float ya[4], yb[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  const float a = rbf(xa[j] * alpha + bv[ni][j]), b = rbf(xb[j] * alpha + bv[ni + 2][j]);
+                  ya[j] = rbf(a * c[j]) + rbf(-b * sn[j]);
+                  yb[j] = rbf(b * c[j]) + rbf(a * sn[j]);
+                }
+                pk[mh][ni][mi] = uint2{pack2(ya[0], ya[1]), pack2(ya[2], ya[3])};
+                pk[mh][ni + 2][mi] = uint2{pack2(yb[0], yb[1]), pack2(yb[2], yb[3])};
+              }
+              __builtin_amdgcn_sched_barrier(0);      // (one row block's table segments at a time)
+            }
+        };
+        if (p.rope_mode == 1 && wn0 < p.rope_cols) phase_a_rope();
+        else if (p.bias_post) phase_a([](float v) { return v; }, std::true_type{});       // (plain epilogue only: checked by the host)
         else if (p.act == VLA_ACT_GELU) phase_a([](float v) { return gelu_erf(rbf(v)); }, std::false_type{});
         else if (p.act == VLA_ACT_RELU) phase_a([](float v) { return fmaxf(v, 0.f); }, std::false_type{});
         else if (p.act == VLA_ACT_GELU_TANH) phase_a([](float v) { return gelu_tanh(rbf(v)); }, std::false_type{});
