@@ -123,9 +123,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
       S = mfma32(kf, qf[ks], S);
     }
     // scale, then (only when the tile is not entirely visible to every query of the wave - a wave-uniform test) mask.
-    // The mask-only branch replaces an earlier if/else of two complete loops, for which the compiler produced wrong
-    // values for accumulator register 15 (key rows 27 / 31) whenever the masked arm ran with those rows unmasked
-    // (tests/test_kernels_gpu.py::test_attention_fwd_sparse_key_masks).
+    // The mask-only branch replaces an earlier if/else of two complete loops; with that form accumulator register 15
+    // (key rows 27 / 31) came out wrong whenever the masked arm ran with those rows unmasked.  The cause was NOT isolated
+    // (no ISA diff or minimal repro was kept, so "miscompiled" is a guess, not a finding); what guards this code is the
+    // sweep that caught it: tests/test_kernels_gpu.py::test_attention_fwd_sparse_key_masks (single keys, runs, both halves).
 #pragma unroll
     for (int r = 0; r < 16; ++r) S[r] *= p.scale_log2;
     if (!(km == 0xffffffffu && (!p.causal || k0 + 31 <= q0 + p.q_off))) {
