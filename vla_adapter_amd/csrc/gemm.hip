@@ -506,13 +506,15 @@ inline bool use_256(int M, int N, int K, int batch, int act) {
   return M >= 1024 && N >= 768 && K >= 256 && tiles >= 96;
 }
 inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode, int batch = 1, int split = 1, int act = 0) {
-  // rotate_half RoPE is fused in both kernels (bit-identical); the LLM's q|k|v projection stays on the 128-row kernel unless
-  // VLA_ROPE256 is set: isolated the 256-row kernel is 25 % faster on it (28 vs 36 us), on the whole step it measured
-  // 26.10-26.20 ms against 26.07-26.10 (same box, three alternating runs each)
-  static const bool rope256 = getenv("VLA_ROPE256") != nullptr;
+  // rotate_half RoPE is fused in both kernels (bit-identical).  The LLM's q|k|v projection goes to the 256-row kernel when it
+  // fills most of the chip with its tiles (whole-batch launch, M = 11264: 220 tiles, 26.64-26.69 vs 26.84-26.85 ms on the step,
+  // same box); the half-batch launches of the two-pipeline forward (110 tiles) measured 26.10-26.20 vs 26.07-26.10 and stay
+  // on the 128-row kernel.  VLA_NO_ROPE256 switches it off.
+  static const bool no_rope256 = getenv("VLA_NO_ROPE256") != nullptr;
   if ((rope_mode == 0 || rope_mode == 1) && split == 1) {     // (interleaved RoPE: 128-row kernel only)
     if (force == 6 || force == 4) return {256, 257};   // 256 x 256 staggered 8-phase kernel (gemm256.hip); 4 = its round-1 predecessor
-    if (force == 0 && (rope_mode == 0 || rope256) && use_256(M, N, K, batch, act)) return {256, 257};
+    const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256) * batch;
+    if (force == 0 && (rope_mode == 0 || (!no_rope256 && t256 >= 192)) && use_256(M, N, K, batch, act)) return {256, 257};
   }
   if (rope_mode == 1) return {128, 128};   // rotate_half: 8 waves, each owning 16 columns of both halves of one head
   if (force == 1 && rope_mode == 0) return {256, 128};

@@ -1150,6 +1150,8 @@ class VLAEngine:
         # long chunks at the bottom layers, single layers at the top: the head's last forward chunk and first backward
         # chunk (the serial turn-around) stay short; the backward walks the same ranges top-down
         fch = self._chunks(n, [4] * max(0, (n - 4) // 4) + [2, 1, 1]) if n >= 8 else self._chunks(n, [1])
+        if os.environ.get("VLA_FWD_CHUNKS"):                  # A/B knob: "4,4,4,4,4,2,1,1"
+            fch = self._chunks(n, [int(x) for x in os.environ["VLA_FWD_CHUNKS"].split(",")])
         segs = []
 
         def m_begin():
@@ -1203,7 +1205,11 @@ class VLAEngine:
         # leaves the chip idle in every kernel's tail and at every kernel boundary; two half-batch chains fill each other's
         # gaps (the backward phase already has three streams and is bound by total GEMM throughput instead).
         # (three and four pipelines measured 33-34.6 ms against 27.9 for two and 28.4 for one, same box)
-        npipe = int(os.environ.get("VLA_LLM_PIPES", "2")) if self.B >= 8 and not os.environ.get("VLA_NO_LLM_SPLIT") else 1
+        # Round 2: that was the 128-row GEMM (two workgroups per CU: a half-batch launch is 1.6 rounds of tiles and its tail
+        # is filled by the other pipeline).  With the persistent 256 x 256 kernel (one workgroup per CU, whole-batch launches =
+        # 6.5 rounds of gate/up tiles instead of 3.3 twice, half the launches) ONE pipeline is faster: 25.27-25.34 vs
+        # 25.61-25.75 ms, 25.96-26.01 vs 26.59 on a second box.  VLA_LLM_PIPES=2 restores the two pipelines.
+        npipe = int(os.environ.get("VLA_LLM_PIPES", "1")) if self.B >= 8 and not os.environ.get("VLA_NO_LLM_SPLIT") else 1
         if npipe > 1:
             cuts = [self.B * j // npipe for j in range(npipe + 1)]
             segs.append(("M", m_begin, None, ("e", 0)))
@@ -1334,7 +1340,8 @@ class VLAEngine:
         # layer each and are latency-bound with the head trailing them); same-box sweep at B = 32: last 31.52 ms/step,
         # second-last 31.33, third-last 31.14, fourth-last 31.35.  VLA_VIS_AFTER overrides.
         m_fwd = [k for k, sg in enumerate(self._segs) if sg[0] == "M" and sg[3] is not None and sg[3][0] == "f"]
-        self._vis_after = m_fwd[min(len(m_fwd) - 1, max(0, int(os.environ.get("VLA_VIS_AFTER", len(m_fwd) - 3))))]
+        # (fourth-last forward segment: 26.51 vs 26.64-26.69 ms for the third-last with the one-pipeline forward, same box)
+        self._vis_after = m_fwd[min(len(m_fwd) - 1, max(0, int(os.environ.get("VLA_VIS_AFTER", len(m_fwd) - 4))))]
         self._launch_vision()                        # vision stage of the FIRST step (the pixels given to capture)
 
     def stage_next_pixels(self, pixel_values: torch.Tensor):
