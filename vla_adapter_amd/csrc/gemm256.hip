@@ -1,7 +1,7 @@
 // bf16 NT GEMM, 256 x 256 x 64 tile, for the large products of the step (LLM gate/up, down, ViT qkv / fc1 / fc2, the
 // head's task K/V, the full-sequence backward):  C[M,N] = epilogue(A[M,K] . B[N,K]^T), fp32 accumulation on
 // v_mfma_f32_16x16x32_bf16.  Same contract and epilogue rounding points as gemm.hip (which keeps the 128-row tiles for
-// small-M / small-N problems and the fused RoPE epilogues).
+// small-M / small-N problems, the SwiGLU-backward epilogue and the interleaved RoPE epilogue).
 //
 // Why a second kernel: the 128 x 128 tile moves 32 KB of operands per 2.1 MFLOP (64 FLOP per staged byte) and sits at the
 // CU's global->LDS fill rate; this tile stages half the bytes per FLOP and keeps its LDS-DMA in flight
@@ -126,8 +126,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
   auto stage_k0 = [&](int buf) {
     stage_b(buf * 4 + 0, 0, 0); stage_a(buf * 4 + 1, 0, 0); stage_b(buf * 4 + 2, 1, 0); stage_a(buf * 4 + 3, 1, 0);
   };
-  // bias slice of this wave's 64 columns (4 per lane and n tile): requested at the top of the tile BEHIND K-tile 1, as exactly
-  // four loads when the vector path applies (the top's counted wait leaves them in flight), none otherwise
+  // bias slice of this wave's 64 columns (4 per lane and n tile): requested at the top of the tile BEHIND K-tile 1, always as
+  // exactly four loads (the top's counted wait leaves them in flight; its count is hand-written)
   uint2 braw[4];
   auto bias_vec = [&]() {
     const bf16_t* bias = (EPI != 2 && p.bias) ? p.bias + (long long)z * p.sBias : nullptr;
