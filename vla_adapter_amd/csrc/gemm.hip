@@ -636,7 +636,37 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   const TileChoice tc = choose_tile(d->M, d->N, d->K / split, e ? atoi(e) : 0, d->rope_mode, split > 1 ? split : d->batch, split, d->act);
   hipStream_t st = (hipStream_t)stream;
   if (tc.bm == 256 && tc.bn == 257) {          // 256 x 256 staggered 8-phase kernel (gemm256.hip)
-    vla_gemm256_launch(p, d->act == VLA_ACT_SWIGLU ? 1 : d->act == VLA_ACT_SWIGLU_BWD ? 2 : 0, d->batch, st);
+    const int epi = d->act == VLA_ACT_SWIGLU ? 1 : d->act == VLA_ACT_SWIGLU_BWD ? 2 : 0;
+    // Tail round.  A launch of r full rounds of tiles plus a few more (ViT fc1: 32 x 17 = 544 tiles on 256 CUs = two rounds
+    // and 32 tiles, which cost a third tile time on every CU's clock: 105 us instead of ~70) is cut along N: the leading
+    // column tiles that make exactly r rounds stay here, the last column tile(s) go to the 128-row kernel behind it (same
+    // stream, ~a quarter of the chip for ~20 us).  Every epilogue option addresses rows and columns independently, so the
+    // second launch is the same problem on shifted column pointers.  OFF unless VLA_COLPEEL is set: isolated it turns fc1's
+    // 105 us into ~80, on the whole step it measured 24.85-24.94 ms against 24.75-24.81 without (same box, three alternating
+    // runs; round-2a's Python-side version of the same cut: 26.9 vs 26.8) - the other streams already fill the tail round.
+    static const bool no_peel = getenv("VLA_COLPEEL") == nullptr;
+    const int ncu = vla_num_cus();
+    const int tm = (p.M + 255) / 256, tn = (p.N + 255) / 256;
+    int peel = 0;
+    if (!no_peel && e == nullptr && d->batch == 1 && epi != 2 && d->rope_mode == 0 && (long long)tm * tn > ncu) {
+      for (int c = 1; c <= 2 && c < tn; ++c)
+        if (((long long)tm * (tn - c)) % ncu == 0 && (long long)tm * c * 4 <= 2 * ncu) { peel = c; break; }   // tail <= one round of 128-row tiles
+    }
+    if (peel == 0) {
+      vla_gemm256_launch(p, epi, d->batch, st);
+    } else {
+      const int n1 = (tn - peel) * 256;          // columns of the main launch; the tail takes [n1, N)
+      GemmP a = p, b = p;
+      a.N = n1;
+      b.N = p.N - n1;
+      b.B = p.B + (long long)n1 * p.ldb;
+      if (p.bias) b.bias = p.bias + n1;
+      if (p.C) b.C = p.C + n1;
+      if (p.R) b.R = p.R + n1;
+      if (p.C2) b.C2 = p.C2 + n1 / 2;             // SwiGLU: h columns are half the interleaved gate/up columns
+      vla_gemm256_launch(a, epi, 1, st);
+      launch<128, 128, 2, 0, 4>(b, b.M, b.N, 1, st);
+    }
   } else if (d->act == VLA_ACT_SWIGLU_BWD) launch<128, 128, 2, 3, 4>(p, d->M, d->N, d->batch, st);
   else if (d->rope_mode == 1) launch<128, 128, 2, 1, 4>(p, d->M, d->N, d->batch, st);   // 8 waves, rotation pairs inside a lane
   else if (d->rope_mode == 2) {

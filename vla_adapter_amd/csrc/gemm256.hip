@@ -703,6 +703,8 @@ int launch256(const GemmP& p0, int batch, hipStream_t st) {
 
 }  // namespace
 
+int vla_num_cus() { return num_cus(); }
+
 int vla_gemm256_launch(const GemmP& p, int epi, int batch, hipStream_t st) {
   if (epi == 1) return launch256<1>(p, batch, st);
   if (epi == 2) return launch256<2>(p, batch, st);

@@ -21,3 +21,4 @@ struct GemmP {
 
 // gemm256.hip: 256x256x64 tile, 8 waves, staggered 8-phase schedule.  epi: 0 plain, 1 SwiGLU forward, 2 SwiGLU backward.
 int vla_gemm256_launch(const GemmP& p, int epi, int batch, hipStream_t st);
+int vla_num_cus();      // compute units of the current device (cached)
