@@ -259,6 +259,43 @@ def bench_full(args, cfg, W, eng, batch, noise, lr, rank, local, world, B, P):
         dist.destroy_process_group()
 
 
+def bench_lora(args, cfg, W, eng, batch, noise, lr, rank, local, world, B, P):
+    """LoRA fine-tune step (reference --use_lora, rank 64, all Linears of the ViT / projector / LLM + the adapter head), the 0.5B
+    backbone of BASELINE configs[1]: forward with the low-rank terms, full-sequence dX chain, dA / dB, AdamW over adapters + head.
+    Not the headline metric; same JSON contract."""
+    from vla_adapter_amd import flops
+    from vla_adapter_amd.lora_finetune import LoRAFinetune
+    ft = LoRAFinetune(eng, rank=args.lora_rank)
+    if args.eager:
+        step = lambda: ft.train_step(batch, lr, noise)
+    else:
+        ft.capture(batch, noise)
+        step = lambda: ft.train_step_graphed(lr)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss3 = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = dt / args.steps * 1e3
+    fl = flops.step_flops_per_sample(cfg, L=P + 64, row0=0)
+    work = 2.0 * fl["forward"]                                 # forward + dX of every op (base dW is not computed; rank-64 terms ~2 %)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "fine-tune samples/sec (224px img + 32-tok prompt), LoRA rank %d on every Linear + adapter head, fwd+bwd+AdamW" % args.lora_rank,
+            "value": round(B * args.steps / dt, 2), "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "Prismatic SigLIP-224 + Qwen2.5-0.5B + Pro action head, LoRA fine-tune (the 0.5B stand-in for BASELINE configs[4]), "
+                                   "1 image (256 patches) + 32-token prompt + 64 action queries (S=352)",
+                       "global_batch": B, "per_gpu_batch": B, "seq_len": cfg.n_patches + P + 64, "parallelism": "dp1", "weights": "random-init",
+                       "launch": "eager" if args.eager else "hipGraph replay", "final_loss": round(float(loss3[0]), 5)},
+            "step_tflops_per_gpu": round(work * B / (ms * 1e-3) / 1e12, 1),
+            "step_frac_of_bf16_mfma_peak": round(work * B / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+        }), flush=True)
+
+
 MARKER_BYTES = 16 * 256 * 4099      # 4099 workgroups of 256 threads x 16 B (tools/summarise_profiles.py looks for this grid)
 
 
@@ -268,8 +305,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (BASELINE configs[1]: 32; --mode full = configs[3]: 16)")
-    ap.add_argument("--mode", default="adapter", choices=["adapter", "full"],
-                    help="adapter: BASELINE configs[1]/[2] (the headline metric); full: configs[3], every VLM parameter trains")
+    ap.add_argument("--mode", default="adapter", choices=["adapter", "full", "lora"],
+                    help="adapter: BASELINE configs[1]/[2] (the headline metric); full: configs[3], every VLM parameter trains; "
+                         "lora: rank-r adapters on every Linear (the reference's --use_lora) on the 0.5B backbone")
+    ap.add_argument("--lora-rank", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=4, help="samples of the batch the CPU oracle is timed on (3 steps each: about 12 s of CPU work)")
     ap.add_argument("--no-full-backward", action="store_true", help="skip the extra timing of the reference-shaped full LLM backward")
@@ -307,6 +346,9 @@ def main():
     lr = 5e-4
     if args.mode == "full":
         return bench_full(args, cfg, W, eng, batch, noise, lr, rank, local, world, B, P)
+    if args.mode == "lora":
+        assert world == 1, "--mode lora: single-GPU measurement"
+        return bench_lora(args, cfg, W, eng, batch, noise, lr, rank, local, world, B, P)
 
     def barrier():
         if dist.get_backend() == "nccl":

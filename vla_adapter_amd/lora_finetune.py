@@ -371,6 +371,35 @@ class LoRAFinetune:
         self.optimizer_step(lr)
         return loss3
 
+    # ---- hipGraph replay (as FullFinetune.capture): a LoRA step is ~4000 launches, more host time than GPU time from Python ------
+    def capture(self, batch: Dict[str, torch.Tensor], noise: Optional[torch.Tensor] = None, warmup: int = 2):
+        """Forward + backward as ONE linear hipGraph on the static ``batch`` / ``noise`` buffers (copy new data into them before
+        each replay); AdamW stays outside (host-side bias corrections), the derived-operand rebuild is a second small graph."""
+        self._cap_stream = torch.cuda.Stream()
+        for _ in range(warmup):
+            self.head.dirty = True
+            self.backward(self.forward(batch, noise), batch["actions"])
+        torch.cuda.synchronize()
+        self.head.dirty = True                       # the head's own W^T / padded-operand refresh becomes part of the graph
+        pool = torch.cuda.graph_pool_handle()
+        self._g_step = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_step, pool=pool, stream=self._cap_stream, capture_error_mode="thread_local"):
+            self._loss3 = self.backward(self.forward(batch, noise), batch["actions"])
+        self._g_r = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_r, pool=pool, stream=self._cap_stream, capture_error_mode="thread_local"):
+            self.refresh()
+        torch.cuda.synchronize()
+
+    def train_step_graphed(self, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, wd=0.01):
+        assert self.eng.reducer is None, "captured LoRA step: single process (the exchange of train_step is not in the graph)"
+        self._g_step.replay()
+        self.step_count += 1
+        P, HP = self.P, self.head.P
+        ops.adamw_(P.data, P.grad, P.m, P.v, self.step_count, lr, beta1, beta2, eps, wd)
+        ops.adamw_(HP.data, HP.grad, HP.m, HP.v, self.step_count, lr, beta1, beta2, eps, wd)
+        self._g_r.replay()
+        return self._loss3
+
     def merged_weights(self) -> Dict[str, torch.Tensor]:
         """W + 2 B A per target under the engine's fused names (merge_lora_weights_and_save.py / finetune.py:579-601 merge the
         adapter into a fresh bf16 base): fp32 product, one rounding."""
