@@ -1001,6 +1001,36 @@ def test_gemm256_repeatable_under_load(ops, monkeypatch):
     assert all(torch.equal(o, first) for o in outs) and all(torch.equal(o, first2) for o in outs2)
 
 
+def test_gemm256_persistent_step_shapes_repeatable_under_load(ops, monkeypatch):
+    """Race screen of the persistent walk at the step's whole-batch shapes: gate/up with the SwiGLU epilogue and live-row stores
+    (1672 tiles, 6.5 per workgroup: next tile's K-tile 0 lands in one K-tile buffer while the epilogue stages through the
+    other) and the down projection with residual (176 tiles), repeated back to back while a second stream runs the ViT's fc1 -
+    every repetition bit-identical to the first, and the first bit-identical to the 128-row kernel."""
+    M, D, I, S, r0 = 11264, 896, 4864, 352, 288
+    x, wgu, wd = gen(M, D, seed=281).to(DEV), gen(2 * I, D, seed=282, scale=0.05).to(DEV), gen(D, I, seed=283, scale=0.05).to(DEV)
+    res = gen(M, D, seed=284).to(DEV)
+    a2, b2 = gen(8192, 1152, seed=285).to(DEV), gen(4352, 1152, seed=286, scale=0.05).to(DEV)
+    pre = torch.zeros(M, 2 * I, dtype=BF, device=DEV)
+    monkeypatch.setenv("VLA_GEMM_TILE", "2")
+    pre_r = torch.zeros(M, 2 * I, dtype=BF, device=DEV)
+    _, h_r = ops.gemm_nt(x, wgu, act=ops.ACT_SWIGLU, out=pre_r, c_live=(S, r0))
+    y_r = ops.gemm_nt(h_r, wd, residual=res)
+    monkeypatch.setenv("VLA_GEMM_TILE", "0")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    hs, ys, others = [], [], []
+    for _ in range(8):
+        _, h = ops.gemm_nt(x, wgu, act=ops.ACT_SWIGLU, out=pre, c_live=(S, r0))
+        hs.append(h)
+        ys.append(ops.gemm_nt(h, wd, residual=res))
+        with torch.cuda.stream(side):
+            others.append(ops.gemm_nt(a2, b2, act=1))
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert all(torch.equal(h, h_r) for h in hs) and all(torch.equal(y, y_r) for y in ys) and torch.equal(pre, pre_r)
+    assert all(torch.equal(o, others[0]) for o in others)
+
+
 @pytest.mark.parametrize("grid", ["1", "3", "8", "37"])
 def test_gemm256_persistent_walk_small_grids(ops, grid, monkeypatch):
     """The persistent walk proper: a forced grid of 1 / 3 / 8 / 37 workgroups makes each of them run many tiles back to back
