@@ -68,7 +68,16 @@ typedef struct vla_gemm_desc {
    * projections of the strided h_t slice at batch size > 1 (action_heads.py:57, 118, 366-367); pinned by the reference-run
    * fixtures tests/golden/head_bf16_*.npz.  0 = the fused single rounding bf16(alpha A.B^T + bias). */
   int bias_post_round;
+  /* optional (round 2; BASELINE configs[4]'s "fp8 MFMA weight path" - the reference has no fp8 code, parity unpinned):
+   * fp8 = 1: A and B point at OCP e4m3 bytes (lda / ldb in elements, multiples of 16; K % 128 == 0), a_scale[M] / b_scale[N]
+   * are the per-row dequantisation factors (vla_quant_fp8_rows): C = epilogue(a_scale[m] b_scale[n] (A . B^T)[m, n]).
+   * Plain / activation / residual / SwiGLU-forward / rotate_half epilogues; no split-K, no batch. */
+  int fp8; const float* a_scale; const float* b_scale;
 } vla_gemm_desc;
+
+/* Row-wise dynamic fp8 quantisation: q[r, :] = e4m3(x[r, :] * 448 / amax_r) (round to nearest even, saturating), scale[r] =
+ * amax_r / 448 (1 for an all-zero row).  x bf16 [rows, cols] (ldx), q bytes [rows, cols] (ldq, % 16 == 0), cols % 8 == 0. */
+int vla_quant_fp8_rows(void* stream, const void* x, void* q, float* scale, int rows, int cols, int ldx, int ldq);
 
 /* C = epilogue(A . B^T).  Replaces nn.Linear forward and, with pre-transposed operands, its dX / dW products:
  * timm ViT qkv/proj/mlp (modeling_prismatic.py:120-144), PrismaticProjector (:261-273), Qwen2 q/k/v/o/gate/up/down

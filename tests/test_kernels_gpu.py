@@ -1087,3 +1087,80 @@ def test_gemm_forced_tile_with_split_k(ops, monkeypatch):
         monkeypatch.setenv("VLA_GEMM_TILE", str(tile))
         out = ops.gemm_nt(a, w, bias=bias, split_k=4)
         check(out, f(ref), rel=2e-3, name=f"split-K 4 with forced tile {tile}")
+
+
+# ------------------------------------------------------------------------------------------------ fp8 (OCP e4m3) weight path
+# BASELINE configs[4] names an "fp8 MFMA weight path"; the reference has no fp8 code, so there is nothing to pin against:
+# PARITY UNPINNED.  What is checked: the quantiser against torch's own e4m3 conversion of the same scaled values (bit-exact
+# codes), and the GEMM against the fp32 product of the DEQUANTISED operands (the arithmetic the kernel claims to do).
+def _q8_ref(x):
+    amax = x.float().abs().amax(dim=1, keepdim=True)
+    inv = torch.where(amax > 0, 448.0 / amax, torch.ones_like(amax))
+    q = (x.float() * inv).to(torch.float8_e4m3fn)
+    return q, torch.where(amax > 0, amax / 448.0, torch.ones_like(amax)).squeeze(1)
+
+
+@pytest.mark.parametrize("rows,cols", [(37, 896), (256, 1152), (5, 64), (300, 4864)])
+def test_quant_fp8_rows_matches_torch_e4m3(ops, rows, cols):
+    x = gen(rows, cols, seed=301, scale=1.7)
+    x[1] = 0                                                     # an all-zero row: scale 1, codes 0
+    q, s = ops.quant_fp8_rows(x.to(DEV))
+    qr, sr = _q8_ref(x)
+    assert torch.equal(s.cpu(), sr), (s.cpu() - sr).abs().max()
+    # Codes equal torch's round-to-nearest-even conversion - except where the scaled fp32 value sits within two of its ulps of a
+    # rounding tie: v_cvt_pk_fp8_f32 resolves those as ties (to the even code; observed: 10.500000954 -> 10, torch -> 11).
+    # There the kernel's code must be one of the two neighbours, and such elements must be rare.
+    got, want = q.cpu().view(torch.float8_e4m3fn).float(), qr.float()
+    diff = got != want
+    assert diff.float().mean().item() < 2e-3, diff.sum()
+    if diff.any():
+        amax = x.float().abs().amax(dim=1, keepdim=True)
+        v = (x.float() * torch.where(amax > 0, 448.0 / amax, torch.ones_like(amax)))[diff]
+        tie = (got[diff] + want[diff]) / 2
+        ulp = torch.ldexp(torch.ones_like(v), torch.floor(torch.log2(v.abs())).int() - 23)
+        assert bool(((v - tie).abs() <= 2 * ulp).all()), (v - tie).abs().max()
+
+
+@pytest.mark.parametrize("M,N,K,act,res", [(256, 256, 128, 0, False), (300, 200, 384, 0, True), (1000, 896, 896, 1, False), (2048, 1152, 4352, 0, True),
+                                           (64, 24, 256, 2, False)])
+def test_gemm_fp8_matches_dequantised_product(ops, M, N, K, act, res):
+    x, w, bias, r = gen(M, K, seed=311), gen(N, K, seed=312, scale=0.05), gen(N, seed=313), gen(M, N, seed=314)
+    qa, sa = ops.quant_fp8_rows(x.to(DEV))
+    qb, sb = ops.quant_fp8_rows(w.to(DEV))
+    out = ops.gemm_nt(qa, qb, bias=bias.to(DEV), residual=r.to(DEV) if res else None, act=act, fp8=(sa, sb))
+    A = qa.cpu().view(torch.float8_e4m3fn).float() * sa.cpu()[:, None]
+    B = qb.cpu().view(torch.float8_e4m3fn).float() * sb.cpu()[:, None]
+    y = O.rnd(A @ B.t() + bias.float(), True)
+    y = {0: y, 1: O.gelu(y, True), 2: torch.relu(y)}[act]
+    check(out, O.rnd(y + r.float(), True) if res else y, name=f"fp8 gemm {M}x{N}x{K}")
+    # and the quantisation error itself stays what e4m3 with per-row scales gives (~3 % of the product's norm)
+    exact = x.float() @ w.float().t()
+    assert ((A @ B.t() - exact).norm() / exact.norm()).item() < 0.06
+
+
+def test_gemm_fp8_swiglu_and_rope_epilogues(ops):
+    M, D, I = 600, 512, 640
+    x, w = gen(M, D, seed=321), gen(2 * I, D, seed=322, scale=0.05)
+    qa, sa = ops.quant_fp8_rows(x.to(DEV))
+    qb, sb = ops.quant_fp8_rows(w.to(DEV))
+    pre, h = ops.gemm_nt(qa, qb, act=ops.ACT_SWIGLU, fp8=(sa, sb))
+    A = qa.cpu().view(torch.float8_e4m3fn).float() * sa.cpu()[:, None]
+    B = qb.cpu().view(torch.float8_e4m3fn).float() * sb.cpu()[:, None]
+    y = O.rnd(A @ B.t(), True)
+    check(pre, y, name="fp8 swiglu pre-activations")
+    g, u = y.view(M, I // 16, 2, 16)[:, :, 0].reshape(M, I), y.view(M, I // 16, 2, 16)[:, :, 1].reshape(M, I)
+    check(h, O.rnd(O.rnd(g * torch.sigmoid(g), True) * u, True), rel=6e-3, name="fp8 swiglu h")
+    Bq, S, H, KV, dh, K = 2, 40, 4, 2, 64, 256
+    N = (H + 2 * KV) * dh
+    x2, w2, bias = gen(Bq * S, K, seed=323), gen(N, K, seed=324, scale=0.1), gen(N, seed=325)
+    qa, sa = ops.quant_fp8_rows(x2.to(DEV))
+    qb, sb = ops.quant_fp8_rows(w2.to(DEV))
+    cos, sin = ops.rope_half_tables(S, dh, 1e6, DEV)
+    out = ops.gemm_nt(qa, qb, bias=bias.to(DEV), rope=(1, cos, sin, S, dh, (H + KV) * dh), fp8=(sa, sb))
+    A = qa.cpu().view(torch.float8_e4m3fn).float() * sa.cpu()[:, None]
+    B = qb.cpu().view(torch.float8_e4m3fn).float() * sb.cpu()[:, None]
+    y = O.rnd(A @ B.t() + bias.float(), True)
+    c, s = O.rope_half_tables(S, dh, 1e6, True)
+    q = O.rope_half(y[:, :H * dh].view(Bq, S, H, dh).transpose(1, 2), c, s, True).transpose(1, 2).reshape(Bq * S, H * dh)
+    k = O.rope_half(y[:, H * dh:(H + KV) * dh].view(Bq, S, KV, dh).transpose(1, 2), c, s, True).transpose(1, 2).reshape(Bq * S, KV * dh)
+    check(out, torch.cat([q, k, y[:, (H + KV) * dh:]], 1), name="fp8 gemm + rope_half")

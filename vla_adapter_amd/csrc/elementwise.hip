@@ -685,6 +685,47 @@ __global__ void copy2d_kernel(const TS* __restrict__ src, TD* __restrict__ dst, 
   }
 }
 
+// Row-wise dynamic fp8 (OCP e4m3) quantisation: one wave per row, 8 elements per lane and pass; amax by wave reduction, then
+// q = cvt(x * 448 / amax) through v_cvt_pk_fp8_f32 (RNE, saturating on gfx950), 8 bytes per lane per pass.
+__global__ void quant_fp8_rows_kernel(const bf16_t* __restrict__ x, unsigned char* __restrict__ q, float* __restrict__ scale, int rows, int cols,
+                                      long long ldx, long long ldq) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + (long long)row * ldx;
+  float amax = 0.f;
+  for (int c = lane * 8; c < cols; c += 512) {
+    const uint4 v = *reinterpret_cast<const uint4*>(xr + c);
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) amax = fmaxf(amax, fmaxf(fabsf(bf2f((bf16_t)(w[k] & 0xffff))), fabsf(bf2f((bf16_t)(w[k] >> 16)))));
+  }
+  amax = wave_max(amax);
+  // (IEEE divisions, one per row: with the approximate form a value that sits one ulp above a rounding tie lands below it)
+  const float inv = amax > 0.f ? __fdiv_rn(448.f, amax) : 1.f;
+  if (lane == 0) scale[row] = amax > 0.f ? __fdiv_rn(amax, 448.f) : 1.f;
+  unsigned char* qr = q + (long long)row * ldq;
+  for (int c = lane * 8; c < cols; c += 512) {
+    const uint4 v = *reinterpret_cast<const uint4*>(xr + c);
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f((bf16_t)(w[0] & 0xffff)) * inv, bf2f((bf16_t)(w[0] >> 16)) * inv, lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f((bf16_t)(w[1] & 0xffff)) * inv, bf2f((bf16_t)(w[1] >> 16)) * inv, lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f((bf16_t)(w[2] & 0xffff)) * inv, bf2f((bf16_t)(w[2] >> 16)) * inv, hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f((bf16_t)(w[3] & 0xffff)) * inv, bf2f((bf16_t)(w[3] >> 16)) * inv, hi, true);
+    *reinterpret_cast<uint2*>(qr + c) = uint2{(unsigned)lo, (unsigned)hi};
+  }
+}
+
+extern "C" int vla_quant_fp8_rows(void* stream, const void* x, void* q, float* scale, int rows, int cols, int ldx, int ldq) {
+  VLA_REQUIRE(x && q && scale && rows > 0 && cols > 0 && cols % 8 == 0 && ldx % 8 == 0 && ldx >= cols && ldq >= cols && ldq % 16 == 0 &&
+                  ((((uintptr_t)x) | ((uintptr_t)q)) & 15) == 0,
+              "quant_fp8_rows: cols % 8, ldx % 8, ldq % 16, 16-B aligned pointers");
+  hipLaunchKernelGGL(quant_fp8_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (unsigned char*)q, scale, rows,
+                     cols, (long long)ldx, (long long)ldq);
+  VLA_CHECK_LAUNCH("quant_fp8_rows");
+  return VLA_OK;
+}
+
 // same-type rows of whole 16-B chunks (the staged pixel tensor: one row of 9.6 MB): 16 B per lane
 __global__ void copy2d_vec_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long long rows, long long cols16, long long ld_src16,
                                   long long ld_dst16) {

@@ -62,9 +62,14 @@ struct Cfg {
 
 // ROPE is a compile-time switch (0 none / 1 rotate_half / 2 interleaved): the epilogue's extra registers and table
 // loads must not leak into the plain kernel that every other GEMM of the step runs.
-template <int BM, int BN, int STAGES, int ROPE, int WN = 2>
+// F8: operands are OCP e4m3 bytes with per-row fp32 scales (p.scaleA[m], p.scaleB[n]); a K-tile is still 128 B per row = 128
+// elements = ONE v_mfma_scale_f32_16x16x128_f8f6f4 per 16 x 16 tile (unit block scales): the same bytes moved, the same LDS
+// reads and the same MFMA cycles per K-tile as the bf16 form, at twice the FLOPs (lane l holds row l % 16, k = 32 (l / 16) +
+// byte: tools/probe_f8.py).  The scales are applied to the fp32 accumulator before anything else of the epilogue.
+template <int BM, int BN, int STAGES, int ROPE, int WN = 2, bool F8 = false>
 __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
   using C = Cfg<BM, BN, STAGES, WN>;
+  constexpr int EB = F8 ? 1 : 2;                           // bytes per operand element
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -88,28 +93,28 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
   const int bm = grp * GM + rem % gm, bn = rem / gm;
   const int m0 = bm * BM, n0 = bn * BN;
   const int z = blockIdx.z;
-  const bf16_t* Ab = p.A + (long long)z * p.sA;
-  const bf16_t* Bb = p.B + (long long)z * p.sB;
+  const char* Ab = reinterpret_cast<const char*>(p.A) + (long long)z * p.sA * EB;
+  const char* Bb = reinterpret_cast<const char*>(p.B) + (long long)z * p.sB * EB;
 
   // ---- staging: piece pc (1 KiB = 8 LDS rows) of a stage; pieces [0, BM/8) are A rows, the rest B rows.
   //      lane -> row 8pc + (lane>>3); LDS chunk lane&7 holds global chunk (lane&7) ^ (row&7)
-  const int kc = ((lane & 7) ^ ((lane >> 3) & 7)) * 8;
-  const bf16_t* pp[C::PPW];
+  const int kc = ((lane & 7) ^ ((lane >> 3) & 7)) * 16;      // bytes
+  const char* pp[C::PPW];
 #pragma unroll
   for (int i = 0; i < C::PPW; ++i) {
     const int pc = wid * C::PPW + i;                      // wave-uniform
     if (pc < BM / 8) {
       const int ra = min(m0 + pc * 8 + (lane >> 3), p.M - 1);
-      pp[i] = Ab + (p.gA > 0 ? (long long)(ra / p.gA) * p.sgA + (long long)(ra % p.gA) * p.lda : (long long)ra * p.lda) + kc;
+      pp[i] = Ab + (p.gA > 0 ? (long long)(ra / p.gA) * p.sgA + (long long)(ra % p.gA) * p.lda : (long long)ra * p.lda) * EB + kc;
     } else {
       const int rb = min(n0 + (pc - BM / 8) * 8 + (lane >> 3), p.N - 1);
-      pp[i] = Bb + (long long)rb * p.ldb + kc;
+      pp[i] = Bb + (long long)rb * p.ldb * EB + kc;
     }
   }
   auto stage = [&](int buf, int k0) {
     char* base = smem + buf * C::STAGE_BYTES + wid * C::PPW * 1024;
 #pragma unroll
-    for (int i = 0; i < C::PPW; ++i) glds16(pp[i] + k0, base + i * 1024);
+    for (int i = 0; i < C::PPW; ++i) glds16(pp[i] + k0 * 2, base + i * 1024);      // k0 in units of bf16 columns: 128 B per K-tile either way
   };
 
   f32x4 acc[C::NT][4];  // [ni][mi]
@@ -122,7 +127,8 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
   const int frow = lane & 15;
   int foff[2];
 #pragma unroll
-  for (int s = 0; s < 2; ++s) foff[s] = frow * 128 + (((4 * s + (lane >> 4)) ^ (lane & 7)) << 4);
+  for (int s = 0; s < 2; ++s)                 // (fp8: the lane's 32 contiguous bytes = chunks 2q and 2q + 1, q = lane >> 4)
+    foff[s] = frow * 128 + (((F8 ? 2 * (lane >> 4) + s : 4 * s + (lane >> 4)) ^ (lane & 7)) << 4);
 
   // epilogue coordinates: lane owns, for tile (ni, mi): m = 16mi + (lane&15), n = 16ni + 4(lane>>4) + {0..3}.
   // The bias slice is fetched HERE (one 8-B load per n-tile) so its latency hides under the main loop; fetched in the
@@ -152,7 +158,7 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
     }
   }
 
-  const int nt = p.K / BK;
+  const int nt = p.K / (F8 ? 2 * BK : BK);         // K-tiles of 128 B per row
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < nt) stage(s, s * BK);
@@ -181,13 +187,28 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
 #pragma unroll
         for (int i = 0; i < C::NT; ++i) fn[s][i] = *reinterpret_cast<const bf16x8*>(sb + cbase(i) * 128 + foff[s]);
       }
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
+      if constexpr (F8) {
+        typedef int v8i __attribute__((ext_vector_type(8)));
+        auto cat = [](bf16x8 lo, bf16x8 hi) {
+          const f32x4 l = __builtin_bit_cast(f32x4, lo), h = __builtin_bit_cast(f32x4, hi);
+          typedef float f32x8 __attribute__((ext_vector_type(8)));
+          return __builtin_bit_cast(v8i, f32x8{l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]});
+        };
 #pragma unroll
         for (int ni = 0; ni < C::NT; ++ni)
 #pragma unroll
           for (int mi = 0; mi < 4; ++mi)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[s][ni], fm[s][mi], acc[ni][mi], 0, 0, 0);
+            acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(cat(fn[0][ni], fn[1][ni]), cat(fm[0][mi], fm[1][mi]), acc[ni][mi],
+                                                                            0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int ni = 0; ni < C::NT; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+              acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[s][ni], fm[s][mi], acc[ni][mi], 0, 0, 0);
+      }
     } else {
       // 64 x 128 wave tile (128 accumulator registers): fragments per k-step, 12 reads feed 32 MFMAs
 #pragma unroll
@@ -211,6 +232,22 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
   asm volatile("" ::: "memory");
 
   // ---------------- epilogue ----------------
+  if constexpr (F8) {
+    // dequantisation: acc[m][n] *= scaleA[m] * scaleB[n] (fp32, before alpha / bias / activation)
+    float sa[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) sa[mi] = p.scaleA[min(wm0 + mi * 16 + lr, p.M - 1)];
+#pragma unroll
+    for (int ni = 0; ni < C::NT; ++ni) {
+      const int n = n0 + cbase(ni) + lq * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float sbv = p.scaleB[min(n + j, p.N - 1)];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[ni][mi][j] *= sa[mi] * sbv;
+      }
+    }
+  }
   if (ROPE == 0 && p.ws != nullptr) {
     // split-K slice z: park the raw accumulators in its own fp32 plane ws[z][M][N] (plain 16-B stores; fp32 atomics into one
     // plane were throughput-bound: 4 M atomics per GEMM); the planes are summed and bias / activation / residual / bf16
@@ -549,7 +586,7 @@ __global__ void splitk_finalize_kernel(const float* __restrict__ ws, const bf16_
   }
 }
 
-template <int BM, int BN, int STAGES, int ROPE, int WN = 2>
+template <int BM, int BN, int STAGES, int ROPE, int WN = 2, bool F8 = false>
 int launch(const GemmP& p0, int M, int N, int batch, hipStream_t st) {
   using C = Cfg<BM, BN, STAGES, WN>;
   GemmP p = p0;
@@ -557,10 +594,10 @@ int launch(const GemmP& p0, int M, int N, int batch, hipStream_t st) {
   p.ntiles = ((M + BM - 1) / BM) * p.tiles_n;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, STAGES, ROPE, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, STAGES, ROPE, WN, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, STAGES, ROPE, WN>), dim3(p.ntiles, 1, batch), dim3(C::NTHREADS), C::LDS_BYTES, st, p);
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, STAGES, ROPE, WN, F8>), dim3(p.ntiles, 1, batch), dim3(C::NTHREADS), C::LDS_BYTES, st, p);
   return 0;
 }
 
@@ -571,6 +608,10 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   VLA_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->batch > 0, "gemm: empty problem");
   VLA_REQUIRE(d->K % BK == 0, "gemm: K must be a multiple of 64 (pad the operands)");
   VLA_REQUIRE(d->lda % 8 == 0 && d->ldb % 8 == 0, "gemm: lda/ldb must be multiples of 8 elements (16-B rows)");
+  if (d->fp8)
+    VLA_REQUIRE(d->fp8 == 1 && d->a_scale && d->b_scale && d->K % 128 == 0 && d->lda % 16 == 0 && d->ldb % 16 == 0 && d->batch == 1 &&
+                    d->split_k <= 1 && d->rope_mode != 2 && d->act != VLA_ACT_SWIGLU_BWD && d->a_group == 0,
+                "gemm: fp8 needs scales, K % 128 == 0, 16-B rows, batch 1, no split-K / interleaved RoPE / SwiGLU backward / row groups on A");
   VLA_REQUIRE(((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->B & 15) == 0, "gemm: A/B must be 16-B aligned");
   VLA_REQUIRE(d->sA % 8 == 0 && d->sB % 8 == 0, "gemm: batch strides of A/B must keep 16-B alignment");
   if (d->act == VLA_ACT_SWIGLU_BWD) {
@@ -625,6 +666,7 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
               "gemm: r_group stride must keep 16-B alignment; r_group and res_mod are exclusive");
   p.rope_mode = d->rope_mode; p.rope_T = d->rope_T; p.rope_dh = d->rope_dh; p.rope_cols = d->rope_cols;
   p.rope_cos = d->rope_cos; p.rope_sin = d->rope_sin;
+  p.scaleA = d->a_scale; p.scaleB = d->b_scale;
   if (d->rope_mode != 0) {
     VLA_REQUIRE(d->rope_mode == 1 || d->rope_mode == 2, "gemm: rope_mode 0/1/2");
     VLA_REQUIRE(d->rope_cos && d->rope_sin && d->rope_T > 0 && d->rope_dh > 0 && d->rope_dh % 4 == 0 && d->rope_cols % 64 == 0 &&
@@ -635,6 +677,12 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   const char* e = getenv("VLA_GEMM_TILE");     // 0/unset auto, 1: 256x128, 2: 128x128, 3: 128x64  (benchmarking aid)
   const TileChoice tc = choose_tile(d->M, d->N, d->K / split, e ? atoi(e) : 0, d->rope_mode, split > 1 ? split : d->batch, split, d->act);
   hipStream_t st = (hipStream_t)stream;
+  if (d->fp8) {                                // e4m3 operands: the 8-wave 128 x 128 tile (the only fp8 geometry so far)
+    if (d->rope_mode == 1) launch<128, 128, 2, 1, 4, true>(p, d->M, d->N, 1, st);
+    else launch<128, 128, 2, 0, 4, true>(p, d->M, d->N, 1, st);
+    VLA_CHECK_LAUNCH("gemm_fp8_nt");
+    return VLA_OK;
+  }
   if (tc.bm == 256 && tc.bn == 257) {          // 256 x 256 staggered 8-phase kernel (gemm256.hip)
     const int epi = d->act == VLA_ACT_SWIGLU ? 1 : d->act == VLA_ACT_SWIGLU_BWD ? 2 : 0;
     // Tail round.  A launch of r full rounds of tiles plus a few more (ViT fc1: 32 x 17 = 544 tiles on 256 CUs = two rounds

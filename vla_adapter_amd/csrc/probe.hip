@@ -42,7 +42,23 @@ __global__ void probe_mfma16_kernel(float* out) {
   c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
   for (int i = 0; i < 4; ++i) out[lane * 4 + i] = c[i];
 }
+// One v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3 x e4m3, unit block scales) on operands given PER LANE (8 dwords = 32 fp8 each):
+// tests/test_kernels_gpu.py derives the (lane, byte) -> (row, k) map of the fp8 GEMM's fragments from it.
+typedef int v8i_probe __attribute__((ext_vector_type(8)));
+__global__ void probe_mfma_f8_kernel(const v8i_probe* a, const v8i_probe* b, float* out) {
+  const int lane = threadIdx.x;
+  f32x4 c = {0.f, 0.f, 0.f, 0.f};
+  c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[lane], b[lane], c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+  for (int i = 0; i < 4; ++i) out[lane * 4 + i] = c[i];
+}
 }  // namespace
+
+extern "C" int vla_probe_mfma_f8(void* stream, const void* a /*[64][32] fp8*/, const void* b /*[64][32] fp8*/, float* out /*[64*4]*/) {
+  VLA_REQUIRE(a && b && out, "probe_f8: null");
+  hipLaunchKernelGGL(probe_mfma_f8_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const v8i_probe*)a, (const v8i_probe*)b, out);
+  VLA_CHECK_LAUNCH("probe_f8");
+  return VLA_OK;
+}
 
 /* Test-only entry points (not part of the product ABI; declared in tests via ctypes). */
 extern "C" int vla_probe_layouts(void* stream, short* tr_out /*[64*4]*/, float* mfma32_out /*[64*16]*/, float* mfma16_out /*[64*4]*/) {

@@ -29,7 +29,8 @@ class GemmDesc(C.Structure):
                 ("rope_mode", C.c_int), ("rope_T", C.c_int), ("rope_dh", C.c_int), ("rope_cols", C.c_int),
                 ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
                 ("r_group", C.c_int), ("r_group_stride", C.c_longlong), ("c_live_mod", C.c_int), ("c_live_from", C.c_int),
-                ("split_k", C.c_int), ("ws", C.c_void_p), ("bias_post_round", C.c_int)]
+                ("split_k", C.c_int), ("ws", C.c_void_p), ("bias_post_round", C.c_int),
+                ("fp8", C.c_int), ("a_scale", C.c_void_p), ("b_scale", C.c_void_p)]
 
 
 class AttnDesc(C.Structure):
@@ -94,6 +95,7 @@ _PROTOS = {
     "vla_token_ce": ([_P, _P, _L, _P, _I, _I, _P], _I),
     "vla_copy2d": ([_P, _P, _P, _L, _I, _L, _L, _I, _I, _I, _I, _L], _I),
     "vla_fill_zero": ([_P, _P, _L], _I),
+    "vla_quant_fp8_rows": ([_P, _P, _P, _P, _I, _I, _I, _I], _I),
     "vla_head_index_prep": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I], _I),
     "vla_add_scalar_f32": ([_P, _P, _P, _I], _I),
     "vla_head_attn_fwd": ([_P, C.POINTER(HeadAttnDesc)], _I),

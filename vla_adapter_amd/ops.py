@@ -39,10 +39,16 @@ def _chk_bf16(*ts):
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_mod: int = 0, act: int = ACT_NONE,
             out: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, alpha: float = 1.0,
             want_pre: bool = True, a_group=None, c_group=None, r_group=None, rope=None, c_live=None,
-            split_k: Optional[int] = None, bias_post_round: bool = False) -> torch.Tensor:
+            split_k: Optional[int] = None, bias_post_round: bool = False, fp8=None) -> torch.Tensor:
     """C = epilogue(A @ B^T).  a: [M,K] or [batch,M,K] (row stride = a.stride(-2)); b: [N,K] or [batch,N,K].
-    SwiGLU: returns (pre [.., N] or None, h [.., N/2]).  split_k: None = automatic, 0/1 = off, k = forced."""
-    _chk_bf16(a, b, bias, residual, out, out2)
+    SwiGLU: returns (pre [.., N] or None, h [.., N/2]).  split_k: None = automatic, 0/1 = off, k = forced.
+    fp8=(a_scale [M] f32, b_scale [N] f32): a and b are uint8 tensors of OCP e4m3 codes (quant_fp8_rows)."""
+    if fp8 is not None:
+        assert a.dtype == torch.uint8 and b.dtype == torch.uint8 and a.dim() == 2 and split_k in (None, 0, 1)
+        _chk_bf16(bias, residual, out, out2)
+        split_k = 0
+    else:
+        _chk_bf16(a, b, bias, residual, out, out2)
     assert a.stride(-1) == 1 and b.stride(-1) == 1
     batched = a.dim() == 3
     if batched:
@@ -98,6 +104,10 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_m
     # K loop of a tile is serial, so a problem with fewer tiles than the chip has workgroup slots (2 x 256) runs at the
     # latency of ONE long loop on part of the CUs; K slices meet in a per-stream fp32 workspace and are summed by
     # splitk_finalize_kernel
+    if fp8 is not None:
+        sa, sb = fp8
+        assert sa.dtype == torch.float32 and sb.dtype == torch.float32 and sa.numel() == M and sb.numel() == Nn and sa.is_contiguous() and sb.is_contiguous()
+        d.fp8, d.a_scale, d.b_scale = 1, sa.data_ptr(), sb.data_ptr()
     if bias_post_round:          # C = bf16(bf16(A.B^T) + bias): torch CPU Linear on a strided bf16 input (vla_native.h)
         assert bias is not None
         d.bias_post_round = 1
@@ -493,6 +503,19 @@ def copy2d(src: torch.Tensor, dst: torch.Tensor, rows: int, cols: int, ld_src: i
     g, gs = d_group if d_group is not None else (0, 0)
     N.check(_lib().vla_copy2d(_st(), _p(src), _p(dst), rows, cols, ld_src, ld_dst, _DT[src.dtype], _DT[dst.dtype], src_mod, g, gs), "copy2d")
     return dst
+
+
+def quant_fp8_rows(x: torch.Tensor, out: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None):
+    """x bf16 [rows, cols] -> (uint8 [rows, cols] of OCP e4m3 codes, f32 [rows] dequantisation scales = amax / 448)."""
+    assert x.dtype == BF16 and x.dim() == 2 and x.stride(1) == 1
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty(rows, cols, device=x.device, dtype=torch.uint8)
+    if scale is None:
+        scale = torch.empty(rows, device=x.device, dtype=torch.float32)
+    assert out.dtype == torch.uint8 and out.stride(1) == 1 and tuple(out.shape) == (rows, cols)
+    N.check(_lib().vla_quant_fp8_rows(_st(), _p(x), _p(out), _p(scale), rows, cols, x.stride(0), out.stride(0)), "quant_fp8_rows")
+    return out, scale
 
 
 def zero_(t: torch.Tensor):
