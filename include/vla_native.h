@@ -78,6 +78,12 @@ typedef struct vla_gemm_desc {
 /* Row-wise dynamic fp8 quantisation: q[r, :] = e4m3(x[r, :] * 448 / amax_r) (round to nearest even, saturating), scale[r] =
  * amax_r / 448 (1 for an all-zero row).  x bf16 [rows, cols] (ldx), q bytes [rows, cols] (ldq, % 16 == 0), cols % 8 == 0. */
 int vla_quant_fp8_rows(void* stream, const void* x, void* q, float* scale, int rows, int cols, int ldx, int ldq);
+/* The norms with that quantisation fused behind them (the row is still in registers): q8 / qscale as vla_quant_fp8_rows of the
+ * bf16 output; y may be null when only the fp8 form is consumed (frozen Linears: the backward needs x and the statistics). */
+int vla_rmsnorm_fwd_q8(void* stream, const void* x, const void* w, void* y, float* rstd, void* q8, float* qscale, int rows, int cols, int ldq,
+                       float eps);
+int vla_layernorm_fwd_q8(void* stream, const void* x, const void* w, const void* b, void* y, float* stats, void* q8, float* qscale, int rows,
+                         int cols, int ldx, int ldy, int ldq, float eps);
 
 /* C = epilogue(A . B^T).  Replaces nn.Linear forward and, with pre-transposed operands, its dX / dW products:
  * timm ViT qkv/proj/mlp (modeling_prismatic.py:120-144), PrismaticProjector (:261-273), Qwen2 q/k/v/o/gate/up/down

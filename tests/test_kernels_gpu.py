@@ -1164,3 +1164,27 @@ def test_gemm_fp8_swiglu_and_rope_epilogues(ops):
     q = O.rope_half(y[:, :H * dh].view(Bq, S, H, dh).transpose(1, 2), c, s, True).transpose(1, 2).reshape(Bq * S, H * dh)
     k = O.rope_half(y[:, H * dh:(H + KV) * dh].view(Bq, S, KV, dh).transpose(1, 2), c, s, True).transpose(1, 2).reshape(Bq * S, KV * dh)
     check(out, torch.cat([q, k, y[:, (H + KV) * dh:]], 1), name="fp8 gemm + rope_half")
+
+
+def test_norms_with_fused_fp8_output_match_norm_then_quantise(ops):
+    """rmsnorm_fwd_q8 / layernorm_fwd_q8 == the plain norm followed by quant_fp8_rows, bit for bit (codes, scales, and the
+    optional bf16 output / statistics)."""
+    rows, cols = 77, 896
+    x, w, b = gen(rows, cols, seed=331).to(DEV), (1 + 0.1 * gen(cols, seed=332).float()).to(BF).to(DEV), gen(cols, seed=333, scale=0.1).to(DEV)
+    y, rstd = ops.rmsnorm_fwd(x, w, 1e-6, want_rstd=True)
+    q_ref, s_ref = ops.quant_fp8_rows(y)
+    q, s = torch.empty(rows, cols, dtype=torch.uint8, device=DEV), torch.empty(rows, dtype=torch.float32, device=DEV)
+    y2, r2 = torch.empty_like(y), torch.empty_like(rstd)
+    ops.rmsnorm_fwd_q8(x, w, 1e-6, q, s, rstd=r2, y=y2)
+    assert torch.equal(q, q_ref) and torch.equal(s, s_ref) and torch.equal(y2, y) and torch.equal(r2, rstd)
+    q3, s3 = torch.empty_like(q), torch.empty_like(s)
+    ops.rmsnorm_fwd_q8(x, w, 1e-6, q3, s3)                        # no bf16 output at all
+    assert torch.equal(q3, q_ref) and torch.equal(s3, s_ref)
+    cols = 1152
+    x, w, b = gen(rows, cols, seed=334).to(DEV), (1 + 0.1 * gen(cols, seed=335).float()).to(BF).to(DEV), gen(cols, seed=336, scale=0.1).to(DEV)
+    y = ops.layernorm_fwd(x, w, b, 1e-6)
+    q_ref, s_ref = ops.quant_fp8_rows(y)
+    q, s = torch.empty(rows, cols, dtype=torch.uint8, device=DEV), torch.empty(rows, dtype=torch.float32, device=DEV)
+    y2 = torch.empty_like(y)
+    ops.layernorm_fwd_q8(x, w, b, 1e-6, q, s, y=y2)
+    assert torch.equal(q, q_ref) and torch.equal(s, s_ref) and torch.equal(y2, y)

@@ -29,11 +29,44 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
   return uint4{pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7])};
 }
 
+
+// Row-wise e4m3 quantisation of a normalised row that is still in registers (packed bf16, the values the bf16 output holds):
+// the fused form of vla_quant_fp8_rows - same scale, same conversion, no second pass over the row.
+template <int NCH>
+__device__ __forceinline__ void quant_row_q8(const uint4 (&yo)[NCH], int cols, int lane, unsigned char* __restrict__ q, float* __restrict__ scale) {
+  float amax = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if ((c * 64 + lane) * 8 >= cols) continue;
+    float f[8];
+    unpack8(yo[c], f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(f[k]));
+  }
+  amax = wave_max(amax);
+  const float inv = amax > 0.f ? __fdiv_rn(448.f, amax) : 1.f;
+  if (lane == 0) *scale = amax > 0.f ? __fdiv_rn(amax, 448.f) : 1.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int e = (c * 64 + lane) * 8;
+    if (e >= cols) continue;
+    float f[8];
+    unpack8(yo[c], f);
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, hi, true);
+    *reinterpret_cast<uint2*>(q + e) = uint2{(unsigned)lo, (unsigned)hi};
+  }
+}
+
 template <int NCH>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                             const bf16_t* __restrict__ b, bf16_t* __restrict__ y,
                                                             float* __restrict__ stats, int rows, int cols, int ldx,
-                                                            int ldy, float eps) {
+                                                            int ldy, float eps, unsigned char* __restrict__ q8 = nullptr,
+                                                            float* __restrict__ qscale = nullptr, int ldq = 0) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -75,8 +108,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
     unpack8(*reinterpret_cast<const uint4*>(b + e), fb);
 #pragma unroll
     for (int k = 0; k < 8; ++k) o[k] = (f[k] - mean) * rstd * fw[k] + fb[k];
-    *reinterpret_cast<uint4*>(y + (long long)row * ldy + e) = pack8(o);
+    v[c] = pack8(o);                                           // (the input chunk is dead: keep the output for the fp8 pass)
+    if (y) *reinterpret_cast<uint4*>(y + (long long)row * ldy + e) = v[c];
   }
+  if (q8) quant_row_q8<NCH>(v, cols, lane, q8 + (long long)row * ldq, qscale + row);
 }
 
 template <int NCH>
@@ -149,7 +184,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_wb_kernel(const bf16_t* __r
 template <int NCH>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                           bf16_t* __restrict__ y, float* __restrict__ rstd_out, int rows,
-                                                          int cols, float eps) {
+                                                          int cols, float eps, unsigned char* __restrict__ q8 = nullptr,
+                                                          float* __restrict__ qscale = nullptr, int ldq = 0) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -174,8 +210,10 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
     unpack8(*reinterpret_cast<const uint4*>(w + e), fw);
 #pragma unroll
     for (int k = 0; k < 8; ++k) o[k] = fw[k] * rbf(f[k] * rstd);  // two rounding points, as Qwen2RMSNorm in bf16
-    *reinterpret_cast<uint4*>(y + (long long)row * cols + e) = pack8(o);
+    v[c] = pack8(o);
+    if (y) *reinterpret_cast<uint4*>(y + (long long)row * cols + e) = v[c];
   }
+  if (q8) quant_row_q8<NCH>(v, cols, lane, q8 + (long long)row * ldq, qscale + row);
 }
 
 template <int NCH>
@@ -248,6 +286,21 @@ extern "C" int vla_layernorm_fwd(void* stream, const void* x, const void* w, con
   return VLA_OK;
 }
 
+extern "C" int vla_layernorm_fwd_q8(void* stream, const void* x, const void* w, const void* b, void* y, float* stats, void* q8, float* qscale,
+                                    int rows, int cols, int ldx, int ldy, int ldq, float eps) {
+  VLA_REQUIRE(x && w && b && q8 && qscale && rows > 0 && cols > 0, "layernorm_fwd_q8: null/empty");
+  VLA_REQUIRE(cols % 8 == 0 && ldx % 8 == 0 && (!y || ldy % 8 == 0) && ldq % 16 == 0 && ldq >= cols && cols <= 12288, "layernorm_fwd_q8: cols%8, ld%8, ldq%16");
+  VLA_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)w | (uintptr_t)b | (uintptr_t)q8) & 15) == 0, "layernorm_fwd_q8: 16-B alignment");
+  const int n = nch_for(cols);
+  dim3 grid((rows + 3) / 4);
+#define CALL(N) hipLaunchKernelGGL(layernorm_fwd_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w, \
+                                   (const bf16_t*)b, (bf16_t*)y, stats, rows, cols, ldx, ldy, eps, (unsigned char*)q8, qscale, ldq)
+  DISPATCH_NCH(n, CALL)
+#undef CALL
+  VLA_CHECK_LAUNCH("layernorm_fwd_q8");
+  return VLA_OK;
+}
+
 extern "C" int vla_layernorm_bwd(void* stream, const void* dy, const void* x, const void* w, const float* stats, void* dx,
                                  float* dw, float* db, int rows, int cols, int ldx, int lddy, int lddx) {
   VLA_REQUIRE(dy && x && w && stats && rows > 0 && cols > 0, "layernorm_bwd: null/empty");
@@ -286,6 +339,21 @@ extern "C" int vla_rmsnorm_fwd(void* stream, const void* x, const void* w, void*
   DISPATCH_NCH(n, CALL)
 #undef CALL
   VLA_CHECK_LAUNCH("rmsnorm_fwd");
+  return VLA_OK;
+}
+
+extern "C" int vla_rmsnorm_fwd_q8(void* stream, const void* x, const void* w, void* y, float* rstd, void* q8, float* qscale, int rows, int cols,
+                                  int ldq, float eps) {
+  VLA_REQUIRE(x && w && q8 && qscale && rows > 0 && cols > 0, "rmsnorm_fwd_q8: null/empty");
+  VLA_REQUIRE(cols % 8 == 0 && cols <= 12288 && ldq % 16 == 0 && ldq >= cols, "rmsnorm_fwd_q8: cols%8==0, cols<=12288, ldq%16");
+  VLA_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)w | (uintptr_t)q8) & 15) == 0, "rmsnorm_fwd_q8: 16-B alignment");
+  const int n = nch_for(cols);
+  dim3 grid((rows + 3) / 4);
+#define CALL(N) hipLaunchKernelGGL(rmsnorm_fwd_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, \
+                                   rstd, rows, cols, eps, (unsigned char*)q8, qscale, ldq)
+  DISPATCH_NCH(n, CALL)
+#undef CALL
+  VLA_CHECK_LAUNCH("rmsnorm_fwd_q8");
   return VLA_OK;
 }
 

@@ -96,6 +96,8 @@ _PROTOS = {
     "vla_copy2d": ([_P, _P, _P, _L, _I, _L, _L, _I, _I, _I, _I, _L], _I),
     "vla_fill_zero": ([_P, _P, _L], _I),
     "vla_quant_fp8_rows": ([_P, _P, _P, _P, _I, _I, _I, _I], _I),
+    "vla_rmsnorm_fwd_q8": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F], _I),
+    "vla_layernorm_fwd_q8": ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F], _I),
     "vla_head_index_prep": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I], _I),
     "vla_add_scalar_f32": ([_P, _P, _P, _I], _I),
     "vla_head_attn_fwd": ([_P, C.POINTER(HeadAttnDesc)], _I),

@@ -217,6 +217,27 @@ def rmsnorm_fwd(x, w, eps: float, want_rstd: bool = False, out=None):
     return (y, rstd) if want_rstd else y
 
 
+def rmsnorm_fwd_q8(x, w, eps: float, q8: torch.Tensor, qscale: torch.Tensor, rstd: Optional[torch.Tensor] = None, y: Optional[torch.Tensor] = None):
+    """RMSNorm with the row-wise e4m3 quantisation of its bf16 output fused behind it: fills q8 (uint8 [rows, cols]) and
+    qscale (f32 [rows]); rstd / y (the bf16 output) are optional."""
+    _chk_bf16(x, w, y)
+    cols = x.shape[-1]
+    assert x.is_contiguous() and q8.dtype == torch.uint8 and q8.stride(-1) == 1
+    rows = x.numel() // cols
+    N.check(_lib().vla_rmsnorm_fwd_q8(_st(), _p(x), _p(w), _p(y), _p(rstd), _p(q8), _p(qscale), rows, cols, q8.stride(-2), eps), "rmsnorm_fwd_q8")
+    return q8, qscale
+
+
+def layernorm_fwd_q8(x2, w, b, eps: float, q8: torch.Tensor, qscale: torch.Tensor, y: Optional[torch.Tensor] = None, stats=None):
+    """LayerNorm (rows of x2 [rows, cols], row stride x2.stride(0)) + fused row-wise e4m3 quantisation of its bf16 output."""
+    _chk_bf16(x2, w, b, y)
+    rows, cols = x2.shape
+    assert x2.stride(-1) == 1 and q8.dtype == torch.uint8 and q8.stride(-1) == 1
+    N.check(_lib().vla_layernorm_fwd_q8(_st(), _p(x2), _p(w), _p(b), _p(y), _p(stats), _p(q8), _p(qscale), rows, cols, x2.stride(0),
+                                        y.stride(0) if y is not None else 0, q8.stride(0), eps), "layernorm_fwd_q8")
+    return q8, qscale
+
+
 def rmsnorm_bwd(dy, x, w, rstd, dres=None, out=None, x_rows=None):
     """dy/dres/out compact [rows, cols].  x_rows=(group, group_rows, row0): x / rstd are the forward's full tensors and
     compact row r maps to row (r // group) * group_rows + row0 + r % group (live-row window of every sequence)."""
