@@ -312,6 +312,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=4, help="samples of the batch the CPU oracle is timed on (3 steps each: about 12 s of CPU work)")
     ap.add_argument("--no-full-backward", action="store_true", help="skip the extra timing of the reference-shaped full LLM backward")
+    ap.add_argument("--no-fp8-variant", action="store_true", help="skip the extra timing of the opt-in fp8 frozen-weight forward (NOT the headline: reduced precision)")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
     ap.add_argument("--rehearse-exchange", action="store_true", help="one GPU: run the step with a one-rank RCCL group and forced gradient collectives")
     ap.add_argument("--no-probe", action="store_true", help="skip the isolated GEMM replays (profiling runs: the trace then holds training steps only)")
@@ -424,6 +425,26 @@ def main():
                           "gemm_launches_per_step": rec["launches"], "gemm_algorithmic_bytes_per_step": rec["bytes"]}), flush=True)
     elif rank == 0:
         roof = measure_gemm_roofline(eng, batch, noise, lr)
+        fp8_var = None
+        if world == 1 and not args.eager and not args.no_fp8_variant and not args.no_full_backward:
+            # the same step with the frozen backbones' norm-fed projections on e4m3 operands (engine.enable_fp8_frozen: BASELINE
+            # configs[4]'s "fp8 MFMA weight path", first part).  Reduced precision, therefore NEVER `value`: reported beside it.
+            eng.enable_fp8_frozen()
+            eng.capture(batch, noise)
+            for _ in range(2):
+                step()
+            eng.flush()
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                l8 = step()
+            eng.flush()
+            sync()
+            dt8 = (time.perf_counter() - t1) / args.steps
+            fp8_var = {"value": round(B / dt8, 2), "unit": "samples/s", "ms_per_step": round(dt8 * 1e3, 3), "steps": args.steps,
+                       "final_loss": round(float(l8[0]), 5),
+                       "what": "ViT qkv / fc1 and LLM q|k|v / gate|up forward products on OCP e4m3 (per-row input scales from the fused "
+                               "norm+quantise kernels, per-channel weight scales); everything else, incl. the whole backward, bf16"}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(cfg, W, batch, noise, args.cpu_samples)
@@ -446,6 +467,7 @@ def main():
             "step_frac_of_bf16_mfma_peak": round(fl["step_live"] * B / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
             "gflop_per_sample": {"executed": round(fl["step_live"] / 1e9, 1), "autograd_convention": round(fl["step"] / 1e9, 1)},
             "full_backward_variant": full_bwd,
+            "fp8_frozen_forward_variant": fp8_var,
             "roofline": {"bound": "mfma", "kernel": "gemm256_kernel + gemm_nt_kernel (bf16 MFMA NT GEMMs, all launches of one step)",
                          "achieved": round(roof["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(roof["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),

@@ -51,6 +51,8 @@ def linear(x, w, b=None, emu=False, strided_input=False):
     (action_heads.py:57, 118) - for batch size > 1 only: with B = 1 the slice [1, K, D] counts as contiguous (size-1
     dimensions are ignored) and the fused path is taken (batch-1 inference!).  Verified op by op against the reference module in this container and pinned by
     tests/golden/head_bf16_*.npz; every other Linear of the head sees a contiguous input (cat / view outputs)."""
+    if id(w) in FP8:             # opt-in fp8 weight path: both operands fake-quantised per row (e4m3, scale amax / 448)
+        x, w = fake_quant_e4m3_rows(x), fake_quant_e4m3_rows(w)
     y = x @ w.t()
     if b is not None:
         y = (rnd(y, emu) if strided_input else y) + b
@@ -60,6 +62,20 @@ def linear(x, w, b=None, emu=False, strided_input=False):
         A, Bm, scale = l
         y = rnd(y + rnd(rnd(rnd(x @ A.t(), emu) @ Bm.t(), emu) * scale, emu), emu)
     return y
+
+
+# fp8 registry (BASELINE configs[4] "fp8 MFMA weight path"; the reference has no fp8 code: PARITY UNPINNED): ids of the weight
+# tensors whose Linear runs on e4m3 operands in the native build (vla_quant_fp8_rows semantics: per-row dynamic scale for the
+# input, per-output-channel scale for the weight, fp32 accumulation of the dequantised values).
+FP8: set = set()
+
+
+def fake_quant_e4m3_rows(t):
+    """Quantise-dequantise every row of the last dimension to OCP e4m3 with the scale amax / 448 (vla_quant_fp8_rows)."""
+    a = t.detach().abs().amax(dim=-1, keepdim=True)
+    inv = torch.where(a > 0, 448.0 / a, torch.ones_like(a))
+    q = (t.detach() * inv).to(torch.float8_e4m3fn).to(t.dtype)
+    return q * torch.where(a > 0, a / 448.0, torch.ones_like(a))
 
 
 # LoRA registry (a11, parity unpinned: peft absent): id(base weight tensor) -> (A [r, in], B [out, r], alpha / r).  Tests fill it

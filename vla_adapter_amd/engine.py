@@ -174,6 +174,22 @@ class ViT:
                                     bqkv=g(p + "attn.qkv.bias"), wproj=wproj, bproj=bproj, n2w=g(p + "norm2.weight"),
                                     n2b=g(p + "norm2.bias"), w1=w1, b1=b1, w2=w2, b2=b2))
 
+    def enable_fp8(self):
+        """BASELINE configs[4] 'fp8 MFMA weight path', first part: the frozen qkv and fc1 weights as OCP e4m3 with one scale per
+        output channel; their inputs come out of LayerNorm already quantised per row (vla_layernorm_fwd_q8), the products run on
+        the fp8 MFMA.  proj / fc2 (inputs produced by attention / a GEMM epilogue: no row statistics at hand) stay bf16."""
+        for b in self.blocks:
+            b["wqkv_q"], b["wqkv_s"] = ops.quant_fp8_rows(b["wqkv"])
+            b["w1_q"], b["w1_s"] = ops.quant_fp8_rows(b["w1"])
+        self.fp8 = True
+
+    def _ln_q8(self, x, w, b_):
+        rows, cols = x.shape
+        if getattr(self, "_q8", None) is None or self._q8.shape != (rows, cols):
+            self._q8 = torch.empty(rows, cols, device=x.device, dtype=torch.uint8)
+            self._qs = torch.empty(rows, device=x.device, dtype=torch.float32)
+        return ops.layernorm_fwd_q8(x, w, b_, self.cfg.eps, self._q8, self._qs)
+
     def forward(self, pixels: torch.Tensor, c0: int, out: torch.Tensor, c_group=None):
         """pixels [B, C, H, W] (channels c0..c0+2 used) -> writes patch features into ``out`` (a [B*Np, d] window,
         possibly a column slice of the fused feature buffer)."""
@@ -191,13 +207,22 @@ class ViT:
         act = ACT_GELU_TANH if cfg.gelu_tanh else ACT_GELU
         dh = d // cfg.heads
         nb = len(self.blocks)
+        fp8 = getattr(self, "fp8", False)
         for i, b in enumerate(self.blocks):
-            h = ops.layernorm_fwd(x, b["n1w"], b["n1b"], cfg.eps)
-            qkv = ops.gemm_nt(h, b["wqkv"], bias=b["bqkv"]).view(B, T, 3 * d)
+            if fp8:
+                q8, qs = self._ln_q8(x, b["n1w"], b["n1b"])
+                qkv = ops.gemm_nt(q8, b["wqkv_q"], bias=b["bqkv"], fp8=(qs, b["wqkv_s"])).view(B, T, 3 * d)
+            else:
+                h = ops.layernorm_fwd(x, b["n1w"], b["n1b"], cfg.eps)
+                qkv = ops.gemm_nt(h, b["wqkv"], bias=b["bqkv"]).view(B, T, 3 * d)
             a = ops.attn_fwd(qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], cfg.heads, cfg.heads, dh, False)
             ops.gemm_nt(a.view(B * T, d), b["wproj"], bias=b["bproj"], residual=x, out=x)
-            h = ops.layernorm_fwd(x, b["n2w"], b["n2b"], cfg.eps)
-            m = ops.gemm_nt(h, b["w1"], bias=b["b1"], act=act)
+            if fp8:
+                q8, qs = self._ln_q8(x, b["n2w"], b["n2b"])
+                m = ops.gemm_nt(q8, b["w1_q"], bias=b["b1"], act=act, fp8=(qs, b["w1_s"]))
+            else:
+                h = ops.layernorm_fwd(x, b["n2w"], b["n2b"], cfg.eps)
+                m = ops.gemm_nt(h, b["w1"], bias=b["b1"], act=act)
             if i == nb - 1 and cfg.n_prefix == 0:
                 ops.gemm_nt(m, b["w2"], bias=b["b2"], residual=x, out=out, c_group=c_group)
             else:
@@ -250,6 +275,7 @@ class LLM:
         self.LSE = e(n, B, c.heads, S, dt=torch.float32)
         self.R1, self.R2, self.RF = e(n, M, dt=torch.float32), e(n, M, dt=torch.float32), e(M, dt=torch.float32)
         self.nbuf, self.hbuf = e(M, D), e(M, c.inter)
+        self.q8, self.qs = e(M, D, dt=torch.uint8), e(M, dt=torch.float32)      # fp8 form of the normalised rows (enable_fp8)
         self.d_a, self.d_b, self.d_h, self.d_gu, self.d_qkv, self.d_n = e(M, D), e(M, D), e(M, c.inter), e(M, 2 * c.inter), e(M, W), e(M, D)
         self.cos, self.sin = ops.rope_half_tables(S, c.dh, c.theta, dev)
         self._buf_key = (B, S)
@@ -282,9 +308,20 @@ class LLM:
         L = self.layers[i]
         x = self.HS[i].view(-1, D)[r0:r1]
         nbuf, hbuf = self.nbuf[r0:r1], self.hbuf[r0:r1]
-        self._rms(x, L["n1"], nbuf, self.R1[i][r0:r1])
+        fp8 = getattr(self, "fp8", False)
+        q8, qs = self.q8[r0:r1], self.qs[r0:r1]
         qkv = self.QKV[i][r0:r1]
-        if dh == 64:          # RoPE fused into the projection's epilogue
+        if fp8:
+            ops.rmsnorm_fwd_q8(x, L["n1"], c.eps, q8, qs, rstd=self.R1[i][r0:r1])
+        else:
+            self._rms(x, L["n1"], nbuf, self.R1[i][r0:r1])
+        if fp8 and dh == 64:
+            ops.gemm_nt(q8, L["wqkv_q"], bias=L["bqkv"], out=qkv, rope=(1, self.cos, self.sin, S, dh, (H + KV) * dh), fp8=(qs, L["wqkv_s"]))
+        elif fp8:
+            ops.gemm_nt(q8, L["wqkv_q"], bias=L["bqkv"], out=qkv, fp8=(qs, L["wqkv_s"]))
+            ops.rope_half_(qkv[:, :H * dh], self.cos, self.sin, S, H, dh)
+            ops.rope_half_(qkv[:, H * dh:(H + KV) * dh], self.cos, self.sin, S, KV, dh)
+        elif dh == 64:          # RoPE fused into the projection's epilogue
             ops.gemm_nt(nbuf, L["wqkv"], bias=L["bqkv"], out=qkv, rope=(1, self.cos, self.sin, S, dh, (H + KV) * dh))
         else:
             ops.gemm_nt(nbuf, L["wqkv"], bias=L["bqkv"], out=qkv)
@@ -293,10 +330,15 @@ class LLM:
         self._attn_fwd(qkv.view(B, S, -1), i, b0, b1, S)
         x1 = self.X1[i][r0:r1]
         ops.gemm_nt(self.AO[i][r0:r1], L["wo"], residual=x, out=x1)
-        self._rms(x1, L["n2"], nbuf, self.R2[i][r0:r1])
         # the pre-activations are kept for the backward only: rows below the live window are never read again
-        ops.gemm_nt(nbuf, L["wgu"], act=ACT_SWIGLU, out=self.GU[i][r0:r1], out2=hbuf,
-                    c_live=(S, self.gu_row0) if self.gu_row0 else None)
+        if fp8:
+            ops.rmsnorm_fwd_q8(x1, L["n2"], c.eps, q8, qs, rstd=self.R2[i][r0:r1])
+            ops.gemm_nt(q8, L["wgu_q"], act=ACT_SWIGLU, out=self.GU[i][r0:r1], out2=hbuf,
+                        c_live=(S, self.gu_row0) if self.gu_row0 else None, fp8=(qs, L["wgu_s"]))
+        else:
+            self._rms(x1, L["n2"], nbuf, self.R2[i][r0:r1])
+            ops.gemm_nt(nbuf, L["wgu"], act=ACT_SWIGLU, out=self.GU[i][r0:r1], out2=hbuf,
+                        c_live=(S, self.gu_row0) if self.gu_row0 else None)
         ops.gemm_nt(hbuf, L["wd"], residual=x1, out=self.HS[self.out_slot(i)].view(-1, D)[r0:r1])
 
     def fwd_final(self, b0: int = 0, b1: Optional[int] = None):
@@ -304,6 +346,14 @@ class LLM:
         n, D, S = self.cfg.n_layers, self.cfg.d, self.S
         r0, r1 = b0 * S, (self.B if b1 is None else b1) * S
         self._rms(self.HS[n + 1].view(-1, D)[r0:r1], self.norm, self.HS[n].view(-1, D)[r0:r1], self.RF[r0:r1])
+
+    def enable_fp8(self):
+        """fp8 weight path (see ViT.enable_fp8): the frozen q|k|v and gate/up weights in e4m3, their inputs quantised inside
+        RMSNorm (vla_rmsnorm_fwd_q8); o-proj / down stay bf16.  Forward only: the dX products keep the bf16 W^T."""
+        for L in self.layers:
+            L["wqkv_q"], L["wqkv_s"] = ops.quant_fp8_rows(L["wqkv"])
+            L["wgu_q"], L["wgu_s"] = ops.quant_fp8_rows(L["wgu"])
+        self.fp8 = True
 
     def _rms(self, x, w, out, rstd):
         ops.N.check(ops._lib().vla_rmsnorm_fwd(ops._st(), ops._p(x), ops._p(w), ops._p(out), ops._p(rstd), x.shape[0],
@@ -833,6 +883,18 @@ class VLAEngine:
         self.reducer = None        # ddp.FlatGradReducer when world_size > 1
         self.ga, self._micro, self._gacc = 1, 0, None     # gradient accumulation (set_grad_accumulation)
         self.executed_steps = 0    # forward+backward passes enqueued so far (eager, pipelined or replayed): profile bookkeeping
+        self.fp8_frozen = False
+        if os.environ.get("VLA_FP8_FROZEN"):
+            self.enable_fp8_frozen()
+
+    def enable_fp8_frozen(self):
+        """Opt-in, NOT the reference's arithmetic (it is bf16 throughout; BASELINE configs[4] names an fp8 weight path, the
+        reference has no code for it): run the frozen backbones' LayerNorm/RMSNorm-fed projections (ViT qkv / fc1, LLM q|k|v /
+        gate|up) on e4m3 weights and row-quantised inputs.  Adapter-only training and inference; the backward is unchanged."""
+        for v in self.vits:
+            v.enable_fp8()
+        self.llm.enable_fp8()
+        self.fp8_frozen = True
 
     def set_grad_accumulation(self, n: int):
         """finetune.py:1039-1042, 1078-1082: loss / n on every micro-batch, gradients summed over n micro-batches (in bf16, as

@@ -53,6 +53,7 @@ class _Slot:
 class FullFinetune:
     def __init__(self, eng: E.VLAEngine):
         cfg = eng.cfg
+        assert not getattr(eng, "fp8_frozen", False), "full fine-tune trains the backbone weights: the fp8 frozen-weight path does not apply"
         assert len(eng.vits) == 1 and cfg.n_img == 1, "full fine-tune path: single-backbone, single-image configuration (BASELINE configs[3])"
         vc = cfg.vit[0]
         if vc.layerscale or vc.n_prefix:

@@ -113,6 +113,7 @@ class LoraLinear:
 class LoRAFinetune:
     def __init__(self, eng: E.VLAEngine, rank: int = 32, seed: int = 0):
         cfg = eng.cfg
+        assert not getattr(eng, "fp8_frozen", False), "LoRA trains the backbone weights: the fp8 frozen-weight path does not apply"
         assert len(eng.vits) == 1 and cfg.n_img == 1, "LoRA path: single-backbone, single-image configuration"
         vc = cfg.vit[0]
         if vc.layerscale or vc.n_prefix:
