@@ -1188,3 +1188,30 @@ def test_norms_with_fused_fp8_output_match_norm_then_quantise(ops):
     y2 = torch.empty_like(y)
     ops.layernorm_fwd_q8(x, w, b, 1e-6, q, s, y=y2)
     assert torch.equal(q, q_ref) and torch.equal(s, s_ref) and torch.equal(y2, y)
+
+
+@pytest.mark.parametrize("grid", [None, "3"])
+def test_gemm256_fp8_bit_identical_to_128_row_fp8(ops, grid, monkeypatch):
+    """The fp8 form of the 256-row persistent kernel against the fp8 form of the 128-row kernel (same K order, one 128-deep MFMA
+    per K-tile in both): bit-identical on plain / GELU / residual / SwiGLU / rotate_half epilogues, ragged shapes, small grids."""
+    if grid:
+        monkeypatch.setenv("VLA_GEMM256_GRID", grid)
+    for (M, N, K, act, res) in [(1300, 900, 384, 0, True), (1100, 1152, 128, 1, False), (777, 520, 512, 2, True), (2048, 896, 896, 0, False)]:
+        x, w, bias, r = gen(M, K, seed=341), gen(N, K, seed=342, scale=0.05), gen(N, seed=343).to(DEV), gen(M, N, seed=344).to(DEV)
+        qa, sa = ops.quant_fp8_rows(x.to(DEV))
+        qb, sb = ops.quant_fp8_rows(w.to(DEV))
+        out, ref = _both_tiles(monkeypatch, lambda: ops.gemm_nt(qa, qb, bias=bias, residual=r if res else None, act=act, fp8=(sa, sb)))
+        assert torch.equal(out, ref), f"fp8 gemm256 {M}x{N}x{K} act {act}: {(out.float() - ref.float()).abs().max().item()}"
+    M, D, I = 1100, 512, 640
+    qa, sa = ops.quant_fp8_rows(gen(M, D, seed=345).to(DEV))
+    qb, sb = ops.quant_fp8_rows(gen(2 * I, D, seed=346, scale=0.05).to(DEV))
+    (pre, h), (pre_r, h_r) = _both_tiles(monkeypatch, lambda: ops.gemm_nt(qa, qb, act=ops.ACT_SWIGLU, fp8=(sa, sb)))
+    assert torch.equal(pre, pre_r) and torch.equal(h, h_r)
+    B, S, H, KV, dh, K = 4, 352, 14, 2, 64, 896
+    N = (H + 2 * KV) * dh
+    qa, sa = ops.quant_fp8_rows(gen(B * S, K, seed=347).to(DEV))
+    qb, sb = ops.quant_fp8_rows(gen(N, K, seed=348, scale=0.05).to(DEV))
+    bias = gen(N, seed=349).to(DEV)
+    cos, sin = ops.rope_half_tables(S, dh, 1e6, DEV)
+    out, ref = _both_tiles(monkeypatch, lambda: ops.gemm_nt(qa, qb, bias=bias, rope=(1, cos, sin, S, dh, (H + KV) * dh), fp8=(sa, sb)))
+    assert torch.equal(out, ref)

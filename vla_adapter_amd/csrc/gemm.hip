@@ -666,7 +666,7 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
               "gemm: r_group stride must keep 16-B alignment; r_group and res_mod are exclusive");
   p.rope_mode = d->rope_mode; p.rope_T = d->rope_T; p.rope_dh = d->rope_dh; p.rope_cols = d->rope_cols;
   p.rope_cos = d->rope_cos; p.rope_sin = d->rope_sin;
-  p.scaleA = d->a_scale; p.scaleB = d->b_scale;
+  p.scaleA = d->fp8 ? d->a_scale : nullptr; p.scaleB = d->fp8 ? d->b_scale : nullptr;
   if (d->rope_mode != 0) {
     VLA_REQUIRE(d->rope_mode == 1 || d->rope_mode == 2, "gemm: rope_mode 0/1/2");
     VLA_REQUIRE(d->rope_cos && d->rope_sin && d->rope_T > 0 && d->rope_dh > 0 && d->rope_dh % 4 == 0 && d->rope_cols % 64 == 0 &&
@@ -677,8 +677,14 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   const char* e = getenv("VLA_GEMM_TILE");     // 0/unset auto, 1: 256x128, 2: 128x128, 3: 128x64  (benchmarking aid)
   const TileChoice tc = choose_tile(d->M, d->N, d->K / split, e ? atoi(e) : 0, d->rope_mode, split > 1 ? split : d->batch, split, d->act);
   hipStream_t st = (hipStream_t)stream;
-  if (d->fp8) {                                // e4m3 operands: the 8-wave 128 x 128 tile (the only fp8 geometry so far)
-    if (d->rope_mode == 1) launch<128, 128, 2, 1, 4, true>(p, d->M, d->N, 1, st);
+  if (d->fp8) {
+    // e4m3 operands.  With the K loop halved, the 256 x 256 kernel's per-tile costs weigh twice as much: on the step's shapes the
+    // 128-row kernel (two workgroups per CU, one's epilogue under the other's K loop) is as fast or faster (gate/up 162 vs 162 us,
+    // down 62 vs 70, ViT fc1 63 vs 87), on big squares the 256-row kernel wins (8192^3: 2503 vs 2108 TF/s) - it takes those.
+    const int force = e ? atoi(e) : 0;
+    if ((force == 6 || (force == 0 && d->M >= 4096 && d->N >= 4096 && d->K >= 4096)) && d->c_group == 0 && d->r_group == 0)
+      vla_gemm256_launch(p, d->act == VLA_ACT_SWIGLU ? 1 : 0, 1, st);
+    else if (d->rope_mode == 1) launch<128, 128, 2, 1, 4, true>(p, d->M, d->N, 1, st);
     else launch<128, 128, 2, 0, 4, true>(p, d->M, d->N, 1, st);
     VLA_CHECK_LAUNCH("gemm_fp8_nt");
     return VLA_OK;

@@ -62,9 +62,13 @@ __device__ __forceinline__ void glds16s(const char* base, unsigned voff, unsigne
     __builtin_amdgcn_sched_barrier(0);     \
   } while (0)
 
-template <int EPI>
+// F8: OCP e4m3 operands with per-row fp32 scales (gemm.hip's fp8 form, same conventions): a K-tile stays 128 B per row = 128
+// elements = ONE v_mfma_scale_f32_16x16x128_f8f6f4 per 16 x 16 tile instead of two bf16 MFMAs - identical staging, LDS image and
+// barrier structure, half the K-tiles per product.  The scales are applied to the accumulators at the start of the epilogue.
+template <int EPI, bool F8 = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int EB = F8 ? 1 : 2;      // bytes per operand element
   constexpr bool PRE = EPI != 2;      // next tile's K-tile 0 in flight during the epilogue (SwiGLU backward stages wider rows)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
   auto setup = [&](int swz) {
     int sl = lane;
     asm volatile("" : "+v"(sl));       // per-tile address arithmetic stays here (hoisted out of the tile loop it costs registers
-    const int kc = ((sl & 7) ^ ((sl >> 3) & 7)) * 8;   // across the K loop); LDS chunk lane&7 of row r holds global chunk (lane&7)^(r&7)
+    const int kc = ((sl & 7) ^ ((sl >> 3) & 7)) * 16;  // (bytes) across the K loop); LDS chunk lane&7 of row r holds global chunk (lane&7)^(r&7)
     const int lrow = sl >> 3;
     int gA = p.gA;
     asm volatile("" : "+s"(gA));       // (the same for the reciprocal of a divisor: recomputed per tile, not carried in VGPRs)
@@ -101,16 +105,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
     const int gmr = min(GM, tiles_m - grp * GM);
     m0 = (grp * GM + rem % gmr) * 256;
     n0 = (rem / gmr) * 256;
-    Ab = reinterpret_cast<const char*>(p.A + (long long)z * p.sA);
-    Bb = reinterpret_cast<const char*>(p.B + (long long)z * p.sB);
+    Ab = reinterpret_cast<const char*>(p.A) + (long long)z * p.sA * EB;
+    Bb = reinterpret_cast<const char*>(p.B) + (long long)z * p.sB * EB;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int ra = min(m0 + wr * 128 + h * 64 + (wid & 3) * 16 + j * 8 + lrow, p.M - 1);
-        oa[h][j] = (unsigned)(((gA > 0 ? (long long)(ra / gA) * p.sgA + (long long)(ra % gA) * p.lda : (long long)ra * p.lda) + kc) * 2);
+        oa[h][j] = (unsigned)((gA > 0 ? (long long)(ra / gA) * p.sgA + (long long)(ra % gA) * p.lda : (long long)ra * p.lda) * EB + kc);
         const int rb = min(n0 + (wid >> 1) * 64 + h * 32 + (wid & 1) * 16 + j * 8 + lrow, p.N - 1);
-        ob[h][j] = (unsigned)(((long long)rb * p.ldb + kc) * 2);
+        ob[h][j] = (unsigned)((long long)rb * p.ldb * EB + kc);
       }
   };
   const unsigned wdst = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem) + wid * 2048;
@@ -155,10 +159,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
 #if G256_ABL == 3
   const int nt = 1;                 // diagnostic build: prologue + one K-tile + epilogue only
 #else
-  const int nt = p.K / BK;
+  const int nt = p.K / (F8 ? 2 * BK : BK);
 #endif
 #else
-  const int nt = p.K / BK;
+  const int nt = p.K / (F8 ? 2 * BK : BK);      // K-tiles of 128 B per row
 #endif
 
   const int aoff = wr * 64 * 128, boff = wc * 32 * 128;
@@ -188,8 +192,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
     // fragment read offsets: row * 128 + ((4 s + lq) ^ (row & 7)) * 16, row & 7 == lane & 7
     int fl = lane;
     asm volatile("" : "+v"(fl));
-    const int fo0 = (fl & 15) * 128 + (((0 + (fl >> 4)) ^ (fl & 7)) << 4);
-    const int fo1 = (fl & 15) * 128 + (((4 + (fl >> 4)) ^ (fl & 7)) << 4);
+    // (fp8: the lane's 32 contiguous bytes of the row = chunks 2 lq and 2 lq + 1)
+    const int fo0 = (fl & 15) * 128 + ((((F8 ? 2 * (fl >> 4) : 0 + (fl >> 4))) ^ (fl & 7)) << 4);
+    const int fo1 = (fl & 15) * 128 + ((((F8 ? 2 * (fl >> 4) + 1 : 4 + (fl >> 4))) ^ (fl & 7)) << 4);
     if (wr == 1) VLA_BARRIER();      // stagger: the wr = 1 waves run one segment behind
 
     f32x4 acc[2][2][2][4];           // [mh][nh][ni][mi]
@@ -203,6 +208,31 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
           for (int e = 0; e < 4; ++e) acc[a][b][c][e] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+    // one quadrant x one K-tile: 16 bf16 MFMAs (two 32-deep k-steps) or 8 fp8 MFMAs (one 128-deep step)
+    auto mma = [&](f32x4 (&q)[2][4], const bf16x8 (&fb)[2][2], const bf16x8 (&fav)[4][2]) {
+      if constexpr (F8) {
+        typedef int v8i __attribute__((ext_vector_type(8)));
+        typedef float f32x8 __attribute__((ext_vector_type(8)));
+        auto cat = [](bf16x8 lo, bf16x8 hi) {
+          const f32x4 l = __builtin_bit_cast(f32x4, lo), h = __builtin_bit_cast(f32x4, hi);
+          return __builtin_bit_cast(v8i, f32x8{l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]});
+        };
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+            q[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(cat(fb[ni][0], fb[ni][1]), cat(fav[mi][0], fav[mi][1]), q[ni][mi], 0, 0, 0,
+                                                                          0x7f7f7f7f, 0, 0x7f7f7f7f);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+              q[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni][s], fav[mi][s], q[ni][mi], 0, 0, 0);
+      }
+    };
     for (int t = 0; t < nt; ++t) {
       const char* kb = smem + d * 4 * HT;
       const int so = d * 4, sn = (d ^ 1) * 4;
@@ -228,13 +258,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-              acc[0][0][ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[ni][s], fa[mi][s], acc[0][0][ni][mi], 0, 0, 0);
+        mma(acc[0][0], fb0, fa);
         __builtin_amdgcn_s_setprio(0);
         VLA_BARRIER();
       }
@@ -252,13 +276,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-              acc[0][1][ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[ni][s], fa[mi][s], acc[0][1][ni][mi], 0, 0, 0);
+        mma(acc[0][1], fb1, fa);
         __builtin_amdgcn_s_setprio(0);
         VLA_BARRIER();
       }
@@ -276,13 +294,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-              acc[1][1][ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[ni][s], fa[mi][s], acc[1][1][ni][mi], 0, 0, 0);
+        mma(acc[1][1], fb1, fa);
         __builtin_amdgcn_s_setprio(0);
         VLA_BARRIER();
       }
@@ -296,13 +308,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
         }
         VLA_BARRIER();
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-              acc[1][0][ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[ni][s], fa[mi][s], acc[1][0][ni][mi], 0, 0, 0);
+        mma(acc[1][0], fb0, fa);
         __builtin_amdgcn_s_setprio(0);
         VLA_BARRIER();
       }
@@ -338,6 +344,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
     asm volatile("" : "+s"(gR), "+s"(gC), "+s"(res_mod), "+s"(c_live_mod));
     const bf16_t* bias = (EPI != 2 && p.bias) ? p.bias + (long long)ez * p.sBias : nullptr;
     const int wn0 = en0 + wc * 64;
+    if constexpr (F8) {                  // dequantisation: acc[m][n] *= scaleA[m] * scaleB[n], before anything else
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) {
+        float sbv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sbv[j] = p.scaleB[min(wn0 + t4 * 16 + lq * 4 + j, p.N - 1)];
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) {
+            const float sav = p.scaleA[min(em0 + wr * 128 + mh * 64 + mi * 16 + lr, p.M - 1)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[mh][t4 >> 1][t4 & 1][mi][j] *= sav * sbv[j];
+          }
+      }
+    }
     float bv[4][4];
     int ebvec = __builtin_amdgcn_readfirstlane(bias_vec() ? 1 : 0);
     asm volatile("" : "+s"(ebvec));      // (opaque: the four loads of the top are read on every path, so that nothing stays pending)
@@ -681,7 +703,7 @@ int num_cus() {
   return n;
 }
 
-template <int EPI>
+template <int EPI, bool F8 = false>
 int launch256(const GemmP& p0, int batch, hipStream_t st) {
   GemmP p = p0;
   p.tiles_n = (p.N + 255) / 256;
@@ -689,7 +711,7 @@ int launch256(const GemmP& p0, int batch, hipStream_t st) {
   p.batch = batch;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
   // one workgroup per CU walks the tiles (VLA_GEMM256_GRID overrides the workgroup count: 0 = one workgroup per tile)
@@ -697,7 +719,7 @@ int launch256(const GemmP& p0, int batch, hipStream_t st) {
   const long long total = (long long)p.ntiles * batch;
   long long grid = ge ? atoll(ge) : num_cus();
   if (grid <= 0 || grid > total) grid = total;
-  hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3((unsigned)grid), dim3(512), LDS_BYTES, st, p);
+  hipLaunchKernelGGL((gemm256_kernel<EPI, F8>), dim3((unsigned)grid), dim3(512), LDS_BYTES, st, p);
   return 0;
 }
 
@@ -706,6 +728,7 @@ int launch256(const GemmP& p0, int batch, hipStream_t st) {
 int vla_num_cus() { return num_cus(); }
 
 int vla_gemm256_launch(const GemmP& p, int epi, int batch, hipStream_t st) {
+  if (p.scaleA != nullptr) return epi == 1 ? launch256<1, true>(p, batch, st) : launch256<0, true>(p, batch, st);     // fp8 operands
   if (epi == 1) return launch256<1>(p, batch, st);
   if (epi == 2) return launch256<2>(p, batch, st);
   return launch256<0>(p, batch, st);
