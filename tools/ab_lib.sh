@@ -1,5 +1,3 @@
-# same-box A/B of two builds of the native library: $1 = path of the alternative .so
-run() { env "$@" timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-full-backward 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', d['ms_per_step'])"; }
+# same-box A/B of two builds of the native library: $1 = path of the alternative .so (only compare numbers from ONE gpurun call)
+run() { env "$@" timeout -k 10 300 python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-full-backward --no-probe 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', d['ms_per_step'])"; }
 for i in 1 2 3; do run A=new; run VLA_NATIVE_LIB=$1; done
-env VLA_NATIVE_LIB=$1 python tools/bench_kernels.py 2>/dev/null | grep "^attn" | sed 's/^/old /'
-python tools/bench_kernels.py 2>/dev/null | grep "^attn" | sed 's/^/new /'
