@@ -540,6 +540,11 @@ inline bool use_256(int M, int N, int K, int batch, int act) {
   // loop, HBM-bound on the full sequence): the 128-row kernel's second resident workgroup overlaps it with the other one's
   // K loop (live rows, M = 2048: 38 vs 44 us; full sequence, M = 11264: 166 vs 191 us)
   if (act == VLA_ACT_SWIGLU_BWD) return false;
+  // a GELU epilogue (10 us of VALU per round of tiles) with a thin tail round (ViT fc1: 544 tiles = two rounds + 32) is the one
+  // large shape the 128-row kernel still wins isolated (96 vs 106-114 us: its second resident workgroup computes under the
+  // first one's epilogue); on the step the two routings tie (25.25-25.34 vs 25.29-25.32 ms)
+  const int ncu = vla_num_cus();
+  if ((act == VLA_ACT_GELU || act == VLA_ACT_GELU_TANH) && tiles > ncu && (tiles % ncu) != 0 && (tiles % ncu) * 4 < ncu) return false;
   return M >= 1024 && N >= 768 && K >= 256 && tiles >= 96;
 }
 inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode, int batch = 1, int split = 1, int act = 0) {
