@@ -316,6 +316,9 @@ def main():
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
     ap.add_argument("--rehearse-exchange", action="store_true", help="one GPU: run the step with a one-rank RCCL group and forced gradient collectives")
     ap.add_argument("--no-probe", action="store_true", help="skip the isolated GEMM replays (profiling runs: the trace then holds training steps only)")
+    ap.add_argument("--backbone", default="config2", choices=["config2", "config5"],
+                    help="config2: SigLIP-224 + Qwen2.5-0.5B (the headline); config5: DINOv2+SigLIP fused + Qwen2.5-1.5B (BASELINE configs[4]'s "
+                         "backbone, adapter-only; not the headline)")
     ap.add_argument("--ragged", action="store_true", help="prompt lengths in [24, 32], right-padded (exercises the mask path; SURVEY 8d)")
     args = ap.parse_args()
 
@@ -325,7 +328,7 @@ def main():
     local = local % torch.cuda.device_count()      # ranks > GPUs only in the gloo rehearsal on a one-GPU box
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
-    cfg = E.config2()
+    cfg = E.config5_backbone() if args.backbone == "config5" else E.config2()
     B, P = (args.batch or (32 if args.mode == "adapter" else 16)), 32
     W = S.make_weights(cfg, dev, seed=0)                    # identical on every rank (== DDP's initial broadcast)
     eng = E.VLAEngine(cfg, W, dev)
@@ -453,8 +456,10 @@ def main():
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: Prismatic SigLIP-224 + Qwen2.5-0.5B + Pro action head, adapter-only fine-tune, "
-                                   "1 image (256 patches) + 32-token prompt + 64 action queries (S=352)",
+            "config": {"workload": ("BASELINE configs[1]: Prismatic SigLIP-224 + Qwen2.5-0.5B + Pro action head, adapter-only fine-tune, "
+                                    "1 image (256 patches) + 32-token prompt + 64 action queries (S=352)") if args.backbone == "config2" else
+                                   ("BASELINE configs[4] BACKBONE (DINOv2-L + SigLIP-so400m fused, Qwen2.5-1.5B) + Pro action head, adapter-only "
+                                    "fine-tune (not the config's LoRA + fp8 mode), 1 image + 32-token prompt + 64 action queries"),
                        "global_batch": world * B, "per_gpu_batch": B, "seq_len": cfg.n_patches + P + 64,
                        "parallelism": f"dp{world}", "weights": "random-init", "launch": "eager" if args.eager else "hipGraph replay",
                        "prompts": "ragged 24..32 tokens, right-padded" if args.ragged else "32 tokens",

@@ -118,6 +118,13 @@ def tiny_config() -> VLACfg:
                   llm=LLMCfg(256, 2, 4, 2, 64, 512, 1e-6, 1e6, 1024), num_blocks=2)
 
 
+def config5_backbone() -> VLACfg:
+    """BASELINE.json configs[4]'s backbone at full size: DINOv2-L/14 (reg4) + SigLIP-so400m fused vision, Qwen2.5-1.5B language
+    model (28 layers, d 1536, 12 heads of 128, 2 KV heads, MLP 8960), Pro action head on 24 of the 28 hidden states.  (The
+    config's LoRA + fp8 training mode is a separate matter: bench.py runs this backbone adapter-only.)"""
+    return VLACfg(vit=[DINOV2_L_REG4, SIGLIP_SO400M], llm=LLMCfg(1536, 28, 12, 2, 128, 8960, 1e-6, 1e6, 151936))
+
+
 def qwen15b_geometry_config(n_layers: int = 2) -> VLACfg:
     """BASELINE.json configs[4]'s language-model GEOMETRY at plumbing depth: Qwen2.5-1.5B's layer (d 1536, 12 heads of 128,
     2 KV heads, MLP 8960) - head dim 128 (unfused RoPE, the 128-wide attention kernels) and a 7 x 1536-wide first head
