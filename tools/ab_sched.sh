@@ -2,5 +2,6 @@
 run() { env "$@" timeout -k 10 300 python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-full-backward --no-probe 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', d['ms_per_step'])"; }
 for i in 1 2 3; do
 run A=default
-run VLA_GELU_128=1
+run VLA_GEMM_GM=6
+run VLA_GEMM_GM=8
 done

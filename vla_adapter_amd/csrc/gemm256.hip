@@ -109,7 +109,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
   int vt = bid;
 
   // ---- tile identity + staging sources: this wave fills rows [16 wid, 16 wid + 16) of every half-tile (2 pieces of 8 rows)
-  const int GM = p.gm > 0 ? p.gm : 4;
+  // group-M width of the tile order (A row panels an XCD keeps L2-resident while B tiles stream): 6, as for the 128-row tiles -
+  // on the one-pipeline step 25.84-25.87 ms against 25.93-26.09 for 4 and 25.95-26.02 for 8 (same box, three alternating runs)
+  const int GM = p.gm > 0 ? p.gm : 6;
   const int tiles_m = p.ntiles / p.tiles_n, per_group = GM * p.tiles_n;
   int m0, n0, z;
   // sources as wave-uniform bases + 32-bit per-lane byte offsets (half the address registers of eight pointers)
