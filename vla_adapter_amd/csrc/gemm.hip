@@ -545,7 +545,8 @@ inline bool use_256(int M, int N, int K, int batch, int act) {
   // first one's epilogue); on the step the two routings tie (25.25-25.34 vs 25.29-25.32 ms)
   const int ncu = vla_num_cus();
   if ((act == VLA_ACT_GELU || act == VLA_ACT_GELU_TANH) && tiles > ncu && (tiles % ncu) != 0 && (tiles % ncu) * 4 < ncu) return false;
-  return M >= 1024 && N >= 768 && K >= 256 && tiles >= 96;
+  static const int min_tiles = getenv("VLA_GEMM256_MIN_TILES") ? atoi(getenv("VLA_GEMM256_MIN_TILES")) : 96;      // (A/B aid)
+  return M >= 1024 && N >= 768 && K >= 256 && tiles >= min_tiles;
 }
 inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode, int batch = 1, int split = 1, int act = 0) {
   // rotate_half RoPE is fused in both kernels (bit-identical).  The LLM's q|k|v projection goes to the 256-row kernel when it

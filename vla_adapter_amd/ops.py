@@ -117,8 +117,9 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_m
         split_k = 0
         tiles = ((M + 127) // 128) * ((Nn + 127) // 128)
         if plain and K >= 2048 and tiles <= 256 and not os.environ.get("VLA_NO_SPLITK"):
+            cap = int(os.environ.get("VLA_SPLITK_WGS", "512"))          # workgroup slots a split may fill (A/B aid; 512 = two per CU)
             for sk in (8, 4, 2):
-                if tiles * sk <= 512 and K % (64 * sk) == 0 and K // sk >= 512:
+                if tiles * sk <= cap and K % (64 * sk) == 0 and K // sk >= 512:
                     split_k = sk
                     break
     if split_k > 1:
