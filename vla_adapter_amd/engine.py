@@ -1185,7 +1185,9 @@ class VLAEngine:
     # forward->backward turn-around (little pipeline fill/drain) and longer elsewhere (fewer graph launches).
     def _ensure_streams(self):
         if getattr(self, "side", None) is None:
-            self.side = torch.cuda.Stream()            # head stream (a high-priority stream measured 0.7 % slower on the step)
+            # head stream (a high-priority stream measured 0.7 % slower on the step in round 1; VLA_PRIO=h: A/B knob)
+            prio = os.environ.get("VLA_PRIO", "")
+            self.side = torch.cuda.Stream(priority=-1) if "h" in prio else torch.cuda.Stream()
             self._cap_main = torch.cuda.Stream()       # capture stream of the "M" graphs (replayed on the current stream)
             self.llm_streams = [torch.cuda.Stream()]   # further LLM forward pipelines (the other parts of the batch)
             self.vis_stream = torch.cuda.Stream()      # vision stage of the NEXT step (fills the backward's idle CUs)
