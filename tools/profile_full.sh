@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_full
 rm -rf $OUT && mkdir -p $OUT
-timeout -k 10 500 rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 bench.py --mode full --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench.json 2> $OUT/run.log
+timeout -k 10 500 rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 bench.py --mode ${MODE:-full} --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench.json 2> $OUT/run.log
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob("$OUT/**/*kernel_trace.csv", recursive=True)[0]
