@@ -25,7 +25,16 @@ extern "C" {
 #define VLA_ERR_LAUNCH (-2)
 #define VLA_ERR_UNSUPPORTED (-3)
 
-int vla_version(void);                 /* ABI version, currently 1 */
+/* ABI version.  It changes whenever an entry point's signature or a descriptor struct's layout changes:
+ *   1  rounds 1-2 (vla_gemm_desc ended at `bias_post_round`, later at `b_scale`);
+ *   2  round 3: vla_gemm_desc gained the K extension (A2 .. ldb2), new entry points vla_gemm_bf16_tn, vla_gemm256_extent_ok,
+ *      vla_copy_rows3d, vla_layerscale_fwd / _bwd, vla_token_ce_bwd, vla_desc_size.
+ * A binder checks vla_version() AND vla_desc_size() against its own struct definitions before the first call. */
+#define VLA_ABI_VERSION 2
+int vla_version(void);
+/* sizeof() of the descriptor structs as this library was compiled: which = 0 vla_gemm_desc, 1 vla_attn_desc, 2 vla_head_attn_desc,
+ * 3 vla_gemm_tn_desc; -1 for an unknown index.  A caller whose struct is shorter would make the library read past its end. */
+int vla_desc_size(int which);
 const char* vla_last_error(void);      /* thread-local message of the last failing call */
 
 /* ---------------------------------------------------------------- GEMM */
@@ -73,7 +82,41 @@ typedef struct vla_gemm_desc {
    * are the per-row dequantisation factors (vla_quant_fp8_rows): C = epilogue(a_scale[m] b_scale[n] (A . B^T)[m, n]).
    * Plain / activation / residual / SwiGLU-forward / rotate_half epilogues; no split-K, no batch. */
   int fp8; const float* a_scale; const float* b_scale;
+  /* optional K extension (ABI 2; K2 = 0: off): the contraction continues over a second operand pair,
+   * C = epilogue(A . B^T + A2 . B2^T) with A2 bf16 [M, K2] (row stride lda2) and B2 bf16 [N, K2] (ldb2), K2 % 64 == 0, in ONE fp32
+   * accumulator.  A LoRA-wrapped Linear (peft, vla-scripts/finetune.py:832-844) as one product: y = x W^T + (2 x A^T) B^T with the
+   * base GEMM's epilogue intact; its backward dx = dy W + dt A likewise.  batch 1, no split-K / fp8 / interleaved RoPE. */
+  const void* A2; const void* B2; int K2, lda2, ldb2;
 } vla_gemm_desc;
+
+/* 1 when every operand row a 256-row tile of this problem can touch lies below 4 GiB from its base (the 256 x 256 kernel keeps
+ * 32-bit per-lane byte offsets; larger operands are routed to the 128-row kernel, which uses 64-bit pointers).  Host arithmetic. */
+int vla_gemm256_extent_ok(const vla_gemm_desc* desc /* host */);
+
+/* ---------------------------------------------------------------- TN GEMM (weight gradients) */
+typedef struct vla_gemm_tn_desc {
+  const void* A;    /* [batch][M, N1] bf16, row stride lda: dY (rows = tokens, columns = output features) */
+  const void* B;    /* [batch][M, N2] bf16, row stride ldb: X  (rows = tokens, columns = input features) */
+  void* C;          /* [batch][N1, N2] bf16, row stride ldc: C = bf16(alpha sum_m A[m, :]^T B[m, :])  (+ R: bf16(bf16(..) + R)) */
+  const void* R;    /* optional addend [batch][N1, N2] (ldr); may alias C (gradient accumulation) */
+  int M, N1, N2, lda, ldb, ldc, ldr, batch;
+  long long sA, sB, sC, sR;            /* batch strides (elements) */
+  float alpha;                         /* 0 -> 1 */
+  /* contraction-row groups (0 = plain): row m of A lives at (m / a_group) * a_group_stride + (m % a_group) * lda, a_group % 64 == 0
+   * (likewise B): the first Kt rows of every sequence of a [B, S, D] hidden state, read in place */
+  int a_group, b_group; long long a_group_stride, b_group_stride;
+  /* column groups on A (0 = plain): column c of the product's N1 axis is column (c / g) * stride + c % g of A (g % 8 == 0): the
+   * gate (or up) columns of a gate/up-interleaved dY */
+  int a_col_group, a_col_group_stride;
+  /* split of the contraction (0/1 = off): `split` slices of M as extra blocks, fp32 planes in ws [batch, split, N1, N2] (device,
+   * no initialisation needed), summed by a second kernel - for few-tile long-M products (LoRA pairs) */
+  int split; float* ws;
+} vla_gemm_tn_desc;
+/* dW = dY^T . X for every trainable nn.Linear - torch.autograd's weight gradient behind loss.backward() (vla-scripts/finetune.py:
+ * 1039-1042): the action head's Linears (action_heads.py:111-121, 337-410), the LoRA pairs (finetune.py:832-844), every VLM
+ * Linear in the full fine-tune (:846-849) - on dY and X as the backward / forward left them (no operand transposes).
+ * N1 % 8 == 0, N2 % 8 == 0, lda / ldb % 8 == 0; M arbitrary. */
+int vla_gemm_bf16_tn(void* stream, const vla_gemm_tn_desc* desc /* host */);
 
 /* Row-wise dynamic fp8 quantisation: q[r, :] = e4m3(x[r, :] * 448 / amax_r) (round to nearest even, saturating), scale[r] =
  * amax_r / 448 (1 for an all-zero row).  x bf16 [rows, cols] (ldx), q bytes [rows, cols] (ldq, % 16 == 0), cols % 8 == 0. */
@@ -241,6 +284,16 @@ int vla_token_ce(void* stream, const void* logits, long long ld_logits, const lo
  * (r / d_group) * d_group_stride + (r % d_group) * ld_dst when d_group > 0.  dtype codes: 0 = bf16, 1 = f32. */
 int vla_copy2d(void* stream, const void* src, void* dst, long long rows, int cols, long long ld_src, long long ld_dst,
                int src_dtype, int dst_dtype, int src_mod, int d_group, long long d_group_stride);
+/* dst[g][r][0:cols] = src[g][r][0:cols] for g < groups, r < rows (bf16; strides in elements): moves between the fused feature
+ * buffer [B, n_img * 256, sum of backbone widths] and the per-backbone [n_img * B, tokens, d] layouts (modeling_prismatic.py:
+ * 226-237 cat / split), drops or inserts the DINOv2 prefix tokens, compacts the patch rows of d inputs_embeds. */
+int vla_copy_rows3d(void* stream, const void* src, void* dst, int groups, int rows, int cols, long long src_group_stride,
+                    long long src_row_stride, long long dst_group_stride, long long dst_row_stride);
+/* LayerScale as a parameter (timm LayerScale patched at modeling_prismatic.py:58-66: `x * self.scale_factor`) fused with the
+ * block's residual add: out = bf16(x + bf16(a * ls)); a, x, out bf16 [rows, cols] contiguous (out may alias x), ls bf16 [cols]. */
+int vla_layerscale_fwd(void* stream, const void* a, const void* ls, const void* x, void* out, long long rows, int cols);
+/* its backward: da = bf16(dy * ls); dls (f32 [cols], +=, may be NULL when the scale is frozen - LoRA) += sum_r dy[r, :] * a[r, :]. */
+int vla_layerscale_bwd(void* stream, const void* dy, const void* a, const void* ls, void* da, float* dls, int rows, int cols);
 /* Zero nbytes at ptr (16-B aligned) with a store kernel on the given stream (gradient accumulators, dHS); graph-capturable. */
 int vla_fill_zero(void* stream, void* ptr, long long nbytes);
 /* Gather / scatter row indices of the 64 action-query hidden states (+ the proprio slot) for engine.Head, and the NaN guard of a

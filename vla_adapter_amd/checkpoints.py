@@ -10,7 +10,9 @@
   key names (finetune.py:527-572) are written by ``finetune.save_training_checkpoint`` and read back through
   ``Head.load_state_dicts``; DDP's ``module.`` prefix is stripped on load (finetune.py:132-154).
 Only loaders that execute nothing from the file are used (torch.load(weights_only=True) / safetensors).
-LoRA adapters (``lora_adapter/``, merge_lora_weights_and_save.py) are not handled: LoRA itself is not built yet.
+* LoRA adapters: ``lora_adapter/adapter_model.safetensors`` under peft's key names is written by
+  ``finetune.save_training_checkpoint`` and read back by ``load_lora_adapter`` (resume) / ``merge_lora_into_state_dict`` (the
+  offline merge of vla-scripts/merge_lora_weights_and_save.py:44-103: W + (alpha / r) B A into a base state dict).
 """
 from __future__ import annotations
 
@@ -131,9 +133,11 @@ def engine_vlm_state_dict(eng) -> Dict[str, torch.Tensor]:
     names = ["vision_backbone.featurizer."] + (["vision_backbone.fused_featurizer."] if cfg.fused else [])
     for pre, v in zip(names, eng.vits):
         vc = v.cfg
-        if vc.layerscale:
-            raise NotImplementedError("LayerScale is folded into the projections at load time: the original tensors cannot be recovered")
         P_ = vc.patch
+        if vc.n_prefix:                              # DINOv2: cls + register tokens (timm names)
+            out[pre + "cls_token"] = v.prefix[:1].reshape(1, 1, vc.d).clone()
+            if vc.n_prefix > 1:
+                out[pre + "reg_token"] = v.prefix[1:].reshape(1, vc.n_prefix - 1, vc.d).clone()
         out[pre + "patch_embed.proj.weight"] = v.wpe[:, :3 * P_ * P_].reshape(vc.d, 3, P_, P_).clone()
         out[pre + "patch_embed.proj.bias"], out[pre + "pos_embed"] = cl(v.bpe), v.pos.reshape(1, -1, vc.d).clone()
         for i, b in enumerate(v.blocks):
@@ -143,6 +147,8 @@ def engine_vlm_state_dict(eng) -> Dict[str, torch.Tensor]:
             out[q + "attn.proj.weight"], out[q + "attn.proj.bias"] = cl(b["wproj"]), cl(b["bproj"])
             out[q + "mlp.fc1.weight"], out[q + "mlp.fc1.bias"] = b["w1"][:vc.mlp].clone(), b["b1"][:vc.mlp].clone()
             out[q + "mlp.fc2.weight"], out[q + "mlp.fc2.bias"] = b["w2"][:, :vc.mlp].clone(), cl(b["b2"])
+            if vc.layerscale:                        # the parameters themselves (engine.ViT keeps them beside the folded copies)
+                out[q + "ls1.scale_factor"], out[q + "ls2.scale_factor"] = cl(b["ls1"]), cl(b["ls2"])
     for k, t in eng.proj.items():
         out["projector." + k] = cl(t)
     out["action_queries.weight"] = cl(eng.head.P.view("action_queries"))

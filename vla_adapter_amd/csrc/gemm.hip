@@ -66,7 +66,12 @@ struct Cfg {
 // elements = ONE v_mfma_scale_f32_16x16x128_f8f6f4 per 16 x 16 tile (unit block scales): the same bytes moved, the same LDS
 // reads and the same MFMA cycles per K-tile as the bf16 form, at twice the FLOPs (lane l holds row l % 16, k = 32 (l / 16) +
 // byte: tools/probe_f8.py).  The scales are applied to the fp32 accumulator before anything else of the epilogue.
-template <int BM, int BN, int STAGES, int ROPE, int WN = 2, bool F8 = false>
+// EXT: K extension - the contraction continues over a second operand pair, C = epilogue(A . B^T + A2 . B2^T) with A2 [M, K2]
+// (lda2) and B2 [N, K2] (ldb2): K-tiles [0, K / 64) stream from (A, B), the rest from (A2, B2), one accumulator, one rounding.
+// This is how a LoRA-wrapped Linear runs (vla-scripts/finetune.py:832-844): y = x W^T + (2 x A^T) B^T with the low-rank
+// branch inside the base GEMM's fp32 accumulator - the base product keeps its bias / RoPE / SwiGLU epilogue and no
+// read-modify-write pass over y exists (backward alike: dx = dy W + dt A).
+template <int BM, int BN, int STAGES, int ROPE, int WN = 2, bool F8 = false, bool EXT = false>
 __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
   using C = Cfg<BM, BN, STAGES, WN>;
   constexpr int EB = F8 ? 1 : 2;                           // bytes per operand element
@@ -111,10 +116,25 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
       pp[i] = Bb + (long long)rb * p.ldb * EB + kc;
     }
   }
-  auto stage = [&](int buf, int k0) {
-    char* base = smem + buf * C::STAGE_BYTES + wid * C::PPW * 1024;
+  const char* pp2[EXT ? C::PPW : 1];
+  if constexpr (EXT) {
 #pragma unroll
-    for (int i = 0; i < C::PPW; ++i) glds16(pp[i] + k0 * 2, base + i * 1024);      // k0 in units of bf16 columns: 128 B per K-tile either way
+    for (int i = 0; i < C::PPW; ++i) {
+      const int pc = wid * C::PPW + i;
+      if (pc < BM / 8) pp2[i] = reinterpret_cast<const char*>(p.A2) + (long long)min(m0 + pc * 8 + (lane >> 3), p.M - 1) * p.lda2 * 2 + kc;
+      else pp2[i] = reinterpret_cast<const char*>(p.B2) + (long long)min(n0 + (pc - BM / 8) * 8 + (lane >> 3), p.N - 1) * p.ldb2 * 2 + kc;
+    }
+  }
+  const int nt1 = p.K / (F8 ? 2 * BK : BK);        // K-tiles of 128 B per row from (A, B)
+  auto stage = [&](int buf, int t) {               // K-tile t: 128 B further along every row per tile
+    char* base = smem + buf * C::STAGE_BYTES + wid * C::PPW * 1024;
+    if (EXT && t >= nt1) {
+#pragma unroll
+      for (int i = 0; i < C::PPW; ++i) glds16(pp2[i] + (t - nt1) * 128, base + i * 1024);
+    } else {
+#pragma unroll
+      for (int i = 0; i < C::PPW; ++i) glds16(pp[i] + t * 128, base + i * 1024);
+    }
   };
 
   f32x4 acc[C::NT][4];  // [ni][mi]
@@ -158,10 +178,10 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
     }
   }
 
-  const int nt = p.K / (F8 ? 2 * BK : BK);         // K-tiles of 128 B per row
+  const int nt = nt1 + (EXT ? p.K2 / BK : 0);
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
-    if (s < nt) stage(s, s * BK);
+    if (s < nt) stage(s, s);
   int buf = 0;
   for (int t = 0; t < nt; ++t) {
     // retire this wave's pieces of tile t; up to STAGES-2 younger tiles stay in flight
@@ -172,7 +192,7 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
     if (t + STAGES - 1 < nt) {
       int nb = buf + STAGES - 1;
       if (nb >= STAGES) nb -= STAGES;
-      stage(nb, (t + STAGES - 1) * BK);
+      stage(nb, t + STAGES - 1);
     }
     const char* sa = smem + buf * C::STAGE_BYTES + wr * 64 * 128;
     const char* sb = smem + buf * C::STAGE_BYTES + C::A_BYTES;     // B tile; n tile i of this wave starts at row cbase(i)
@@ -592,7 +612,7 @@ __global__ void splitk_finalize_kernel(const float* __restrict__ ws, const bf16_
   }
 }
 
-template <int BM, int BN, int STAGES, int ROPE, int WN = 2, bool F8 = false>
+template <int BM, int BN, int STAGES, int ROPE, int WN = 2, bool F8 = false, bool EXT = false>
 int launch(const GemmP& p0, int M, int N, int batch, hipStream_t st) {
   using C = Cfg<BM, BN, STAGES, WN>;
   GemmP p = p0;
@@ -600,14 +620,27 @@ int launch(const GemmP& p0, int M, int N, int batch, hipStream_t st) {
   p.ntiles = ((M + BM - 1) / BM) * p.tiles_n;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, STAGES, ROPE, WN, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, STAGES, ROPE, WN, F8, EXT>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, STAGES, ROPE, WN, F8>), dim3(p.ntiles, 1, batch), dim3(C::NTHREADS), C::LDS_BYTES, st, p);
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, STAGES, ROPE, WN, F8, EXT>), dim3(p.ntiles, 1, batch), dim3(C::NTHREADS), C::LDS_BYTES, st, p);
   return 0;
 }
 
 }  // namespace
+
+// gemm256_kernel keeps its per-lane operand addresses as 32-bit BYTE offsets from a wave-uniform base (the 128-row kernel uses
+// 64-bit pointers): every operand row a 256-row tile can touch - tiles round M and N up to 256, row groups included - must
+// start below 4 GiB minus one row.  Pure host arithmetic (no device query): exported so that the routing is unit-testable.
+extern "C" int vla_gemm256_extent_ok(const vla_gemm_desc* d) {
+  if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+  const unsigned long long EB = d->fp8 ? 1 : 2, lim = 1ull << 32;
+  const unsigned long long ra = (unsigned long long)((d->M + 255) / 256) * 256 - 1, rb = (unsigned long long)((d->N + 255) / 256) * 256 - 1;
+  const unsigned long long offA = d->a_group > 0 ? (ra / d->a_group) * (unsigned long long)d->a_group_stride + (ra % d->a_group) * (unsigned long long)d->lda
+                                                 : ra * (unsigned long long)d->lda;
+  const unsigned long long offB = rb * (unsigned long long)d->ldb;
+  return (offA + d->K) * EB < lim && (offB + d->K) * EB < lim;
+}
 
 extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   VLA_REQUIRE(d && d->A && d->B, "gemm: null operand");
@@ -673,6 +706,11 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   p.rope_mode = d->rope_mode; p.rope_T = d->rope_T; p.rope_dh = d->rope_dh; p.rope_cols = d->rope_cols;
   p.rope_cos = d->rope_cos; p.rope_sin = d->rope_sin;
   p.scaleA = d->fp8 ? d->a_scale : nullptr; p.scaleB = d->fp8 ? d->b_scale : nullptr;
+  p.A2 = (const bf16_t*)d->A2; p.B2 = (const bf16_t*)d->B2; p.K2 = d->K2; p.lda2 = d->lda2; p.ldb2 = d->ldb2;
+  if (d->K2 != 0)
+    VLA_REQUIRE(d->K2 > 0 && d->K2 % BK == 0 && d->A2 && d->B2 && d->lda2 % 8 == 0 && d->ldb2 % 8 == 0 && (((uintptr_t)d->A2 | (uintptr_t)d->B2) & 15) == 0 &&
+                    d->batch == 1 && split == 1 && !d->fp8 && d->rope_mode != 2,
+                "gemm: the K extension needs A2 / B2 (16-B aligned rows, K2 % 64 == 0), batch 1, no split-K / fp8 / interleaved RoPE");
   if (d->rope_mode != 0) {
     VLA_REQUIRE(d->rope_mode == 1 || d->rope_mode == 2, "gemm: rope_mode 0/1/2");
     VLA_REQUIRE(d->rope_cos && d->rope_sin && d->rope_T > 0 && d->rope_dh > 0 && d->rope_dh % 4 == 0 && d->rope_cols % 64 == 0 &&
@@ -681,14 +719,23 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
     if (d->rope_mode == 1) VLA_REQUIRE(d->rope_dh == 64, "gemm: fused rotate_half RoPE needs head dim 64");
   }
   const char* e = getenv("VLA_GEMM_TILE");     // 0/unset auto, 1: 256x128, 2: 128x128, 3: 128x64  (benchmarking aid)
-  const TileChoice tc = choose_tile(d->M, d->N, d->K / split, e ? atoi(e) : 0, d->rope_mode, split > 1 ? split : d->batch, split, d->act);
+  TileChoice tc = choose_tile(d->M, d->N, d->K / split, e ? atoi(e) : 0, d->rope_mode, split > 1 ? split : d->batch, split, d->act);
+  const bool fits256 = vla_gemm256_extent_ok(d) != 0;          // operands of 4 GiB and more stay on the 64-bit-pointer kernel
+  if (tc.bm == 256 && tc.bn == 257 && !fits256) tc = TileChoice{128, 128};
+  if (d->K2 > 0) {                 // K extension: 128-row kernel (the 256-row kernel's hand-counted DMA schedule has one operand pair)
+    if (d->act == VLA_ACT_SWIGLU_BWD) launch<128, 128, 2, 3, 4, false, true>(p, d->M, d->N, 1, (hipStream_t)stream);
+    else if (d->rope_mode == 1) launch<128, 128, 2, 1, 4, false, true>(p, d->M, d->N, 1, (hipStream_t)stream);
+    else launch<128, 128, 2, 0, 4, false, true>(p, d->M, d->N, 1, (hipStream_t)stream);
+    VLA_CHECK_LAUNCH("gemm_bf16_nt(ext)");
+    return VLA_OK;
+  }
   hipStream_t st = (hipStream_t)stream;
   if (d->fp8) {
     // e4m3 operands.  With the K loop halved, the 256 x 256 kernel's per-tile costs weigh twice as much: on the step's shapes the
     // 128-row kernel (two workgroups per CU, one's epilogue under the other's K loop) is as fast or faster (gate/up 162 vs 162 us,
     // down 62 vs 70, ViT fc1 63 vs 87), on big squares the 256-row kernel wins (8192^3: 2503 vs 2108 TF/s) - it takes those.
     const int force = e ? atoi(e) : 0;
-    if ((force == 6 || (force == 0 && d->M >= 4096 && d->N >= 4096 && d->K >= 4096)) && d->c_group == 0 && d->r_group == 0)
+    if ((force == 6 || (force == 0 && d->M >= 4096 && d->N >= 4096 && d->K >= 4096)) && d->c_group == 0 && d->r_group == 0 && fits256)
       vla_gemm256_launch(p, d->act == VLA_ACT_SWIGLU ? 1 : 0, 1, st);
     else if (d->rope_mode == 1) launch<128, 128, 2, 1, 4, true>(p, d->M, d->N, 1, st);
     else launch<128, 128, 2, 0, 4, true>(p, d->M, d->N, 1, st);

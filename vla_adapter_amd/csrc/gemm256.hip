@@ -182,15 +182,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
     }
   };
 
-#ifdef G256_ABL
-#if G256_ABL == 3
-  const int nt = 1;                 // diagnostic build: prologue + one K-tile + epilogue only
-#else
-  const int nt = p.K / (F8 ? 2 * BK : BK);
-#endif
-#else
   const int nt = p.K / (F8 ? 2 * BK : BK);      // K-tiles of 128 B per row
-#endif
 
   const int aoff = wr * 64 * 128, boff = wc * 32 * 128;
 
@@ -319,23 +311,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
     if (wr == 0) VLA_BARRIER();      // pairs with the last barrier of the wr = 1 waves: every operand read is finished
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-#if defined(G256_ABL) && G256_ABL == 1
-    {                                 // diagnostic build: no epilogue at all (accumulators kept alive)
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) asm volatile("" ::"v"(acc[a][b][c][e]));
-      if (nxt < 0) break;
-      VLA_BARRIER();
-      setup(nxt); stage_k0(d);
-      cur = nxt;
-      continue;
-    }
-#endif
     // ---------------- epilogue of tile (em0, en0, ez): two 64 x 64 passes per wave through its private staging region,
     //                  in the K-tile buffer that the next tile's K-tile 0 (issued first) does not occupy
     const int em0 = m0, en0 = n0, ez = z;

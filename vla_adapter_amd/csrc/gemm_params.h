@@ -18,6 +18,7 @@ struct GemmP {
   int bias_post;                            // 1: round alpha * acc to bf16 before adding the bias (torch CPU Linear on a strided input)
   int rope_mode, rope_T, rope_dh, rope_cols; const float* rope_cos; const float* rope_sin;
   const float* scaleA; const float* scaleB;   // fp8 operands (A, B point at OCP e4m3 bytes): per-row dequantisation scales [M], [N]
+  const bf16_t* A2; const bf16_t* B2; int K2, lda2, ldb2;   // K extension (gemm.hip EXT): C = epilogue(A . B^T + A2 . B2^T)
 };
 
 // gemm256.hip: 256x256x64 tile, 8 waves, staggered 8-phase schedule.  epi: 0 plain, 1 SwiGLU forward, 2 SwiGLU backward.

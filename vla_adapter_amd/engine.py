@@ -171,15 +171,32 @@ class ViT:
             w2 = torch.zeros(d, self.mlp_pad, device=device, dtype=BF16)
             w2[:, :cfg.mlp] = g(p + "mlp.fc2.weight")
             wproj, bproj, b2 = g(p + "attn.proj.weight"), g(p + "attn.proj.bias"), g(p + "mlp.fc2.bias")
-            if cfg.layerscale:                  # fold LayerScale (modeling_prismatic.py:58-66) into the projections
-                ls1, ls2 = g(p + "ls1.scale_factor").float(), g(p + "ls2.scale_factor").float()
-                wproj = (wproj.float() * ls1[:, None]).to(BF16)
-                bproj = (bproj.float() * ls1).to(BF16)
-                w2 = (w2.float() * ls2[:, None]).to(BF16)
-                b2 = (b2.float() * ls2).to(BF16)
-            self.blocks.append(dict(n1w=g(p + "norm1.weight"), n1b=g(p + "norm1.bias"), wqkv=g(p + "attn.qkv.weight"),
-                                    bqkv=g(p + "attn.qkv.bias"), wproj=wproj, bproj=bproj, n2w=g(p + "norm2.weight"),
-                                    n2b=g(p + "norm2.bias"), w1=w1, b1=b1, w2=w2, b2=b2))
+            blk = dict(n1w=g(p + "norm1.weight"), n1b=g(p + "norm1.bias"), wqkv=g(p + "attn.qkv.weight"),
+                       bqkv=g(p + "attn.qkv.bias"), wproj=wproj, bproj=bproj, n2w=g(p + "norm2.weight"),
+                       n2b=g(p + "norm2.bias"), w1=w1, b1=b1, w2=w2, b2=b2)
+            if cfg.layerscale:                  # LayerScale (modeling_prismatic.py:58-66): the parameters themselves ...
+                blk["ls1"], blk["ls2"] = g(p + "ls1.scale_factor"), g(p + "ls2.scale_factor")
+            self.blocks.append(blk)
+        # ... and, for the FROZEN forward (adapter-only fine-tune, inference), folded into the projections: y = ls * (W x + b) =
+        # (ls W) x + ls b - one bf16 rounding point moves (scale applied to the weight instead of to the bf16 output), no extra
+        # kernel on the step.  A trainer of the backbone (LoRA / full fine-tune) calls fold_layerscale(False): ViT.forward then
+        # applies the scale as the reference does (vla_layerscale_fwd), on the weights that are being trained.
+        self.ls_folded = False
+        self.fold_layerscale(True)
+
+    def fold_layerscale(self, on: bool):
+        if not self.cfg.layerscale or on == self.ls_folded:
+            self.ls_folded = on and self.cfg.layerscale
+            return
+        for b in self.blocks:
+            if on:
+                ls1, ls2 = b["ls1"].float(), b["ls2"].float()
+                b["wproj_f"], b["bproj_f"] = (b["wproj"].float() * ls1[:, None]).to(BF16), (b["bproj"].float() * ls1).to(BF16)
+                b["w2_f"], b["b2_f"] = (b["w2"].float() * ls2[:, None]).to(BF16), (b["b2"].float() * ls2).to(BF16)
+            else:
+                for k in ("wproj_f", "bproj_f", "w2_f", "b2_f"):
+                    b.pop(k, None)
+        self.ls_folded = on
 
     def enable_fp8(self):
         """BASELINE configs[4] 'fp8 MFMA weight path', first part: the frozen qkv and fc1 weights as OCP e4m3 with one scale per
@@ -223,17 +240,27 @@ class ViT:
                 h = ops.layernorm_fwd(x, b["n1w"], b["n1b"], cfg.eps)
                 qkv = ops.gemm_nt(h, b["wqkv"], bias=b["bqkv"]).view(B, T, 3 * d)
             a = ops.attn_fwd(qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], cfg.heads, cfg.heads, dh, False)
-            ops.gemm_nt(a.view(B * T, d), b["wproj"], bias=b["bproj"], residual=x, out=x)
+            unf = cfg.layerscale and not self.ls_folded          # scale applied to the bf16 projection output, as the reference does
+            wp, bp, w2, b2 = (b["wproj"], b["bproj"], b["w2"], b["b2"]) if (unf or not cfg.layerscale) else (b["wproj_f"], b["bproj_f"], b["w2_f"], b["b2_f"])
+            if unf:
+                ops.layerscale_fwd(ops.gemm_nt(a.view(B * T, d), wp, bias=bp), b["ls1"], x, out=x)
+            else:
+                ops.gemm_nt(a.view(B * T, d), wp, bias=bp, residual=x, out=x)
             if fp8:
                 q8, qs = self._ln_q8(x, b["n2w"], b["n2b"])
                 m = ops.gemm_nt(q8, b["w1_q"], bias=b["b1"], act=act, fp8=(qs, b["w1_s"]))
             else:
                 h = ops.layernorm_fwd(x, b["n2w"], b["n2b"], cfg.eps)
                 m = ops.gemm_nt(h, b["w1"], bias=b["b1"], act=act)
-            if i == nb - 1 and cfg.n_prefix == 0:
-                ops.gemm_nt(m, b["w2"], bias=b["b2"], residual=x, out=out, c_group=c_group)
+            if unf:
+                ops.layerscale_fwd(ops.gemm_nt(m, w2, bias=b2), b["ls2"], x, out=x)
+                if i == nb - 1 and cfg.n_prefix == 0:
+                    assert c_group is None
+                    out.copy_(x)
+            elif i == nb - 1 and cfg.n_prefix == 0:
+                ops.gemm_nt(m, w2, bias=b2, residual=x, out=out, c_group=c_group)
             else:
-                ops.gemm_nt(m, b["w2"], bias=b["b2"], residual=x, out=x)
+                ops.gemm_nt(m, w2, bias=b2, residual=x, out=x)
         if cfg.n_prefix:
             assert c_group is None
             out.view(B, Np, -1).copy_(x.view(B, T, d)[:, cfg.n_prefix:])

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = (os.environ.get("VLA_NATIVE_LIB") or None) or os.path.join(_HERE, "libvla_native.so")   # override: same-box A/B of two builds
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_TANH, ACT_SWIGLU, ACT_SWIGLU_BWD = 0, 1, 2, 3, 4, 5
+ABI_VERSION = 2          # include/vla_native.h: VLA_ABI_VERSION
 
 
 class NativeLibraryMissing(ImportError):
@@ -30,7 +31,17 @@ class GemmDesc(C.Structure):
                 ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
                 ("r_group", C.c_int), ("r_group_stride", C.c_longlong), ("c_live_mod", C.c_int), ("c_live_from", C.c_int),
                 ("split_k", C.c_int), ("ws", C.c_void_p), ("bias_post_round", C.c_int),
-                ("fp8", C.c_int), ("a_scale", C.c_void_p), ("b_scale", C.c_void_p)]
+                ("fp8", C.c_int), ("a_scale", C.c_void_p), ("b_scale", C.c_void_p),
+                ("A2", C.c_void_p), ("B2", C.c_void_p), ("K2", C.c_int), ("lda2", C.c_int), ("ldb2", C.c_int)]
+
+
+class GemmTnDesc(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("R", C.c_void_p),
+                ("M", C.c_int), ("N1", C.c_int), ("N2", C.c_int), ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int),
+                ("ldr", C.c_int), ("batch", C.c_int),
+                ("sA", C.c_longlong), ("sB", C.c_longlong), ("sC", C.c_longlong), ("sR", C.c_longlong), ("alpha", C.c_float),
+                ("a_group", C.c_int), ("b_group", C.c_int), ("a_group_stride", C.c_longlong), ("b_group_stride", C.c_longlong),
+                ("a_col_group", C.c_int), ("a_col_group_stride", C.c_int), ("split", C.c_int), ("ws", C.c_void_p)]
 
 
 class AttnDesc(C.Structure):
@@ -62,6 +73,12 @@ class HeadAttnDesc(C.Structure):
 _P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double
 _PROTOS = {
     "vla_version": ([], _I),
+    "vla_desc_size": ([_I], _I),
+    "vla_gemm256_extent_ok": ([C.POINTER(GemmDesc)], _I),
+    "vla_gemm_bf16_tn": ([_P, C.POINTER(GemmTnDesc)], _I),
+    "vla_copy_rows3d": ([_P, _P, _P, _I, _I, _I, _L, _L, _L, _L], _I),
+    "vla_layerscale_fwd": ([_P, _P, _P, _P, _P, _L, _I], _I),
+    "vla_layerscale_bwd": ([_P, _P, _P, _P, _P, _P, _I, _I], _I),
     "vla_gemm_bf16_nt": ([_P, C.POINTER(GemmDesc)], _I),
     "vla_transpose_bf16": ([_P, _P, _P, _I, _I, _I, _I, _I, _L, _L], _I),
     "vla_layernorm_fwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F], _I),
@@ -125,6 +142,12 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes, fn.restype = args, res
     lib.vla_last_error.argtypes, lib.vla_last_error.restype = [], C.c_char_p
+    # the struct ABI: a library built from another header revision would read past (or short of) the descriptors passed to it
+    if lib.vla_version() != ABI_VERSION:
+        raise NativeLibraryMissing(f"{LIB_PATH} speaks ABI {lib.vla_version()}, this binding ABI {ABI_VERSION}: rebuild (make -C csrc)")
+    for which, st in enumerate((GemmDesc, AttnDesc, HeadAttnDesc, GemmTnDesc)):
+        if lib.vla_desc_size(which) != C.sizeof(st):
+            raise NativeLibraryMissing(f"{LIB_PATH}: sizeof({st.__name__}) is {lib.vla_desc_size(which)} in the library, {C.sizeof(st)} in the binding")
     _lib = lib
     return lib
 

@@ -39,10 +39,11 @@ def _chk_bf16(*ts):
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_mod: int = 0, act: int = ACT_NONE,
             out: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, alpha: float = 1.0,
             want_pre: bool = True, a_group=None, c_group=None, r_group=None, rope=None, c_live=None,
-            split_k: Optional[int] = None, bias_post_round: bool = False, fp8=None) -> torch.Tensor:
+            split_k: Optional[int] = None, bias_post_round: bool = False, fp8=None, ext=None) -> torch.Tensor:
     """C = epilogue(A @ B^T).  a: [M,K] or [batch,M,K] (row stride = a.stride(-2)); b: [N,K] or [batch,N,K].
     SwiGLU: returns (pre [.., N] or None, h [.., N/2]).  split_k: None = automatic, 0/1 = off, k = forced.
-    fp8=(a_scale [M] f32, b_scale [N] f32): a and b are uint8 tensors of OCP e4m3 codes (quant_fp8_rows)."""
+    fp8=(a_scale [M] f32, b_scale [N] f32): a and b are uint8 tensors of OCP e4m3 codes (quant_fp8_rows).
+    ext=(a2 [M, K2], b2 [N, K2]): K extension, C = epilogue(A @ B^T + A2 @ B2^T) in one fp32 accumulator (LoRA branch)."""
     if fp8 is not None:
         assert a.dtype == torch.uint8 and b.dtype == torch.uint8 and a.dim() == 2 and split_k in (None, 0, 1)
         _chk_bf16(bias, residual, out, out2)
@@ -108,6 +109,13 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_m
         sa, sb = fp8
         assert sa.dtype == torch.float32 and sb.dtype == torch.float32 and sa.numel() == M and sb.numel() == Nn and sa.is_contiguous() and sb.is_contiguous()
         d.fp8, d.a_scale, d.b_scale = 1, sa.data_ptr(), sb.data_ptr()
+    if ext is not None:
+        a2, b2 = ext
+        _chk_bf16(a2, b2)
+        assert not batched and a2.dim() == 2 and b2.dim() == 2 and a2.shape[0] == M and b2.shape[0] == Nn and a2.shape[1] == b2.shape[1]
+        assert a2.stride(1) == 1 and b2.stride(1) == 1 and a2.shape[1] % 64 == 0 and split_k in (None, 0, 1)
+        d.A2, d.B2, d.K2, d.lda2, d.ldb2 = a2.data_ptr(), b2.data_ptr(), a2.shape[1], a2.stride(0), b2.stride(0)
+        split_k = 0
     if bias_post_round:          # C = bf16(bf16(A.B^T) + bias): torch CPU Linear on a strided bf16 input (vla_native.h)
         assert bias is not None
         d.bias_post_round = 1
@@ -144,7 +152,7 @@ def _splitk_ws(numel: int, device) -> torch.Tensor:
 
 
 def gemm_swiglu_bwd(d: torch.Tensor, w_downT: torch.Tensor, gu: torch.Tensor, out: Optional[torch.Tensor] = None,
-                    gu_group=None) -> torch.Tensor:
+                    gu_group=None, ext=None) -> torch.Tensor:
     """dGU[M, 2I] = swiglu'(GU) * (d[M, D] @ w_downT[I, D]^T): the dH GEMM with the SwiGLU backward in its epilogue.
     gu_group=(rows per group, element stride between groups): ``gu`` is then the first row-group window of a larger
     tensor (row m of the product reads gu row (m // g) * stride + (m % g) * ld)."""
@@ -162,7 +170,97 @@ def gemm_swiglu_bwd(d: torch.Tensor, w_downT: torch.Tensor, gu: torch.Tensor, ou
     desc.act, desc.alpha = ACT_SWIGLU_BWD, 1.0
     if gu_group is not None:
         desc.r_group, desc.r_group_stride = gu_group
+    if ext is not None:          # K extension: dH = d . W_down + dt . A_down (LoRA on down_proj)
+        a2, b2 = ext
+        _chk_bf16(a2, b2)
+        assert a2.shape == (M, b2.shape[1]) and b2.shape[0] == I and a2.stride(1) == 1 and b2.stride(1) == 1 and a2.shape[1] % 64 == 0
+        desc.A2, desc.B2, desc.K2, desc.lda2, desc.ldb2 = a2.data_ptr(), b2.data_ptr(), a2.shape[1], a2.stride(0), b2.stride(0)
     N.check(_lib().vla_gemm_bf16_nt(_st(), C.byref(desc)), "gemm_bf16_nt(swiglu_bwd)")
+    return out
+
+
+_TN_WS = {}
+
+
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = None, alpha: float = 1.0, accumulate: bool = False,
+            a_group=None, b_group=None, a_cols=None, rows: Optional[int] = None, split: Optional[int] = None) -> torch.Tensor:
+    """C[.., N1, N2] = alpha * a[.., M, N1]^T @ b[.., M, N2]  (contraction over the ROWS: dW = dY^T X, no operand transposes).
+    a / b: [M, N] or [batch, M, N] views with last stride 1.  accumulate: C = bf16(bf16(product) + C).
+    rows: contraction length when it differs from a.shape[-2] (row groups).  a_group / b_group = (rows per group, element stride
+    between groups): a / b is then the first group's [g, N] view of a larger tensor.  a_cols = (n1, group, stride, offset): the
+    product's N1 axis is the n1 columns {offset + (c // group) * stride + c % group} of a (gate / up halves of an interleaved dY).
+    split: None = automatic (few-tile long-M products), 0 / 1 = off."""
+    _chk_bf16(a, b, out)
+    assert a.stride(-1) == 1 and b.stride(-1) == 1 and a.dim() == b.dim()
+    batched = a.dim() == 3
+    nb = a.shape[0] if batched else 1
+    M = rows if rows is not None else a.shape[-2]
+    assert rows is not None or b.shape[-2] == M
+    N1, N2 = a.shape[-1], b.shape[-1]
+    d = N.GemmTnDesc()
+    a_ptr = a.data_ptr()
+    if a_cols is not None:
+        N1, cg, cgs, off = a_cols
+        assert cg % 8 == 0 and cgs % 8 == 0 and off % 8 == 0
+        d.a_col_group, d.a_col_group_stride = cg, cgs
+        a_ptr += off * 2
+    shape = (nb, N1, N2) if batched else (N1, N2)
+    if out is None:
+        assert not accumulate
+        out = torch.empty(shape, device=a.device, dtype=BF16)
+    assert tuple(out.shape) == shape and out.stride(-1) == 1, f"out shape {tuple(out.shape)} != {shape}"
+    d.A, d.B, d.C = a_ptr, b.data_ptr(), out.data_ptr()
+    d.M, d.N1, d.N2, d.lda, d.ldb, d.ldc, d.batch = M, N1, N2, a.stride(-2), b.stride(-2), out.stride(-2), nb
+    d.sA, d.sB, d.sC = (a.stride(0), b.stride(0), out.stride(0)) if batched else (0, 0, 0)
+    d.alpha = alpha
+    if accumulate:
+        d.R, d.ldr, d.sR = out.data_ptr(), out.stride(-2), d.sC
+    if a_group is not None:
+        d.a_group, d.a_group_stride = a_group
+    if b_group is not None:
+        d.b_group, d.b_group_stride = b_group
+    if split is None:
+        split = 0
+        tiles = ((N1 + 127) // 128) * ((N2 + 127) // 128) * nb
+        if tiles <= 128 and M >= 1024:
+            split = max(1, min(16, 512 // tiles, M // 256))
+    if split > 1:
+        per = ((M + split - 1) // split + 63) // 64 * 64
+        split = (M + per - 1) // per                  # no empty slice
+    if split > 1:
+        key = (torch.cuda.current_stream().cuda_stream, str(a.device))
+        need = nb * split * N1 * N2
+        ws = _TN_WS.get(key)
+        if ws is None or ws.numel() < need:
+            ws = _TN_WS[key] = torch.empty(max(need, 4 << 20), device=a.device, dtype=torch.float32)
+        d.split, d.ws = split, ws.data_ptr()
+    N.check(_lib().vla_gemm_bf16_tn(_st(), C.byref(d)), "gemm_bf16_tn")
+    return out
+
+
+def copy_rows3d(src: torch.Tensor, dst: torch.Tensor, groups: int, rows: int, cols: int, s_sg: int, s_sr: int, d_sg: int, d_sr: int):
+    """dst[g][r][:cols] = src[g][r][:cols] over raw element strides (src / dst: tensors whose data_ptr is element [0][0][0])."""
+    _chk_bf16(src, dst)
+    N.check(_lib().vla_copy_rows3d(_st(), _p(src), _p(dst), groups, rows, cols, s_sg, s_sr, d_sg, d_sr), "copy_rows3d")
+    return dst
+
+
+def layerscale_fwd(a: torch.Tensor, ls: torch.Tensor, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = bf16(x + bf16(a * ls))  (modeling_prismatic.py:58-66 + the residual add); out may be x."""
+    _chk_bf16(a, ls, x, out)
+    assert a.is_contiguous() and x.is_contiguous() and a.shape == x.shape and ls.numel() == a.shape[-1]
+    out = torch.empty_like(x) if out is None else out
+    N.check(_lib().vla_layerscale_fwd(_st(), _p(a), _p(ls), _p(x), _p(out), a.numel() // a.shape[-1], a.shape[-1]), "layerscale_fwd")
+    return out
+
+
+def layerscale_bwd(dy: torch.Tensor, a: Optional[torch.Tensor], ls: torch.Tensor, dls_f32: Optional[torch.Tensor] = None,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """da = bf16(dy * ls); dls_f32 (optional, +=) += column sums of dy * a."""
+    _chk_bf16(dy, a, ls, out)
+    assert dy.is_contiguous() and (a is None or (a.is_contiguous() and a.shape == dy.shape))
+    out = torch.empty_like(dy) if out is None else out
+    N.check(_lib().vla_layerscale_bwd(_st(), _p(dy), _p(a), _p(ls), _p(out), _p(dls_f32), dy.numel() // dy.shape[-1], dy.shape[-1]), "layerscale_bwd")
     return out
 
 

@@ -1,0 +1,781 @@
+"""Backbone-training steps: LoRA (the reference's documented recipe, README.md:254-274 / vla-scripts/finetune.py:832-844) and the
+full fine-tune (``use_lora=False``: every VLM parameter keeps ``requires_grad``, :846-849, 903-910) through ANY backbone the
+engine runs - one or two ViTs (SigLIP; DINOv2 with cls + register prefix tokens and LayerScale as its own parameter,
+modeling_prismatic.py:58-66), one or two images per sample (the fused layout of :196-237), Qwen2.5-0.5B or -1.5B geometry.
+
+``engine.VLAEngine`` covers the adapter-only step (frozen backbones, live-row backward).  This module adds, for both modes, ONE
+training forward that keeps what the backward needs and ONE explicit backward; what differs between the modes is what a
+Linear does with its weight (the ``_lin`` / ``_lin_bwd`` pair):
+
+  full   y = x W^T + b through the base GEMM's fused epilogues; backward dx = dy W (NT GEMM on the kept W^T) and dW = dy^T x as a
+         TN GEMM on dy and x as they lie in memory (vla_gemm_bf16_tn: no operand transposes), bias gradient by column sums.
+         Every VLM tensor is a view into ONE flat bf16 buffer in the fused layouts the kernels read (q|k|v stacked, gate/up
+         interleaved, zero-padded ViT MLP, K-padded patch embedding): they are row permutations / zero paddings of the
+         reference tensors and AdamW is elementwise, so updating them IS updating the reference tensors.
+  lora   peft ``LoraConfig(r, lora_alpha=2r, target_modules="all-linear", init_lora_weights="gaussian")``:
+         y = x W^T + b + 2 (x A^T) B^T.  The low-rank branch runs INSIDE the base product (the GEMM's K extension):
+         t = 2 x A_cat^T (one skinny GEMM), then y = [x | t] . [W | B_blk]^T in one fp32 accumulator - the base GEMM keeps its
+         bias / RoPE / SwiGLU / residual epilogue and no read-modify-write pass over y exists.  Backward alike:
+         dt = 2 dy B_blk (skinny), dx = [dy | dt] . [W^T | A_cat^T]^T, dA_cat = dt^T x and dB_j = dy_j^T t_j as TN GEMMs.
+         One rounding of y instead of peft's three (base output, branch, sum): closer to the fp32 result than the reference's
+         own bf16 arithmetic; the oracle's LORA_FUSED switch restates it.  PARITY UNPINNED either way (peft is not importable).
+         Parameters are stored per pair under peft's names in one flat buffer; a fused base Linear (q|k|v, gate/up) carries
+         several pairs: A_cat is a view of adjacent A's, B_blk the dense block matrix (rebuilt after every update).
+         Ranks are zero-padded to a multiple of 64 (the GEMM's K granule); padding has zero value and zero gradient.
+
+Frozen in LoRA mode, as under peft: patch embedding (Conv2d), position embedding, cls / register tokens, LayerScale, norms,
+biases, the token embedding.  The action head, the proprio projector and the action queries train in both modes (engine.Head).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import engine as E
+from . import ops
+from .ops import ACT_GELU, ACT_GELU_TANH, ACT_NONE, ACT_SWIGLU, BF16
+
+rup = E.rup
+
+
+# ------------------------------------------------------------------------------------------------ LoRA pairs of one fused Linear
+class LoraLinear:
+    """LoRA pairs of one fused base Linear W [n_out, k_in].  projs: [(peft leaf name, ("range", lo, hi) | ("group16", offset, n_rows))].
+    k_real / n_real: the Linear's true in / out width when the engine pads it (ViT MLP 4304 -> 4352): padding columns of A and
+    padding rows of B are zero and stay zero (zero gradient: their activations / output gradients are zero)."""
+
+    def __init__(self, name: str, n_out: int, k_in: int, projs, r: int, k_real: Optional[int] = None, n_real: Optional[int] = None):
+        self.name, self.n_out, self.k_in, self.projs, self.r = name, n_out, k_in, projs, r
+        self.k_real, self.n_real = k_real or k_in, n_real or n_out
+        self.rp = rup(r, 64)
+        self.Rr = self.rp * len(projs)
+
+    def spec(self):
+        out = [(f"{self.name}.{p}.lora_A", (self.rp, self.k_in)) for p, _ in self.projs]
+        return out, [(f"{self.name}.{p}.lora_B", (self._rows(d), self.rp)) for p, d in self.projs]
+
+    @staticmethod
+    def _rows(d):
+        return d[2] - d[1] if d[0] == "range" else d[2]
+
+    def bind(self, P: E.FlatParams, device):
+        self.P = P
+        a0 = P.offsets[f"{self.name}.{self.projs[0][0]}.lora_A"][0]
+        self.A_cat = P.data[a0:a0 + self.Rr * self.k_in].view(self.Rr, self.k_in)
+        self.gA_cat = P.grad[a0:a0 + self.Rr * self.k_in].view(self.Rr, self.k_in)
+        self.A_catT = torch.empty(self.k_in, self.Rr, device=device, dtype=BF16)
+        self.single = len(self.projs) == 1 and self.projs[0][1][0] == "range"
+        if self.single:
+            self.B_blk = P.view(f"{self.name}.{self.projs[0][0]}.lora_B")
+        else:
+            self.B_blk = torch.zeros(self.n_out, self.Rr, device=device, dtype=BF16)
+        self.B_blkT = torch.empty(self.Rr, self.n_out, device=device, dtype=BF16)
+
+    def init_(self, gen):
+        """init_lora_weights="gaussian": A ~ N(0, (1/r)^2), B = 0; rank padding and width padding zero."""
+        for p, _ in self.projs:
+            A = self.P.view(f"{self.name}.{p}.lora_A")
+            A.zero_()
+            A[:self.r, :self.k_real] = (torch.randn(self.r, self.k_real, generator=gen, device=A.device) / self.r).to(BF16)
+            self.P.view(f"{self.name}.{p}.lora_B").zero_()
+
+    def refresh(self):
+        """Derived operands after a parameter change: B_blk (dense block matrix), A_cat^T, B_blk^T."""
+        if not self.single:
+            for j, (p, d) in enumerate(self.projs):
+                Bj = self.P.view(f"{self.name}.{p}.lora_B")
+                dst = self.B_blk[d[1], j * self.rp:]
+                if d[0] == "range":
+                    ops.copy2d(Bj, dst, Bj.shape[0], self.rp, self.rp, self.Rr)
+                else:               # 16-row groups every 32 rows (gate / up interleave), starting at row d[1]
+                    ops.copy2d(Bj, dst, Bj.shape[0], self.rp, self.rp, self.Rr, d_group=(16, 32 * self.Rr))
+        ops.transpose(self.A_cat, out=self.A_catT)
+        ops.transpose(self.B_blk, out=self.B_blkT)
+
+    def grads(self, dy2d, x2d, t2d, dt2d):
+        """dA_cat = dt^T x (one TN GEMM into the flat gradient), dB_j = dy_j^T t_j per pair (the columns of dy that belong to
+        pair j: a range, or 16-column groups every 32 for gate / up)."""
+        ops.gemm_tn(dt2d, x2d, out=self.gA_cat)
+        for j, (p, d) in enumerate(self.projs):
+            gB = self.P.g(f"{self.name}.{p}.lora_B")
+            tj = t2d[:, j * self.rp:(j + 1) * self.rp]
+            if d[0] == "range":
+                ops.gemm_tn(dy2d[:, d[1]:d[2]], tj, out=gB)
+            else:
+                ops.gemm_tn(dy2d, tj, out=gB, a_cols=(d[2], 16, 32, d[1]))
+
+
+# ------------------------------------------------------------------------------------------------ shared training core
+class _Slot:
+    """One trainable tensor of the full fine-tune: where it lives (dict / attribute) and its name in the flat buffer."""
+
+    def __init__(self, name, holder, key, vector: bool):
+        self.name, self.holder, self.key, self.vector = name, holder, key, vector
+
+    def get(self):
+        return self.holder[self.key] if isinstance(self.holder, dict) else getattr(self.holder, self.key)
+
+    def set(self, t):
+        if isinstance(self.holder, dict):
+            self.holder[self.key] = t
+        else:
+            setattr(self.holder, self.key, t)
+
+
+class BackboneTrainer:
+    """Training forward / backward through ViT(s) -> projector -> Qwen2 stack -> action head, shared by both modes."""
+
+    mode = "?"
+
+    def __init__(self, eng: E.VLAEngine):
+        cfg = eng.cfg
+        assert not getattr(eng, "fp8_frozen", False), "the backbone weights train: the fp8 frozen-weight path does not apply"
+        self.eng, self.cfg, self.dev = eng, cfg, eng.device
+        self.vits, self.llm, self.head = eng.vits, eng.llm, eng.head
+        for v in self.vits:
+            assert not v.cfg.gelu_tanh, "tanh-GELU backward is not built (no backbone of the reference uses it)"
+            v.fold_layerscale(False)                 # LayerScale acts as its own (trainable or frozen) parameter from here on
+        eng.full_llm_backward = True
+        self.step_count = 0
+        self._key = None
+        self.n_streams = 1
+
+    # ---- mode hooks ---------------------------------------------------------------------------------------------
+    def _lin(self, key, x, W, bias=None, **kw):
+        raise NotImplementedError
+
+    def _lin_bwd(self, key, dy, x, WT, out=None, swiglu_gu=None):
+        raise NotImplementedError
+
+    trains_vectors = False       # norms / biases / LayerScale / pos-embed / prefix tokens / patch embedding / token embedding
+
+    def A(self, name):
+        return None              # fp32 accumulator of a vector parameter (full mode)
+
+    # ---- buffers ------------------------------------------------------------------------------------------------
+    def _alloc(self, B: int, S: int):
+        if self._key == (B, S):
+            return
+        cfg, dev = self.cfg, self.dev
+        e = lambda *s, dt=BF16: torch.empty(*s, device=dev, dtype=dt)
+        self.V = []
+        Bv = B * cfg.n_img
+        for v in self.vits:
+            vc = v.cfg
+            nb, d, T = len(v.blocks), vc.d, vc.n_patches + vc.n_prefix
+            Mv = Bv * T
+            st = dict(X=e(nb + 1, Mv, d), H1=e(nb, Mv, d), H2=e(nb, Mv, d), A=e(nb, Mv, d), Xm=e(nb, Mv, d),
+                      S1=e(nb, Mv, 2, dt=torch.float32), S2=e(nb, Mv, 2, dt=torch.float32), QKV=e(nb, Mv, 3 * d),
+                      LSE=e(nb, Bv, vc.heads, T, dt=torch.float32), Mpre=e(nb, Mv, v.mlp_pad), Mact=e(nb, Mv, v.mlp_pad),
+                      g_d=e(Mv, d), g_d2=e(Mv, d), g_big=e(Mv, v.mlp_pad), g_mid=e(Mv, 3 * d), dxa=e(Mv, d), dxb=e(Mv, d), dxc=e(Mv, d))
+            if vc.layerscale:                        # pre-scale outputs of proj / fc2: the LayerScale gradient needs them
+                st["PA"], st["PM"] = e(nb, Mv, d), e(nb, Mv, d)
+            if vc.n_prefix:
+                st["pe"] = e(Bv * vc.n_patches, d)
+            self.V.append(st)
+        c = cfg.llm
+        n, D, I = c.n_layers, c.d, c.inter
+        M = B * S
+        self.N1, self.N2, self.Hs = e(n, M, D), e(n, M, D), e(n, M, I)
+        self.dres = [e(M, D) for _ in range(3)]
+        self.dfeats = e(B * cfg.n_patches, cfg.vis_dim)
+        self.dp = e(B * cfg.n_patches, D)
+        self.pj = {}
+        self._key = (B, S)
+
+    # ---- forward ------------------------------------------------------------------------------------------------
+    def _ln(self, x, w, b, y, st, eps):
+        d = x.shape[1]
+        ops.N.check(ops._lib().vla_layernorm_fwd(ops._st(), ops._p(x), ops._p(w), ops._p(b), ops._p(y), ops._p(st), x.shape[0], d, d, d, eps), "layernorm_fwd")
+
+    def _ln_bwd(self, dy, x, w, st, dx, dw, db):
+        d = x.shape[1]
+        ops.N.check(ops._lib().vla_layernorm_bwd(ops._st(), ops._p(dy), ops._p(x), ops._p(w), ops._p(st), ops._p(dx), ops._p(dw), ops._p(db),
+                                                 x.shape[0], d, d, d, d), "layernorm_bwd")
+
+    def _stacked_pixels(self, j: int, px: torch.Tensor):
+        """Images of backbone j stacked along the batch: ([n_img * B, C, H, W] tensor, first channel) - engine._vision_backbone."""
+        cfg, nbk = self.cfg, len(self.cfg.vit)
+        if cfg.n_img == 1:
+            return px, 3 * j
+        return torch.cat([px[:, 3 * (im * nbk + j):3 * (im * nbk + j) + 3] for im in range(cfg.n_img)], 0).contiguous(), 0
+
+    def _vit_forward(self, j: int, px: torch.Tensor):
+        v, st, cfg = self.vits[j], self.V[j], self.cfg
+        vc = v.cfg
+        stacked, c0 = self._stacked_pixels(j, px)
+        Bv, Np, T, d = stacked.shape[0], vc.n_patches, vc.n_patches + vc.n_prefix, vc.d
+        X = st["X"]
+        st["cols"] = ops.im2col_patch(stacked, c0, vc.patch, v.kpe)
+        if vc.n_prefix:
+            ops.gemm_nt(st["cols"], v.wpe, bias=v.bpe, residual=v.pos, res_mod=Np, out=st["pe"])
+            x3 = X[0].view(Bv, T, d)
+            ops.copy_rows3d(st["pe"], x3[0, vc.n_prefix:], Bv, Np, d, Np * d, d, T * d, d)
+            ops.copy_rows3d(v.prefix, x3, Bv, vc.n_prefix, d, 0, d, T * d, d)               # cls + register tokens, broadcast over the batch
+        else:
+            ops.gemm_nt(st["cols"], v.wpe, bias=v.bpe, residual=v.pos, res_mod=Np, out=X[0])
+        dh = d // vc.heads
+        for i, b in enumerate(v.blocks):
+            x, k = X[i], f"vit{j}.{i}."
+            self._ln(x, b["n1w"], b["n1b"], st["H1"][i], st["S1"][i], vc.eps)
+            qkv = self._lin(k + "qkv", st["H1"][i], b["wqkv"], b["bqkv"], out=st["QKV"][i]).view(Bv, T, 3 * d)
+            dsc = ops._attn_desc(qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], st["A"][i].view(Bv, T, d), st["LSE"][i], None, False,
+                                 dh ** -0.5, vc.heads, vc.heads, dh)
+            ops.N.check(ops._lib().vla_attn_fwd(ops._st(), C.byref(dsc)), "attn_fwd")
+            if vc.layerscale:
+                self._lin(k + "proj", st["A"][i], b["wproj"], b["bproj"], out=st["PA"][i])
+                ops.layerscale_fwd(st["PA"][i], b["ls1"], x, out=st["Xm"][i])
+            else:
+                self._lin(k + "proj", st["A"][i], b["wproj"], b["bproj"], out=st["Xm"][i], residual=x)
+            xm = st["Xm"][i]
+            self._ln(xm, b["n2w"], b["n2b"], st["H2"][i], st["S2"][i], vc.eps)
+            self._lin(k + "fc1", st["H2"][i], b["w1"], b["b1"], out=st["Mpre"][i])          # pre-activation kept for the GELU backward
+            ops.N.check(ops._lib().vla_gelu_fwd(ops._st(), ops._p(st["Mpre"][i]), ops._p(st["Mact"][i]), st["Mpre"][i].numel()), "gelu_fwd")
+            if vc.layerscale:
+                self._lin(k + "fc2", st["Mact"][i], b["w2"], b["b2"], out=st["PM"][i])
+                ops.layerscale_fwd(st["PM"][i], b["ls2"], xm, out=X[i + 1])
+            else:
+                self._lin(k + "fc2", st["Mact"][i], b["w2"], b["b2"], out=X[i + 1], residual=xm)
+        # patch features (prefix tokens dropped, no final norm) -> this backbone's column block of the fused feature buffer
+        feats, B, npi = self.eng.feats, self.eng.B, vc.n_patches
+        vis, col = cfg.vis_dim, sum(u.cfg.d for u in self.vits[:j])
+        out3 = X[len(v.blocks)].view(Bv, T, d)
+        for im in range(cfg.n_img):
+            ops.copy_rows3d(out3[im * B, vc.n_prefix:], feats[0, im * npi:, col:], B, npi, d, T * d, d, feats.shape[1] * vis, vis)
+
+    def _proj_forward(self):
+        eng, cfg, pj = self.eng, self.cfg, self.eng.proj
+        feats = eng.feats.view(-1, cfg.vis_dim)
+        P = self.pj
+        P["in"] = feats
+        P["pre1"] = self._lin("proj.fc1", feats, pj["fc1.weight"], pj["fc1.bias"])
+        P["act1"] = ops.gelu_fwd(P["pre1"])
+        dst = eng.patches.view(-1, cfg.llm.d)
+        if cfg.fused:
+            P["pre2"] = self._lin("proj.fc2", P["act1"], pj["fc2.weight"], pj["fc2.bias"])
+            P["act2"] = ops.gelu_fwd(P["pre2"])
+            self._lin("proj.fc3", P["act2"], pj["fc3.weight"], pj["fc3.bias"], out=dst)
+        else:
+            self._lin("proj.fc2", P["act1"], pj["fc2.weight"], pj["fc2.bias"], out=dst)
+
+    def _llm_forward(self, B, S, kmask):
+        llm, c = self.llm, self.cfg.llm
+        D, H, KV, dh = c.d, c.heads, c.kv_heads, c.dh
+        llm.fwd_begin(B, S, kmask, 0)
+        for i, L in enumerate(llm.layers):
+            x, k = llm.HS[i].view(-1, D), f"llm.{i}."
+            llm._rms(x, L["n1"], self.N1[i], llm.R1[i])
+            qkv = llm.QKV[i]
+            if dh == 64:          # RoPE in the projection's epilogue (the LoRA delta is already inside the accumulator)
+                self._lin(k + "qkv", self.N1[i], L["wqkv"], L["bqkv"], out=qkv, rope=(1, llm.cos, llm.sin, S, dh, (H + KV) * dh))
+            else:
+                self._lin(k + "qkv", self.N1[i], L["wqkv"], L["bqkv"], out=qkv)
+                ops.rope_half_(qkv[:, :H * dh], llm.cos, llm.sin, S, H, dh)
+                ops.rope_half_(qkv[:, H * dh:(H + KV) * dh], llm.cos, llm.sin, S, KV, dh)
+            llm._attn_fwd(qkv.view(B, S, -1), i, 0, B, S)
+            x1 = llm.X1[i]
+            self._lin(k + "o", llm.AO[i], L["wo"], None, out=x1, residual=x)
+            llm._rms(x1, L["n2"], self.N2[i], llm.R2[i])
+            self._lin(k + "gu", self.N2[i], L["wgu"], None, act=ACT_SWIGLU, out=llm.GU[i], out2=self.Hs[i])
+            self._lin(k + "down", self.Hs[i], L["wd"], None, out=llm.HS[llm.out_slot(i)].view(-1, D), residual=x1)
+        llm.fwd_final()
+
+    def forward(self, batch: Dict[str, torch.Tensor], noise: Optional[torch.Tensor] = None):
+        eng = self.eng
+        eng._vision_begin(batch)
+        B, S = eng.B, eng.S
+        self._alloc(B, S)
+        for j in range(len(self.vits)):
+            self._vit_forward(j, batch["pixel_values"])
+        self._proj_forward()
+        mm = eng._embed(batch)
+        self._batch = batch
+        self._llm_forward(B, S, mm)
+        return self.head.forward(self.llm.HS, eng.pos1, batch["proprio"], eng.Np, noise)
+
+    # ---- backward -----------------------------------------------------------------------------------------------
+    def _llm_backward(self, dHS):
+        llm, c, B, S = self.llm, self.cfg.llm, self.eng.B, self.eng.S
+        n, D, H, KV, dh, I = c.n_layers, c.d, c.heads, c.kv_heads, c.dh, c.inter
+        M = B * S
+        lib, st, p = ops._lib(), ops._st, ops._p
+        llm.bwd_begin(dHS, 0)                              # d = backward of the final norm (into llm.d_a)
+        if self.trains_vectors:
+            ops.N.check(lib.vla_rmsnorm_dw(st(), p(dHS[n].view(M, D)), p(llm.HS[n + 1].view(M, D)), p(llm.RF), p(self.A("llm.norm")), M, D), "rmsnorm_dw")
+        d = llm._d
+        ring, r = [llm.d_a[:M], llm.d_b[:M]] + self.dres, 0   # residual-stream gradients rotate through five buffers (dW readers lag)
+        assert d.data_ptr() == ring[0].data_ptr()
+        for i in range(n - 1, -1, -1):
+            L, k = llm.layers[i], f"llm.{i}."
+            if i < n - 1:
+                ops.add_(d, dHS[i + 1].view(M, D))
+            d_gu = self._lin_bwd(k + "down", d, self.Hs[i], L["wdT"], out=llm.d_gu[:M], swiglu_gu=llm.GU[i])
+            d_n = self._lin_bwd(k + "gu", d_gu, self.N2[i], L["wguT"], out=llm.d_n[:M])
+            if self.trains_vectors:
+                ops.N.check(lib.vla_rmsnorm_dw(st(), p(d_n), p(llm.X1[i]), p(llm.R2[i]), p(self.A(k + "n2")), M, D), "rmsnorm_dw")
+            d1 = ops.rmsnorm_bwd(d_n, llm.X1[i], L["n2"], llm.R2[i], dres=d, out=ring[(r + 1) % 5])
+            dao = self._lin_bwd(k + "o", d1, llm.AO[i], L["woT"], out=llm.d_n[:M])
+            q, kk, v = llm._attn_views(llm.QKV[i].view(B, S, -1))
+            d_qkv = llm.d_qkv[:M]
+            dq, dk, dv = llm._attn_views(d_qkv.view(B, S, -1))
+            ops.attn_bwd(dao.view(B, S, -1), q, kk, v, llm.AO[i].view(B, S, -1), llm.LSE[i], H, KV, dh, True, llm.kmask, dq=dq, dk=dk, dv=dv,
+                         rope=(llm.cos, llm.sin) if dh == 64 else None)
+            if dh != 64:
+                ops.rope_half_(d_qkv[:, :H * dh], llm.cos, llm.sin, S, H, dh, sign=-1)
+                ops.rope_half_(d_qkv[:, H * dh:(H + KV) * dh], llm.cos, llm.sin, S, KV, dh, sign=-1)
+            d_n = self._lin_bwd(k + "qkv", d_qkv, self.N1[i], L["wqkvT"], out=llm.d_n[:M])
+            if self.trains_vectors:
+                ops.colsum_(d_qkv, self.A(k + "bqkv"))
+                ops.N.check(lib.vla_rmsnorm_dw(st(), p(d_n), p(llm.HS[i].view(M, D)), p(llm.R1[i]), p(self.A(k + "n1")), M, D), "rmsnorm_dw")
+            d = ops.rmsnorm_bwd(d_n, llm.HS[i].view(M, D), L["n1"], llm.R1[i], dres=d1, out=ring[(r + 2) % 5])
+            r = (r + 2) % 5
+        return d.view(B, S, D)           # gradient w.r.t. inputs_embeds
+
+    def _proj_backward(self, dX0):
+        eng, cfg = self.eng, self.cfg
+        B, S, Np, D = eng.B, eng.S, eng.Np, cfg.llm.d
+        P, pjT = self.pj, self.projT
+        dp = self.dp
+        ops.copy_rows3d(dX0[0, 1], dp, B, Np, D, S * D, D, Np * D, D)          # rows 1..Np of every sequence: the projected patches
+        tv = self.trains_vectors
+        if cfg.fused:
+            if tv:
+                ops.colsum_(dp, self.A("proj.fc3.bias"))
+            dh2 = self._lin_bwd("proj.fc3", dp, P["act2"], pjT["fc3.weight"])
+            dpre = ops.gelu_bwd(dh2, P["pre2"])
+            if tv:
+                ops.colsum_(dpre, self.A("proj.fc2.bias"))
+            dh1 = self._lin_bwd("proj.fc2", dpre, P["act1"], pjT["fc2.weight"])
+        else:
+            if tv:
+                ops.colsum_(dp, self.A("proj.fc2.bias"))
+            dh1 = self._lin_bwd("proj.fc2", dp, P["act1"], pjT["fc2.weight"])
+        dpre1 = ops.gelu_bwd(dh1, P["pre1"])
+        if tv:
+            ops.colsum_(dpre1, self.A("proj.fc1.bias"))
+        return self._lin_bwd("proj.fc1", dpre1, P["in"], pjT["fc1.weight"], out=self.dfeats)       # d features [B*Np, vis_dim]
+
+    def _vit_backward(self, j: int, dfeat: torch.Tensor):
+        v, st, cfg = self.vits[j], self.V[j], self.cfg
+        vc = v.cfg
+        B, npi, T, d = self.eng.B, vc.n_patches, vc.n_patches + vc.n_prefix, vc.d
+        Bv = B * cfg.n_img
+        nb, dh = len(v.blocks), d // vc.heads
+        tv = self.trains_vectors
+        vis, col = cfg.vis_dim, sum(u.cfg.d for u in self.vits[:j])
+        # gradient w.r.t. the last useful block's output: this backbone's column block of d feats on the patch rows, zero on the prefix
+        dx = st["dxa"]
+        if vc.n_prefix:
+            ops.zero_(dx)
+        dx3, df3 = dx.view(Bv, T, d), dfeat.view(B, cfg.n_patches, vis)
+        for im in range(cfg.n_img):
+            ops.copy_rows3d(df3[0, im * npi:, col:], dx3[im * B, vc.n_prefix:], B, npi, d, cfg.n_patches * vis, vis, T * d, d)
+        free = [st["dxb"], st["dxc"]]
+        for i in range(nb - 1, -1, -1):
+            b, k = v.blocks[i], f"vit{j}.{i}."
+            a = (lambda n: self.A(k + n)) if tv else (lambda n: None)
+            # x_out = x_mid + ls2 * fc2(gelu(fc1(LN2(x_mid))))
+            dh_ = ops.layerscale_bwd(dx, st["PM"][i] if tv else None, b["ls2"], a("ls2"), out=st["g_d2"]) if vc.layerscale else dx
+            if tv:
+                ops.colsum_(dh_, a("b2"))
+            dm = self._lin_bwd(k + "fc2", dh_, st["Mact"][i], b["w2T"], out=st["g_big"])
+            ops.N.check(ops._lib().vla_gelu_bwd(ops._st(), ops._p(dm), ops._p(st["Mpre"][i]), ops._p(dm), dm.numel()), "gelu_bwd")   # in place
+            dpre = dm
+            if tv:
+                ops.colsum_(dpre, a("b1"))
+            dh2 = self._lin_bwd(k + "fc1", dpre, st["H2"][i], b["w1T"], out=st["g_d"])
+            dxm = free.pop()
+            self._ln_bwd(dh2, st["Xm"][i], b["n2w"], st["S2"][i], dxm, a("n2w"), a("n2b"))
+            ops.add_(dxm, dx)                            # residual
+            free.append(dx)
+            # x_mid = x_in + ls1 * proj(attn(qkv(LN1(x_in))))
+            da_ = ops.layerscale_bwd(dxm, st["PA"][i] if tv else None, b["ls1"], a("ls1"), out=st["g_d2"]) if vc.layerscale else dxm
+            if tv:
+                ops.colsum_(da_, a("bproj"))
+            da = self._lin_bwd(k + "proj", da_, st["A"][i], b["wprojT"], out=st["g_d"])
+            qkv = st["QKV"][i].view(Bv, T, 3 * d)
+            dqkv = st["g_mid"].view(Bv, T, 3 * d)
+            ops.attn_bwd(da.view(Bv, T, d), qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], st["A"][i].view(Bv, T, d), st["LSE"][i],
+                         vc.heads, vc.heads, dh, False, None, dq=dqkv[:, :, :d], dk=dqkv[:, :, d:2 * d], dv=dqkv[:, :, 2 * d:])
+            if tv:
+                ops.colsum_(st["g_mid"], a("bqkv"))
+            dh1 = self._lin_bwd(k + "qkv", st["g_mid"], st["H1"][i], b["wqkvT"], out=st["g_d"])
+            if i == 0 and not tv:
+                return                                   # below block 0 everything is frozen (Conv2d patch embedding, pos_embed, tokens)
+            dxi = free.pop()
+            self._ln_bwd(dh1, st["X"][i], b["n1w"], st["S1"][i], dxi, a("n1w"), a("n1b"))
+            ops.add_(dxi, dxm)
+            free.append(dxm)
+            dx = dxi
+        # full fine-tune: patch embedding x0 = cols . Wpe^T + bpe + pos on the patch rows; cls / register tokens on the prefix rows
+        lib, p = ops._lib(), ops._p
+        if vc.n_prefix:
+            dx3 = dx.view(Bv, T, d)
+            dpe = st["pe"]
+            ops.copy_rows3d(dx3[0, vc.n_prefix:], dpe, Bv, npi, d, T * d, d, npi * d, d)
+            ops.N.check(lib.vla_colsum_bf16(ops._st(), p(dx), p(self.A(f"vit{j}.prefix")), Bv, vc.n_prefix * d, T * d, 1, 0, 0), "colsum(prefix)")
+        else:
+            dpe = dx
+        ops.gemm_tn(dpe, st["cols"], out=self.G(f"vit{j}.wpe"))
+        ops.colsum_(dpe, self.A(f"vit{j}.bpe"))
+        ops.N.check(lib.vla_colsum_bf16(ops._st(), p(dpe), p(self.A(f"vit{j}.pos")), Bv, npi * d, npi * d, 1, 0, 0), "colsum(pos)")   # sum over the batch
+
+    def _backward_vlm(self, pred, actions, gscale: float = 1.0):
+        eng, head = self.eng, self.head
+        Np = eng.Np
+        loss3, dpred = ops.l1_loss(pred, eng._to_bf16(actions), True, gscale)
+        dHS = eng._dhs(0)
+        head.backward(dpred, dHS, 0)
+        self._after_group("head")
+        dX0 = self._llm_backward(dHS)
+        dq = ops.action_query_grad(dX0, eng.pos0, Np, 0)
+        ops.cast_f32_bf16(dq, out=head.P.g("action_queries"))
+        self._embed_backward(dX0)
+        self._after_group("llm")
+        dfeat = self._proj_backward(dX0)
+        for j in range(len(self.vits)):
+            self._vit_backward(j, dfeat)
+        self._after_group("vision")
+        return loss3
+
+    def _embed_backward(self, dX0):
+        pass
+
+    def _after_group(self, name: str):
+        """Hook: the gradients of parameter group `name` ("head", "llm", "vision") are final on the current stream."""
+
+    # ---- update / capture (shared shape) ---------------------------------------------------------------------------
+    def train_step(self, batch, lr: float, noise=None):
+        pred = self.forward(batch, noise)
+        loss3 = self.backward(pred, batch["actions"])
+        self.optimizer_step(lr)
+        return loss3
+
+    def capture(self, batch: Dict[str, torch.Tensor], noise: Optional[torch.Tensor] = None, warmup: int = 2):
+        """Forward + backward as ONE linear hipGraph on the static ``batch`` / ``noise`` buffers (copy new data into them before
+        each replay); AdamW stays outside (host-side bias corrections), the derived-operand rebuild is a second small graph.
+        A step is 3000-5000 launches: issued from Python they cost more host time than GPU time."""
+        self._cap_stream = torch.cuda.Stream()
+        for _ in range(warmup):
+            self.head.dirty = True
+            self.backward(self.forward(batch, noise), batch["actions"])
+        torch.cuda.synchronize()
+        self.head.dirty = True                       # the head's own W^T / padded-operand refresh becomes part of the graph
+        pool = torch.cuda.graph_pool_handle()
+        self._g_step = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_step, pool=pool, stream=self._cap_stream, capture_error_mode="thread_local"):
+            self._loss3 = self.backward(self.forward(batch, noise), batch["actions"])
+        self._g_r = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_r, pool=pool, stream=self._cap_stream, capture_error_mode="thread_local"):
+            self.refresh()
+        torch.cuda.synchronize()
+
+    def train_step_graphed(self, lr: float):
+        self._g_step.replay()
+        self.optimizer_step(lr, refresh=False)
+        self._g_r.replay()
+        return self._loss3
+
+    def _exchange_and_scale(self) -> float:
+        """Data-parallel exchange of both flat gradient buffers (blocking form: after the whole backward); returns the 1/N scale."""
+        red = self.eng.reducer
+        if red is None:
+            return 1.0
+        red.reduce_async(self.P.grad, 0, None)
+        red.reduce_async(self.head.P.grad, 0, None)
+        red.wait()
+        return red.grad_scale
+
+    def optimizer_step(self, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, wd=0.01, refresh: bool = True):
+        self.step_count += 1
+        gscale = self._exchange_and_scale()
+        P, HP = self.P, self.head.P
+        ops.adamw_(P.data, P.grad, P.m, P.v, self.step_count, lr, beta1, beta2, eps, wd, gscale=gscale)
+        ops.adamw_(HP.data, HP.grad, HP.m, HP.v, self.step_count, lr, beta1, beta2, eps, wd, gscale=gscale)
+        self.head.dirty = True
+        if refresh:
+            self.refresh()
+
+
+# ------------------------------------------------------------------------------------------------ full fine-tune
+class FullFinetune(BackboneTrainer):
+    mode = "full"
+    trains_vectors = True
+
+    def __init__(self, eng: E.VLAEngine):
+        super().__init__(eng)
+        cfg = self.cfg
+        slots: List[_Slot] = []
+        # ---- adopt every VLM tensor into one flat buffer: matrices first (per parameter group contiguous: ViT blocks, projector,
+        #      LLM layers - the data-parallel exchange starts per group), then the vector section (fp32-accumulated gradients)
+        for j, v in enumerate(self.vits):
+            slots.append(_Slot(f"vit{j}.wpe", v, "wpe", False))
+            for i, b in enumerate(v.blocks):
+                for k in ("wqkv", "wproj", "w1", "w2"):
+                    slots.append(_Slot(f"vit{j}.{i}.{k}", b, k, False))
+        for k in eng.proj:
+            if k.endswith("weight"):
+                slots.append(_Slot("proj." + k, eng.proj, k, False))
+        for i, L in enumerate(self.llm.layers):
+            for k in ("wqkv", "wo", "wgu", "wd"):
+                slots.append(_Slot(f"llm.{i}.{k}", L, k, False))
+        slots.append(_Slot("llm.embed", self.llm, "embed", False))
+        first_vec = len(slots)
+        for j, v in enumerate(self.vits):
+            slots += [_Slot(f"vit{j}.bpe", v, "bpe", True), _Slot(f"vit{j}.pos", v, "pos", True)]
+            if v.cfg.n_prefix:
+                slots.append(_Slot(f"vit{j}.prefix", v, "prefix", True))
+            for i, b in enumerate(v.blocks):
+                for k in ("n1w", "n1b", "bqkv", "bproj", "n2w", "n2b", "b1", "b2") + (("ls1", "ls2") if v.cfg.layerscale else ()):
+                    slots.append(_Slot(f"vit{j}.{i}.{k}", b, k, True))
+        for k in eng.proj:
+            if k.endswith("bias"):
+                slots.append(_Slot("proj." + k, eng.proj, k, True))
+        for i, L in enumerate(self.llm.layers):
+            for k in ("n1", "n2", "bqkv"):
+                slots.append(_Slot(f"llm.{i}.{k}", L, k, True))
+        slots.append(_Slot("llm.norm", self.llm, "norm", True))
+        self.slots = slots
+        self.P = E.FlatParams([(s.name, tuple(s.get().shape)) for s in slots], self.dev)
+        for s in slots:
+            self.P.view(s.name).copy_(s.get())
+            s.set(self.P.view(s.name))
+        self.vec_off = self.P.offsets[slots[first_vec].name][0]
+        self.acc32 = torch.zeros(self.P.numel - self.vec_off, device=self.dev, dtype=torch.float32)
+        # W^T operands of the ViT / projector dX products (the LLM's already exist: frozen-path dX)
+        z = lambda r, c: torch.empty(r, c, device=self.dev, dtype=BF16)
+        for v in self.vits:
+            for b in v.blocks:
+                b["wqkvT"], b["wprojT"], b["w1T"], b["w2T"] = z(v.cfg.d, 3 * v.cfg.d), z(v.cfg.d, v.cfg.d), z(v.cfg.d, v.mlp_pad), z(v.mlp_pad, v.cfg.d)
+        self.projT = {k: z(w.shape[1], w.shape[0]) for k, w in eng.proj.items() if k.endswith("weight")}
+        self.refresh()
+
+    vit = property(lambda self: self.vits[0])
+
+    # ---- bookkeeping
+    def G(self, name):
+        return self.P.g(name)
+
+    def A(self, name):
+        """fp32 accumulator of a vector-section parameter."""
+        off, shape = self.P.offsets[name]
+        return self.acc32[off - self.vec_off:off - self.vec_off + math.prod(shape)].view(shape)
+
+    _KEYMAP = {"qkv": "wqkv", "proj": "wproj", "fc1": "w1", "fc2": "w2", "o": "wo", "gu": "wgu", "down": "wd"}
+
+    def _gname(self, key: str) -> str:
+        part, leaf = key.rsplit(".", 1)
+        return f"{part}.{leaf}.weight" if part == "proj" else f"{part}.{self._KEYMAP[leaf]}"
+
+    def refresh(self):
+        """W^T operands of the dX products, rebuilt after every update."""
+        for v in self.vits:
+            for b in v.blocks:
+                for k in ("wqkv", "wproj", "w1", "w2"):
+                    ops.transpose(b[k], out=b[k + "T"])
+        for k, t in self.projT.items():
+            ops.transpose(self.eng.proj[k], out=t)
+        for L in self.llm.layers:
+            for k in ("wqkv", "wo", "wgu", "wd"):
+                ops.transpose(L[k], out=L[k + "T"])
+
+    refresh_transposes = refresh
+
+    # ---- the Linear of this mode
+    def _lin(self, key, x, W, bias=None, **kw):
+        return ops.gemm_nt(x, W, bias=bias, **kw)
+
+    def _lin_bwd(self, key, dy, x, WT, out=None, swiglu_gu=None):
+        if swiglu_gu is not None:            # down_proj: dW from dy, then dGU = swiglu'(GU) * (dy W_down) in the dX GEMM's epilogue
+            ops.gemm_tn(dy, x, out=self.G(self._gname(key)))
+            return ops.gemm_swiglu_bwd(dy, WT, swiglu_gu, out=out)
+        ops.gemm_tn(dy, x, out=self.G(self._gname(key)))
+        return ops.gemm_nt(dy, WT, out=out)
+
+    def _embed_backward(self, dX0):
+        ids = self._batch["input_ids"]
+        ops.N.check(ops._lib().vla_embed_grad(ops._st(), ops._p(dX0), ops._p(ids), ops._p(self.eng.qidx0), ops._p(self.G("llm.embed")),
+                                              self.eng.B, ids.shape[1], self.eng.Np, self.cfg.llm.d, self.cfg.llm.vocab), "embed_grad")
+
+    def backward(self, pred, actions, gscale: float = 1.0):
+        ops.zero_(self.acc32)
+        ops.zero_(self.G("llm.embed"))
+        loss3 = self._backward_vlm(pred, actions, gscale)
+        ops.cast_f32_bf16(self.acc32, out=self.P.grad[self.vec_off:])       # every bias / norm / LayerScale / pos-embed / token gradient in one cast
+        return loss3
+
+    def reference_named_gradients(self) -> Dict[str, torch.Tensor]:
+        """Gradients under the reference's state-dict names (fused layouts undone) - for parity tests / checkpoints."""
+        cfg, out = self.cfg, {}
+        c = cfg.llm
+        H, KV, dh, I, D = c.heads, c.kv_heads, c.dh, c.inter, c.d
+        for i in range(c.n_layers):
+            p = f"language_model.model.layers.{i}."
+            gq = self.G(f"llm.{i}.wqkv")
+            out[p + "self_attn.q_proj.weight"], out[p + "self_attn.k_proj.weight"], out[p + "self_attn.v_proj.weight"] = gq[:H * dh], gq[H * dh:(H + KV) * dh], gq[(H + KV) * dh:]
+            gb = self.G(f"llm.{i}.bqkv")
+            out[p + "self_attn.q_proj.bias"], out[p + "self_attn.k_proj.bias"], out[p + "self_attn.v_proj.bias"] = gb[:H * dh], gb[H * dh:(H + KV) * dh], gb[(H + KV) * dh:]
+            out[p + "self_attn.o_proj.weight"] = self.G(f"llm.{i}.wo")
+            ggu = self.G(f"llm.{i}.wgu").view(I // 16, 2, 16, D)
+            out[p + "mlp.gate_proj.weight"], out[p + "mlp.up_proj.weight"] = ggu[:, 0].reshape(I, D), ggu[:, 1].reshape(I, D)
+            out[p + "mlp.down_proj.weight"] = self.G(f"llm.{i}.wd")
+            out[p + "input_layernorm.weight"], out[p + "post_attention_layernorm.weight"] = self.G(f"llm.{i}.n1"), self.G(f"llm.{i}.n2")
+        out["language_model.model.norm.weight"], out["language_model.model.embed_tokens.weight"] = self.G("llm.norm"), self.G("llm.embed")
+        names = ["vision_backbone.featurizer."] + (["vision_backbone.fused_featurizer."] if cfg.fused else [])
+        for j, (pre, v) in enumerate(zip(names, self.vits)):
+            vc, P_ = v.cfg, v.cfg.patch
+            out[pre + "patch_embed.proj.weight"] = self.G(f"vit{j}.wpe")[:, :3 * P_ * P_].reshape(vc.d, 3, P_, P_)
+            out[pre + "patch_embed.proj.bias"], out[pre + "pos_embed"] = self.G(f"vit{j}.bpe"), self.G(f"vit{j}.pos").reshape(1, -1, vc.d)
+            if vc.n_prefix:
+                gp = self.G(f"vit{j}.prefix")
+                out[pre + "cls_token"] = gp[:1].reshape(1, 1, vc.d)
+                if vc.n_prefix > 1:
+                    out[pre + "reg_token"] = gp[1:].reshape(1, vc.n_prefix - 1, vc.d)
+            for i in range(len(v.blocks)):
+                q = f"{pre}blocks.{i}."
+                g = lambda k: self.G(f"vit{j}.{i}.{k}")
+                out[q + "norm1.weight"], out[q + "norm1.bias"], out[q + "norm2.weight"], out[q + "norm2.bias"] = g("n1w"), g("n1b"), g("n2w"), g("n2b")
+                out[q + "attn.qkv.weight"], out[q + "attn.qkv.bias"] = g("wqkv"), g("bqkv")
+                out[q + "attn.proj.weight"], out[q + "attn.proj.bias"] = g("wproj"), g("bproj")
+                out[q + "mlp.fc1.weight"], out[q + "mlp.fc1.bias"] = g("w1")[:vc.mlp], g("b1")[:vc.mlp]
+                out[q + "mlp.fc2.weight"], out[q + "mlp.fc2.bias"] = g("w2")[:, :vc.mlp], g("b2")
+                if vc.layerscale:
+                    out[q + "ls1.scale_factor"], out[q + "ls2.scale_factor"] = g("ls1"), g("ls2")
+        for k in self.eng.proj:
+            out["projector." + k] = self.G("proj." + k)
+        return out
+
+
+# ------------------------------------------------------------------------------------------------ LoRA
+class LoRAFinetune(BackboneTrainer):
+    mode = "lora"
+    trains_vectors = False
+
+    def __init__(self, eng: E.VLAEngine, rank: int = 32, seed: int = 0):
+        super().__init__(eng)
+        cfg, self.rank = self.cfg, rank
+        c = cfg.llm
+        H, KV, dh, I, D = c.heads, c.kv_heads, c.dh, c.inter, c.d
+        L: Dict[str, LoraLinear] = {}
+        pre = "base_model.model."
+        names = ["vision_backbone.featurizer."] + (["vision_backbone.fused_featurizer."] if cfg.fused else [])
+        for j, (vn, v) in enumerate(zip(names, self.vits)):
+            d = v.cfg.d
+            for i in range(len(v.blocks)):
+                q = f"{pre}{vn}blocks.{i}."
+                L[f"vit{j}.{i}.qkv"] = LoraLinear(q + "attn", 3 * d, d, [("qkv", ("range", 0, 3 * d))], rank)
+                L[f"vit{j}.{i}.proj"] = LoraLinear(q + "attn", d, d, [("proj", ("range", 0, d))], rank)
+                L[f"vit{j}.{i}.fc1"] = LoraLinear(q + "mlp", v.mlp_pad, d, [("fc1", ("range", 0, v.mlp_pad))], rank, n_real=v.cfg.mlp)
+                L[f"vit{j}.{i}.fc2"] = LoraLinear(q + "mlp", d, v.mlp_pad, [("fc2", ("range", 0, d))], rank, k_real=v.cfg.mlp)
+        for k, w in eng.proj.items():
+            if k.endswith("weight"):
+                n = k.split(".")[0]
+                L[f"proj.{n}"] = LoraLinear(pre + "projector", w.shape[0], w.shape[1], [(n, ("range", 0, w.shape[0]))], rank)
+        for i in range(c.n_layers):
+            q = f"{pre}language_model.model.layers.{i}."
+            L[f"llm.{i}.qkv"] = LoraLinear(q + "self_attn", (H + 2 * KV) * dh, D, [("q_proj", ("range", 0, H * dh)), ("k_proj", ("range", H * dh, (H + KV) * dh)),
+                                                                                ("v_proj", ("range", (H + KV) * dh, (H + 2 * KV) * dh))], rank)
+            L[f"llm.{i}.o"] = LoraLinear(q + "self_attn", D, H * dh, [("o_proj", ("range", 0, D))], rank)
+            L[f"llm.{i}.gu"] = LoraLinear(q + "mlp", 2 * I, D, [("gate_proj", ("group16", 0, I)), ("up_proj", ("group16", 16, I))], rank)
+            L[f"llm.{i}.down"] = LoraLinear(q + "mlp", D, I, [("down_proj", ("range", 0, D))], rank)
+        self.L = L
+        specA, specB = [], []
+        for l in L.values():
+            a, b = l.spec()
+            specA += a
+            specB += b
+        self.P = E.FlatParams(specA + specB, self.dev)
+        gen = torch.Generator(device=self.dev).manual_seed(seed)
+        for l in L.values():
+            l.bind(self.P, self.dev)
+            l.init_(gen)
+        # W^T operands of the ViT / projector dX products (the LLM's exist already); the base weights are frozen: built once
+        for v in self.vits:
+            for b in v.blocks:
+                for k in ("wqkv", "wproj", "w1", "w2"):
+                    b[k + "T"] = ops.transpose(b[k])
+        self.projT = {k: ops.transpose(w) for k, w in eng.proj.items() if k.endswith("weight")}
+        self.T, self.DT = {}, {}              # t = 2 x A^T per LoRA Linear (kept for dB), dt = 2 dy B scratch per shape
+        self.refresh()
+
+    vit = property(lambda self: self.vits[0])
+
+    def refresh(self):
+        for l in self.L.values():
+            l.refresh()
+
+    def _alloc(self, B, S):
+        if self._key != (B, S):
+            self.T, self.DT = {}, {}
+        super()._alloc(B, S)
+
+    # ---- the Linear of this mode: base product with the low-rank branch inside its accumulator (GEMM K extension)
+    def _lin(self, key, x, W, bias=None, **kw):
+        l = self.L[key]
+        t = self.T.get(key)
+        if t is None or t.shape[0] != x.shape[0]:
+            t = self.T[key] = torch.empty(x.shape[0], l.Rr, device=self.dev, dtype=BF16)
+        ops.gemm_nt(x, l.A_cat, alpha=2.0, out=t)                   # t = 2 x A_cat^T   (alpha / r = 2)
+        return ops.gemm_nt(x, W, bias=bias, ext=(t, l.B_blk), **kw)
+
+    def _lin_bwd(self, key, dy, x, WT, out=None, swiglu_gu=None):
+        l = self.L[key]
+        M = dy.shape[0]
+        dt = self.DT.get((M, l.Rr))
+        if dt is None:
+            dt = self.DT[(M, l.Rr)] = torch.empty(M, l.Rr, device=self.dev, dtype=BF16)
+        ops.gemm_nt(dy, l.B_blkT, alpha=2.0, out=dt)                # dt = 2 dy B_blk
+        l.grads(dy, x, self.T[key], dt)
+        if swiglu_gu is not None:
+            return ops.gemm_swiglu_bwd(dy, WT, swiglu_gu, out=out, ext=(dt, l.A_catT))
+        return ops.gemm_nt(dy, WT, out=out, ext=(dt, l.A_catT))     # dx = dy W + dt A_cat
+
+    def backward(self, pred, actions, gscale: float = 1.0):
+        return self._backward_vlm(pred, actions, gscale)
+
+    # ---- adapters in and out
+    def lora_state_dict(self) -> Dict[str, torch.Tensor]:
+        """peft's adapter key layout ('....q_proj.lora_A.weight' [r, in], '....lora_B.weight' [out, r]); rank padding and the
+        ViT MLP's width padding removed."""
+        out = {}
+        for l in self.L.values():
+            for p, d in l.projs:
+                A, B = self.P.view(f"{l.name}.{p}.lora_A")[:l.r, :l.k_real], self.P.view(f"{l.name}.{p}.lora_B")[:l.n_real, :l.r]
+                out[f"{l.name}.{p}.lora_A.weight"], out[f"{l.name}.{p}.lora_B.weight"] = A, B
+        return out
+
+    def load_lora_state_dict(self, sd: Dict[str, torch.Tensor]):
+        """Inverse of lora_state_dict (``lora_adapter/adapter_model.safetensors``: resume, offline merge).  Every pair must be
+        present with this trainer's rank; paddings are re-zeroed."""
+        for l in self.L.values():
+            for p, d in l.projs:
+                A, B = self.P.view(f"{l.name}.{p}.lora_A"), self.P.view(f"{l.name}.{p}.lora_B")
+                a, b = sd[f"{l.name}.{p}.lora_A.weight"], sd[f"{l.name}.{p}.lora_B.weight"]
+                assert tuple(a.shape) == (l.r, l.k_real) and tuple(b.shape) == (min(l.n_real, B.shape[0]), l.r), \
+                    f"{l.name}.{p}: adapter shapes {tuple(a.shape)} / {tuple(b.shape)} do not match rank {l.r}"
+                A.zero_()
+                B.zero_()
+                A[:l.r, :l.k_real].copy_(a.to(self.dev, BF16))
+                B[:b.shape[0], :l.r].copy_(b.to(self.dev, BF16))
+        self.refresh()
+
+    def merged_weights(self) -> Dict[str, torch.Tensor]:
+        """W + 2 B A per target under the engine's fused names (merge_lora_weights_and_save.py / finetune.py:579-601 merge the
+        adapter into a fresh bf16 base): fp32 product, one rounding."""
+        out = {}
+        for key, l in self.L.items():
+            holder, wk = self._base(key)
+            delta = 2.0 * (l.B_blk.float() @ l.A_cat.float())
+            out[key] = (holder[wk].float() + delta).to(BF16)
+        return out
+
+    def _base(self, key: str):
+        part, *rest = key.split(".")
+        if part.startswith("vit"):
+            return self.vits[int(part[3:])].blocks[int(rest[0])], {"qkv": "wqkv", "proj": "wproj", "fc1": "w1", "fc2": "w2"}[rest[1]]
+        if part == "proj":
+            return self.eng.proj, rest[0] + ".weight"
+        return self.llm.layers[int(rest[0])], {"qkv": "wqkv", "o": "wo", "gu": "wgu", "down": "wd"}[rest[1]]
