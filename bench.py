@@ -77,7 +77,8 @@ def measure_gemm_roofline(eng, batch, noise, lr, reps=10, record_only=False):
 
     orig_sw = ops.gemm_swiglu_bwd
 
-    def rec_sw(d_, w_, gu_, out=None, gu_group=None):        # the dH GEMM with the SwiGLU backward in its epilogue
+    def rec_sw(d_, w_, gu_, out=None, gu_group=None, ext=None):        # the dH GEMM with the SwiGLU backward in its epilogue
+        assert ext is None
         r = orig_sw(d_, w_, gu_, out=out, gu_group=gu_group)
         sig = (tuple(d_.shape), tuple(w_.shape), d_.stride(-2), w_.stride(-2), 5, False, True)
         if sig not in calls:
@@ -86,19 +87,35 @@ def measure_gemm_roofline(eng, batch, noise, lr, reps=10, record_only=False):
         calls[sig][0] += 1
         return r
 
+    orig_tn = ops.gemm_tn
+
+    def rec_tn(a, b, **kw):                                   # dW = dY^T X (vla_gemm_bf16_tn): contraction over the rows
+        r = orig_tn(a, b, **kw)
+        M = kw.get("rows") or a.shape[-2]
+        N1 = kw["a_cols"][0] if kw.get("a_cols") else a.shape[-1]
+        N2, nb = b.shape[-1], (a.shape[0] if a.dim() == 3 else 1)
+        sig = ("tn", tuple(a.shape), tuple(b.shape), M, a.stride(-2), b.stride(-2), bool(kw.get("accumulate")))
+        if sig not in calls:
+            kw2 = dict(kw, out=r, _tn=True)
+            calls[sig] = [0, 2.0 * nb * M * N1 * N2, a, b, kw2, 2.0 * nb * (M * N1 + M * N2 + N1 * N2 * (2 if kw.get("accumulate") else 1))]
+        calls[sig][0] += 1
+        return r
+
     def replay(a, b, kw):
         if "_swiglu_bwd" in kw:
             gu_, out_, grp = kw["_swiglu_bwd"]
             return orig_sw(a, b, gu_, out=out_, gu_group=grp)
+        if kw.get("_tn"):
+            return orig_tn(a, b, **{k: v for k, v in kw.items() if k != "_tn"})
         return orig(a, b, **kw)
 
-    ops.gemm_nt, ops.gemm_swiglu_bwd = rec, rec_sw
+    ops.gemm_nt, ops.gemm_swiglu_bwd, ops.gemm_tn = rec, rec_sw, rec_tn
     reducer, eng.reducer = eng.reducer, None      # rank-0-only probe step: it must not issue collectives
     try:
         eng.train_step(batch, lr, noise)
         torch.cuda.synchronize()
     finally:
-        ops.gemm_nt, ops.gemm_swiglu_bwd = orig, orig_sw
+        ops.gemm_nt, ops.gemm_swiglu_bwd, ops.gemm_tn = orig, orig_sw, orig_tn
         eng.reducer = reducer
     if record_only:
         return dict(launches=sum(c[0] for c in calls.values()), flops=sum(c[0] * c[1] for c in calls.values()),
@@ -120,7 +137,7 @@ def measure_gemm_roofline(eng, batch, noise, lr, reps=10, record_only=False):
         total_f += cnt * fl
         total_b += cnt * nbytes
         n += cnt
-        per.append((cnt * t, cnt, sig[0], sig[1], fl / t / 1e12))
+        per.append((cnt * t, cnt, ("TN",) + tuple(sig[1]) if sig[0] == "tn" else sig[0], sig[2] if sig[0] == "tn" else sig[1], fl / t / 1e12))
     per.sort(reverse=True)
     if os.environ.get("VLA_DUMP_GEMMS"):          # full per-signature table (tuning aid)
         with open(os.environ["VLA_DUMP_GEMMS"], "w") as fdump:
@@ -473,7 +490,7 @@ def main():
             "gflop_per_sample": {"executed": round(fl["step_live"] / 1e9, 1), "autograd_convention": round(fl["step"] / 1e9, 1)},
             "full_backward_variant": full_bwd,
             "fp8_frozen_forward_variant": fp8_var,
-            "roofline": {"bound": "mfma", "kernel": "gemm256_kernel + gemm_nt_kernel (bf16 MFMA NT GEMMs, all launches of one step)",
+            "roofline": {"bound": "mfma", "kernel": "gemm256_kernel + gemm_nt_kernel + gemm_tn_kernel (bf16 MFMA GEMMs, all launches of one step)",
                          "achieved": round(roof["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(roof["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
                          "frac_in_situ": (in_situ_roofline(roof["flops"]) or {}).get("frac_in_situ"), "in_situ": in_situ_roofline(roof["flops"]),

@@ -58,6 +58,12 @@ def linear(x, w, b=None, emu=False, strided_input=False):
         y = (rnd(y, emu) if strided_input else y) + b
     y = rnd(y, emu)
     l = LORA.get(id(w))
+    if l is not None and LORA_FUSED:
+        # the native build's form (vla_adapter_amd/trainers.py): the low-rank branch inside the base product's fp32 accumulator -
+        # t = bf16(scale x A^T), y = bf16(x W^T + t B^T + b): ONE rounding of y where peft's module-by-module evaluation has three
+        A, Bm, scale = l
+        y = x @ w.t() + rnd(scale * (x @ A.t()), emu) @ Bm.t()
+        return rnd(y + b, emu) if b is not None else rnd(y, emu)
     if l is not None:            # peft Linear.forward: result = base(x) + lora_B(lora_A(x)) * scaling, every step a bf16 tensor
         A, Bm, scale = l
         y = rnd(y + rnd(rnd(rnd(x @ A.t(), emu) @ Bm.t(), emu) * scale, emu), emu)
@@ -81,6 +87,7 @@ def fake_quant_e4m3_rows(t):
 # LoRA registry (a11, parity unpinned: peft absent): id(base weight tensor) -> (A [r, in], B [out, r], alpha / r).  Tests fill it
 # to evaluate the LoRA-wrapped model (vla-scripts/finetune.py:832-844) through the unchanged restated forward.
 LORA: Dict[int, Tuple[torch.Tensor, torch.Tensor, float]] = {}
+LORA_FUSED = False     # True: restate the native build's single-rounding evaluation instead of peft's module-by-module one
 
 
 def gelu(x, emu=False, tanh=False):
@@ -181,26 +188,30 @@ def vit_forward(pixels, p: Dict[str, torch.Tensor], cfg: Dict, emu=False) -> tor
         if "reg_token" in p:
             pref.append(p["reg_token"].expand(B, -1, -1))
         x = torch.cat(pref + [x], dim=1)
-    dh = d // heads
     last = cfg["depth"] - 2                                        # modeling_prismatic.py:141-142
     for i in range(last + 1):                                      # blocks after `last` are dead work
-        pre = f"blocks.{i}."
-        h = layer_norm(x, p[pre + "norm1.weight"], p[pre + "norm1.bias"], cfg["eps"], emu)
-        qkv = linear(h, p[pre + "attn.qkv.weight"], p[pre + "attn.qkv.bias"], emu)
-        T = x.shape[1]
-        q, k, v = qkv.reshape(B, T, 3, heads, dh).permute(2, 0, 3, 1, 4)
-        a = attention(q, k, v, False, None, dh ** -0.5, emu).transpose(1, 2).reshape(B, T, d)
-        a = linear(a, p[pre + "attn.proj.weight"], p[pre + "attn.proj.bias"], emu)
-        if cfg.get("layerscale"):
-            a = rnd(a * p[pre + "ls1.scale_factor"], emu)          # modeling_prismatic.py:58-66
-        x = rnd(x + a, emu)
-        h = layer_norm(x, p[pre + "norm2.weight"], p[pre + "norm2.bias"], cfg["eps"], emu)
-        h = gelu(linear(h, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"], emu), emu, cfg.get("gelu_tanh", False))
-        h = linear(h, p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"], emu)
-        if cfg.get("layerscale"):
-            h = rnd(h * p[pre + "ls2.scale_factor"], emu)
-        x = rnd(x + h, emu)
+        x = vit_block(x, p, f"blocks.{i}.", cfg, emu)
     return x[:, cfg.get("n_prefix", 0):]
+
+
+def vit_block(x, p: Dict[str, torch.Tensor], pre: str, cfg: Dict, emu=False):
+    """One timm Block: x + ls1(attn(norm1 x)); x + ls2(mlp(norm2 x))  (film_vit_wrapper.py:69-75; LayerScale modeling_prismatic.py:58-66)."""
+    d, heads = cfg["d"], cfg["heads"]
+    B, T, dh = x.shape[0], x.shape[1], d // heads
+    h = layer_norm(x, p[pre + "norm1.weight"], p[pre + "norm1.bias"], cfg["eps"], emu)
+    qkv = linear(h, p[pre + "attn.qkv.weight"], p[pre + "attn.qkv.bias"], emu)
+    q, k, v = qkv.reshape(B, T, 3, heads, dh).permute(2, 0, 3, 1, 4)
+    a = attention(q, k, v, False, None, dh ** -0.5, emu).transpose(1, 2).reshape(B, T, d)
+    a = linear(a, p[pre + "attn.proj.weight"], p[pre + "attn.proj.bias"], emu)
+    if cfg.get("layerscale"):
+        a = rnd(a * p[pre + "ls1.scale_factor"], emu)              # modeling_prismatic.py:58-66
+    x = rnd(x + a, emu)
+    h = layer_norm(x, p[pre + "norm2.weight"], p[pre + "norm2.bias"], cfg["eps"], emu)
+    h = gelu(linear(h, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"], emu), emu, cfg.get("gelu_tanh", False))
+    h = linear(h, p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"], emu)
+    if cfg.get("layerscale"):
+        h = rnd(h * p[pre + "ls2.scale_factor"], emu)
+    return rnd(x + h, emu)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -244,29 +255,34 @@ def qwen2_forward(x, mask, p: Dict[str, torch.Tensor], cfg: Dict, emu=False) -> 
     cfg: dict(n_layers, heads, kv_heads, dh, eps, theta).  Params use HF names under ``layers.N.``.
     Attention: causal AND key-padding, softmax fp32, P rounded to bf16 before P@V (eager path).
     """
-    B, S, D = x.shape
-    H, KV, dh = cfg["heads"], cfg["kv_heads"], cfg["dh"]
-    cos, sin = rope_half_tables(S, dh, cfg["theta"], emu)
+    S = x.shape[1]
     hs = [x]
     for i in range(cfg["n_layers"]):
-        pre = f"layers.{i}."
-        h = rms_norm(x, p[pre + "input_layernorm.weight"], cfg["eps"], emu)
-        q = linear(h, p[pre + "self_attn.q_proj.weight"], p[pre + "self_attn.q_proj.bias"], emu)
-        k = linear(h, p[pre + "self_attn.k_proj.weight"], p[pre + "self_attn.k_proj.bias"], emu)
-        v = linear(h, p[pre + "self_attn.v_proj.weight"], p[pre + "self_attn.v_proj.bias"], emu)
-        q = rope_half(q.reshape(B, S, H, dh).transpose(1, 2), cos, sin, emu)
-        k = rope_half(k.reshape(B, S, KV, dh).transpose(1, 2), cos, sin, emu)
-        v = v.reshape(B, S, KV, dh).transpose(1, 2)
-        a = attention(q, k, v, True, mask, dh ** -0.5, emu).transpose(1, 2).reshape(B, S, H * dh)
-        x = rnd(x + linear(a, p[pre + "self_attn.o_proj.weight"], None, emu), emu)
-        h = rms_norm(x, p[pre + "post_attention_layernorm.weight"], cfg["eps"], emu)
-        g = linear(h, p[pre + "mlp.gate_proj.weight"], None, emu)
-        u = linear(h, p[pre + "mlp.up_proj.weight"], None, emu)
-        m = rnd(rnd(g * torch.sigmoid(g), emu) * u, emu)
-        x = rnd(x + linear(m, p[pre + "mlp.down_proj.weight"], None, emu), emu)
+        x = qwen2_layer(x, mask, p, f"layers.{i}.", cfg, emu)
         hs.append(x)
     hs[-1] = rms_norm(x, p["norm.weight"], cfg["eps"], emu)
     return hs
+
+
+def qwen2_layer(x, mask, p: Dict[str, torch.Tensor], pre: str, cfg: Dict, emu=False):
+    """One Qwen2DecoderLayer (transformers): x + o(attn(rope(q, k), v)) ; x + down(silu(gate) * up)."""
+    B, S, D = x.shape
+    H, KV, dh = cfg["heads"], cfg["kv_heads"], cfg["dh"]
+    cos, sin = rope_half_tables(S, dh, cfg["theta"], emu)
+    h = rms_norm(x, p[pre + "input_layernorm.weight"], cfg["eps"], emu)
+    q = linear(h, p[pre + "self_attn.q_proj.weight"], p[pre + "self_attn.q_proj.bias"], emu)
+    k = linear(h, p[pre + "self_attn.k_proj.weight"], p[pre + "self_attn.k_proj.bias"], emu)
+    v = linear(h, p[pre + "self_attn.v_proj.weight"], p[pre + "self_attn.v_proj.bias"], emu)
+    q = rope_half(q.reshape(B, S, H, dh).transpose(1, 2), cos, sin, emu)
+    k = rope_half(k.reshape(B, S, KV, dh).transpose(1, 2), cos, sin, emu)
+    v = v.reshape(B, S, KV, dh).transpose(1, 2)
+    a = attention(q, k, v, True, mask, dh ** -0.5, emu).transpose(1, 2).reshape(B, S, H * dh)
+    x = rnd(x + linear(a, p[pre + "self_attn.o_proj.weight"], None, emu), emu)
+    h = rms_norm(x, p[pre + "post_attention_layernorm.weight"], cfg["eps"], emu)
+    g = linear(h, p[pre + "mlp.gate_proj.weight"], None, emu)
+    u = linear(h, p[pre + "mlp.up_proj.weight"], None, emu)
+    m = rnd(rnd(g * torch.sigmoid(g), emu) * u, emu)
+    return rnd(x + linear(m, p[pre + "mlp.down_proj.weight"], None, emu), emu)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -339,8 +355,11 @@ def head_attention_core(q, segs, ratio_g, emu=False):
     return rnd(w @ torch.cat([v for _, v in segs], dim=2), emu)
 
 
-def head_block_pro(x, h_t, h_a, pp, p: Dict[str, torch.Tensor], pre: str, emu=False, H: int = 8):
-    """MLPResNetBlock_Pro.forward (action_heads.py:337-410)."""
+def head_block_pro(x, h_t, h_a, pp, p: Dict[str, torch.Tensor], pre: str, emu=False, H: int = 8, relu_mask=None):
+    """MLPResNetBlock_Pro.forward (action_heads.py:337-410).
+    relu_mask (tests only): evaluate the closing ReLU with THIS 0/1 pattern instead of the sign of the recomputed pre-activation -
+    a single-block gradient check compares backward arithmetic at the SAME activation pattern as the run under test (a
+    pre-activation within rounding of zero that falls on the other side is a forward difference, not a backward one)."""
     B, T, C = x.shape
     dh = C // H
     ratio_g = torch.tanh(p[pre + "gating_factor"])                 # :343-344
@@ -362,7 +381,8 @@ def head_block_pro(x, h_t, h_a, pp, p: Dict[str, torch.Tensor], pre: str, emu=Fa
     o = L("o_proj", o.transpose(1, 2).reshape(B, T, C))
     y = rnd(o + x, emu)                                            # :409 (no outer residual)
     y = layer_norm(y, p[pre + "ffn.0.weight"], p[pre + "ffn.0.bias"], 1e-5, emu)
-    return rnd(torch.relu(L("ffn.1", y)), emu)
+    z = L("ffn.1", y)
+    return rnd(torch.relu(z) if relu_mask is None else z * relu_mask, emu)
 
 
 def head_block_orig(x, h_t, h_a, pp, p: Dict[str, torch.Tensor], pre: str, emu=False, H: int = 8):

@@ -57,3 +57,46 @@ def test_run_dir_files_roundtrip(tmp_path):
     from safetensors.torch import save_file
     save_file({"a.b": torch.arange(3.0)}, str(tmp_path / "m.safetensors"))
     assert torch.equal(C.load_file(str(tmp_path / "m.safetensors"))["a.b"], torch.arange(3.0))
+
+
+def test_infer_config_reads_the_geometry_off_a_state_dict():
+    """finetune.py picks the model from the checkpoint (VERDICT r2 #1c): synthetic CPU weights of every named geometry, exported
+    under the reference's HF key names, give the same geometry back - incl. the DINOv2 prefix tokens / LayerScale, the fused
+    3-layer projector and the 1.5B head dim."""
+    from vla_adapter_amd import engine as E, synthetic as S
+    for name in ("tiny", "tiny_fused"):
+        cfg = E.NAMED_CONFIGS[name]()
+        W = S.make_weights(cfg, "cpu", seed=1)
+        sd = C.merge_reference_state_dict(W, cfg)
+        got = C.infer_config({"module." + k: v for k, v in sd.items()})
+        assert [v.as_oracle() for v in got.vit] == [v.as_oracle() for v in cfg.vit] and [v.img for v in got.vit] == [v.img for v in cfg.vit]
+        assert got.llm == cfg.llm and got.num_blocks == cfg.num_blocks and got.fused == cfg.fused
+    # full-size geometries from shapes alone (meta tensors: no memory)
+    real_rn = S._rn
+    S._rn = lambda gen, shape, std, device: torch.empty(*shape, device="meta", dtype=torch.bfloat16)
+    try:
+        sds = {name: C.merge_reference_state_dict(S.make_weights(E.NAMED_CONFIGS[name](), "cpu", seed=0), E.NAMED_CONFIGS[name]())
+               for name in ("config2", "dinosiglip-0_5b", "config5")}
+    finally:
+        S._rn = real_rn
+    for name, sd in sds.items():
+        cfg = E.NAMED_CONFIGS[name]()
+        got = C.infer_config(sd)
+        assert [v.as_oracle() for v in got.vit] == [v.as_oracle() for v in cfg.vit] and got.llm == cfg.llm and got.num_blocks == 24
+
+
+def test_offline_lora_merge_matches_w_plus_scaled_ba():
+    """merge_lora_weights_and_save.py:44-103: W + (alpha / r) B A for every adapted Linear, everything else untouched."""
+    g = torch.Generator().manual_seed(0)
+    base = {"language_model.model.layers.0.self_attn.q_proj.weight": torch.randn(16, 8, generator=g).to(torch.bfloat16),
+            "language_model.model.layers.0.self_attn.q_proj.bias": torch.randn(16, generator=g).to(torch.bfloat16),
+            "projector.fc1.weight": torch.randn(4, 8, generator=g).to(torch.bfloat16)}
+    A, B = torch.randn(2, 8, generator=g).to(torch.bfloat16), torch.randn(16, 2, generator=g).to(torch.bfloat16)
+    pre = "base_model.model.language_model.model.layers.0.self_attn.q_proj."
+    merged = C.merge_lora_into_state_dict(base, {pre + "lora_A.weight": A, pre + "lora_B.weight": B})
+    k = "language_model.model.layers.0.self_attn.q_proj.weight"
+    assert torch.equal(merged[k], (base[k].float() + 2.0 * (B.float() @ A.float())).to(torch.bfloat16)) and merged[k].dtype == torch.bfloat16
+    assert all(torch.equal(merged[n], base[n]) for n in base if n != k)
+    import pytest
+    with pytest.raises(KeyError):
+        C.merge_lora_into_state_dict(base, {"base_model.model.nope.lora_A.weight": A, "base_model.model.nope.lora_B.weight": B})

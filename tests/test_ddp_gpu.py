@@ -34,3 +34,17 @@ def test_single_rank_rccl_exchange_is_the_identity():
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "rccl-single-rank-ok" in r.stdout, r.stdout[-3000:]
+
+
+@pytest.mark.parametrize("mode,captured", [("full", "0"), ("full", "1"), ("lora", "1")])
+def test_two_rank_backbone_trainers_exchange_during_the_backward(mode, captured):
+    """Full fine-tune (BASELINE configs[3]: "grad-bucket overlap") and LoRA on the plumbing-size DINOv2 + SigLIP geometry, two gloo
+    ranks on one GPU: gradient ranges go to the exchange as the backward finishes them (eager and as a chain of captured segment
+    graphs); ranks end bit-identical and equal to the single-process run on the summed gradients (tools/ddp_rehearsal_trainers.py)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, VLA_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", VLA_TRAINER=mode, VLA_CAPTURED=captured)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join("tools", "ddp_rehearsal_trainers.py")],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("ranks-in-sync-ok") == 2, r.stdout[-3000:]

@@ -586,7 +586,7 @@ def test_full_size_full_finetune_step_config4():
     torch.cuda.synchronize()
     g = ft.P.grad.float()
     assert l0 == l0 and torch.isfinite(g).all()
-    for name in ("llm.0.wqkv", "llm.23.wd", "vit.0.wqkv", "vit.25.w2", "proj.fc1.weight", "llm.norm", "vit.pos", "llm.11.n2", "vit.12.b1"):
+    for name in ("llm.0.wqkv", "llm.23.wd", "vit0.0.wqkv", "vit0.25.w2", "proj.fc1.weight", "llm.norm", "vit0.pos", "llm.11.n2", "vit0.12.b1"):
         off, shape = ft.P.offsets[name]
         n = 1
         for d in shape:

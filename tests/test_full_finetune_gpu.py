@@ -30,18 +30,23 @@ def _ref_grads(OW, cfg):
     for k, v in OW["llm"].items():
         if v.grad is not None:
             out["language_model.model." + k] = v.grad
-    for k, v in OW["vit"][0].items():
-        if v.grad is not None:
-            out["vision_backbone.featurizer." + k] = v.grad
+    for pre, sd in zip(("vision_backbone.featurizer.", "vision_backbone.fused_featurizer."), OW["vit"]):
+        for k, v in sd.items():
+            if v.grad is not None:
+                out[pre + k] = v.grad
     for k, v in OW["proj"].items():
         out["projector." + k] = v.grad
     return out
 
 
-def test_full_finetune_gradients_match_oracle_autograd():
+@pytest.mark.parametrize("which", ["tiny", "tiny_fused"])
+def test_full_finetune_gradients_match_oracle_autograd(which):
+    """tiny: BASELINE configs[0].  tiny_fused: the reference's default setup at plumbing size - a DINOv2-like backbone (cls + 4
+    register tokens, LayerScale as its own parameter) fused with a SigLIP-like one, two images per sample, 3-layer projector
+    (modeling_prismatic.py:58-66, 196-237): gradients of ls1 / ls2.scale_factor, cls_token, reg_token and both pos_embeds included."""
     from vla_adapter_amd import engine as E, synthetic as S, ops
     from vla_adapter_amd.full_finetune import FullFinetune
-    cfg = E.tiny_config()
+    cfg = E.tiny_config() if which == "tiny" else E.tiny_fused_config()
     W = S.make_weights(cfg, DEV, seed=3, std=0.05)
     batch = S.make_batch(cfg, 3, DEV, seed=4, P=20, ragged=True)
     eng = E.VLAEngine(cfg, W, DEV)
@@ -60,7 +65,10 @@ def test_full_finetune_gradients_match_oracle_autograd():
         if not emu:
             budget(budget_pred[0], budget_pred[1], out["pred"], "full fine-tune forward (unfused GELU, saved activations): actions")
     got = ft.reference_named_gradients()
-    n, nbv = cfg.llm.n_layers, len(eng.vits[0].blocks)
+    n, nbv = cfg.llm.n_layers, sum(len(v.blocks) for v in eng.vits)
+    if which == "tiny_fused":
+        for need in ("ls1.scale_factor", "ls2.scale_factor", "cls_token", "reg_token", "fused_featurizer.pos_embed", "projector.fc3.weight"):
+            assert any(need in k for k in got), need
     fam = []
     skipped = []
     for k, g in got.items():
@@ -70,7 +78,7 @@ def test_full_finetune_gradients_match_oracle_autograd():
         r_e, r_t = G[True][0][k], G[False][0][k]
         fam.append((k, g, r_e.reshape(g.shape), r_t.reshape(g.shape)))
     # the oracle computes the (dead) last ViT block too; the engine's parameter list stops at the last useful block
-    assert all("blocks.%d." % (cfg.vit[0].depth - 1) not in k for k in got), "last ViT block is never part of the path"
+    assert all("featurizer.blocks.%d." % (cfg.vit[0].depth - 1) not in k for k in got), "last ViT block is never part of the path"
     assert len(fam) >= 8 * nbv + 10 * n + 6, (len(fam), skipped[:5])
     gmax = max(t[3].norm().item() for t in fam)
     mats = [t for t in fam if t[1].dim() >= 2 and "embed_tokens" not in t[0]]

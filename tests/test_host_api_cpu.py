@@ -69,10 +69,14 @@ def test_loop_plan_follows_the_reference_bookkeeping():
     checkpoint when gradient_step_idx > 0 and log_step % save_freq == 0, stop after the batch with log_step == max_steps."""
     cfg = F.FinetuneConfig(max_steps=6, save_freq=3, grad_accumulation_steps=2)
     plan = list(F.loop_plan(cfg))
-    assert len(plan) == 2 * 7                                             # gradient steps 0..6 inclusive, two micro-batches each
-    assert [x[3] for x in plan] == [False, True] * 7                      # optimizer step on every second micro-batch
-    assert [x[2] for x in plan if x[4]] == [3, 6]                         # checkpoints at log_step 3 and 6
-    assert plan[-1][5] and not any(x[5] for x in plan[:-1])
+    # the reference breaks behind the FIRST micro-batch whose log_step == max_steps (:1119-1121): with accumulation that is the
+    # first micro-batch of gradient step 6 - its backward runs, its optimizer step never does (ADVICE r2)
+    assert len(plan) == 2 * 6 + 1
+    assert [x[3] for x in plan] == [False, True] * 6 + [False]            # optimizer step on every second micro-batch
+    assert [x[2] for x in plan if x[4]] == [3]                            # checkpoint behind the optimizer step of log_step 3
+    assert plan[-1][5] and plan[-1][2] == 6 and not any(x[5] for x in plan[:-1])
+    plan = list(F.loop_plan(F.FinetuneConfig(max_steps=6, save_freq=3)))  # no accumulation: steps 0..6 inclusive, all applied
+    assert len(plan) == 7 and all(x[3] for x in plan) and [x[2] for x in plan if x[4]] == [3, 6] and plan[-1][5]
     cfg = F.FinetuneConfig(max_steps=105, save_freq=100, resume=True, resume_step=100)
     plan = list(F.loop_plan(cfg))
     assert [x[2] for x in plan] == [100, 101, 102, 103, 104, 105]          # log_step continues from resume_step

@@ -277,10 +277,82 @@ def test_finetune_entry_point_lora_and_full_modes(tmp_path, mode):
     d = glob.glob(os.path.join(str(tmp_path), "*--10_chkpt"))[0]
     names = set(os.listdir(d))
     assert {"action_head--10_checkpoint.pt", "proprio_projector--10_checkpoint.pt"} <= names
-    vlm = load_file(os.path.join(d, "model.safetensors"))
+    # where the VLM goes follows the reference: merged LoRA model at the top level (:579-601), the full fine-tune's
+    # save_pretrained(adapter_dir) under lora_adapter/ (:553-554)
+    vlm = load_file(os.path.join(d, "model.safetensors") if mode == "lora" else os.path.join(d, "lora_adapter", "model.safetensors"))
     assert "language_model.model.layers.0.self_attn.q_proj.weight" in vlm and "vision_backbone.featurizer.blocks.0.mlp.fc1.weight" in vlm
     assert "projector.fc1.weight" in vlm and "action_queries.weight" in vlm
     if mode == "lora":
         ad = load_file(os.path.join(d, "lora_adapter", "adapter_model.safetensors"))
         k = "base_model.model.language_model.model.layers.1.mlp.gate_proj.lora_B.weight"
         assert k in ad and ad[k].shape[1] == 8 and ad[k].abs().max() > 0
+
+
+
+def _fused_batches(n, B=3, seed0=500):
+    from vla_adapter_amd import engine as E, synthetic as S
+    return [S.make_batch(E.tiny_fused_config(), B, "cuda", seed=seed0 + i, P=24, ragged=True) for i in range(n)]
+
+
+def test_documented_recipe_runs_on_the_tiny_dual_config(tmp_path):
+    """README.md:254-274 of the reference: ``--vlm_path ...dinosiglip-224px-0_5b --num_images_in_input 2 --use_lora True
+    --lora_rank 64 --merge_lora_during_training True`` - here on the plumbing-size DINOv2 + SigLIP geometry: the
+    run completes, the loss falls, the adapter holds pairs for BOTH backbones, the merged VLM carries LayerScale and the cls /
+    register tokens under the reference's key names."""
+    from vla_adapter_amd import finetune as F
+    from safetensors.torch import load_file
+    import glob
+    cfg = F.parse_args(["--tiny", "true", "--backbone", "tiny_fused", "--num_images_in_input", "2", "--use_lora", "True", "--lora_rank", "64",
+                        "--merge_lora_during_training", "True", "--batch_size", "3", "--max_steps", "10", "--learning_rate", "1e-3", "--wandb_log_freq", "5",
+                        "--save_freq", "10", "--run_root_dir", str(tmp_path), "--phase", "Training", "--use_proprio", "True"])
+    out = F.finetune(cfg, batches=_fused_batches(2))
+    assert out["mode"] == "lora" and out["model"]["n_img"] == 2 and len(out["model"]["vit"]) == 2
+    assert out["log"][-1]["loss_value"] < out["log"][0]["loss_value"], out["log"]
+    d = glob.glob(os.path.join(str(tmp_path), "*--10_chkpt"))[0]
+    ad = load_file(os.path.join(d, "lora_adapter", "adapter_model.safetensors"))
+    for k in ("base_model.model.vision_backbone.featurizer.blocks.0.attn.qkv.lora_A.weight",
+              "base_model.model.vision_backbone.fused_featurizer.blocks.1.mlp.fc2.lora_B.weight",
+              "base_model.model.projector.fc3.lora_A.weight", "base_model.model.language_model.model.layers.1.mlp.down_proj.lora_B.weight"):
+        assert k in ad and 64 in ad[k].shape, k
+    vlm = load_file(os.path.join(d, "model.safetensors"))
+    for k in ("vision_backbone.featurizer.blocks.0.ls1.scale_factor", "vision_backbone.featurizer.cls_token", "vision_backbone.featurizer.reg_token",
+              "vision_backbone.fused_featurizer.pos_embed", "projector.fc3.weight", "action_queries.weight"):
+        assert k in vlm, k
+
+
+@pytest.mark.parametrize("mode", ["lora", "full"])
+def test_lora_and_full_resume_restore_what_they_trained(tmp_path, mode):
+    """--resume in LoRA / full mode used to restore head + proprio + queries only: now the adapter
+    (lora_adapter/adapter_model.safetensors) / the trained VLM come back too - a resumed run at lr 0 hands back what it loaded."""
+    from vla_adapter_amd import finetune as F
+    from safetensors.torch import load_file
+    extra = ["--use_lora", "True", "--lora_rank", "8"] if mode == "lora" else []
+    base = ["--tiny", "true", "--batch_size", "4", "--wandb_log_freq", "1", "--phase", "Inference", "--use_proprio", "True", "--run_root_dir", str(tmp_path),
+            "--run_id_override", "r"] + extra
+    bs = _tiny_batches(2, seed0=380)
+    F.finetune(F.parse_args(base + ["--max_steps", "4", "--save_freq", "4", "--learning_rate", "1e-3"]), batches=bs)
+    ck = str(tmp_path / "r--4_chkpt")
+    F.finetune(F.parse_args(base + ["--max_steps", "6", "--save_freq", "100", "--resume", "True", "--resume_step", "4", "--resum_vla_path", ck,
+                                    "--learning_rate", "0.0"]), batches=bs)
+    f = "adapter_model.safetensors" if mode == "lora" else "model.safetensors"
+    a, b = load_file(os.path.join(ck, "lora_adapter", f)), load_file(os.path.join(str(tmp_path / "r--6_chkpt"), "lora_adapter", f))
+    assert set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a)
+    if mode == "lora":
+        assert any(v.abs().max() > 0 for k, v in a.items() if "lora_B" in k), "the checkpoint must hold TRAINED adapters"
+
+
+def test_finetune_picks_the_model_from_the_checkpoint(tmp_path):
+    """Without --backbone / --tiny the geometry is read off the --vlm_path state dict (the reference builds the model from the
+    checkpoint's config, finetune.py:777-816): a fused DINOv2 + SigLIP checkpoint selects the fused geometry."""
+    from vla_adapter_amd import finetune as F, engine as E, synthetic as S, checkpoints as CK
+    from safetensors.torch import save_file
+    cfg = E.tiny_fused_config()
+    W = S.make_weights(cfg, "cuda", seed=7)
+    f = str(tmp_path / "vlm.safetensors")
+    save_file({k: v.contiguous().cpu() for k, v in CK.merge_reference_state_dict(W, cfg).items()}, f)
+    out = F.finetune(F.parse_args(["--vlm_path", f, "--num_images_in_input", "2", "--use_fz", "True", "--batch_size", "3", "--max_steps", "2",
+                                   "--wandb_log_freq", "1", "--save_freq", "100", "--run_root_dir", str(tmp_path), "--phase", "Inference", "--use_proprio", "True"]),
+                     batches=_fused_batches(2, seed0=520))
+    m = out["model"]
+    assert [v["d"] for v in m["vit"]] == [192, 128] and m["vit"][0]["n_prefix"] == 5 and m["vit"][0]["layerscale"] and m["llm"]["d"] == 256
+    assert all(l["loss_value"] == l["loss_value"] for l in out["log"])

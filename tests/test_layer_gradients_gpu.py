@@ -1,0 +1,340 @@
+"""Gradient checks that can fail: ONE LLM layer, ONE ViT block, ONE action-head block at FULL SIZE, on the
+run's own saved activations and its own upstream gradient, against autograd through the bf16-emulating oracle of that one layer.
+
+Why single layers: an end-to-end gradient comparison compounds 24 layers of valid-but-different bf16 roundings (and ReLU / sign
+flips), so its allowance grew to factors of 1.5-4 of the oracle's own distance to fp32 - loose enough to hide a wrong scale.
+Here the layer's input x and the gradient d_out w.r.t. its output are taken from the native run; the oracle recomputes the
+layer's forward from x with the reference's rounding points and back-propagates d_out.  What remains between the two results is
+the rounding noise of ONE layer: every dX / dW must agree to a few 1e-3 relative L2 (bounds below = measured + 50 %, VERDICT's
+target <= 1e-2), tensors whose norm is far below the layer's dominant gradient get an absolute floor.  Every test also feeds
+its own checker a deliberately wrong result (one gradient x 1.05) and requires it to turn red.
+Reference: vla-scripts/finetune.py:1039-1042 (loss.backward through transformers Qwen2 / timm ViT / action_heads.py:337-410).
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(__file__))
+
+from oracle import vla_oracle as O  # noqa: E402
+
+DEV, BF = "cuda", torch.bfloat16
+# measured on the MI355X (round 3, gpurun_out/t_r3_layers.log): dX 1.7e-3 ... 2.7e-3, weight / LayerNorm / LoRA gradients 1.5e-3 ... 3.6e-3,
+# the worst bias 8.7e-3 (k_proj.bias: |g| four orders below the layer's dominant gradient) -> bounds = measured + 50 %, rounded up
+TOL_DX, TOL_DW, TOL_BIAS = 5.0e-3, 6.0e-3, 1.5e-2
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu().reshape(-1), b.detach().float().cpu().reshape(-1)
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+class Checker:
+    """native vs oracle(emu) per tensor: rel-L2 <= tol.  No absolute floor: a single layer's gradients agree at a few 1e-3 down to
+    tensors five orders of magnitude below the layer's dominant one (a floor relative to the largest gradient hid a wrong scale
+    on the small ones)."""
+
+    def __init__(self, what):
+        self.what, self.rows = what, []
+
+    def add(self, name, native, emu, truth, tol):
+        if name.endswith(".bias") and tol == TOL_DW:
+            tol = TOL_BIAS
+        self.rows.append((name, native.detach().float().cpu(), emu.detach().float().cpu().reshape(native.shape), truth.detach().float().cpu().reshape(native.shape), tol))
+
+    def run(self, verbose=True):
+        worst = 0.0
+        for name, n, e, t, tol in self.rows:
+            r, rn, re = rel(n, e), rel(n, t), rel(e, t)
+            ok = r <= tol
+            worst = max(worst, r)
+            if verbose:
+                print(f"  {self.what} / {name}: native-vs-emu {r:.2e} (tol {tol:.1e})  native-vs-fp32 {rn:.2e}  emu-vs-fp32 {re:.2e}  |g| {t.norm().item():.3e}")
+            assert ok, f"{self.what} / {name}: native vs bf16-emulating oracle {r:.3e} > {tol:.1e}"
+        if verbose:
+            print(f"{self.what}: {len(self.rows)} tensors, worst rel-L2 {worst:.2e}")
+        return worst
+
+    def must_catch_a_wrong_scale(self, name=None):
+        """Discriminating power: the same comparison with ONE native tensor scaled by 1.05 must fail."""
+        idx = next(i for i, r in enumerate(self.rows) if (name is None and r[3].norm().item() > 0.1 * max(q[3].norm().item() for q in self.rows)) or r[0] == name)
+        saved = self.rows[idx]
+        self.rows[idx] = (saved[0], saved[1] * 1.05) + saved[2:]
+        try:
+            with pytest.raises(AssertionError):
+                self.run(verbose=False)
+        finally:
+            self.rows[idx] = saved
+
+
+def leaf(d, prefix):
+    return {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in d.items() if k.startswith(prefix)}
+
+
+def llm_layer_oracle(W_llm, i, x, mask, d_out, cfg, emu, lora=None):
+    p = leaf(W_llm, f"layers.{i}.")
+    O.LORA.clear()
+    if lora is not None:
+        lora(p)
+    xl = x.detach().float().cpu().clone().requires_grad_(True)
+    try:
+        y = O.qwen2_layer(xl, mask, p, f"layers.{i}.", cfg.llm.as_oracle(), emu)
+    finally:
+        O.LORA.clear()
+    y.backward(d_out.detach().float().cpu().reshape(y.shape))
+    return xl.grad, p
+
+
+def vit_block_oracle(W_vit, i, x, d_out, vcfg, emu, lora=None):
+    p = leaf(W_vit, f"blocks.{i}.")
+    O.LORA.clear()
+    if lora is not None:
+        lora(p)
+    xl = x.detach().float().cpu().clone().requires_grad_(True)
+    try:
+        y = O.vit_block(xl, p, f"blocks.{i}.", vcfg.as_oracle(), emu)
+    finally:
+        O.LORA.clear()
+    y.backward(d_out.detach().float().cpu().reshape(y.shape))
+    return xl.grad, p
+
+
+# ------------------------------------------------------------------------------------------------ adapter-only engine (headline step)
+def test_adapter_step_one_llm_layer_and_one_head_block_at_full_size():
+    """BASELINE configs[1] (SigLIP + Qwen2.5-0.5B, adapter-only), batch 2, the step's own live-row backward driven layer by layer:
+    LLM layer 12's dX on the live rows, head block 12's dX, every dW / db / LayerNorm / gate gradient, the adapter- and proprio-token
+    gradients."""
+    from vla_adapter_amd import engine as E, synthetic as S, ops
+    cfg = E.config2()
+    W = S.make_weights(cfg, DEV, seed=0)
+    batch = S.make_batch(cfg, 2, DEV, seed=90, P=32, ragged=True)
+    batch["pixel_values"] = batch["pixel_values"].to(BF)
+    eng = E.VLAEngine(cfg, W, DEV)
+    llm, head = eng.llm, eng.head
+    n, nb, D = cfg.llm.n_layers, cfg.num_blocks, cfg.llm.d
+    pred = eng.forward(batch, None, for_training=True)
+    _, dpred = ops.l1_loss(pred, batch["actions"].to(BF), True)
+    row0 = eng.live_row0()
+    assert row0 > 0, "the adapter-only step runs the live-row backward"
+    dHS = eng._dhs(row0)
+    B, S_, Np = eng.B, eng.S, eng.Np
+    kb, kl = 12, 12
+    head.prep_backward(eng.pos1, Np, B, S_, row0)
+    head.bwd_begin(dpred, row0)
+    for i in range(nb - 1, kb, -1):
+        head.bwd_layer(i, dHS)
+    dx_out = head.dx.clone()
+    head.bwd_layer(kb, dHS)
+    dx_in = head.dx.clone()
+    for i in range(kb - 1, -1, -1):
+        head.bwd_layer(i, dHS)
+    head.bwd_end()
+    llm.bwd_begin(dHS, row0)
+    for j in range(n - 1, kl, -1):
+        llm.bwd_layer(j, dHS)
+    R = S_ - row0
+    d_out = llm._d.clone()
+    ops.add_(d_out, dHS[kl + 1].view(B * R, D))          # what bwd_layer(kl) starts from
+    llm.bwd_layer(kl, dHS)
+    d_in = llm._d.clone()
+    torch.cuda.synchronize()
+    # ---- LLM layer kl: upstream gradient lives on the live rows only (rows < row0 receive none: frozen inputs, SURVEY a5 / DESIGN 5a)
+    g_full = torch.zeros(B, S_, D)
+    g_full[:, row0:] = d_out.view(B, R, D).float().cpu()
+    Wl = {k: v for k, v in W["llm"].items()}
+    ck = Checker(f"adapter-only: LLM layer {kl}")
+    res = {}
+    for emu in (True, False):
+        res[emu], _ = llm_layer_oracle(Wl, kl, llm.HS[kl], llm.kmask.bool().cpu(), g_full, cfg, emu)
+    ck.add("dX (live rows)", d_in.view(B, R, D), res[True][:, row0:], res[False][:, row0:], TOL_DX)
+    ck.run()
+    ck.must_catch_a_wrong_scale()
+    # ---- head block kb (action_heads.py:337-410) on its own inputs
+    pre = f"model.mlp_resnet_blocks.{kb}."
+    x_in = head.X[kb].view(B, cfg.chunk, D)
+    h_t = llm.HS[kb + 1][:, :Np]
+    h_a = head.h_adp[kb][:, :64]
+    pp = head.pf.view(B, 1, D)
+    out = {}
+    for emu in (True, False):
+        p = leaf(W["head"], pre)
+        L = {k: t.detach().float().cpu().clone().requires_grad_(True) for k, t in (("x", x_in), ("h_t", h_t), ("h_a", h_a), ("pp", pp))}
+        # same activation pattern as the run under test: the closing ReLU's mask is the native block output's (the backward
+        # kernel reads that output); how many pre-activations the oracle's own forward puts on the other side is printed
+        mask = (head.X[kb + 1].view(B, cfg.chunk, D) > 0).float().cpu()
+        y = O.head_block_pro(L["x"], L["h_t"], L["h_a"], L["pp"], p, pre, emu, relu_mask=mask)
+        if emu:
+            with torch.no_grad():
+                own = O.head_block_pro(L["x"], L["h_t"], L["h_a"], L["pp"], p, pre, emu)
+            print(f"  head block {kb}: {int(((own > 0).float() != mask).sum())} of {mask.numel()} ReLU decisions differ between the native forward "
+                  "and the oracle's recomputation (mask of the native run used for both backward passes)")
+        y.backward(dx_out.view(B, cfg.chunk, D).float().cpu())
+        out[emu] = (L, p)
+    ck = Checker(f"adapter-only: head block {kb}")
+    ck.add("dX", dx_in.view(B, cfg.chunk, D), out[True][0]["x"].grad, out[False][0]["x"].grad, TOL_DX)
+    ck.add("d h_adapter (64 action-query states)", head.dh_adp[kb].view(B, 65, D)[:, :64], out[True][0]["h_a"].grad, out[False][0]["h_a"].grad, TOL_DX)
+    ck.add("d proprio token", head.dh_adp[kb].view(B, 65, D)[:, 64:], out[True][0]["pp"].grad, out[False][0]["pp"].grad, TOL_DX)
+    G = head.named_views(head.P.grad)
+    for k in sorted(out[True][1]):
+        if out[False][1][k].grad is None:
+            continue                      # film_gen: in the state dict, never used (action_heads.py:327-329)
+        ck.add(k[len(pre):], G[k], out[True][1][k].grad, out[False][1][k].grad, TOL_DW)
+    ck.run()
+    ck.must_catch_a_wrong_scale("k_task.weight")
+    ck.must_catch_a_wrong_scale("q_proj.weight")
+
+
+# ------------------------------------------------------------------------------------------------ backbone trainers at full size
+def _dual_setup(B=2, seed=0):
+    """The reference's documented recipe at full size (README.md:254-274): DINOv2-L reg4 + SigLIP-so400m fused, two images,
+    Qwen2.5-0.5B."""
+    from vla_adapter_amd import engine as E, synthetic as S
+    cfg = E.dinosiglip_05b_config(2)
+    W = S.make_weights(cfg, DEV, seed=seed)
+    batch = S.make_batch(cfg, B, DEV, seed=91, P=32, ragged=True)
+    batch["pixel_values"] = batch["pixel_values"].to(BF)
+    return cfg, W, batch
+
+
+def test_full_finetune_one_layer_of_every_kind_at_full_size_dual_backbone():
+    """Full fine-tune (vla-scripts/finetune.py:846-849) of DINOv2 + SigLIP + 0.5B, two images, batch 2: LLM layer 11, DINOv2 block 9
+    (LayerScale gradients included), SigLIP block 14 - dX and every parameter gradient of the layer; plus the whole-step
+    properties (finite, every parameter group fed)."""
+    from vla_adapter_amd import engine as E
+    from vla_adapter_amd.trainers import FullFinetune
+    cfg, W, batch = _dual_setup()
+    eng = E.VLAEngine(cfg, W, DEV)
+    ft = FullFinetune(eng)
+    kl, kd, ks = 11, 9, 14
+    ft.taps = {("llm", kl): {}, ("vit", 0, kd): {}, ("vit", 1, ks): {}}
+    pred = ft.forward(batch, None)
+    loss3 = ft.backward(pred, batch["actions"])
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss3).all() and torch.isfinite(ft.P.grad.float()).all()
+    G = ft.reference_named_gradients()
+    B, S_, D = eng.B, eng.S, cfg.llm.d
+    # ---- LLM layer
+    t = ft.taps[("llm", kl)]
+    res = {emu: llm_layer_oracle(W["llm"], kl, eng.llm.HS[kl], eng.llm.kmask.bool().cpu(), t["d_out"].view(B, S_, D), cfg, emu) for emu in (True, False)}
+    ck = Checker(f"full fine-tune: LLM layer {kl}")
+    ck.add("dX", t["d_in"].view(B, S_, D), res[True][0], res[False][0], TOL_DX)
+    for k in sorted(res[True][1]):
+        ck.add(k, G["language_model.model." + k], res[True][1][k].grad, res[False][1][k].grad, TOL_DW)
+    ck.run()
+    ck.must_catch_a_wrong_scale(f"layers.{kl}.mlp.down_proj.weight")
+    ck.must_catch_a_wrong_scale(f"layers.{kl}.self_attn.q_proj.weight")
+    # ---- one block of each backbone
+    for j, kb, pre in ((0, kd, "vision_backbone.featurizer."), (1, ks, "vision_backbone.fused_featurizer.")):
+        vc, st = cfg.vit[j], ft.V[j]
+        Bv, T = B * cfg.n_img, vc.n_patches + vc.n_prefix
+        t = ft.taps[("vit", j, kb)]
+        res = {emu: vit_block_oracle(W["vit"][j], kb, st["X"][kb].view(Bv, T, vc.d), t["d_out"].view(Bv, T, vc.d), vc, emu) for emu in (True, False)}
+        ck = Checker(f"full fine-tune: backbone {j} ({'DINOv2-L' if vc.layerscale else 'SigLIP'}) block {kb}")
+        ck.add("dX", t["d_in"].view(Bv, T, vc.d), res[True][0], res[False][0], TOL_DX)
+        for k in sorted(res[True][1]):
+            ck.add(k, G[pre + k], res[True][1][k].grad, res[False][1][k].grad, TOL_DW)
+        ck.run()
+        ck.must_catch_a_wrong_scale(f"blocks.{kb}.mlp.fc1.weight")
+        if vc.layerscale:
+            ck.must_catch_a_wrong_scale(f"blocks.{kb}.ls2.scale_factor")
+    # ---- the step as a whole: prefix tokens, both position embeddings, both patch embeddings receive a gradient; it trains
+    for k in ("vision_backbone.featurizer.cls_token", "vision_backbone.featurizer.reg_token", "vision_backbone.featurizer.pos_embed",
+              "vision_backbone.fused_featurizer.pos_embed", "vision_backbone.featurizer.patch_embed.proj.weight", "projector.fc3.weight"):
+        assert G[k].float().abs().max().item() > 0, k
+    ft.taps = None
+    l0 = loss3[0].item()
+    ft.optimizer_step(1e-4)
+    ls = [ft.train_step(batch, 1e-4)[0].item() for _ in range(5)]
+    torch.cuda.synchronize()
+    assert all(v == v for v in ls) and min(ls) < l0, (l0, ls)
+
+
+def test_lora_one_layer_of_every_kind_at_full_size_dual_backbone():
+    """The documented LoRA recipe (rank 64 on every Linear of DINOv2 + SigLIP + projector + Qwen2.5-0.5B, two images) at full size,
+    batch 2: dX and the A / B gradients of one LLM layer, one DINOv2 block (frozen LayerScale on the path) and one SigLIP block
+    (padded MLP width 4304 -> 4352) against the oracle with peft's Linear (LORA registry, the native single-rounding form)."""
+    from vla_adapter_amd import engine as E
+    from vla_adapter_amd.trainers import LoRAFinetune
+    cfg, W, batch = _dual_setup()
+    eng = E.VLAEngine(cfg, W, DEV)
+    lo = LoRAFinetune(eng, rank=64, seed=1)
+    g = torch.Generator(device=DEV).manual_seed(2)
+    for l in lo.L.values():               # peft starts at B = 0: give B a value so that both branches carry signal
+        for p_, _ in l.projs:
+            Bv_ = lo.P.view(f"{l.name}.{p_}.lora_B")
+            Bv_[:l.n_real, :l.r] = (torch.randn(l.n_real if Bv_.shape[0] >= l.n_real else Bv_.shape[0], l.r, generator=g, device=DEV) * 0.01).to(BF)
+    lo.refresh()
+    kl, kd, ks = 11, 9, 14
+    lo.taps = {("llm", kl): {}, ("vit", 0, kd): {}, ("vit", 1, ks): {}}
+    pred = lo.forward(batch, None)
+    loss3 = lo.backward(pred, batch["actions"])
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss3).all() and torch.isfinite(lo.P.grad.float()).all()
+    sd = {k: v.detach().float().cpu().clone() for k, v in lo.lora_state_dict().items()}
+    gsd = {}
+    for l in lo.L.values():
+        for p_, _ in l.projs:
+            gA, gB = lo.P.g(f"{l.name}.{p_}.lora_A"), lo.P.g(f"{l.name}.{p_}.lora_B")
+            assert bool((gA[l.r:] == 0).all()) and bool((gA[:, l.k_real:] == 0).all()) and bool((gB[:, l.r:] == 0).all()) and bool((gB[l.n_real:] == 0).all()), l.name
+            gsd[f"{l.name}.{p_}.lora_A.weight"], gsd[f"{l.name}.{p_}.lora_B.weight"] = gA[:l.r, :l.k_real], gB[:l.n_real, :l.r]
+    B, S_, D = eng.B, eng.S, cfg.llm.d
+    pre = "base_model.model."
+
+    def registrar(module_prefix, names, store):
+        def reg(p):
+            for n in names:
+                A = sd[f"{pre}{module_prefix}{n}.lora_A.weight"].clone().requires_grad_(True)
+                Bm = sd[f"{pre}{module_prefix}{n}.lora_B.weight"].clone().requires_grad_(True)
+                store[n] = (A, Bm)
+                key = [k for k in p if k.endswith(n + ".weight")][0]
+                O.LORA[id(p[key])] = (A, Bm, 2.0)
+        return reg
+
+    O.LORA_FUSED = True
+    try:
+        # ---- LLM layer
+        t = lo.taps[("llm", kl)]
+        names = ["self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj"]
+        res, stores = {}, {}
+        for emu in (True, False):
+            stores[emu] = {}
+            res[emu] = llm_layer_oracle(W["llm"], kl, eng.llm.HS[kl], eng.llm.kmask.bool().cpu(), t["d_out"].view(B, S_, D), cfg, emu,
+                                        lora=registrar(f"language_model.model.layers.{kl}.", names, stores[emu]))
+        ck = Checker(f"LoRA: LLM layer {kl}")
+        ck.add("dX", t["d_in"].view(B, S_, D), res[True][0], res[False][0], TOL_DX)
+        for nme in names:
+            for w, idx in (("lora_A", 0), ("lora_B", 1)):
+                ck.add(f"{nme}.{w}", gsd[f"{pre}language_model.model.layers.{kl}.{nme}.{w}.weight"], stores[True][nme][idx].grad, stores[False][nme][idx].grad, TOL_DW)
+        ck.run()
+        ck.must_catch_a_wrong_scale("mlp.up_proj.lora_B")
+        ck.must_catch_a_wrong_scale("self_attn.k_proj.lora_A")
+        # ---- one block of each backbone
+        for j, kb, vn in ((0, kd, "featurizer"), (1, ks, "fused_featurizer")):
+            vc, st = cfg.vit[j], lo.V[j]
+            Bv, T = B * cfg.n_img, vc.n_patches + vc.n_prefix
+            t = lo.taps[("vit", j, kb)]
+            names = ["attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2"]
+            res, stores = {}, {}
+            for emu in (True, False):
+                stores[emu] = {}
+                res[emu] = vit_block_oracle(W["vit"][j], kb, st["X"][kb].view(Bv, T, vc.d), t["d_out"].view(Bv, T, vc.d), vc, emu,
+                                            lora=registrar(f"vision_backbone.{vn}.blocks.{kb}.", names, stores[emu]))
+            ck = Checker(f"LoRA: backbone {j} ({'DINOv2-L' if vc.layerscale else 'SigLIP'}) block {kb}")
+            ck.add("dX", t["d_in"].view(Bv, T, vc.d), res[True][0], res[False][0], TOL_DX)
+            for nme in names:
+                for w, idx in (("lora_A", 0), ("lora_B", 1)):
+                    ck.add(f"{nme}.{w}", gsd[f"{pre}vision_backbone.{vn}.blocks.{kb}.{nme}.{w}.weight"], stores[True][nme][idx].grad, stores[False][nme][idx].grad, TOL_DW)
+            ck.run()
+            ck.must_catch_a_wrong_scale("mlp.fc2.lora_A")
+    finally:
+        O.LORA_FUSED = False
+        O.LORA.clear()
+    lo.taps = None
+    l0 = loss3[0].item()
+    lo.optimizer_step(1e-4)          # (AdamW's first steps move every one of the head's 218 M random-init parameters by lr: small lr)
+    ls = [lo.train_step(batch, 1e-4)[0].item() for _ in range(5)]
+    torch.cuda.synchronize()
+    assert all(v == v for v in ls) and min(ls) < l0, (l0, ls)

@@ -153,3 +153,66 @@ def engine_vlm_state_dict(eng) -> Dict[str, torch.Tensor]:
         out["projector." + k] = cl(t)
     out["action_queries.weight"] = cl(eng.head.P.view("action_queries"))
     return out
+
+
+# heads are not recoverable from tensor shapes: the widths the reference's backbones use (timm vit_so400m / vit_large / the
+# plumbing-size configs of engine.py); anything else is read as 64-wide heads
+_VIT_HEADS = {1152: 16, 1024: 16, 768: 12, 384: 6, 256: 4, 192: 3, 128: 2}
+_LLM_HEAD_DIM = {896: 64, 1536: 128, 2048: 128, 3584: 128}      # Qwen2.5-0.5B / 1.5B / 3B / 7B
+
+
+def infer_config(sd: Dict[str, torch.Tensor]) -> VLACfg:
+    """Model geometry read off a VLM state dict (HF-style or native Prismatic keys): which vision backbones (one, or DINOv2 + SigLIP
+    fused), their widths / depths / prefix tokens / LayerScale, the projector form, the Qwen2 geometry.  The reference gets this
+    from the checkpoint's config.json (vla-scripts/finetune.py:777-816); a bare state dict carries the same information in its
+    keys and shapes, except the head counts (table above)."""
+    from .engine import LLMCfg, ViTCfg, VLACfg as _V
+    sd = strip_ddp_prefix(rename_prismatic_keys(sd))
+    vits = []
+    for pre in ("vision_backbone.featurizer.", "vision_backbone.fused_featurizer."):
+        sub = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+        if not sub:
+            continue
+        pos, pw = sub["pos_embed"], sub["patch_embed.proj.weight"]
+        d, n_patches, patch = pos.shape[-1], pos.shape[-2], pw.shape[-1]
+        depth = 1 + max(int(k.split(".")[1]) for k in sub if k.startswith("blocks."))
+        n_prefix = (1 if "cls_token" in sub else 0) + (sub["reg_token"].shape[-2] if "reg_token" in sub else 0)
+        ls = any(".ls1." in k for k in sub)
+        side = int(round(n_patches ** 0.5))
+        assert side * side == n_patches, "square patch grids only"
+        vits.append(ViTCfg(d, depth, _VIT_HEADS.get(d, max(1, d // 64)), sub["blocks.0.mlp.fc1.weight"].shape[0], patch, patch * side, n_prefix, ls))
+    assert vits, "state dict holds no vision_backbone.(fused_)featurizer.* weights"
+    lm = {k[len("language_model.model."):]: v for k, v in sd.items() if k.startswith("language_model.model.")}
+    D, vocab = lm["embed_tokens.weight"].shape[1], lm["embed_tokens.weight"].shape[0]
+    n_layers = 1 + max(int(k.split(".")[1]) for k in lm if k.startswith("layers."))
+    dh = _LLM_HEAD_DIM.get(D, 64)
+    heads, kv = lm["layers.0.self_attn.q_proj.weight"].shape[0] // dh, lm["layers.0.self_attn.k_proj.weight"].shape[0] // dh
+    llm = LLMCfg(D, n_layers, heads, kv, dh, lm["layers.0.mlp.gate_proj.weight"].shape[0], 1e-6, 1e6, vocab)
+    cfg = _V(vit=vits, llm=llm, num_blocks=min(24, n_layers))
+    assert ("projector.fc3.weight" in sd) == cfg.fused, "a fused (two-backbone) VLM has the 3-layer projector, a single-backbone one fc1 / fc2"
+    return cfg
+
+
+def load_lora_adapter(adapter_dir: str) -> Dict[str, torch.Tensor]:
+    """``lora_adapter/adapter_model.safetensors`` (peft key names) of a run directory written by finetune.save_training_checkpoint
+    or by peft's ``save_pretrained`` (vla-scripts/finetune.py:553-554)."""
+    return load_file(os.path.join(adapter_dir, "adapter_model.safetensors"))
+
+
+def merge_lora_into_state_dict(base: Dict[str, torch.Tensor], adapter: Dict[str, torch.Tensor], scaling: float = 2.0) -> Dict[str, torch.Tensor]:
+    """Offline merge of vla-scripts/merge_lora_weights_and_save.py:44-103 (PeftModel.from_pretrained(...).merge_and_unload()):
+    W <- W + scaling * B @ A for every adapted Linear of an HF-style VLM state dict (fp32 product, one bf16 rounding); scaling =
+    lora_alpha / r = 2 in every reference script (finetune.py:835).  Keys: '<prefix>base_model.model.<module>.lora_A.weight'."""
+    out = dict(base)
+    pre = "base_model.model."
+    for k, A in adapter.items():
+        if not k.endswith(".lora_A.weight"):
+            continue
+        mod = k[:-len(".lora_A.weight")]
+        B = adapter[mod + ".lora_B.weight"]
+        name = (mod[len(pre):] if mod.startswith(pre) else mod) + ".weight"
+        if name not in out:
+            raise KeyError(f"adapter targets {name}, which the base state dict does not hold")
+        W = out[name]
+        out[name] = (W.float() + scaling * (B.float() @ A.float())).to(W.dtype)
+    return out

@@ -684,8 +684,8 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   p.c_live_mod = d->c_live_mod; p.c_live_from = d->c_live_from;
   const int split = d->split_k > 1 ? d->split_k : 1;
   p.bias_post = d->bias_post_round;
-  VLA_REQUIRE(d->bias_post_round == 0 || (d->bias_post_round == 1 && d->bias && d->rope_mode == 0 && split == 1 && d->act == VLA_ACT_NONE),
-              "gemm: bias_post_round needs a bias and a plain epilogue (no rope / split-K / activation)");
+  VLA_REQUIRE(d->bias_post_round == 0 || (d->bias_post_round == 1 && d->bias && d->rope_mode != 1 && split == 1 && d->act == VLA_ACT_NONE),
+              "gemm: bias_post_round needs a bias and a plain epilogue (no rotate_half rope / split-K / activation)");
   { const char* ge = getenv("VLA_GEMM_GM"); p.gm = ge ? atoi(ge) : 0; }
   p.ws = nullptr;
   if (split > 1) {

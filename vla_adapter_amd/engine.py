@@ -140,6 +140,23 @@ def tiny_fused_config() -> VLACfg:
                   llm=LLMCfg(256, 2, 4, 2, 64, 512, 1e-6, 1e6, 1024), num_blocks=2)
 
 
+def dinosiglip_05b_config(n_img: int = 2) -> VLACfg:
+    """The reference's documented recipe (README.md:254-274: ``--vlm_path .../prism-qwen25-extra-dinosiglip-224px-0_5b
+    --num_images_in_input 2``): DINOv2-L/14 reg4 + SigLIP-so400m fused vision, 3-layer projector, Qwen2.5-0.5B."""
+    return VLACfg(vit=[DINOV2_L_REG4, SIGLIP_SO400M], llm=LLMCfg(), n_img=n_img)
+
+
+def _config5_two_images() -> VLACfg:
+    c = config5_backbone()
+    c.n_img = 2
+    return c
+
+
+# names accepted by ``finetune.py --backbone`` / ``bench.py --backbone`` (n_img follows --num_images_in_input where given)
+NAMED_CONFIGS = {"config2": config2, "dinosiglip-0_5b": dinosiglip_05b_config, "config5": config5_backbone, "tiny": tiny_config,
+                 "tiny_fused": tiny_fused_config, "qwen15b-geometry": qwen15b_geometry_config}
+
+
 # ------------------------------------------------------------------------------------------------ frozen ViT
 class ViT:
     """timm VisionTransformer forward up to block depth-2, no final norm (modeling_prismatic.py:120-144,196-237;
@@ -658,12 +675,9 @@ class Head:
         self.guard = torch.zeros(1, device=dev, dtype=torch.float32)
         self.x_in = z(R, self.Din)
         self.pr_in = z(B, 64)
-        # transposed operands for the batched dW products (K-dim = rows, zero-padded to a multiple of 64)
-        self.RK, self.AK, self.TK = rup(R, 64), rup(B * Ka, 64), rup(B * Kt, 64)
-        self.XT, self.dQKVxT = z(nb, D, self.RK), z(nb, 3 * D, self.RK)
-        self.AOxT, self.dO2T, self.LNoT, self.dFFT = z(nb, D, self.RK), z(nb, D, self.RK), z(nb, D, self.RK), z(nb, D, self.RK)
-        self.h_adpT, self.dKV_adpT = z(nb, D, self.AK), z(nb, 2 * D, self.AK)
-        self.h_taskT, self.dKV_taskT = z(nb, D, self.TK), z(nb, 2 * D, self.TK)
+        # (the dW products read dY and X as they lie: vla_gemm_bf16_tn contracts over their rows - no transposed operand copies)
+        self.h_task_c = e(nb, B * Kt, D) if Kt % 64 else None      # plumbing sizes only: task rows compacted (row groups need Kt % 64 == 0)
+        self.dfc2 = e(64, D)
         self.dh_adp = e(nb, B * Ka, D)
         self.dpad = z(R, 64)
         self.rope_tab = ops.rope_inter_tables(max(T, Ka, Kt), D // self.H, dev)
@@ -719,17 +733,22 @@ class Head:
         hs2 = HS[i + 1].view(B * S, D)
         # adapter tokens: the 64 action-query hidden states + the proprio token (:347); K/V projections, RoPE on K
         ops.gather_rows(hs2, self.row_idx_ka.view(-1), self.h_adp[i].view(B * Ka, D))
+        # RoPE (positions restart per segment, action_heads.py:383-388) on q and on every segment's k rides in the projections'
+        # epilogues (columns [0, D) of the k|v outputs: the K halves; position = row % segment length); the original block has none
+        fuse = self.pro and D % 64 == 0 and not os.environ.get("VLA_NO_KV_ROPE_FUSE")
         wa, ba, _ = self._kv("adp", i)
-        ops.gemm_nt(self.h_adp[i].view(B * Ka, D), wa, bias=ba, out=self.KV_adp[i])
+        ops.gemm_nt(self.h_adp[i].view(B * Ka, D), wa, bias=ba, out=self.KV_adp[i], rope=(2, rc, rs_, Ka, dh, D) if fuse else None)
         # task tokens = HS[i+1][:, :Np] read in place (row-group addressing)
         wt, bt, _ = self._kv("task", i)
         # the reference feeds a STRIDED slice here: torch's CPU Linear then rounds the product before adding the bias, for B > 1
         # only (oracle.linear, vla_native.h bias_post_round) - reproduced so that the head tracks the reference's bf16 run
-        ops.gemm_nt(hs2[:B * Kt], wt, bias=bt, out=self.KV_task[i], a_group=(Kt, S * D), bias_post_round=B > 1)
+        ops.gemm_nt(hs2[:B * Kt], wt, bias=bt, out=self.KV_task[i], a_group=(Kt, S * D), bias_post_round=B > 1,
+                    rope=(2, rc, rs_, Kt, dh, D) if fuse else None)
         x = self.X[i]
-        if self.pro:      # RoPE (positions restart per segment) on q and on every segment's k; the original block has none
-            ops.rope_inter_(self.KV_adp[i][:, :D], rc, rs_, Ka, H, dh, 0)
-            ops.rope_inter_(self.KV_task[i][:, :D], rc, rs_, Kt, H, dh, 0)
+        if self.pro:
+            if not fuse:
+                ops.rope_inter_(self.KV_adp[i][:, :D], rc, rs_, Ka, H, dh, 0)
+                ops.rope_inter_(self.KV_task[i][:, :D], rc, rs_, Kt, H, dh, 0)
             ops.gemm_nt(x, P.view("w_x")[i], bias=P.view("b_x")[i], out=self.QKVx[i], rope=(2, rc, rs_, T, dh, 2 * D))  # q, k_self
         else:
             ops.gemm_nt(x, P.view("w_x")[i], bias=P.view("b_x")[i], out=self.QKVx[i])
@@ -802,7 +821,8 @@ class Head:
         ops.zero_(self.dpad)
         ops.copy2d(dp, self.dpad, R, Da, Da, 64)
         ops.colsum_(dp, self.b_f32["fc2_b"])
-        self._dw(dp, self.xf_ln, out=P.g("fc2_w"))
+        self._dw(self.dpad, self.xf_ln, out=self.dfc2)                         # action_dim 7 rides zero-padded to 64 columns
+        ops.copy2d(self.dfc2, P.g("fc2_w"), Da, self.D, self.D, self.D)
         d_ln2 = ops.gemm_nt(self.dpad, self.fc2T)                              # [R, D]
         self.dx = ops.layernorm_bwd(d_ln2, self.X[nb], P.view("ln2_w"), self.st2, self.ln2_dw, self.ln2_db)
 
@@ -846,25 +866,28 @@ class Head:
         d_pre = ops.gelu_bwd(d_act, self.pp_pre)
         ops.colsum_(d_pre, self.b_f32["p_fc1_b"])
         self._dw(d_pre, self.pr_in[:, :cfg.proprio_dim], out=G("p_fc1_w"))
-        # batched dW products: dW = dY^T . X  as NT GEMMs on transposed operands
-        bt = lambda src, dst: ops.transpose(src, out=dst)
-        bt(self.X[:nb], self.XT); bt(self.dQKVx, self.dQKVxT); bt(self.AOx, self.AOxT); bt(self.dO2, self.dO2T)
-        bt(self.LNo, self.LNoT); bt(self.dFF, self.dFFT); bt(self.h_adp.view(nb, B * Ka, D), self.h_adpT); bt(self.dKV_adp, self.dKV_adpT)
-        bt(self.dKV_task, self.dKV_taskT)
-        for i in range(nb):
-            self._transpose_task(i)
-        ops.gemm_nt(self.dQKVxT, self.XT, out=G("w_x"))
-        ops.gemm_nt(self.dO2T, self.AOxT, out=G("w_o"))
-        ops.gemm_nt(self.dFFT, self.LNoT, out=G("w_ffn"))
+        # batched dW products over the nb blocks: dW = dY^T . X as TN GEMMs on dY and X as they lie in memory (the contraction
+        # runs over their rows); the task tokens are read in place from the hidden states (row groups: Kt rows of every sequence)
+        Kt, S = self.Kt, self.S
+        h_adp = self.h_adp.view(nb, B * Ka, D)
+        if self.h_task_c is None:
+            h_task, tg = self.HSref[1:nb + 1, 0, :Kt], (Kt, S * D)
+        else:
+            for i in range(nb):
+                ops.copy_rows3d(self.HSref[i + 1], self.h_task_c[i], B, Kt, D, S * D, D, Kt * D, D)
+            h_task, tg = self.h_task_c, None
+        ops.gemm_tn(self.dQKVx, self.X[:nb], out=G("w_x"))
+        ops.gemm_tn(self.dO2, self.AOx, out=G("w_o"))
+        ops.gemm_tn(self.dFF, self.LNo, out=G("w_ffn"))
         ops.colsum_(self.dQKVx, self.b_f32["b_x"]); ops.colsum_(self.dO2, self.b_f32["b_o"]); ops.colsum_(self.dFF, self.b_f32["b_ffn"])
         if self.pro:
-            ops.gemm_nt(self.dKV_adpT, self.h_adpT, out=G("w_adp"))
-            ops.gemm_nt(self.dKV_taskT, self.h_taskT, out=G("w_task"))
+            ops.gemm_tn(self.dKV_adp, h_adp, out=G("w_adp"))
+            ops.gemm_tn(self.dKV_task, h_task, out=G("w_task"), rows=B * Kt, b_group=tg)
             ops.colsum_(self.dKV_adp, self.b_f32["b_adp"]); ops.colsum_(self.dKV_task, self.b_f32["b_task"])
         else:             # shared k_proj / v_proj: the three segments' gradients add up (autograd accumulates them in bf16 too)
             gkv = G("w_x")[:, self.D:]
-            ops.gemm_nt(self.dKV_adpT, self.h_adpT, out=gkv, residual=gkv)
-            ops.gemm_nt(self.dKV_taskT, self.h_taskT, out=gkv, residual=gkv)
+            ops.gemm_tn(self.dKV_adp, h_adp, out=gkv, accumulate=True)
+            ops.gemm_tn(self.dKV_task, h_task, out=gkv, accumulate=True, rows=B * Kt, b_group=tg)
             bkv = self.b_f32["b_x"][:, self.D:]
             ops.colsum_(self.dKV_adp, bkv); ops.colsum_(self.dKV_task, bkv)
         for k, t in self.b_f32.items():
@@ -878,20 +901,12 @@ class Head:
         return ops.transpose(w2d.contiguous())
 
     def _dw(self, dy, x, out=None):
-        """dW[N, K] = dY[R, N]^T . X[R, K] for the small one-off layers (R zero-padded to a multiple of 64)."""
-        Rp = rup(dy.shape[0], 64)
-        return ops.gemm_nt(ops.transpose(dy, ld_out=Rp), ops.transpose(x, ld_out=Rp), out=out)
+        """dW[N, K] = dY[R, N]^T . X[R, K] for the small one-off layers."""
+        return ops.gemm_tn(dy, x, out=out, split=0)
 
     def _ln_bwd(self, dy, x, w, stats, dx, dw, db):
         ops.N.check(ops._lib().vla_layernorm_bwd(ops._st(), ops._p(dy), ops._p(x), ops._p(w), ops._p(stats), ops._p(dx), ops._p(dw),
                                                  ops._p(db), x.shape[0], x.shape[1], x.stride(0), dy.stride(0), dx.stride(0)), "layernorm_bwd")
-
-    def _transpose_task(self, i: int):
-        """h_taskT[i][:, b*Kt:(b+1)*Kt] = HS[i+1][b, :Kt]^T  (one batched transpose over the batch)."""
-        B, S, D, Kt = self.B, self.S, self.D, self.Kt
-        src = self.HSref[i + 1]
-        ops.N.check(ops._lib().vla_transpose_bf16(ops._st(), ops._p(src), ops._p(self.h_taskT[i]), Kt, D, D, self.TK, B, S * D, Kt),
-                    "transpose")
 
 
 # ------------------------------------------------------------------------------------------------ whole model

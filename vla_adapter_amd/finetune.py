@@ -82,6 +82,8 @@ class FinetuneConfig:
     max_seq_len: int = 0                  # static token length every batch is right-padded to (0: length of the first batch)
     conservative_rows: bool = False       # captured live-row window starts at the first text row instead of the first batch's action block
     dataset_statistics_file: Optional[str] = None   # JSON written next to every checkpoint (finetune.py:531)
+    backbone: Optional[str] = None        # model geometry: a name of engine.NAMED_CONFIGS ("config2", "dinosiglip-0_5b", "config5",
+                                          # "tiny", "tiny_fused") - default: inferred from the --vlm_path state dict, else "config2"
     # fmt: on
 
 
@@ -127,6 +129,10 @@ def check_supported(cfg: FinetuneConfig, explicit=()) -> None:
         raise NotImplementedError("--lora_dropout > 0: the low-rank branch is built without dropout (every shipped script uses 0.0)")
     if train_mode(cfg) != "adapter" and cfg.grad_accumulation_steps != 1:
         raise NotImplementedError("grad_accumulation_steps > 1 is built for the adapter-only mode (--use_fz True) only")
+    if cfg.backbone is not None:
+        from .engine import NAMED_CONFIGS
+        if cfg.backbone not in NAMED_CONFIGS:
+            raise ValueError(f"--backbone {cfg.backbone!r}: known geometries are {sorted(NAMED_CONFIGS)}")
     if cfg.use_film or cfg.use_diffusion or not cfg.use_l1_regression:
         raise NotImplementedError("native path = L1-regression action head; --use_film / --use_diffusion are not built")
     if cfg.use_val_set:
@@ -159,10 +165,12 @@ def lr_at(gradient_step_idx: int, cfg: FinetuneConfig) -> float:
 
 def loop_plan(cfg: FinetuneConfig):
     """The reference loop's bookkeeping (finetune.py:1018-1122) as a generator of
-    (batch_idx, gradient_step_idx, log_step, optimizer_step?, save?, last?) - one item per micro-batch.  Runs until
-    log_step == max_steps INCLUSIVE (the reference breaks after processing that batch: max_steps + 1 gradient steps from a
-    fresh start); a checkpoint is due when gradient_step_idx > 0 and log_step % save_freq == 0 (taken once, after the
-    optimizer step that completes the gradient step)."""
+    (batch_idx, gradient_step_idx, log_step, optimizer_step?, save?, last?) - one item per micro-batch.  The reference breaks
+    behind the FIRST micro-batch whose log_step == max_steps (:1119-1121): with grad_accumulation_steps == 1 that batch's
+    optimizer step has run (max_steps + 1 gradient steps from a fresh start); with ga > 1 it is the first micro-batch of gradient
+    step max_steps - its forward / backward run, its gradients are never applied (boundary False).  A checkpoint is due when
+    gradient_step_idx > 0 and log_step % save_freq == 0 (the reference re-saves on every micro-batch of such a step; here once,
+    behind the optimizer step that completes it)."""
     ga = cfg.grad_accumulation_steps
     base = cfg.resume_step if cfg.resume else 0
     batch_idx = 0
@@ -171,7 +179,7 @@ def loop_plan(cfg: FinetuneConfig):
         log_step = base + g
         boundary = (batch_idx + 1) % ga == 0
         save = boundary and g > 0 and log_step % cfg.save_freq == 0
-        last = log_step >= cfg.max_steps and boundary
+        last = log_step >= cfg.max_steps
         yield batch_idx, g, log_step, boundary, save, last
         if last:
             return
@@ -180,9 +188,12 @@ def loop_plan(cfg: FinetuneConfig):
 
 def save_training_checkpoint(cfg: FinetuneConfig, run_dir: Path, step: int, eng, dataset_statistics: Optional[dict] = None,
                              trainer=None) -> Path:
-    """File names / key layout of finetune.py:527-572 (rank 0).  The reference keeps the action queries inside the LoRA /
-    VLM checkpoint; the adapter-only path has neither, so they go to ``action_queries--{suffix}`` (native addition, read back
-    by checkpoints.load_run_dir)."""
+    """File names / key layout of finetune.py:527-572 (rank 0).  Where the VLM goes follows the reference: ``use_fz`` ->
+    ``vla.module.save_pretrained(checkpoint_dir)`` (the whole VLM incl. the trained action queries at the top level, :551-552);
+    otherwise ``save_pretrained(adapter_dir)`` - peft's adapter under ``lora_adapter/`` with LoRA, and, a quirk kept, the whole
+    VLM under ``lora_adapter/`` for the full fine-tune (:553-554); the LoRA-merged VLM at the top level (:579-601).
+    ``action_queries--{suffix}`` is a native addition (peft's adapter file does not hold them; the reference patches them into the
+    merged model, :586-587), read back by checkpoints.load_run_dir."""
     suffix = "latest_checkpoint.pt" if cfg.save_latest_checkpoint_only else f"{step}_checkpoint.pt"
     d = run_dir if cfg.save_latest_checkpoint_only else Path(str(run_dir) + f"--{step}_chkpt")
     os.makedirs(d, exist_ok=True)
@@ -210,7 +221,11 @@ def save_training_checkpoint(cfg: FinetuneConfig, run_dir: Path, step: int, eng,
                 for key, w0 in saved.items():
                     holder, wk = trainer._base(key)
                     holder[wk].copy_(w0)
-    elif trainer is not None:                   # full fine-tune: the whole VLM (finetune.py:556-566 save_pretrained)
+    elif trainer is not None:                   # full fine-tune: vla.module.save_pretrained(adapter_dir) (finetune.py:553-554)
+        ad = d / "lora_adapter"
+        os.makedirs(ad, exist_ok=True)
+        save_file({k: v.contiguous().cpu() for k, v in CK.engine_vlm_state_dict(eng).items()}, str(ad / "model.safetensors"))
+    else:                                       # adapter-only (use_fz): vla.module.save_pretrained(checkpoint_dir) (:551-552)
         save_file({k: v.contiguous().cpu() for k, v in CK.engine_vlm_state_dict(eng).items()}, str(d / "model.safetensors"))
     if dataset_statistics is not None:          # save_dataset_statistics (finetune.py:531): q01/q99 etc. used to un-normalise actions
         json.dump(dataset_statistics, open(d / "dataset_statistics.json", "w"), indent=2)
@@ -267,31 +282,55 @@ def finetune(cfg: FinetuneConfig, batches=None, explicit=()) -> dict:
     rank, local, world = ddp.init_process_group_from_env()
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
-    mcfg = E.tiny_config() if cfg.tiny else E.config2()
+    from . import checkpoints as CK
+    # model geometry: explicit --backbone, else read off the --vlm_path state dict (which backbones, widths, depths), else BASELINE
+    # configs[1].  The reference builds the model from the checkpoint's config.json (finetune.py:777-816); --tiny is the plumbing size.
+    vlm_sd = CK.load_file(cfg.vlm_path) if (cfg.vlm_path and os.path.isfile(cfg.vlm_path)) else None
+    if cfg.tiny:
+        mcfg = E.NAMED_CONFIGS[cfg.backbone or "tiny"]()
+    elif cfg.backbone is not None:
+        mcfg = E.NAMED_CONFIGS[cfg.backbone]()
+    elif vlm_sd is not None:
+        mcfg = CK.infer_config(vlm_sd)
+    else:
+        mcfg = E.config2()
     mcfg.n_img = cfg.num_images_in_input
     mcfg.pro = bool(cfg.use_pro_version)
+    mode = train_mode(cfg)
     W = S.make_weights(mcfg, dev, seed=cfg.seed)                  # identical on all ranks == DDP's initial broadcast
-    from . import checkpoints as CK
-    if cfg.vlm_path and os.path.isfile(cfg.vlm_path):             # local VLM state dict (HF-style or native Prismatic keys)
-        W.update(CK.split_reference_state_dict(CK.load_file(cfg.vlm_path), mcfg))
-    if cfg.resume:                                                # head / proprio (finetune.py:275-278) + the action queries
+    if vlm_sd is not None:                                        # local VLM state dict (HF-style or native Prismatic keys)
+        W.update(CK.split_reference_state_dict(vlm_sd, mcfg))
+    lora_sd = None
+    if cfg.resume:                    # head / proprio (finetune.py:275-278) + the action queries + whatever else this mode trained
         if not (cfg.resum_vla_path and os.path.isdir(cfg.resum_vla_path)):
             raise FileNotFoundError(f"--resume: --resum_vla_path {cfg.resum_vla_path!r} is not a checkpoint directory")
         W["head"], W["proprio"], aq = CK.load_run_dir(cfg.resum_vla_path, cfg.resume_step, with_action_queries=True)
         if aq is not None:
             W["action_queries"] = aq
+        rd = Path(cfg.resum_vla_path)
+        if mode == "full":            # the trained VLM lives under lora_adapter/ (save_training_checkpoint, reference quirk kept)
+            f = rd / "lora_adapter" / "model.safetensors"
+            if not f.exists():
+                raise FileNotFoundError(f"--resume of a full fine-tune needs {f}")
+            W.update(CK.split_reference_state_dict(CK.load_file(str(f)), mcfg))
+        elif mode == "lora":
+            f = rd / "lora_adapter" / "adapter_model.safetensors"
+            if not f.exists():
+                raise FileNotFoundError(f"--resume of a LoRA fine-tune needs {f}")
+            lora_sd = CK.load_file(str(f))
     eng = E.VLAEngine(mcfg, W, dev)
     if world > 1:
         eng.reducer = ddp.FlatGradReducer()
-    mode = train_mode(cfg)
     trainer = None
     if mode == "lora":
-        from .lora_finetune import LoRAFinetune
+        from .trainers import LoRAFinetune
         trainer = LoRAFinetune(eng, rank=cfg.lora_rank, seed=cfg.seed)
+        if lora_sd is not None:
+            trainer.load_lora_state_dict(lora_sd)
     elif mode == "full":
-        from .full_finetune import FullFinetune
+        from .trainers import FullFinetune
         trainer = FullFinetune(eng)
-    use_graph = cfg.use_graph and trainer is None         # LoRA / full fine-tune: eager launches (GEMM-bound steps)
+    use_graph = cfg.use_graph
     eng.set_grad_accumulation(cfg.grad_accumulation_steps)
     stream = batch_stream(cfg, mcfg, dev, rank, batches)
     pad_id = min(S.PAD_ID, mcfg.llm.vocab - 1)
@@ -306,14 +345,21 @@ def finetune(cfg: FinetuneConfig, batches=None, explicit=()) -> dict:
     static = None
     if use_graph:
         static = {k: v.clone() for k, v in cur.items()}
-        eng.capture(static, noise if training else None, conservative_rows=cfg.conservative_rows)
+        if trainer is not None:       # LoRA / full fine-tune: forward + backward as one captured graph (trainers.BackboneTrainer.capture)
+            trainer.capture(static, noise if training else None)
+        else:
+            eng.capture(static, noise if training else None, conservative_rows=cfg.conservative_rows)
     log, t0, saved_at, steps_done = [], time.time(), None, 0
     for batch_idx, g, log_step, boundary, save, last in loop_plan(cfg):
         nxt = _pad_to(next(stream), L, pad_id)                    # one batch of look-ahead: its vision stage runs inside this step
         if training:   # fresh N(0, 0.02^2) perturbation every call (action_heads.py:14-17, 69-72)
             noise.copy_((torch.randn(noise.shape, device=dev, generator=gen) * 0.02).to(torch.bfloat16))
         lr = lr_at(g, cfg)
-        if trainer is not None:
+        if trainer is not None and use_graph:
+            for k in static:
+                static[k].copy_(cur[k])
+            loss3 = trainer.train_step_graphed(lr)
+        elif trainer is not None:
             loss3 = trainer.train_step(cur, lr, noise if training else None)
         elif use_graph:
             for k in static:
@@ -345,4 +391,6 @@ def finetune(cfg: FinetuneConfig, batches=None, explicit=()) -> dict:
     torch.cuda.synchronize()
     if saved_at != final_step and rank == 0:     # never discard a run: the reference only saves on save_freq multiples
         save_training_checkpoint(cfg, run_dir, final_step, eng, stats, trainer)
-    return dict(log=log, seconds=time.time() - t0, steps=steps_done, world=world, final_step=final_step, run_dir=str(run_dir), mode=mode)
+    model = dict(vit=[dict(v.as_oracle(), img=v.img) for v in mcfg.vit], llm=dict(mcfg.llm.as_oracle(), d=mcfg.llm.d, inter=mcfg.llm.inter, vocab=mcfg.llm.vocab),
+                 n_img=mcfg.n_img, num_blocks=mcfg.num_blocks, pro=mcfg.pro)
+    return dict(log=log, seconds=time.time() - t0, steps=steps_done, world=world, final_step=final_step, run_dir=str(run_dir), mode=mode, model=model)

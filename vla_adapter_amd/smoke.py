@@ -27,9 +27,16 @@ def run():
     cb["pixel_values"], cb["proprio"] = cb["pixel_values"].float(), cb["proprio"].bfloat16().float()
     ocfg = dict(vit=[v.as_oracle() for v in cfg.vit], fused=cfg.fused, llm=cfg.llm.as_oracle(), n_img=cfg.n_img, pro=True,
                 num_blocks=cfg.num_blocks)
-    out = O.vla_forward(cb, OW, ocfg, emu=True)
-    rel = ((pred.float().cpu() - out["pred"]).norm() / out["pred"].norm()).item()
-    dl = abs(loss3[0].item() - out["loss"].item()) / abs(out["loss"].item())
-    print(f"smoke: pred rel-L2 vs oracle {rel:.3e}, loss {loss3[0].item():.5f} vs {out['loss'].item():.5f} (rel {dl:.2e})")
-    assert rel < 2e-2 and dl < 1e-2, "native hot path disagrees with the oracle"
+    # the bar of the GPU parity tests (tests/test_engine_gpu.py): an error budget against the fp32 truth,
+    #   |native - oracle_fp32| <= 1.25 x |oracle_emu - oracle_fp32|     (oracle_emu: the reference's bf16 rounding points)
+    # - two valid bf16 evaluations of the same network drift apart by about their own distance to fp32, so a fixed relative
+    # bound between them says little; north_star's 1e-3 is what a single op holds (tests/test_kernels_gpu.py).
+    out, tru = O.vla_forward(cb, OW, ocfg, emu=True), O.vla_forward(cb, OW, ocfg, emu=False)
+    nt = tru["pred"].norm().item()
+    dn, de = (pred.float().cpu() - tru["pred"]).norm().item() / nt, (out["pred"] - tru["pred"]).norm().item() / nt
+    ln, le, lt = loss3[0].item(), out["loss"].item(), tru["loss"].item()
+    print(f"smoke: predicted actions: native-vs-fp32 {dn:.3e}, oracle(bf16 emulation)-vs-fp32 {de:.3e}, ratio {dn / (de + 1e-30):.2f}; "
+          f"loss {ln:.5f} (oracle emu {le:.5f}, fp32 {lt:.5f})")
+    assert dn <= 1.25 * de, "native hot path is further from the fp32 truth than the error budget of its bf16 arithmetic allows"
+    assert abs(ln - lt) <= 1.25 * abs(le - lt) + 1e-3 * abs(lt), "loss outside the error budget"
     print("smoke OK")

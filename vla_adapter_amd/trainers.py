@@ -141,7 +141,13 @@ class BackboneTrainer:
         eng.full_llm_backward = True
         self.step_count = 0
         self._key = None
-        self.n_streams = 1
+        # test hook: {("llm", i) | ("vit", j, i): {}} -> the backward fills "d_out" (gradient w.r.t. the layer's output) and "d_in"
+        # (w.r.t. its input) with clones, so that ONE layer's dX / dW can be checked against the oracle's autograd of that layer
+        # on the run's own activations (tests/test_layer_gradients_gpu.py)
+        self.taps: Optional[dict] = None
+        # granularity of the data-parallel exchange: gradient ranges are handed over every `exchange_layers` LLM layers (4 x 30 MB
+        # of bf16 gradients at the 0.5B geometry: large messages for the point-to-point xGMI links) / `exchange_blocks` ViT blocks
+        self.exchange_layers, self.exchange_blocks = 4, 7
 
     # ---- mode hooks ---------------------------------------------------------------------------------------------
     def _lin(self, key, x, W, bias=None, **kw):
@@ -298,6 +304,8 @@ class BackboneTrainer:
 
     # ---- backward -----------------------------------------------------------------------------------------------
     def _llm_backward(self, dHS):
+        """Generator: yields the gradient ranges that became final after every chunk of `exchange_layers` layers (top-down); the
+        gradient w.r.t. inputs_embeds ends up in self._dX0."""
         llm, c, B, S = self.llm, self.cfg.llm, self.eng.B, self.eng.S
         n, D, H, KV, dh, I = c.n_layers, c.d, c.heads, c.kv_heads, c.dh, c.inter
         M = B * S
@@ -312,6 +320,9 @@ class BackboneTrainer:
             L, k = llm.layers[i], f"llm.{i}."
             if i < n - 1:
                 ops.add_(d, dHS[i + 1].view(M, D))
+            tap = self.taps.get(("llm", i)) if self.taps is not None else None
+            if tap is not None:
+                tap["d_out"] = d.clone()
             d_gu = self._lin_bwd(k + "down", d, self.Hs[i], L["wdT"], out=llm.d_gu[:M], swiglu_gu=llm.GU[i])
             d_n = self._lin_bwd(k + "gu", d_gu, self.N2[i], L["wguT"], out=llm.d_n[:M])
             if self.trains_vectors:
@@ -332,7 +343,11 @@ class BackboneTrainer:
                 ops.N.check(lib.vla_rmsnorm_dw(st(), p(d_n), p(llm.HS[i].view(M, D)), p(llm.R1[i]), p(self.A(k + "n1")), M, D), "rmsnorm_dw")
             d = ops.rmsnorm_bwd(d_n, llm.HS[i].view(M, D), L["n1"], llm.R1[i], dres=d1, out=ring[(r + 2) % 5])
             r = (r + 2) % 5
-        return d.view(B, S, D)           # gradient w.r.t. inputs_embeds
+            if tap is not None:
+                tap["d_in"] = d.clone()
+            self._dX0 = d.view(B, S, D)      # gradient w.r.t. inputs_embeds once i reaches 0
+            if i % self.exchange_layers == 0:
+                yield self._ranges("llm", i, min(n, i + self.exchange_layers) - 1)
 
     def _proj_backward(self, dX0):
         eng, cfg = self.eng, self.cfg
@@ -359,6 +374,7 @@ class BackboneTrainer:
         return self._lin_bwd("proj.fc1", dpre1, P["in"], pjT["fc1.weight"], out=self.dfeats)       # d features [B*Np, vis_dim]
 
     def _vit_backward(self, j: int, dfeat: torch.Tensor):
+        """Generator like _llm_backward: yields after every chunk of `exchange_blocks` blocks of backbone j."""
         v, st, cfg = self.vits[j], self.V[j], self.cfg
         vc = v.cfg
         B, npi, T, d = self.eng.B, vc.n_patches, vc.n_patches + vc.n_prefix, vc.d
@@ -377,6 +393,9 @@ class BackboneTrainer:
         for i in range(nb - 1, -1, -1):
             b, k = v.blocks[i], f"vit{j}.{i}."
             a = (lambda n: self.A(k + n)) if tv else (lambda n: None)
+            tap = self.taps.get(("vit", j, i)) if self.taps is not None else None
+            if tap is not None:
+                tap["d_out"] = dx.clone()
             # x_out = x_mid + ls2 * fc2(gelu(fc1(LN2(x_mid))))
             dh_ = ops.layerscale_bwd(dx, st["PM"][i] if tv else None, b["ls2"], a("ls2"), out=st["g_d2"]) if vc.layerscale else dx
             if tv:
@@ -404,12 +423,17 @@ class BackboneTrainer:
                 ops.colsum_(st["g_mid"], a("bqkv"))
             dh1 = self._lin_bwd(k + "qkv", st["g_mid"], st["H1"][i], b["wqkvT"], out=st["g_d"])
             if i == 0 and not tv:
+                yield self._ranges("vit", 0, min(nb, self.exchange_blocks) - 1, j), True
                 return                                   # below block 0 everything is frozen (Conv2d patch embedding, pos_embed, tokens)
             dxi = free.pop()
             self._ln_bwd(dh1, st["X"][i], b["n1w"], st["S1"][i], dxi, a("n1w"), a("n1b"))
             ops.add_(dxi, dxm)
             free.append(dxm)
             dx = dxi
+            if tap is not None:
+                tap["d_in"] = dx.clone()
+            if i % self.exchange_blocks == 0:
+                yield self._ranges("vit", i, min(nb, i + self.exchange_blocks) - 1, j), i == 0
         # full fine-tune: patch embedding x0 = cols . Wpe^T + bpe + pos on the patch rows; cls / register tokens on the prefix rows
         lib, p = ops._lib(), ops._p
         if vc.n_prefix:
@@ -423,29 +447,68 @@ class BackboneTrainer:
         ops.colsum_(dpe, self.A(f"vit{j}.bpe"))
         ops.N.check(lib.vla_colsum_bf16(ops._st(), p(dpe), p(self.A(f"vit{j}.pos")), Bv, npi * d, npi * d, 1, 0, 0), "colsum(pos)")   # sum over the batch
 
-    def _backward_vlm(self, pred, actions, gscale: float = 1.0):
+    def _backward_gen(self, pred, actions, gscale: float = 1.0):
+        """The backward as a generator of PIECES in the order gradients become final - action head, LLM layers top-down in chunks,
+        action queries + token embedding, projector, ViT blocks top-down in chunks, the fp32-accumulated vector section.  After
+        every piece it yields (ranges, last): ranges = [(flat gradient buffer, lo, hi)] that no later piece writes again - the
+        data-parallel exchange of a range starts right there, underneath the rest of the backward (vla-scripts/finetune.py:
+        215-227, 869: DDP's bucketed all-reduce overlapped with backward; BASELINE configs[3] "grad-bucket overlap").  Run to
+        completion by backward(); captured piece by piece (one linear hipGraph each) by capture()."""
         eng, head = self.eng, self.head
         Np = eng.Np
-        loss3, dpred = ops.l1_loss(pred, eng._to_bf16(actions), True, gscale)
+        self._begin_backward()
+        self._loss3, dpred = ops.l1_loss(pred, eng._to_bf16(actions), True, gscale)
         dHS = eng._dhs(0)
         head.backward(dpred, dHS, 0)
-        self._after_group("head")
-        dX0 = self._llm_backward(dHS)
+        aq_off = head.P.offsets["action_queries"][0]
+        yield [(head.P.grad, 0, aq_off)], False
+        for ranges in self._llm_backward(dHS):
+            yield ranges, False
+        dX0 = self._dX0
         dq = ops.action_query_grad(dX0, eng.pos0, Np, 0)
         ops.cast_f32_bf16(dq, out=head.P.g("action_queries"))
         self._embed_backward(dX0)
-        self._after_group("llm")
         dfeat = self._proj_backward(dX0)
-        for j in range(len(self.vits)):
-            self._vit_backward(j, dfeat)
-        self._after_group("vision")
-        return loss3
+        yield [(head.P.grad, aq_off, head.P.numel)] + self._ranges("embed") + self._ranges("proj"), False
+        nv = len(self.vits)
+        for j in range(nv):
+            for ranges, bottom in self._vit_backward(j, dfeat):
+                # LoRA: nothing trains below block 0 - the bottom piece of the last backbone closes the step
+                yield ranges, bottom and j == nv - 1 and not self.trains_vectors
+        if self.trains_vectors:
+            self._end_backward()
+            yield self._ranges("tail"), True
+
+    def _begin_backward(self):
+        pass
+
+    def _end_backward(self):
+        pass
 
     def _embed_backward(self, dX0):
         pass
 
-    def _after_group(self, name: str):
-        """Hook: the gradients of parameter group `name` ("head", "llm", "vision") are final on the current stream."""
+    def _ranges(self, kind, lo=0, hi=0, j=0):
+        """[(flat gradient buffer, first element, end element)] of a parameter group (mode-specific)."""
+        return []
+
+    def _span(self, first: str, last: str):
+        a = self.P.offsets[first][0]
+        off, shape = self.P.offsets[last]
+        return (self.P.grad, a, off + rup(math.prod(shape), 8))
+
+    def _exchange(self, ranges):
+        red = self.eng.reducer
+        if red is not None:
+            for buf, lo, hi in ranges:
+                if hi > lo:
+                    red.reduce_async(buf, lo, hi)
+
+    def backward(self, pred, actions, gscale: float = 1.0):
+        """Whole backward; with a reducer attached every gradient range is handed to the exchange as soon as it is final."""
+        for ranges, _ in self._backward_gen(pred, actions, gscale):
+            self._exchange(ranges)
+        return self._loss3
 
     # ---- update / capture (shared shape) ---------------------------------------------------------------------------
     def train_step(self, batch, lr: float, noise=None):
@@ -455,37 +518,49 @@ class BackboneTrainer:
         return loss3
 
     def capture(self, batch: Dict[str, torch.Tensor], noise: Optional[torch.Tensor] = None, warmup: int = 2):
-        """Forward + backward as ONE linear hipGraph on the static ``batch`` / ``noise`` buffers (copy new data into them before
-        each replay); AdamW stays outside (host-side bias corrections), the derived-operand rebuild is a second small graph.
-        A step is 3000-5000 launches: issued from Python they cost more host time than GPU time."""
+        """The step on the static ``batch`` / ``noise`` buffers (copy new data into them before each replay) as a CHAIN of linear
+        hipGraphs: forward + head backward, then one graph per backward piece (_backward_gen).  Between two replays the host hands
+        the piece's finished gradient ranges to the exchange stream, so the collectives of a captured multi-rank step run
+        underneath the remaining backward exactly as in the eager step (collectives themselves are not captured).  AdamW stays
+        outside (host-side bias corrections); the derived-operand rebuild is a last small graph.  A step is 3000-5000 launches:
+        issued from Python they cost more host time than GPU time."""
         self._cap_stream = torch.cuda.Stream()
-        for _ in range(warmup):
-            self.head.dirty = True
-            self.backward(self.forward(batch, noise), batch["actions"])
+        red, self.eng.reducer = self.eng.reducer, None            # warm-up passes exchange nothing
+        try:
+            for _ in range(warmup):
+                self.head.dirty = True
+                self.backward(self.forward(batch, noise), batch["actions"])
+        finally:
+            self.eng.reducer = red
         torch.cuda.synchronize()
-        self.head.dirty = True                       # the head's own W^T / padded-operand refresh becomes part of the graph
+        self.head.dirty = True                       # the head's own W^T / padded-operand refresh becomes part of the first graph
         pool = torch.cuda.graph_pool_handle()
-        self._g_step = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_step, pool=pool, stream=self._cap_stream, capture_error_mode="thread_local"):
-            self._loss3 = self.backward(self.forward(batch, noise), batch["actions"])
+        self._segs, gen, last = [], None, False
+        while not last:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, stream=self._cap_stream, capture_error_mode="thread_local"):
+                if gen is None:
+                    gen = self._backward_gen(self.forward(batch, noise), batch["actions"], 1.0)
+                ranges, last = next(gen)
+            self._segs.append((g, ranges))
         self._g_r = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_r, pool=pool, stream=self._cap_stream, capture_error_mode="thread_local"):
             self.refresh()
         torch.cuda.synchronize()
 
     def train_step_graphed(self, lr: float):
-        self._g_step.replay()
+        for g, ranges in self._segs:
+            g.replay()
+            self._exchange(ranges)
         self.optimizer_step(lr, refresh=False)
         self._g_r.replay()
         return self._loss3
 
     def _exchange_and_scale(self) -> float:
-        """Data-parallel exchange of both flat gradient buffers (blocking form: after the whole backward); returns the 1/N scale."""
+        """Join the data-parallel exchange the backward started range by range; returns the 1/N scale folded into AdamW."""
         red = self.eng.reducer
         if red is None:
             return 1.0
-        red.reduce_async(self.P.grad, 0, None)
-        red.reduce_async(self.head.P.grad, 0, None)
         red.wait()
         return red.grad_scale
 
@@ -600,12 +675,25 @@ class FullFinetune(BackboneTrainer):
         ops.N.check(ops._lib().vla_embed_grad(ops._st(), ops._p(dX0), ops._p(ids), ops._p(self.eng.qidx0), ops._p(self.G("llm.embed")),
                                               self.eng.B, ids.shape[1], self.eng.Np, self.cfg.llm.d, self.cfg.llm.vocab), "embed_grad")
 
-    def backward(self, pred, actions, gscale: float = 1.0):
+    def _begin_backward(self):
         ops.zero_(self.acc32)
         ops.zero_(self.G("llm.embed"))
-        loss3 = self._backward_vlm(pred, actions, gscale)
+
+    def _end_backward(self):
         ops.cast_f32_bf16(self.acc32, out=self.P.grad[self.vec_off:])       # every bias / norm / LayerScale / pos-embed / token gradient in one cast
-        return loss3
+
+    def _ranges(self, kind, lo=0, hi=0, j=0):
+        if kind == "llm":
+            return [self._span(f"llm.{lo}.wqkv", f"llm.{hi}.wd")]
+        if kind == "vit":
+            return [self._span(f"vit{j}.{lo}.wqkv", f"vit{j}.{hi}.w2")]
+        if kind == "embed":
+            return [self._span("llm.embed", "llm.embed")]
+        if kind == "proj":
+            names = ["proj." + k for k in self.eng.proj if k.endswith("weight")]
+            return [self._span(names[0], names[-1])]
+        # tail: the patch-embedding matrices (final after each backbone's last block) and the whole vector section
+        return [self._span(f"vit{j}.wpe", f"vit{j}.wpe") for j in range(len(self.vits))] + [(self.P.grad, self.vec_off, self.P.numel)]
 
     def reference_named_gradients(self) -> Dict[str, torch.Tensor]:
         """Gradients under the reference's state-dict names (fused layouts undone) - for parity tests / checkpoints."""
@@ -682,12 +770,11 @@ class LoRAFinetune(BackboneTrainer):
             L[f"llm.{i}.gu"] = LoraLinear(q + "mlp", 2 * I, D, [("gate_proj", ("group16", 0, I)), ("up_proj", ("group16", 16, I))], rank)
             L[f"llm.{i}.down"] = LoraLinear(q + "mlp", D, I, [("down_proj", ("range", 0, D))], rank)
         self.L = L
-        specA, specB = [], []
+        spec = []                      # per fused Linear: its A's (adjacent: A_cat is a view), then its B's - a layer's pairs are one range
         for l in L.values():
             a, b = l.spec()
-            specA += a
-            specB += b
-        self.P = E.FlatParams(specA + specB, self.dev)
+            spec += a + b
+        self.P = E.FlatParams(spec, self.dev)
         gen = torch.Generator(device=self.dev).manual_seed(seed)
         for l in L.values():
             l.bind(self.P, self.dev)
@@ -733,8 +820,17 @@ class LoRAFinetune(BackboneTrainer):
             return ops.gemm_swiglu_bwd(dy, WT, swiglu_gu, out=out, ext=(dt, l.A_catT))
         return ops.gemm_nt(dy, WT, out=out, ext=(dt, l.A_catT))     # dx = dy W + dt A_cat
 
-    def backward(self, pred, actions, gscale: float = 1.0):
-        return self._backward_vlm(pred, actions, gscale)
+    def _ranges(self, kind, lo=0, hi=0, j=0):
+        first = lambda key: f"{self.L[key].name}.{self.L[key].projs[0][0]}.lora_A"
+        last = lambda key: f"{self.L[key].name}.{self.L[key].projs[-1][0]}.lora_B"
+        if kind == "llm":
+            return [self._span(first(f"llm.{lo}.qkv"), last(f"llm.{hi}.down"))]
+        if kind == "vit":
+            return [self._span(first(f"vit{j}.{lo}.qkv"), last(f"vit{j}.{hi}.fc2"))]
+        if kind == "proj":
+            keys = [k for k in self.L if k.startswith("proj.")]
+            return [self._span(first(keys[0]), last(keys[-1]))]
+        return []                       # embed / tail: frozen under LoRA
 
     # ---- adapters in and out
     def lora_state_dict(self) -> Dict[str, torch.Tensor]:
