@@ -150,7 +150,7 @@ def measure_gemm_roofline(eng, batch, noise, lr, reps=10, record_only=False):
 def pmc_traffic():
     """HBM-side bytes per GEMM launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate
     runs of this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if not collected."""
-    for name in ("r02_gemm_traffic_pmc.json", "r01_gemm_traffic_pmc.json"):
+    for name in ("r03_gemm_traffic_pmc.json", "r02_gemm_traffic_pmc.json", "r01_gemm_traffic_pmc.json"):
         f = os.path.join(ROOT, "profiles", name)
         try:
             d = json.load(open(f))
@@ -167,13 +167,21 @@ def in_situ_roofline(gemm_flops_per_step):
     tools/profile_step.sh -> profiles/r02_gemm_in_situ.json; reproducible from profiles/r02_kernel_summary.csv with a calculator:
     sum us_per_step over the gemm rows).  Kernels of concurrent streams share the CUs, so a launch's in-situ duration includes the
     time it waits for CUs other streams hold: this is a LOWER bound on the kernel's own rate."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02_gemm_in_situ.json")))
+    from vla_adapter_amd import flops
+    for name in ("r03_gemm_in_situ.json", "r02_gemm_in_situ.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            continue
         us = d["gemm_us_per_step_in_situ"]
-        return {"frac_in_situ": round(gemm_flops_per_step / us / 1e6 / MFMA_BF16_PEAK_TFLOPS, 4), "gemm_us_per_step_in_situ": us,
-                "gemm_launches_per_step": d["gemm_launches_per_step"], "source": "profiles/r02_gemm_in_situ.json (+ r02_kernel_summary.csv)"}
-    except Exception:
-        return None
+        # the profile is evidence for the code it was taken from: with other kernel / schedule sources it is reported as stale and
+        # frac_in_situ is withheld (null) instead of dividing today's FLOPs by another build's kernel time (ADVICE r2)
+        stale = d.get("source_digest") != flops.source_digest()
+        return {"frac_in_situ": None if stale else round(gemm_flops_per_step / us / 1e6 / MFMA_BF16_PEAK_TFLOPS, 4),
+                "frac_in_situ_of_profiled_build": d.get("frac_in_situ"), "stale": stale, "profile_source_digest": d.get("source_digest"),
+                "gemm_us_per_step_in_situ": us, "gemm_launches_per_step": d["gemm_launches_per_step"],
+                "source": f"profiles/{name} (+ {name[:3]}_kernel_summary_steady.csv)"}
+    return None
 
 
 def host_cores() -> int:
@@ -262,10 +270,12 @@ def bench_full(args, cfg, W, eng, batch, noise, lr, rank, local, world, B, P):
             "metric": "fine-tune samples/sec (224px img + 32-tok prompt), FULL unfreeze (ViT + LLM + adapter), fwd+bwd+AdamW",
             "value": round(world * B * args.steps / dt, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[3]: Prismatic SigLIP-224 + Qwen2.5-0.5B + Pro action head, full-backbone unfreeze, "
-                                   "1 image (256 patches) + 32-token prompt + 64 action queries (S=352)",
+            "config": {"workload": ("BASELINE configs[3]: Prismatic SigLIP-224 + Qwen2.5-0.5B" if args.backbone == "config2" else args.backbone) +
+                                   f" + Pro action head, full-backbone unfreeze, {cfg.n_img} image(s) ({cfg.n_patches} patches) + 32-token prompt + "
+                                   f"64 action queries (S={cfg.n_patches + P + 64})",
                        "global_batch": world * B, "per_gpu_batch": B, "seq_len": cfg.n_patches + P + 64, "parallelism": f"dp{world}",
                        "weights": "random-init", "trainable_parameters": nparam, "launch": "eager" if args.eager else "hipGraph replay",
+                       "captured_segment_graphs": None if args.eager else len(ft._segs),
                        "final_loss": round(float(loss3[0]), 5)},
             "step_tflops_per_gpu": round(full * B / (ms * 1e-3) / 1e12, 1),
             "step_frac_of_bf16_mfma_peak": round(full * B / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
@@ -298,18 +308,22 @@ def bench_lora(args, cfg, W, eng, batch, noise, lr, rank, local, world, B, P):
     dt = time.perf_counter() - t0
     ms = dt / args.steps * 1e3
     fl = flops.step_flops_per_sample(cfg, L=P + 64, row0=0)
-    work = 2.0 * fl["forward"]                                 # forward + dX of every op (base dW is not computed; rank-64 terms ~2 %)
+    work = 2.0 * fl["forward"] + fl["head_fwd"]                # forward + dX of every op + the head's dW (base dW is not computed; rank terms ~2-10 %)
+    desc = {"config2": "Prismatic SigLIP-224 + Qwen2.5-0.5B", "dinosiglip-0_5b": "DINOv2-L + SigLIP-so400m fused + Qwen2.5-0.5B (the reference's documented recipe)",
+            "config5": "BASELINE configs[4] backbone: DINOv2-L + SigLIP-so400m fused + Qwen2.5-1.5B (bf16: the config's fp8 weight path is not part of this mode)"}[args.backbone]
     if rank == 0:
         print(json.dumps({
             "metric": "fine-tune samples/sec (224px img + 32-tok prompt), LoRA rank %d on every Linear + adapter head, fwd+bwd+AdamW" % args.lora_rank,
             "value": round(B * args.steps / dt, 2), "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "Prismatic SigLIP-224 + Qwen2.5-0.5B + Pro action head, LoRA fine-tune (the 0.5B stand-in for BASELINE configs[4]), "
-                                   "1 image (256 patches) + 32-token prompt + 64 action queries (S=352)",
+            "config": {"workload": f"{desc} + Pro action head, LoRA fine-tune (vla-scripts/finetune.py:832-844), {cfg.n_img} image(s) "
+                                   f"({cfg.n_patches} patches) + 32-token prompt + 64 action queries (S={cfg.n_patches + P + 64})",
                        "global_batch": B, "per_gpu_batch": B, "seq_len": cfg.n_patches + P + 64, "parallelism": "dp1", "weights": "random-init",
+                       "trainable_parameters": ft.P.numel + ft.head.P.numel, "captured_segment_graphs": None if args.eager else len(ft._segs),
                        "launch": "eager" if args.eager else "hipGraph replay", "final_loss": round(float(loss3[0]), 5)},
             "step_tflops_per_gpu": round(work * B / (ms * 1e-3) / 1e12, 1),
             "step_frac_of_bf16_mfma_peak": round(work * B / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "gflop_per_sample": {"forward": round(fl["forward"] / 1e9, 1), "counted": round(work / 1e9, 1)},
         }), flush=True)
 
 
@@ -333,9 +347,10 @@ def main():
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
     ap.add_argument("--rehearse-exchange", action="store_true", help="one GPU: run the step with a one-rank RCCL group and forced gradient collectives")
     ap.add_argument("--no-probe", action="store_true", help="skip the isolated GEMM replays (profiling runs: the trace then holds training steps only)")
-    ap.add_argument("--backbone", default="config2", choices=["config2", "config5"],
-                    help="config2: SigLIP-224 + Qwen2.5-0.5B (the headline); config5: DINOv2+SigLIP fused + Qwen2.5-1.5B (BASELINE configs[4]'s "
-                         "backbone, adapter-only; not the headline)")
+    ap.add_argument("--backbone", default="config2", choices=["config2", "dinosiglip-0_5b", "config5"],
+                    help="config2: SigLIP-224 + Qwen2.5-0.5B (the headline); dinosiglip-0_5b: DINOv2+SigLIP fused + Qwen2.5-0.5B (the reference's "
+                         "documented recipe, README.md:254-274); config5: DINOv2+SigLIP fused + Qwen2.5-1.5B (BASELINE configs[4]'s backbone)")
+    ap.add_argument("--n-img", type=int, default=None, help="images per sample (default 1; the documented recipe and BASELINE configs[4] use 2)")
     ap.add_argument("--ragged", action="store_true", help="prompt lengths in [24, 32], right-padded (exercises the mask path; SURVEY 8d)")
     args = ap.parse_args()
 
@@ -345,7 +360,8 @@ def main():
     local = local % torch.cuda.device_count()      # ranks > GPUs only in the gloo rehearsal on a one-GPU box
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
-    cfg = E.config5_backbone() if args.backbone == "config5" else E.config2()
+    cfg = E.NAMED_CONFIGS[args.backbone]()
+    cfg.n_img = args.n_img or 1
     B, P = (args.batch or (32 if args.mode == "adapter" else 16)), 32
     W = S.make_weights(cfg, dev, seed=0)                    # identical on every rank (== DDP's initial broadcast)
     eng = E.VLAEngine(cfg, W, dev)
@@ -442,6 +458,7 @@ def main():
         print(json.dumps({"metric": "fine-tune samples/sec (profiling run, no probe)", "value": round(value, 2), "unit": "samples/s",
                           "ms_per_step": round(ms, 3), "steps": args.steps, "warmup": args.warmup,
                           "executed_steps": eng.executed_steps, "marker_grid_x": MARKER_BYTES // 16, "gemm_flops_per_step": rec["flops"],
+                          "source_digest": flops.source_digest(),
                           "gemm_launches_per_step": rec["launches"], "gemm_algorithmic_bytes_per_step": rec["bytes"]}), flush=True)
     elif rank == 0:
         roof = measure_gemm_roofline(eng, batch, noise, lr)

@@ -27,7 +27,7 @@ extern "C" {
 
 /* ABI version.  It changes whenever an entry point's signature or a descriptor struct's layout changes:
  *   1  rounds 1-2 (vla_gemm_desc ended at `bias_post_round`, later at `b_scale`);
- *   2  round 3: vla_gemm_desc gained the K extension (A2 .. ldb2), new entry points vla_gemm_bf16_tn, vla_gemm256_extent_ok,
+ *   2  round 3: vla_gemm_desc gained the K extension (A2 .. ldb2), new entry points vla_gemm_bf16_tn (+ _grouped), vla_gemm256_extent_ok,
  *      vla_copy_rows3d, vla_layerscale_fwd / _bwd, vla_token_ce_bwd, vla_desc_size.
  * A binder checks vla_version() AND vla_desc_size() against its own struct definitions before the first call. */
 #define VLA_ABI_VERSION 2
@@ -117,6 +117,12 @@ typedef struct vla_gemm_tn_desc {
  * Linear in the full fine-tune (:846-849) - on dY and X as the backward / forward left them (no operand transposes).
  * N1 % 8 == 0, N2 % 8 == 0, lda / ldb % 8 == 0; M arbitrary. */
 int vla_gemm_bf16_tn(void* stream, const vla_gemm_tn_desc* desc /* host */);
+/* GROUPED form: `count` (1 .. 48) independent TN products as ONE launch over the concatenated tile list - the weight gradients of
+ * several Linears / layers, which torch.autograd computes one GEMM at a time (vla-scripts/finetune.py:1039-1042).  A single dW
+ * product is 49 ... 532 tiles on a chip with 512 workgroup slots and leaves up to half of it idle in its tail round; a whole
+ * backward piece's products together run at the granularity of their common tile list.  Plain problems only (batch 1, no split,
+ * no addend, no row groups; column groups on A allowed).  descs: host array; the problem table travels in the kernel arguments. */
+int vla_gemm_bf16_tn_grouped(void* stream, const vla_gemm_tn_desc* descs /* host array */, int count);
 
 /* Row-wise dynamic fp8 quantisation: q[r, :] = e4m3(x[r, :] * 448 / amax_r) (round to nearest even, saturating), scale[r] =
  * amax_r / 448 (1 for an all-zero row).  x bf16 [rows, cols] (ldx), q bytes [rows, cols] (ldq, % 16 == 0), cols % 8 == 0. */

@@ -147,3 +147,32 @@ def test_copy_rows3d(ops):
     dst = torch.zeros(4, 9, 13, device=DEV, dtype=BF)
     ops.copy_rows3d(src, dst[0, 1], 4, 7, 13, 7 * 13, 13, 9 * 13, 13)
     assert torch.equal(dst[:, 1:8], src)
+
+
+def test_gemm_tn_grouped_equals_the_single_launches(ops):
+    """One grouped launch over several products (different shapes, a column-grouped operand, a ragged contraction) == the same
+    products launched one by one, bit for bit (same tiles, same K order)."""
+    M = 1000
+    dy = gen(M, 640, seed=31).to(DEV)
+    xs = [gen(M, n, seed=32 + i, scale=0.1).to(DEV) for i, n in enumerate((896, 64, 136))]
+    probs, refs, outs = [], [], []
+    for i, x in enumerate(xs):
+        o = torch.empty(640, x.shape[1], device=DEV, dtype=BF)
+        probs.append(ops.tn_problem(dy, x, o, alpha=1.0 + i))
+        refs.append(ops.gemm_tn(dy, x, alpha=1.0 + i, split=0))
+        outs.append(o)
+    o = torch.empty(320, 64, device=DEV, dtype=BF)                       # the "up" half of a gate/up-interleaved dY
+    probs.append(ops.tn_problem(dy, xs[1], o, a_cols=(320, 16, 32, 16)))
+    refs.append(ops.gemm_tn(dy, xs[1], a_cols=(320, 16, 32, 16), split=0))
+    outs.append(o)
+    short = gen(200, 128, seed=40).to(DEV)                                 # another contraction length in the same launch
+    o = torch.empty(128, 128, device=DEV, dtype=BF)
+    probs.append(ops.tn_problem(short, short, o))
+    refs.append(ops.gemm_tn(short, short, split=0))
+    outs.append(o)
+    ops.gemm_tn_grouped(probs)
+    for a, b in zip(outs, refs):
+        assert torch.equal(a, b)
+    many = [ops.tn_problem(short, short, torch.empty(128, 128, device=DEV, dtype=BF)) for _ in range(ops.TN_GROUP_MAX + 5)]   # > one table
+    ops.gemm_tn_grouped(many)
+    assert all(torch.equal(p._keep[2], refs[-1]) for p in many)

@@ -37,7 +37,7 @@ eng, tr = make(cfg, W, dev, mode)
 eng.reducer = ddp.FlatGradReducer(bucket_bytes=1 << 16, algo=os.environ.get("VLA_DDP_ALGO", "allreduce"))   # small buckets: many collectives per range
 n_ex = [0]
 orig = tr._exchange
-tr._exchange = lambda ranges: (n_ex.__setitem__(0, n_ex[0] + sum(1 for _, lo, hi in ranges if hi > lo)), orig(ranges))[1]
+tr._exchange = lambda ranges, after_event=None: (n_ex.__setitem__(0, n_ex[0] + sum(1 for _, lo, hi in ranges if hi > lo)), orig(ranges, after_event=after_event))[1]
 if captured:
     tr.capture(batches[rank], None)
     log("captured", len(tr._segs), "segment graphs")

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""gpurun_out/prof_r02 (tools/profile_step.sh) -> profiles/r02_*.
+"""gpurun_out/prof_<round> (tools/profile_step.sh) -> profiles/<round>_*  (<round> = $VLA_ROUND, default r03; "{RND}" below).
 
 --stage box  (on the GPU box, where the multi-100-MB kernel trace lives): reduce the trace to
              gpurun_out/prof_r02/kernel_summary.csv = one row per (kernel, grid, workgroup) with calls, calls per step,
              average / total microseconds - small enough to travel back.
 --stage repo (default, in the repository): copy the summaries into profiles/, derive
-             profiles/r02_gemm_in_situ.json = per-GEMM-instantiation calls/step, FLOPs/launch, average microseconds,
+             profiles/{RND}_gemm_in_situ.json = per-GEMM-instantiation calls/step, FLOPs/launch, average microseconds,
              sum of in-situ GEMM time per step (the denominator of bench.py's roofline.frac_in_situ) and
-             profiles/r02_gemm_traffic_pmc.json (FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md says).
+             profiles/{RND}_gemm_traffic_pmc.json (FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md says).
 """
 import argparse
 import csv
@@ -18,8 +18,9 @@ import shutil
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC, DST = os.path.join(ROOT, "gpurun_out", "prof_r02"), os.path.join(ROOT, "profiles")
-GEMM_KERNELS = ("gemm_nt_kernel", "gemm256_kernel")
+RND = os.environ.get("VLA_ROUND", "r03")                       # profiles are named per round
+SRC, DST = os.path.join(ROOT, "gpurun_out", "prof_" + RND), os.path.join(ROOT, "profiles")
+GEMM_KERNELS = ("gemm_nt_kernel", "gemm256_kernel", "gemm_tn_kernel")
 
 
 def short(name: str) -> str:
@@ -87,27 +88,28 @@ def pmc_sum(sub, counter):
 
 def stage_repo():
     os.makedirs(DST, exist_ok=True)
-    shutil.copy(os.path.join(SRC, "kernel_summary.csv"), os.path.join(DST, "r02_kernel_summary.csv"))
+    shutil.copy(os.path.join(SRC, "kernel_summary.csv"), os.path.join(DST, RND + "_kernel_summary.csv"))
     steady = os.path.join(SRC, "kernel_summary_steady.csv")
     if os.path.exists(steady):
-        shutil.copy(steady, os.path.join(DST, "r02_kernel_summary_steady.csv"))
+        shutil.copy(steady, os.path.join(DST, RND + "_kernel_summary_steady.csv"))
     st = glob.glob(os.path.join(SRC, "stats", "*", "*_kernel_stats.csv"))
     if st:
-        shutil.copy(st[0], os.path.join(DST, "r02_kernel_stats.csv"))
+        shutil.copy(st[0], os.path.join(DST, RND + "_kernel_stats.csv"))
     for n in ("bench.json", "bench_under_rocprof.json"):
         if os.path.exists(os.path.join(SRC, n)):
-            shutil.copy(os.path.join(SRC, n), os.path.join(DST, "r02_" + n))
-    have_steady = os.path.exists(os.path.join(DST, "r02_kernel_summary_steady.csv"))
-    rows = list(csv.DictReader(open(os.path.join(DST, "r02_kernel_summary_steady.csv" if have_steady else "r02_kernel_summary.csv"))))
+            shutil.copy(os.path.join(SRC, n), os.path.join(DST, RND + "_" + n))
+    have_steady = os.path.exists(os.path.join(DST, RND + "_kernel_summary_steady.csv"))
+    rows = list(csv.DictReader(open(os.path.join(DST, RND + "_kernel_summary_steady.csv" if have_steady else RND + "_kernel_summary.csv"))))
     gem = [r for r in rows if any(g in r["kernel"] for g in GEMM_KERNELS)]
     steps = int(rows[0]["steps_in_trace"])
-    bench = json.load(open(os.path.join(DST, "r02_bench_under_rocprof.json")))
+    bench = json.load(open(os.path.join(DST, RND + "_bench_under_rocprof.json")))
     out = {"source": "rocprofv3 --kernel-trace of `bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-full-backward --no-probe` "
                      "(tools/profile_step.sh)" + (": the launches between the two marker launches that bracket the timed graph replays "
-                                                  "(profiles/r02_kernel_summary_steady.csv)" if have_steady else ": whole trace"),
+                                                  f"(profiles/{RND}_kernel_summary_steady.csv)" if have_steady else ": whole trace"),
            "kernels_not_from_this_library_in_timed_region": (sorted({r["kernel"] for r in rows if "at::" in r["kernel"] or "rocclr" in r["kernel"]})
                                                              if have_steady else None),
            "steps_in_trace": steps,
+           "source_digest": bench.get("source_digest"),       # of the code that was profiled (bench.py stamps it; flops.source_digest)
            "gemm_us_per_step_in_situ": round(sum(float(r["total_us"]) for r in gem) / steps, 1),
            "gemm_launches_per_step": round(sum(int(r["calls"]) for r in gem) / steps, 1),
            "all_kernels_us_per_step": round(sum(float(r["total_us"]) for r in rows) / steps, 1),
@@ -117,7 +119,7 @@ def stage_repo():
     if out["gemm_flops_per_step"]:
         out["gemm_tflops_in_situ"] = round(out["gemm_flops_per_step"] / out["gemm_us_per_step_in_situ"] / 1e6, 1)
         out["frac_in_situ"] = round(out["gemm_tflops_in_situ"] / 2500.0, 4)
-    json.dump(out, open(os.path.join(DST, "r02_gemm_in_situ.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(DST, RND + "_gemm_in_situ.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != "instantiations"}, indent=1))
     fetch, n1 = pmc_sum("pmc_fetch", "FETCH_SIZE")      # KB
     write, n2 = pmc_sum("pmc_write", "WRITE_SIZE")
@@ -126,7 +128,7 @@ def stage_repo():
               "bytes_per_launch": (2.0 * fetch + write) * 1024 / n1,
               "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools/profile_step.sh) over bench.py --steps 2 "
                       "--warmup 1 --eager; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B)"}
-        json.dump(pm, open(os.path.join(DST, "r02_gemm_traffic_pmc.json"), "w"), indent=1)
+        json.dump(pm, open(os.path.join(DST, RND + "_gemm_traffic_pmc.json"), "w"), indent=1)
         print(json.dumps(pm, indent=1))
 
 

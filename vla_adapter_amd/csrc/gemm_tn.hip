@@ -44,19 +44,21 @@ __device__ __forceinline__ bf16x4 tr_read(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)p);
 }
 
-__global__ __launch_bounds__(512) void gemm_tn_kernel(TnP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+// XCD-aware bijective order over `nwg` workgroups (as gemm.hip): workgroups b and b + 8 share an XCD (round-robin dispatch); every
+// XCD gets a contiguous run of the tile list, so consecutive tiles (same A column panel) hit the same L2
+__device__ __forceinline__ int xcd_order(int bid, int nwg) {
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+}
+
+// One 128 x 128 output tile (tile index `swz` of problem p; bz = batch * split + contraction slice).
+__device__ __forceinline__ void tn_tile(const TnP& p, const int swz, const int bz, char* smem) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;
-
-  // XCD-aware bijective tile order (as gemm.hip): consecutive tiles of one XCD share the A column panel
-  const int nwg = p.ntiles, bid = blockIdx.x;
-  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int b1 = swz / p.tiles_n2, b2 = swz - b1 * p.tiles_n2;
   const int n1_0 = b1 * 128, n2_0 = b2 * 128;
-  const int zb = blockIdx.z / p.split, zs = blockIdx.z - zb * p.split;
+  const int zb = bz / p.split, zs = bz - zb * p.split;
   const int m_begin = zs * p.mslice, m_end = min(p.M, m_begin + p.mslice);
   const int nt = (m_end - m_begin + TBK - 1) / TBK;
   const char* Ab = reinterpret_cast<const char*>(p.A + (long long)zb * p.sA);
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnP p) {
   const int w1 = n1_0 + wr * 64, w2 = n2_0 + wc * 32;
   const int lq = lane >> 4, lr = lane & 15;
   if (p.ws != nullptr) {                   // contraction slice zs: raw fp32 accumulators into its own plane
-    float* plane = p.ws + ((long long)blockIdx.z) * p.N1 * p.N2;
+    float* plane = p.ws + ((long long)bz) * p.N1 * p.N2;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -186,6 +188,40 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnP p) {
       }
       *reinterpret_cast<uint2*>(Cb + (long long)r * p.ldc + c) = uint2{pack2(v[0], v[1]), pack2(v[2], v[3])};
     }
+}
+
+__global__ __launch_bounds__(512) void gemm_tn_kernel(TnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  tn_tile(p, xcd_order(blockIdx.x, p.ntiles), blockIdx.z, smem);
+}
+
+// GROUPED launch: up to TN_GROUP_MAX independent products (the weight gradients of several Linears / layers) as ONE tile list.
+// A dW product alone is 49 ... 532 tiles on a chip with 512 workgroup slots - its tail round leaves up to half the CUs idle; the
+// products of a whole backward piece together (3600 tiles for four LLM layers) run at the tile list's own granularity.  The
+// problem table travels by value in the kernel arguments (no device-side state, capturable in a hipGraph).
+constexpr int TN_GROUP_MAX = 48;
+struct TnG {
+  const bf16_t* A; const bf16_t* B; bf16_t* C;
+  int M, N1, N2, lda, ldb, ldc, cgA, cgsA;
+  float alpha; int tiles_n2;
+};
+struct TnGroup { TnG g[TN_GROUP_MAX]; int start[TN_GROUP_MAX + 1]; int count, total; };
+
+__global__ __launch_bounds__(512) void gemm_tn_grouped_kernel(TnGroup G) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = xcd_order(blockIdx.x, G.total);
+  int pi = 0;
+  while (pi + 1 < G.count && t >= G.start[pi + 1]) ++pi;          // wave-uniform scan of the (short) table
+  const TnG& g = G.g[pi];
+  TnP p;
+  p.A = g.A; p.B = g.B; p.C = g.C; p.R = nullptr; p.ws = nullptr;
+  p.M = g.M; p.N1 = g.N1; p.N2 = g.N2; p.lda = g.lda; p.ldb = g.ldb; p.ldc = g.ldc; p.ldr = 0;
+  p.sA = p.sB = p.sC = p.sR = 0;
+  p.alpha = g.alpha;
+  p.gA = p.gB = 0; p.sgA = p.sgB = 0;
+  p.cgA = g.cgA; p.cgsA = g.cgsA;
+  p.tiles_n2 = g.tiles_n2; p.ntiles = 0; p.split = 1; p.mslice = g.M;
+  tn_tile(p, t - G.start[pi], 0, smem);
 }
 
 // second pass of the contraction split: C = bf16(bf16(alpha * sum_s ws[b][s]) + R); 4 columns per thread
@@ -257,5 +293,39 @@ extern "C" int vla_gemm_bf16_tn(void* stream, const vla_gemm_tn_desc* d) {
                        d->N1, d->N2, d->ldc, d->ldr, d->sC, d->sR, p.alpha, split);
     VLA_CHECK_LAUNCH("gemm_tn_finalize");
   }
+  return VLA_OK;
+}
+
+extern "C" int vla_gemm_bf16_tn_grouped(void* stream, const vla_gemm_tn_desc* descs, int count) {
+  VLA_REQUIRE(descs && count > 0 && count <= TN_GROUP_MAX, "gemm_tn_grouped: 1 .. 48 problems per launch");
+  TnGroup G;
+  int total = 0;
+  for (int i = 0; i < count; ++i) {
+    const vla_gemm_tn_desc* d = descs + i;
+    VLA_REQUIRE(d->A && d->B && d->C && d->M > 0 && d->N1 > 0 && d->N2 > 0, "gemm_tn_grouped: null operand / empty problem");
+    VLA_REQUIRE(d->batch == 1 && d->split <= 1 && !d->R && d->a_group == 0 && d->b_group == 0,
+                "gemm_tn_grouped: plain problems only (batch 1, no split / addend / row groups)");
+    VLA_REQUIRE(d->N1 % 8 == 0 && d->N2 % 8 == 0 && d->lda % 8 == 0 && d->ldb % 8 == 0 && d->ldc % 4 == 0, "gemm_tn_grouped: N1, N2, lda, ldb % 8, ldc % 4");
+    VLA_REQUIRE(((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->B & 15) == 0 && ((uintptr_t)d->C & 7) == 0, "gemm_tn_grouped: alignment");
+    VLA_REQUIRE(d->a_col_group >= 0 && d->a_col_group % 8 == 0 && d->a_col_group_stride % 8 == 0 &&
+                    (d->a_col_group == 0 || d->a_col_group_stride >= d->a_col_group), "gemm_tn_grouped: bad column groups");
+    TnG& g = G.g[i];
+    g.A = (const bf16_t*)d->A; g.B = (const bf16_t*)d->B; g.C = (bf16_t*)d->C;
+    g.M = d->M; g.N1 = d->N1; g.N2 = d->N2; g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc;
+    g.cgA = d->a_col_group; g.cgsA = d->a_col_group_stride;
+    g.alpha = d->alpha == 0.f ? 1.f : d->alpha;
+    g.tiles_n2 = (d->N2 + 127) / 128;
+    G.start[i] = total;
+    total += ((d->N1 + 127) / 128) * g.tiles_n2;
+  }
+  G.start[count] = total;
+  G.count = count; G.total = total;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(total), dim3(512), LDS_BYTES, (hipStream_t)stream, G);
+  VLA_CHECK_LAUNCH("gemm_bf16_tn_grouped");
   return VLA_OK;
 }

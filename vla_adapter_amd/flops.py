@@ -67,6 +67,23 @@ def step_flops_per_sample(cfg: VLACfg, L: int = 96, row0: int = 0) -> dict:
                 step=total, step_live=live if row0 else total)
 
 
+def source_digest() -> str:
+    """sha256 over the kernel sources and the step schedule (csrc/*.hip, *.h, engine.py, ops.py, trainers.py): stamped into
+    profiles/*_gemm_in_situ.json when a profile is reduced, compared by bench.py - a profile taken from other code is reported
+    as stale instead of being quoted as a fresh measurement."""
+    import glob
+    import hashlib
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(here, "csrc", "*.hip")) + glob.glob(os.path.join(here, "csrc", "*.h"))) + \
+        [os.path.join(here, n) for n in ("engine.py", "ops.py", "trainers.py")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 if __name__ == "__main__":
     from .engine import config2
     for k, v in step_flops_per_sample(config2(), row0=288).items():

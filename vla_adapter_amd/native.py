@@ -76,6 +76,7 @@ _PROTOS = {
     "vla_desc_size": ([_I], _I),
     "vla_gemm256_extent_ok": ([C.POINTER(GemmDesc)], _I),
     "vla_gemm_bf16_tn": ([_P, C.POINTER(GemmTnDesc)], _I),
+    "vla_gemm_bf16_tn_grouped": ([_P, C.POINTER(GemmTnDesc), _I], _I),
     "vla_copy_rows3d": ([_P, _P, _P, _I, _I, _I, _L, _L, _L, _L], _I),
     "vla_layerscale_fwd": ([_P, _P, _P, _P, _P, _L, _I], _I),
     "vla_layerscale_bwd": ([_P, _P, _P, _P, _P, _P, _I, _I], _I),

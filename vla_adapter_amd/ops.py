@@ -238,6 +238,34 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, *, out: Optional[torch.Tensor] = N
     return out
 
 
+TN_GROUP_MAX = 48
+
+
+def tn_problem(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, alpha: float = 1.0, a_cols=None) -> "N.GemmTnDesc":
+    """Descriptor of one plain product out[N1, N2] = alpha a[M, N1]^T b[M, N2] for gemm_tn_grouped (2-D views, last stride 1)."""
+    _chk_bf16(a, b, out)
+    assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1 and a.shape[0] == b.shape[0]
+    d = N.GemmTnDesc()
+    N1, a_ptr = a.shape[1], a.data_ptr()
+    if a_cols is not None:
+        N1, cg, cgs, off = a_cols
+        d.a_col_group, d.a_col_group_stride = cg, cgs
+        a_ptr += off * 2
+    assert tuple(out.shape) == (N1, b.shape[1]), f"out shape {tuple(out.shape)} != {(N1, b.shape[1])}"
+    d.A, d.B, d.C = a_ptr, b.data_ptr(), out.data_ptr()
+    d.M, d.N1, d.N2, d.lda, d.ldb, d.ldc, d.batch, d.alpha = a.shape[0], N1, b.shape[1], a.stride(0), b.stride(0), out.stride(0), 1, alpha
+    d._keep = (a, b, out)                      # the descriptor holds raw pointers: keep the tensors alive with it
+    return d
+
+
+def gemm_tn_grouped(problems):
+    """ONE launch (per 48 problems) over the concatenated tile lists of independent TN products (tn_problem descriptors)."""
+    for i in range(0, len(problems), TN_GROUP_MAX):
+        chunk = problems[i:i + TN_GROUP_MAX]
+        arr = (N.GemmTnDesc * len(chunk))(*chunk)
+        N.check(_lib().vla_gemm_bf16_tn_grouped(_st(), arr, len(chunk)), "gemm_bf16_tn_grouped")
+
+
 def copy_rows3d(src: torch.Tensor, dst: torch.Tensor, groups: int, rows: int, cols: int, s_sg: int, s_sr: int, d_sg: int, d_sr: int):
     """dst[g][r][:cols] = src[g][r][:cols] over raw element strides (src / dst: tensors whose data_ptr is element [0][0][0])."""
     _chk_bf16(src, dst)

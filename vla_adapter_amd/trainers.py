@@ -95,17 +95,17 @@ class LoraLinear:
         ops.transpose(self.A_cat, out=self.A_catT)
         ops.transpose(self.B_blk, out=self.B_blkT)
 
-    def grads(self, dy2d, x2d, t2d, dt2d):
-        """dA_cat = dt^T x (one TN GEMM into the flat gradient), dB_j = dy_j^T t_j per pair (the columns of dy that belong to
-        pair j: a range, or 16-column groups every 32 for gate / up)."""
-        ops.gemm_tn(dt2d, x2d, out=self.gA_cat)
+    def grads(self, dy2d, x2d, t2d, dt2d, emit):
+        """dA_cat = dt^T x (one TN product into the flat gradient), dB_j = dy_j^T t_j per pair (the columns of dy that belong to
+        pair j: a range, or 16-column groups every 32 for gate / up).  emit(a, b, out, alpha, a_cols) launches or collects them."""
+        emit(dt2d, x2d, self.gA_cat)
         for j, (p, d) in enumerate(self.projs):
             gB = self.P.g(f"{self.name}.{p}.lora_B")
             tj = t2d[:, j * self.rp:(j + 1) * self.rp]
             if d[0] == "range":
-                ops.gemm_tn(dy2d[:, d[1]:d[2]], tj, out=gB)
+                emit(dy2d[:, d[1]:d[2]], tj, gB)
             else:
-                ops.gemm_tn(dy2d, tj, out=gB, a_cols=(d[2], 16, 32, d[1]))
+                emit(dy2d, tj, gB, 1.0, (d[2], 16, 32, d[1]))
 
 
 # ------------------------------------------------------------------------------------------------ shared training core
@@ -148,6 +148,14 @@ class BackboneTrainer:
         # granularity of the data-parallel exchange: gradient ranges are handed over every `exchange_layers` LLM layers (4 x 30 MB
         # of bf16 gradients at the 0.5B geometry: large messages for the point-to-point xGMI links) / `exchange_blocks` ViT blocks
         self.exchange_layers, self.exchange_blocks = 4, 7
+        # Two streams: the dX chain (what the next layer's backward waits for) on the caller's stream; everything that only feeds a
+        # parameter gradient - the dW / LoRA-pair TN GEMMs, bias column sums - on `gstream`, one piece behind.  A dW product
+        # fills 266-532 tiles of a 512-slot chip and the chain's own GEMMs 288-308: alone each leaves 40 % of the CUs idle in its
+        # tail round, together they fill each other's gaps (62.4 -> see DESIGN 5d).  VLA_TRAINER_STREAMS=1: everything in line.
+        import os
+        self.gstream = torch.cuda.Stream() if int(os.environ.get("VLA_TRAINER_STREAMS", "2")) > 1 else None
+        self.group_tn = not os.environ.get("VLA_NO_GROUPED_TN")          # (A/B knob)
+        self._deferred = []
 
     # ---- mode hooks ---------------------------------------------------------------------------------------------
     def _lin(self, key, x, W, bias=None, **kw):
@@ -176,7 +184,10 @@ class BackboneTrainer:
             st = dict(X=e(nb + 1, Mv, d), H1=e(nb, Mv, d), H2=e(nb, Mv, d), A=e(nb, Mv, d), Xm=e(nb, Mv, d),
                       S1=e(nb, Mv, 2, dt=torch.float32), S2=e(nb, Mv, 2, dt=torch.float32), QKV=e(nb, Mv, 3 * d),
                       LSE=e(nb, Bv, vc.heads, T, dt=torch.float32), Mpre=e(nb, Mv, v.mlp_pad), Mact=e(nb, Mv, v.mlp_pad),
-                      g_d=e(Mv, d), g_d2=e(Mv, d), g_big=e(Mv, v.mlp_pad), g_mid=e(Mv, 3 * d), dxa=e(Mv, d), dxb=e(Mv, d), dxc=e(Mv, d))
+                      g_d=e(Mv, d), dxa=e(Mv, d), dxb=e(Mv, d), dxc=e(Mv, d),
+                      # dY of every Linear, kept PER BLOCK: the weight-gradient products read them on the second stream, any time
+                      # after the dX chain has moved on (2.2 GB at batch 16 for SigLIP: nothing on a 288 GB part)
+                      G_fc2=e(nb, Mv, d), G_pre=e(nb, Mv, v.mlp_pad), G_proj=e(nb, Mv, d), G_qkv=e(nb, Mv, 3 * d))
             if vc.layerscale:                        # pre-scale outputs of proj / fc2: the LayerScale gradient needs them
                 st["PA"], st["PM"] = e(nb, Mv, d), e(nb, Mv, d)
             if vc.n_prefix:
@@ -186,7 +197,10 @@ class BackboneTrainer:
         n, D, I = c.n_layers, c.d, c.inter
         M = B * S
         self.N1, self.N2, self.Hs = e(n, M, D), e(n, M, D), e(n, M, I)
-        self.dres = [e(M, D) for _ in range(3)]
+        W_ = (c.heads + 2 * c.kv_heads) * c.dh
+        # per-layer dY of the four Linears (residual-stream gradient = dY of down_proj, d1 = dY of o_proj): 3.4 GB at batch 16
+        self.G_res, self.G_d1, self.G_gu, self.G_qkv = e(n, M, D), e(n, M, D), e(n, M, 2 * I), e(n, M, W_)
+        self.d_last = e(M, D)
         self.dfeats = e(B * cfg.n_patches, cfg.vis_dim)
         self.dp = e(B * cfg.n_patches, D)
         self.pj = {}
@@ -305,32 +319,33 @@ class BackboneTrainer:
     # ---- backward -----------------------------------------------------------------------------------------------
     def _llm_backward(self, dHS):
         """Generator: yields the gradient ranges that became final after every chunk of `exchange_layers` layers (top-down); the
-        gradient w.r.t. inputs_embeds ends up in self._dX0."""
+        gradient w.r.t. inputs_embeds ends up in self._dX0.  The dX chain runs here; everything that only feeds a parameter
+        gradient (dW / LoRA-pair TN GEMMs, bias column sums) is handed to _defer() and runs on the gradient stream."""
         llm, c, B, S = self.llm, self.cfg.llm, self.eng.B, self.eng.S
         n, D, H, KV, dh, I = c.n_layers, c.d, c.heads, c.kv_heads, c.dh, c.inter
         M = B * S
         lib, st, p = ops._lib(), ops._st, ops._p
-        llm.bwd_begin(dHS, 0)                              # d = backward of the final norm (into llm.d_a)
-        if self.trains_vectors:
+        tv = self.trains_vectors
+        llm.bwd_begin(dHS, 0)                              # (window bookkeeping; its final-norm backward is redone into G_res below)
+        d = ops.rmsnorm_bwd(dHS[n].view(M, D), llm.HS[n + 1].view(M, D), llm.norm, llm.RF, out=self.G_res[n - 1])
+        if tv:
             ops.N.check(lib.vla_rmsnorm_dw(st(), p(dHS[n].view(M, D)), p(llm.HS[n + 1].view(M, D)), p(llm.RF), p(self.A("llm.norm")), M, D), "rmsnorm_dw")
-        d = llm._d
-        ring, r = [llm.d_a[:M], llm.d_b[:M]] + self.dres, 0   # residual-stream gradients rotate through five buffers (dW readers lag)
-        assert d.data_ptr() == ring[0].data_ptr()
         for i in range(n - 1, -1, -1):
             L, k = llm.layers[i], f"llm.{i}."
+            d = self.G_res[i]
             if i < n - 1:
                 ops.add_(d, dHS[i + 1].view(M, D))
             tap = self.taps.get(("llm", i)) if self.taps is not None else None
             if tap is not None:
                 tap["d_out"] = d.clone()
-            d_gu = self._lin_bwd(k + "down", d, self.Hs[i], L["wdT"], out=llm.d_gu[:M], swiglu_gu=llm.GU[i])
+            d_gu = self._lin_bwd(k + "down", d, self.Hs[i], L["wdT"], out=self.G_gu[i], swiglu_gu=llm.GU[i])
             d_n = self._lin_bwd(k + "gu", d_gu, self.N2[i], L["wguT"], out=llm.d_n[:M])
-            if self.trains_vectors:
+            if tv:
                 ops.N.check(lib.vla_rmsnorm_dw(st(), p(d_n), p(llm.X1[i]), p(llm.R2[i]), p(self.A(k + "n2")), M, D), "rmsnorm_dw")
-            d1 = ops.rmsnorm_bwd(d_n, llm.X1[i], L["n2"], llm.R2[i], dres=d, out=ring[(r + 1) % 5])
+            d1 = ops.rmsnorm_bwd(d_n, llm.X1[i], L["n2"], llm.R2[i], dres=d, out=self.G_d1[i])
             dao = self._lin_bwd(k + "o", d1, llm.AO[i], L["woT"], out=llm.d_n[:M])
             q, kk, v = llm._attn_views(llm.QKV[i].view(B, S, -1))
-            d_qkv = llm.d_qkv[:M]
+            d_qkv = self.G_qkv[i]
             dq, dk, dv = llm._attn_views(d_qkv.view(B, S, -1))
             ops.attn_bwd(dao.view(B, S, -1), q, kk, v, llm.AO[i].view(B, S, -1), llm.LSE[i], H, KV, dh, True, llm.kmask, dq=dq, dk=dk, dv=dv,
                          rope=(llm.cos, llm.sin) if dh == 64 else None)
@@ -338,11 +353,10 @@ class BackboneTrainer:
                 ops.rope_half_(d_qkv[:, :H * dh], llm.cos, llm.sin, S, H, dh, sign=-1)
                 ops.rope_half_(d_qkv[:, H * dh:(H + KV) * dh], llm.cos, llm.sin, S, KV, dh, sign=-1)
             d_n = self._lin_bwd(k + "qkv", d_qkv, self.N1[i], L["wqkvT"], out=llm.d_n[:M])
-            if self.trains_vectors:
-                ops.colsum_(d_qkv, self.A(k + "bqkv"))
+            if tv:
+                self._defer(lambda dy=d_qkv, acc=self.A(k + "bqkv"): ops.colsum_(dy, acc))
                 ops.N.check(lib.vla_rmsnorm_dw(st(), p(d_n), p(llm.HS[i].view(M, D)), p(llm.R1[i]), p(self.A(k + "n1")), M, D), "rmsnorm_dw")
-            d = ops.rmsnorm_bwd(d_n, llm.HS[i].view(M, D), L["n1"], llm.R1[i], dres=d1, out=ring[(r + 2) % 5])
-            r = (r + 2) % 5
+            d = ops.rmsnorm_bwd(d_n, llm.HS[i].view(M, D), L["n1"], llm.R1[i], dres=d1, out=self.G_res[i - 1] if i > 0 else self.d_last)
             if tap is not None:
                 tap["d_in"] = d.clone()
             self._dX0 = d.view(B, S, D)      # gradient w.r.t. inputs_embeds once i reaches 0
@@ -356,21 +370,22 @@ class BackboneTrainer:
         dp = self.dp
         ops.copy_rows3d(dX0[0, 1], dp, B, Np, D, S * D, D, Np * D, D)          # rows 1..Np of every sequence: the projected patches
         tv = self.trains_vectors
+        cs = lambda dy, name: self._defer(lambda: ops.colsum_(dy, self.A(name)))     # (every dY below lives until the next step)
         if cfg.fused:
             if tv:
-                ops.colsum_(dp, self.A("proj.fc3.bias"))
+                cs(dp, "proj.fc3.bias")
             dh2 = self._lin_bwd("proj.fc3", dp, P["act2"], pjT["fc3.weight"])
-            dpre = ops.gelu_bwd(dh2, P["pre2"])
+            dpre = P["dpre2"] = ops.gelu_bwd(dh2, P["pre2"])
             if tv:
-                ops.colsum_(dpre, self.A("proj.fc2.bias"))
+                cs(dpre, "proj.fc2.bias")
             dh1 = self._lin_bwd("proj.fc2", dpre, P["act1"], pjT["fc2.weight"])
         else:
             if tv:
-                ops.colsum_(dp, self.A("proj.fc2.bias"))
+                cs(dp, "proj.fc2.bias")
             dh1 = self._lin_bwd("proj.fc2", dp, P["act1"], pjT["fc2.weight"])
-        dpre1 = ops.gelu_bwd(dh1, P["pre1"])
+        dpre1 = P["dpre1"] = ops.gelu_bwd(dh1, P["pre1"])
         if tv:
-            ops.colsum_(dpre1, self.A("proj.fc1.bias"))
+            cs(dpre1, "proj.fc1.bias")
         return self._lin_bwd("proj.fc1", dpre1, P["in"], pjT["fc1.weight"], out=self.dfeats)       # d features [B*Np, vis_dim]
 
     def _vit_backward(self, j: int, dfeat: torch.Tensor):
@@ -382,53 +397,61 @@ class BackboneTrainer:
         nb, dh = len(v.blocks), d // vc.heads
         tv = self.trains_vectors
         vis, col = cfg.vis_dim, sum(u.cfg.d for u in self.vits[:j])
-        # gradient w.r.t. the last useful block's output: this backbone's column block of d feats on the patch rows, zero on the prefix
-        dx = st["dxa"]
+        # gradient w.r.t. the last useful block's output: this backbone's column block of d feats on the patch rows, zero on the prefix.
+        # Without LayerScale the residual-stream gradients ARE the dY of fc2 / proj: the chain then walks the per-block dY slots
+        # (gradient w.r.t. block i's output lives in G_fc2[i], w.r.t. its x_mid in G_proj[i]) and nothing is copied.
+        slots = not vc.layerscale
+        dx = st["G_fc2"][nb - 1] if slots else st["dxa"]
         if vc.n_prefix:
             ops.zero_(dx)
         dx3, df3 = dx.view(Bv, T, d), dfeat.view(B, cfg.n_patches, vis)
         for im in range(cfg.n_img):
             ops.copy_rows3d(df3[0, im * npi:, col:], dx3[im * B, vc.n_prefix:], B, npi, d, cfg.n_patches * vis, vis, T * d, d)
         free = [st["dxb"], st["dxc"]]
+        cs = lambda dy, acc: self._defer(lambda: ops.colsum_(dy, acc))
         for i in range(nb - 1, -1, -1):
             b, k = v.blocks[i], f"vit{j}.{i}."
             a = (lambda n: self.A(k + n)) if tv else (lambda n: None)
             tap = self.taps.get(("vit", j, i)) if self.taps is not None else None
             if tap is not None:
                 tap["d_out"] = dx.clone()
-            # x_out = x_mid + ls2 * fc2(gelu(fc1(LN2(x_mid))))
-            dh_ = ops.layerscale_bwd(dx, st["PM"][i] if tv else None, b["ls2"], a("ls2"), out=st["g_d2"]) if vc.layerscale else dx
+            # x_out = x_mid + ls2 * fc2(gelu(fc1(LN2(x_mid))));  dY of every Linear goes to its per-block slot (read later by the
+            # gradient stream), the dX chain itself walks three rotating buffers
+            dh_ = dx if slots else ops.layerscale_bwd(dx, st["PM"][i] if tv else None, b["ls2"], a("ls2"), out=st["G_fc2"][i])
             if tv:
-                ops.colsum_(dh_, a("b2"))
-            dm = self._lin_bwd(k + "fc2", dh_, st["Mact"][i], b["w2T"], out=st["g_big"])
+                cs(dh_, a("b2"))
+            dm = self._lin_bwd(k + "fc2", dh_, st["Mact"][i], b["w2T"], out=st["G_pre"][i])
             ops.N.check(ops._lib().vla_gelu_bwd(ops._st(), ops._p(dm), ops._p(st["Mpre"][i]), ops._p(dm), dm.numel()), "gelu_bwd")   # in place
             dpre = dm
             if tv:
-                ops.colsum_(dpre, a("b1"))
+                cs(dpre, a("b1"))
             dh2 = self._lin_bwd(k + "fc1", dpre, st["H2"][i], b["w1T"], out=st["g_d"])
-            dxm = free.pop()
+            dxm = st["G_proj"][i] if slots else free.pop()
             self._ln_bwd(dh2, st["Xm"][i], b["n2w"], st["S2"][i], dxm, a("n2w"), a("n2b"))
             ops.add_(dxm, dx)                            # residual
-            free.append(dx)
+            if not slots:
+                free.append(dx)
             # x_mid = x_in + ls1 * proj(attn(qkv(LN1(x_in))))
-            da_ = ops.layerscale_bwd(dxm, st["PA"][i] if tv else None, b["ls1"], a("ls1"), out=st["g_d2"]) if vc.layerscale else dxm
+            da_ = dxm if slots else ops.layerscale_bwd(dxm, st["PA"][i] if tv else None, b["ls1"], a("ls1"), out=st["G_proj"][i])
             if tv:
-                ops.colsum_(da_, a("bproj"))
+                cs(da_, a("bproj"))
             da = self._lin_bwd(k + "proj", da_, st["A"][i], b["wprojT"], out=st["g_d"])
             qkv = st["QKV"][i].view(Bv, T, 3 * d)
-            dqkv = st["g_mid"].view(Bv, T, 3 * d)
+            g_mid = st["G_qkv"][i]
+            dqkv = g_mid.view(Bv, T, 3 * d)
             ops.attn_bwd(da.view(Bv, T, d), qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], st["A"][i].view(Bv, T, d), st["LSE"][i],
                          vc.heads, vc.heads, dh, False, None, dq=dqkv[:, :, :d], dk=dqkv[:, :, d:2 * d], dv=dqkv[:, :, 2 * d:])
             if tv:
-                ops.colsum_(st["g_mid"], a("bqkv"))
-            dh1 = self._lin_bwd(k + "qkv", st["g_mid"], st["H1"][i], b["wqkvT"], out=st["g_d"])
+                cs(g_mid, a("bqkv"))
+            dh1 = self._lin_bwd(k + "qkv", g_mid, st["H1"][i], b["wqkvT"], out=st["g_d"])
             if i == 0 and not tv:
                 yield self._ranges("vit", 0, min(nb, self.exchange_blocks) - 1, j), True
                 return                                   # below block 0 everything is frozen (Conv2d patch embedding, pos_embed, tokens)
-            dxi = free.pop()
+            dxi = (st["G_fc2"][i - 1] if i > 0 else st["dxa"]) if slots else free.pop()
             self._ln_bwd(dh1, st["X"][i], b["n1w"], st["S1"][i], dxi, a("n1w"), a("n1b"))
             ops.add_(dxi, dxm)
-            free.append(dxm)
+            if not slots:
+                free.append(dxm)
             dx = dxi
             if tap is not None:
                 tap["d_in"] = dx.clone()
@@ -450,7 +473,8 @@ class BackboneTrainer:
     def _backward_gen(self, pred, actions, gscale: float = 1.0):
         """The backward as a generator of PIECES in the order gradients become final - action head, LLM layers top-down in chunks,
         action queries + token embedding, projector, ViT blocks top-down in chunks, the fp32-accumulated vector section.  After
-        every piece it yields (ranges, last): ranges = [(flat gradient buffer, lo, hi)] that no later piece writes again - the
+        every piece it yields (ranges, last, join): ranges = [(flat gradient buffer, lo, hi)] that no later piece writes again
+        (join: the consumer makes the chain wait for the gradient stream before the next piece) - the
         data-parallel exchange of a range starts right there, underneath the rest of the backward (vla-scripts/finetune.py:
         215-227, 869: DDP's bucketed all-reduce overlapped with backward; BASELINE configs[3] "grad-bucket overlap").  Run to
         completion by backward(); captured piece by piece (one linear hipGraph each) by capture()."""
@@ -461,23 +485,26 @@ class BackboneTrainer:
         dHS = eng._dhs(0)
         head.backward(dpred, dHS, 0)
         aq_off = head.P.offsets["action_queries"][0]
-        yield [(head.P.grad, 0, aq_off)], False
+        yield [(head.P.grad, 0, aq_off)], False, False
         for ranges in self._llm_backward(dHS):
-            yield ranges, False
+            yield ranges, False, False
         dX0 = self._dX0
         dq = ops.action_query_grad(dX0, eng.pos0, Np, 0)
         ops.cast_f32_bf16(dq, out=head.P.g("action_queries"))
         self._embed_backward(dX0)
         dfeat = self._proj_backward(dX0)
-        yield [(head.P.grad, aq_off, head.P.numel)] + self._ranges("embed") + self._ranges("proj"), False
+        yield [(head.P.grad, aq_off, head.P.numel)] + self._ranges("embed") + self._ranges("proj"), False, False
         nv = len(self.vits)
         for j in range(nv):
             for ranges, bottom in self._vit_backward(j, dfeat):
                 # LoRA: nothing trains below block 0 - the bottom piece of the last backbone closes the step
-                yield ranges, bottom and j == nv - 1 and not self.trains_vectors
+                last = bottom and j == nv - 1
+                # LoRA: the bottom piece of the last backbone closes the step.  Full: the tail follows, and it needs EVERY piece's
+                # gradient work complete (bias / norm sums meet in one fp32 buffer that the tail casts): join flag on this piece
+                yield ranges, last and not self.trains_vectors, last and self.trains_vectors
         if self.trains_vectors:
             self._end_backward()
-            yield self._ranges("tail"), True
+            yield self._ranges("tail"), True, False
 
     def _begin_backward(self):
         pass
@@ -497,17 +524,70 @@ class BackboneTrainer:
         off, shape = self.P.offsets[last]
         return (self.P.grad, a, off + rup(math.prod(shape), 8))
 
-    def _exchange(self, ranges):
+    def _defer(self, fn):
+        """Gradient-only work (reads a persistent dY / activation, writes a parameter gradient): run now, or - two streams - at
+        the end of the current piece on the gradient stream."""
+        if self.gstream is None:
+            fn()
+        else:
+            self._deferred.append(fn)
+
+    def _defer_tn(self, a, b, out, alpha: float = 1.0, a_cols=None):
+        """A weight-gradient product out = alpha a^T b.  Two streams: collected, and all products of a piece go out as ONE grouped
+        launch over their common tile list (vla_gemm_bf16_tn_grouped) - alone a dW product leaves up to half the chip idle in its
+        tail round."""
+        if self.gstream is None or not self.group_tn:
+            self._defer(lambda: ops.gemm_tn(a, b, out=out, alpha=alpha, a_cols=a_cols))
+            return
+        if not self._deferred or not isinstance(self._deferred[0], list):
+            self._deferred.insert(0, [])             # ONE problem list per piece (the products are independent of the other work)
+        self._deferred[0].append(ops.tn_problem(a, b, out, alpha, a_cols))
+
+    @staticmethod
+    def _run_work(work):
+        for w in work:
+            if isinstance(w, list):
+                ops.gemm_tn_grouped(w)
+            else:
+                w()
+
+    def _run_deferred(self, graph=None):
+        """Enqueue the piece's gradient work on the gradient stream behind everything the current stream has been given so far;
+        returns an event that fires when it is done (None: nothing was deferred).  graph: a captured form of the same work."""
+        if self.gstream is None or (graph is None and not self._deferred):
+            return None
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self.gstream):
+            self.gstream.wait_event(ev)
+            if graph is not None:
+                graph.replay()
+            else:
+                self._run_work(self._deferred)
+            done = torch.cuda.Event()
+            done.record()
+        self._deferred = []
+        return done
+
+    def _join_grads(self):
+        if self.gstream is not None:
+            torch.cuda.current_stream().wait_stream(self.gstream)
+
+    def _exchange(self, ranges, after_event=None):
         red = self.eng.reducer
         if red is not None:
             for buf, lo, hi in ranges:
                 if hi > lo:
-                    red.reduce_async(buf, lo, hi)
+                    red.reduce_async(buf, lo, hi, after_event=after_event)
 
     def backward(self, pred, actions, gscale: float = 1.0):
         """Whole backward; with a reducer attached every gradient range is handed to the exchange as soon as it is final."""
-        for ranges, _ in self._backward_gen(pred, actions, gscale):
-            self._exchange(ranges)
+        for ranges, last, join in self._backward_gen(pred, actions, gscale):
+            done = self._run_deferred()
+            self._exchange(ranges, after_event=done)
+            if join:
+                self._join_grads()
+        self._join_grads()
         return self._loss3
 
     # ---- update / capture (shared shape) ---------------------------------------------------------------------------
@@ -534,24 +614,35 @@ class BackboneTrainer:
             self.eng.reducer = red
         torch.cuda.synchronize()
         self.head.dirty = True                       # the head's own W^T / padded-operand refresh becomes part of the first graph
-        pool = torch.cuda.graph_pool_handle()
+        pool, gpool = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
+        self._gcap_stream = torch.cuda.Stream()
         self._segs, gen, last = [], None, False
         while not last:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool, stream=self._cap_stream, capture_error_mode="thread_local"):
                 if gen is None:
                     gen = self._backward_gen(self.forward(batch, noise), batch["actions"], 1.0)
-                ranges, last = next(gen)
-            self._segs.append((g, ranges))
+                ranges, last, join = next(gen)
+            gg = None
+            if self._deferred:                       # the piece's gradient work: its own linear graph, replayed on the gradient stream
+                gg = torch.cuda.CUDAGraph()
+                work, self._deferred = self._deferred, []
+                with torch.cuda.graph(gg, pool=gpool, stream=self._gcap_stream, capture_error_mode="thread_local"):
+                    self._run_work(work)
+            self._segs.append((g, gg, ranges, join))
         self._g_r = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_r, pool=pool, stream=self._cap_stream, capture_error_mode="thread_local"):
             self.refresh()
         torch.cuda.synchronize()
 
     def train_step_graphed(self, lr: float):
-        for g, ranges in self._segs:
+        for g, gg, ranges, join in self._segs:
             g.replay()
-            self._exchange(ranges)
+            done = self._run_deferred(gg)            # the piece's gradient work, on the gradient stream behind the piece itself
+            self._exchange(ranges, after_event=done)
+            if join:                                 # (stream waits are not part of the captured graphs: issued between replays)
+                self._join_grads()
+        self._join_grads()
         self.optimizer_step(lr, refresh=False)
         self._g_r.replay()
         return self._loss3
@@ -664,10 +755,11 @@ class FullFinetune(BackboneTrainer):
         return ops.gemm_nt(x, W, bias=bias, **kw)
 
     def _lin_bwd(self, key, dy, x, WT, out=None, swiglu_gu=None):
-        if swiglu_gu is not None:            # down_proj: dW from dy, then dGU = swiglu'(GU) * (dy W_down) in the dX GEMM's epilogue
-            ops.gemm_tn(dy, x, out=self.G(self._gname(key)))
+        """dx = dy W on the chain; dW = dy^T x (TN GEMM on dy and x as they lie) handed to the gradient stream: dy is the layer's
+        persistent dY slot, x a saved activation - both stay untouched until the next step."""
+        self._defer_tn(dy, x, self.G(self._gname(key)))
+        if swiglu_gu is not None:            # down_proj: dGU = swiglu'(GU) * (dy W_down) in the dX GEMM's epilogue
             return ops.gemm_swiglu_bwd(dy, WT, swiglu_gu, out=out)
-        ops.gemm_tn(dy, x, out=self.G(self._gname(key)))
         return ops.gemm_nt(dy, WT, out=out)
 
     def _embed_backward(self, dX0):
@@ -811,11 +903,11 @@ class LoRAFinetune(BackboneTrainer):
     def _lin_bwd(self, key, dy, x, WT, out=None, swiglu_gu=None):
         l = self.L[key]
         M = dy.shape[0]
-        dt = self.DT.get((M, l.Rr))
-        if dt is None:
-            dt = self.DT[(M, l.Rr)] = torch.empty(M, l.Rr, device=self.dev, dtype=BF16)
+        dt = self.DT.get(key)                                       # one per Linear: the pair gradients read it on the gradient stream
+        if dt is None or dt.shape[0] != M:
+            dt = self.DT[key] = torch.empty(M, l.Rr, device=self.dev, dtype=BF16)
         ops.gemm_nt(dy, l.B_blkT, alpha=2.0, out=dt)                # dt = 2 dy B_blk
-        l.grads(dy, x, self.T[key], dt)
+        l.grads(dy, x, self.T[key], dt, self._defer_tn)             # dA_cat, dB_j: gradient-only work
         if swiglu_gu is not None:
             return ops.gemm_swiglu_bwd(dy, WT, swiglu_gu, out=out, ext=(dt, l.A_catT))
         return ops.gemm_nt(dy, WT, out=out, ext=(dt, l.A_catT))     # dx = dy W + dt A_cat
