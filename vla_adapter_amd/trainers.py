@@ -148,12 +148,12 @@ class BackboneTrainer:
         # granularity of the data-parallel exchange: gradient ranges are handed over every `exchange_layers` LLM layers (4 x 30 MB
         # of bf16 gradients at the 0.5B geometry: large messages for the point-to-point xGMI links) / `exchange_blocks` ViT blocks
         self.exchange_layers, self.exchange_blocks = 4, 7
-        # Two streams: the dX chain (what the next layer's backward waits for) on the caller's stream; everything that only feeds a
-        # parameter gradient - the dW / LoRA-pair TN GEMMs, bias column sums - on `gstream`, one piece behind.  A dW product
-        # fills 266-532 tiles of a 512-slot chip and the chain's own GEMMs 288-308: alone each leaves 40 % of the CUs idle in its
-        # tail round, together they fill each other's gaps (62.4 -> see DESIGN 5d).  VLA_TRAINER_STREAMS=1: everything in line.
+        # Streams of the step schedule (_segments): the caller's stream carries the dX chain, `gstream` everything that only feeds a
+        # parameter gradient, `hstream` the action head.  VLA_TRAINER_STREAMS=1: everything in line, 2: no separate head stream.
         import os
-        self.gstream = torch.cuda.Stream() if int(os.environ.get("VLA_TRAINER_STREAMS", "2")) > 1 else None
+        nstreams = int(os.environ.get("VLA_TRAINER_STREAMS", "3"))
+        self.gstream = torch.cuda.Stream() if nstreams > 1 else None
+        self.hstream = torch.cuda.Stream() if nstreams > 2 else None
         self.group_tn = not os.environ.get("VLA_NO_GROUPED_TN")          # (A/B knob)
         self._deferred = []
 
@@ -184,12 +184,13 @@ class BackboneTrainer:
             st = dict(X=e(nb + 1, Mv, d), H1=e(nb, Mv, d), H2=e(nb, Mv, d), A=e(nb, Mv, d), Xm=e(nb, Mv, d),
                       S1=e(nb, Mv, 2, dt=torch.float32), S2=e(nb, Mv, 2, dt=torch.float32), QKV=e(nb, Mv, 3 * d),
                       LSE=e(nb, Bv, vc.heads, T, dt=torch.float32), Mpre=e(nb, Mv, v.mlp_pad), Mact=e(nb, Mv, v.mlp_pad),
-                      g_d=e(Mv, d), dxa=e(Mv, d), dxb=e(Mv, d), dxc=e(Mv, d),
+                      g_d=e(Mv, d), dxa=e(Mv, d),
                       # dY of every Linear, kept PER BLOCK: the weight-gradient products read them on the second stream, any time
                       # after the dX chain has moved on (2.2 GB at batch 16 for SigLIP: nothing on a 288 GB part)
                       G_fc2=e(nb, Mv, d), G_pre=e(nb, Mv, v.mlp_pad), G_proj=e(nb, Mv, d), G_qkv=e(nb, Mv, 3 * d))
-            if vc.layerscale:                        # pre-scale outputs of proj / fc2: the LayerScale gradient needs them
-                st["PA"], st["PM"] = e(nb, Mv, d), e(nb, Mv, d)
+            if vc.layerscale:                        # pre-scale outputs of proj / fc2: the LayerScale gradient needs them; the
+                st["PA"], st["PM"] = e(nb, Mv, d), e(nb, Mv, d)      # residual-stream gradients get slots of their own (G_* hold the scaled dY)
+                st["DX"], st["DXM"] = e(nb, Mv, d), e(nb, Mv, d)
             if vc.n_prefix:
                 st["pe"] = e(Bv * vc.n_patches, d)
             self.V.append(st)
@@ -281,11 +282,12 @@ class BackboneTrainer:
         else:
             self._lin("proj.fc2", P["act1"], pj["fc2.weight"], pj["fc2.bias"], out=dst)
 
-    def _llm_forward(self, B, S, kmask):
+    def _llm_fwd_layers(self, lo: int, hi: int):
         llm, c = self.llm, self.cfg.llm
+        B, S = self.eng.B, self.eng.S
         D, H, KV, dh = c.d, c.heads, c.kv_heads, c.dh
-        llm.fwd_begin(B, S, kmask, 0)
-        for i, L in enumerate(llm.layers):
+        for i in range(lo, hi):
+            L = llm.layers[i]
             x, k = llm.HS[i].view(-1, D), f"llm.{i}."
             llm._rms(x, L["n1"], self.N1[i], llm.R1[i])
             qkv = llm.QKV[i]
@@ -301,36 +303,23 @@ class BackboneTrainer:
             llm._rms(x1, L["n2"], self.N2[i], llm.R2[i])
             self._lin(k + "gu", self.N2[i], L["wgu"], None, act=ACT_SWIGLU, out=llm.GU[i], out2=self.Hs[i])
             self._lin(k + "down", self.Hs[i], L["wd"], None, out=llm.HS[llm.out_slot(i)].view(-1, D), residual=x1)
-        llm.fwd_final()
+        if hi == c.n_layers:
+            llm.fwd_final()
 
-    def forward(self, batch: Dict[str, torch.Tensor], noise: Optional[torch.Tensor] = None):
-        eng = self.eng
-        eng._vision_begin(batch)
-        B, S = eng.B, eng.S
-        self._alloc(B, S)
-        for j in range(len(self.vits)):
-            self._vit_forward(j, batch["pixel_values"])
-        self._proj_forward()
-        mm = eng._embed(batch)
-        self._batch = batch
-        self._llm_forward(B, S, mm)
-        return self.head.forward(self.llm.HS, eng.pos1, batch["proprio"], eng.Np, noise)
-
-    # ---- backward -----------------------------------------------------------------------------------------------
-    def _llm_backward(self, dHS):
-        """Generator: yields the gradient ranges that became final after every chunk of `exchange_layers` layers (top-down); the
-        gradient w.r.t. inputs_embeds ends up in self._dX0.  The dX chain runs here; everything that only feeds a parameter
-        gradient (dW / LoRA-pair TN GEMMs, bias column sums) is handed to _defer() and runs on the gradient stream."""
+    # ---- backward pieces (stateless between calls: every gradient that crosses a piece boundary lives in a per-layer slot) -----
+    def _llm_bwd_layers(self, lo: int, hi: int):
+        """dX chain through layers hi-1 .. lo.  Everything that only feeds a parameter gradient (dW / LoRA-pair TN products, bias
+        column sums) is handed to _defer / _defer_tn and runs on the gradient stream."""
         llm, c, B, S = self.llm, self.cfg.llm, self.eng.B, self.eng.S
         n, D, H, KV, dh, I = c.n_layers, c.d, c.heads, c.kv_heads, c.dh, c.inter
         M = B * S
         lib, st, p = ops._lib(), ops._st, ops._p
-        tv = self.trains_vectors
-        llm.bwd_begin(dHS, 0)                              # (window bookkeeping; its final-norm backward is redone into G_res below)
-        d = ops.rmsnorm_bwd(dHS[n].view(M, D), llm.HS[n + 1].view(M, D), llm.norm, llm.RF, out=self.G_res[n - 1])
-        if tv:
-            ops.N.check(lib.vla_rmsnorm_dw(st(), p(dHS[n].view(M, D)), p(llm.HS[n + 1].view(M, D)), p(llm.RF), p(self.A("llm.norm")), M, D), "rmsnorm_dw")
-        for i in range(n - 1, -1, -1):
+        tv, dHS = self.trains_vectors, self._dHS
+        if hi == n:                                        # backward of the final norm into the top layer's slot
+            ops.rmsnorm_bwd(dHS[n].view(M, D), llm.HS[n + 1].view(M, D), llm.norm, llm.RF, out=self.G_res[n - 1])
+            if tv:
+                ops.N.check(lib.vla_rmsnorm_dw(st(), p(dHS[n].view(M, D)), p(llm.HS[n + 1].view(M, D)), p(llm.RF), p(self.A("llm.norm")), M, D), "rmsnorm_dw")
+        for i in range(hi - 1, lo - 1, -1):
             L, k = llm.layers[i], f"llm.{i}."
             d = self.G_res[i]
             if i < n - 1:
@@ -359,9 +348,15 @@ class BackboneTrainer:
             d = ops.rmsnorm_bwd(d_n, llm.HS[i].view(M, D), L["n1"], llm.R1[i], dres=d1, out=self.G_res[i - 1] if i > 0 else self.d_last)
             if tap is not None:
                 tap["d_in"] = d.clone()
-            self._dX0 = d.view(B, S, D)      # gradient w.r.t. inputs_embeds once i reaches 0
-            if i % self.exchange_layers == 0:
-                yield self._ranges("llm", i, min(n, i + self.exchange_layers) - 1)
+
+    def _mid_backward(self):
+        """Between the LLM and the vision backward: action-query gradient, token-embedding gradient, projector."""
+        eng, head = self.eng, self.head
+        dX0 = self.d_last.view(eng.B, eng.S, self.cfg.llm.d)          # gradient w.r.t. inputs_embeds
+        dq = ops.action_query_grad(dX0, eng.pos0, eng.Np, 0)
+        ops.cast_f32_bf16(dq, out=head.P.g("action_queries"))
+        self._embed_backward(dX0)
+        self._proj_backward(dX0)                                      # -> self.dfeats
 
     def _proj_backward(self, dX0):
         eng, cfg = self.eng, self.cfg
@@ -388,36 +383,42 @@ class BackboneTrainer:
             cs(dpre1, "proj.fc1.bias")
         return self._lin_bwd("proj.fc1", dpre1, P["in"], pjT["fc1.weight"], out=self.dfeats)       # d features [B*Np, vis_dim]
 
-    def _vit_backward(self, j: int, dfeat: torch.Tensor):
-        """Generator like _llm_backward: yields after every chunk of `exchange_blocks` blocks of backbone j."""
-        v, st, cfg = self.vits[j], self.V[j], self.cfg
+    def _vit_grad_slots(self, j: int, i: int):
+        """(gradient w.r.t. block i's output, w.r.t. its x_mid) of backbone j.  Without LayerScale these residual-stream gradients
+        ARE the dY of fc2 / proj, so the chain walks the per-block dY slots; with it the scaled dY have slots of their own."""
+        st = self.V[j]
+        return (st["G_fc2"][i], st["G_proj"][i]) if not self.vits[j].cfg.layerscale else (st["DX"][i], st["DXM"][i])
+
+    def _vit_bwd_begin(self, j: int):
+        """Gradient w.r.t. the last useful block's output: this backbone's column block of d feats on the patch rows, zero on the prefix."""
+        v, cfg = self.vits[j], self.cfg
         vc = v.cfg
         B, npi, T, d = self.eng.B, vc.n_patches, vc.n_patches + vc.n_prefix, vc.d
-        Bv = B * cfg.n_img
-        nb, dh = len(v.blocks), d // vc.heads
-        tv = self.trains_vectors
+        Bv, nb = B * cfg.n_img, len(v.blocks)
         vis, col = cfg.vis_dim, sum(u.cfg.d for u in self.vits[:j])
-        # gradient w.r.t. the last useful block's output: this backbone's column block of d feats on the patch rows, zero on the prefix.
-        # Without LayerScale the residual-stream gradients ARE the dY of fc2 / proj: the chain then walks the per-block dY slots
-        # (gradient w.r.t. block i's output lives in G_fc2[i], w.r.t. its x_mid in G_proj[i]) and nothing is copied.
-        slots = not vc.layerscale
-        dx = st["G_fc2"][nb - 1] if slots else st["dxa"]
+        dx = self._vit_grad_slots(j, nb - 1)[0]
         if vc.n_prefix:
             ops.zero_(dx)
-        dx3, df3 = dx.view(Bv, T, d), dfeat.view(B, cfg.n_patches, vis)
+        dx3, df3 = dx.view(Bv, T, d), self.dfeats.view(B, cfg.n_patches, vis)
         for im in range(cfg.n_img):
             ops.copy_rows3d(df3[0, im * npi:, col:], dx3[im * B, vc.n_prefix:], B, npi, d, cfg.n_patches * vis, vis, T * d, d)
-        free = [st["dxb"], st["dxc"]]
+
+    def _vit_bwd_blocks(self, j: int, lo: int, hi: int):
+        v, st, cfg = self.vits[j], self.V[j], self.cfg
+        vc = v.cfg
+        T, d = vc.n_patches + vc.n_prefix, vc.d
+        Bv, dh = self.eng.B * cfg.n_img, d // vc.heads
+        tv, ls = self.trains_vectors, vc.layerscale
         cs = lambda dy, acc: self._defer(lambda: ops.colsum_(dy, acc))
-        for i in range(nb - 1, -1, -1):
+        for i in range(hi - 1, lo - 1, -1):
             b, k = v.blocks[i], f"vit{j}.{i}."
             a = (lambda n: self.A(k + n)) if tv else (lambda n: None)
+            dx, dxm = self._vit_grad_slots(j, i)
             tap = self.taps.get(("vit", j, i)) if self.taps is not None else None
             if tap is not None:
                 tap["d_out"] = dx.clone()
-            # x_out = x_mid + ls2 * fc2(gelu(fc1(LN2(x_mid))));  dY of every Linear goes to its per-block slot (read later by the
-            # gradient stream), the dX chain itself walks three rotating buffers
-            dh_ = dx if slots else ops.layerscale_bwd(dx, st["PM"][i] if tv else None, b["ls2"], a("ls2"), out=st["G_fc2"][i])
+            # x_out = x_mid + ls2 * fc2(gelu(fc1(LN2(x_mid))))
+            dh_ = ops.layerscale_bwd(dx, st["PM"][i] if tv else None, b["ls2"], a("ls2"), out=st["G_fc2"][i]) if ls else dx
             if tv:
                 cs(dh_, a("b2"))
             dm = self._lin_bwd(k + "fc2", dh_, st["Mact"][i], b["w2T"], out=st["G_pre"][i])
@@ -426,13 +427,10 @@ class BackboneTrainer:
             if tv:
                 cs(dpre, a("b1"))
             dh2 = self._lin_bwd(k + "fc1", dpre, st["H2"][i], b["w1T"], out=st["g_d"])
-            dxm = st["G_proj"][i] if slots else free.pop()
             self._ln_bwd(dh2, st["Xm"][i], b["n2w"], st["S2"][i], dxm, a("n2w"), a("n2b"))
             ops.add_(dxm, dx)                            # residual
-            if not slots:
-                free.append(dx)
             # x_mid = x_in + ls1 * proj(attn(qkv(LN1(x_in))))
-            da_ = dxm if slots else ops.layerscale_bwd(dxm, st["PA"][i] if tv else None, b["ls1"], a("ls1"), out=st["G_proj"][i])
+            da_ = ops.layerscale_bwd(dxm, st["PA"][i] if tv else None, b["ls1"], a("ls1"), out=st["G_proj"][i]) if ls else dxm
             if tv:
                 cs(da_, a("bproj"))
             da = self._lin_bwd(k + "proj", da_, st["A"][i], b["wprojT"], out=st["g_d"])
@@ -445,19 +443,20 @@ class BackboneTrainer:
                 cs(g_mid, a("bqkv"))
             dh1 = self._lin_bwd(k + "qkv", g_mid, st["H1"][i], b["wqkvT"], out=st["g_d"])
             if i == 0 and not tv:
-                yield self._ranges("vit", 0, min(nb, self.exchange_blocks) - 1, j), True
                 return                                   # below block 0 everything is frozen (Conv2d patch embedding, pos_embed, tokens)
-            dxi = (st["G_fc2"][i - 1] if i > 0 else st["dxa"]) if slots else free.pop()
+            dxi = self._vit_grad_slots(j, i - 1)[0] if i > 0 else st["dxa"]
             self._ln_bwd(dh1, st["X"][i], b["n1w"], st["S1"][i], dxi, a("n1w"), a("n1b"))
             ops.add_(dxi, dxm)
-            if not slots:
-                free.append(dxm)
-            dx = dxi
             if tap is not None:
-                tap["d_in"] = dx.clone()
-            if i % self.exchange_blocks == 0:
-                yield self._ranges("vit", i, min(nb, i + self.exchange_blocks) - 1, j), i == 0
-        # full fine-tune: patch embedding x0 = cols . Wpe^T + bpe + pos on the patch rows; cls / register tokens on the prefix rows
+                tap["d_in"] = dxi.clone()
+
+    def _vit_bwd_end(self, j: int):
+        """Full fine-tune: patch embedding x0 = cols . Wpe^T + bpe + pos on the patch rows; cls / register tokens on the prefix rows."""
+        v, st, cfg = self.vits[j], self.V[j], self.cfg
+        vc = v.cfg
+        npi, T, d = vc.n_patches, vc.n_patches + vc.n_prefix, vc.d
+        Bv = self.eng.B * cfg.n_img
+        dx = st["dxa"]
         lib, p = ops._lib(), ops._p
         if vc.n_prefix:
             dx3 = dx.view(Bv, T, d)
@@ -466,45 +465,158 @@ class BackboneTrainer:
             ops.N.check(lib.vla_colsum_bf16(ops._st(), p(dx), p(self.A(f"vit{j}.prefix")), Bv, vc.n_prefix * d, T * d, 1, 0, 0), "colsum(prefix)")
         else:
             dpe = dx
-        ops.gemm_tn(dpe, st["cols"], out=self.G(f"vit{j}.wpe"))
+        self._defer_tn(dpe, st["cols"], self.G(f"vit{j}.wpe"))
         ops.colsum_(dpe, self.A(f"vit{j}.bpe"))
         ops.N.check(lib.vla_colsum_bf16(ops._st(), p(dpe), p(self.A(f"vit{j}.pos")), Bv, npi * d, npi * d, 1, 0, 0), "colsum(pos)")   # sum over the batch
 
-    def _backward_gen(self, pred, actions, gscale: float = 1.0):
-        """The backward as a generator of PIECES in the order gradients become final - action head, LLM layers top-down in chunks,
-        action queries + token embedding, projector, ViT blocks top-down in chunks, the fp32-accumulated vector section.  After
-        every piece it yields (ranges, last, join): ranges = [(flat gradient buffer, lo, hi)] that no later piece writes again
-        (join: the consumer makes the chain wait for the gradient stream before the next piece) - the
-        data-parallel exchange of a range starts right there, underneath the rest of the backward (vla-scripts/finetune.py:
-        215-227, 869: DDP's bucketed all-reduce overlapped with backward; BASELINE configs[3] "grad-bucket overlap").  Run to
-        completion by backward(); captured piece by piece (one linear hipGraph each) by capture()."""
-        eng, head = self.eng, self.head
-        Np = eng.Np
-        self._begin_backward()
-        self._loss3, dpred = ops.l1_loss(pred, eng._to_bf16(actions), True, gscale)
-        dHS = eng._dhs(0)
-        head.backward(dpred, dHS, 0)
+    # ---- the step as a list of single-stream segments ---------------------------------------------------------------
+    # Three streams.  "M": vision, LLM forward, the dX chain of the backward.  "H": the action head - 3 % of the FLOPs but a chain
+    # of ~600 small dependent kernels: its forward trails the LLM forward chunk by chunk, its backward runs ahead of the LLM
+    # backward (layer i needs d hidden_states[i + 1] from block i), its batched dW products fill the LLM backward's gaps.  "G":
+    # everything that only feeds a parameter gradient (the dW / LoRA-pair TN products of a piece as ONE grouped launch, bias column
+    # sums), one piece behind the chain: a dW product or a chain GEMM alone fills 270-530 tiles of a 512-slot chip, together they
+    # fill each other's tail rounds.  Segments are ordered so that every event is recorded before it is waited for; eagerly a
+    # segment is a Python call under its stream, captured it is its own linear hipGraph (engine.VLAEngine uses the same scheme for
+    # the adapter-only step).  A segment's `ranges` are the flat gradient ranges that are FINAL when it ends: the data-parallel
+    # exchange of each starts right there, underneath the rest of the backward (vla-scripts/finetune.py:215-227, 869: DDP's
+    # bucketed all-reduce overlapped with backward; BASELINE configs[3] "grad-bucket overlap").
+    def _segments(self, batch, noise, gscale: float = 1.0, actions=None):
+        eng, cfg, llm, head = self.eng, self.cfg, self.llm, self.head
+        n, nb = cfg.llm.n_layers, cfg.num_blocks
+        lch = E.VLAEngine._chunks(n, [self.exchange_layers])
+        two = self.gstream is not None
+        segs = []
+
+        def add(st, fn, wait=None, signal=None, ranges=None):
+            segs.append((st, fn, wait, signal, ranges))
+
+        def grads(after, signal, ranges):
+            """The gradient work the segment signalling `after` has deferred (+ hand-over of the finished ranges)."""
+            if two:
+                add("G", self._flush_work, after, signal, ranges)
+            else:                                   # single stream: nothing was deferred; the ranges are final where the chain stands
+                add("M", None, None, signal, ranges)
+            return signal
+
+        def f_front():
+            eng._vision_begin(batch)
+            self._alloc(eng.B, eng.S)
+            for j in range(len(self.vits)):
+                self._vit_forward(j, batch["pixel_values"])
+            self._proj_forward()
+            self._mm = eng._embed(batch)
+            self._batch = batch
+            llm.fwd_begin(eng.B, eng.S, self._mm, 0)
+            self._begin_backward()                  # (fp32 accumulators / sparse embedding gradient: zero before anything adds to them)
+            self._dHS = eng._dhs(0)                 # zeroed hidden-state gradients: the head's backward scatters into them
+        add("M", f_front, None, ("front", 0))
+        for c, (lo, hi) in enumerate(lch):
+            add("M", lambda lo=lo, hi=hi: self._llm_fwd_layers(lo, hi), None, ("f", c))
+
+            def h_fwd(c=c, lo=lo, hi=hi):
+                if c == 0:
+                    head.fwd_begin(llm.HS, eng.pos1, batch["proprio"], eng.Np, noise)
+                for i in range(lo, min(hi, nb)):
+                    head.fwd_layer(i)
+                if c == len(lch) - 1:
+                    self._pred = head.fwd_end()
+            add("H", h_fwd, ("f", c), None)
+        self._n_forward = len(segs)                 # forward() = these; backward() = the rest
+
+        def h_loss():
+            tgt = eng._to_bf16(batch["actions"] if actions is None else actions)
+            self._loss3, dpred = ops.l1_loss(self._pred, tgt, True, gscale)
+            head.prep_backward(eng.pos1, eng.Np, eng.B, eng.S, 0)
+            head.bwd_begin(dpred, 0)
+        add("H", h_loss, None, None)
         aq_off = head.P.offsets["action_queries"][0]
-        yield [(head.P.grad, 0, aq_off)], False, False
-        for ranges in self._llm_backward(dHS):
-            yield ranges, False, False
-        dX0 = self._dX0
-        dq = ops.action_query_grad(dX0, eng.pos0, Np, 0)
-        ops.cast_f32_bf16(dq, out=head.P.g("action_queries"))
-        self._embed_backward(dX0)
-        dfeat = self._proj_backward(dX0)
-        yield [(head.P.grad, aq_off, head.P.numel)] + self._ranges("embed") + self._ranges("proj"), False, False
-        nv = len(self.vits)
-        for j in range(nv):
-            for ranges, bottom in self._vit_backward(j, dfeat):
-                # LoRA: nothing trains below block 0 - the bottom piece of the last backbone closes the step
-                last = bottom and j == nv - 1
-                # LoRA: the bottom piece of the last backbone closes the step.  Full: the tail follows, and it needs EVERY piece's
-                # gradient work complete (bias / norm sums meet in one fp32 buffer that the tail casts): join flag on this piece
-                yield ranges, last and not self.trains_vectors, last and self.trains_vectors
-        if self.trains_vectors:
-            self._end_backward()
-            yield self._ranges("tail"), True, False
+        gsig = []
+        for k, (lo, hi) in enumerate(reversed(lch)):
+            wait = None
+            if min(hi, nb) > lo:                    # (layers above the head's last block receive no gradient from it)
+                add("H", lambda lo=lo, hi=hi: [head.bwd_layer(i, self._dHS) for i in range(min(hi, nb) - 1, lo - 1, -1)], None, ("b", k))
+                wait = ("b", k)
+            add("M", lambda lo=lo, hi=hi: self._llm_bwd_layers(lo, hi), wait, ("m", k))
+            gsig.append(grads(("m", k), ("g", k), self._ranges("llm", lo, hi - 1)))
+        add("H", head.bwd_end, None, ("hend", 0), [(head.P.grad, 0, aq_off)])
+        add("M", self._mid_backward, None, ("mid", 0))
+        gsig.append(grads(("mid", 0), ("gmid", 0), [(head.P.grad, aq_off, head.P.numel)] + self._ranges("embed") + self._ranges("proj")))
+        for j, v in enumerate(self.vits):
+            nbj = len(v.blocks)
+            vch = E.VLAEngine._chunks(nbj, [self.exchange_blocks])
+            for q, (lo, hi) in enumerate(reversed(vch)):
+                def v_bwd(j=j, lo=lo, hi=hi, first=(q == 0)):
+                    if first:
+                        self._vit_bwd_begin(j)
+                    self._vit_bwd_blocks(j, lo, hi)
+                    if lo == 0 and self.trains_vectors:
+                        self._vit_bwd_end(j)
+                add("M", v_bwd, None, ("v", j, q))
+                gsig.append(grads(("v", j, q), ("gv", j, q), self._ranges("vit", lo, hi - 1, j)))
+        if self.trains_vectors:                     # the tail casts the ONE fp32 buffer every piece's bias / norm sums met in
+            add("M", self._end_backward, [sg for sg in gsig if two], ("end", 0), self._ranges("tail"))
+        return segs
+
+    def _flush_work(self):
+        work, self._deferred = self._deferred, []
+        self._run_work(work)
+
+    def _stream(self, name: str, main):
+        return main if name == "M" else ((self.hstream or main) if name == "H" else (self.gstream or main))
+
+    def _run(self, segs, graphs=None, exchange: bool = True):
+        """Enqueue the segments in order (eagerly, or as replays of their captured graphs); events cross the streams; a segment's
+        finished gradient ranges go to the exchange behind an event of their own.  The caller's stream joins the others at the end."""
+        main = torch.cuda.current_stream()
+        for st in (self.hstream, self.gstream):
+            if st is not None:
+                st.wait_stream(main)                 # fork: inputs / the previous update are ordered before everything
+        ev = {}
+        for k, (st, fn, wait, signal, ranges) in enumerate(segs):
+            stream = self._stream(st, main)
+            with torch.cuda.stream(stream):
+                for w in ([] if wait is None else wait if isinstance(wait, list) else [wait]):
+                    stream.wait_event(ev[w])
+                if fn is not None:
+                    if graphs is None:
+                        fn()
+                    elif graphs[k] is not None:
+                        graphs[k].replay()
+                if signal is not None or ranges:
+                    e = torch.cuda.Event()
+                    e.record(stream)
+                    if signal is not None:
+                        ev[signal] = e
+                    if ranges and exchange:
+                        self._exchange(ranges, after_event=e)
+        for st in (self.hstream, self.gstream):
+            if st is not None:
+                main.wait_stream(st)
+
+    def _run_inline(self, segs):
+        """The same pieces one after the other on the current stream, gradient work in line (forward() / backward())."""
+        g, h, self.gstream, self.hstream = self.gstream, self.hstream, None, None
+        try:
+            for _, fn, _, _, _ in segs:
+                if fn is not None:
+                    fn()
+        finally:
+            self.gstream, self.hstream = g, h
+
+    def forward(self, batch: Dict[str, torch.Tensor], noise: Optional[torch.Tensor] = None):
+        """Training forward on the current stream (keeps what backward() needs) -> predicted actions [B, chunk, action_dim]."""
+        segs = self._segments(batch, noise)
+        self._run_inline(segs[:self._n_forward])
+        self._fwd_args = (batch, noise)
+        return self._pred
+
+    def backward(self, pred, actions, gscale: float = 1.0):
+        """Whole backward of the last forward() on the current stream (tests, eager debugging); train_step runs the same pieces on
+        three streams."""
+        batch, noise = self._fwd_args
+        segs = self._segments(batch, noise, gscale, actions=actions)
+        self._run_inline(segs[self._n_forward:])
+        return self._loss3
 
     def _begin_backward(self):
         pass
@@ -551,28 +663,6 @@ class BackboneTrainer:
             else:
                 w()
 
-    def _run_deferred(self, graph=None):
-        """Enqueue the piece's gradient work on the gradient stream behind everything the current stream has been given so far;
-        returns an event that fires when it is done (None: nothing was deferred).  graph: a captured form of the same work."""
-        if self.gstream is None or (graph is None and not self._deferred):
-            return None
-        ev = torch.cuda.Event()
-        ev.record()
-        with torch.cuda.stream(self.gstream):
-            self.gstream.wait_event(ev)
-            if graph is not None:
-                graph.replay()
-            else:
-                self._run_work(self._deferred)
-            done = torch.cuda.Event()
-            done.record()
-        self._deferred = []
-        return done
-
-    def _join_grads(self):
-        if self.gstream is not None:
-            torch.cuda.current_stream().wait_stream(self.gstream)
-
     def _exchange(self, ranges, after_event=None):
         red = self.eng.reducer
         if red is not None:
@@ -580,69 +670,48 @@ class BackboneTrainer:
                 if hi > lo:
                     red.reduce_async(buf, lo, hi, after_event=after_event)
 
-    def backward(self, pred, actions, gscale: float = 1.0):
-        """Whole backward; with a reducer attached every gradient range is handed to the exchange as soon as it is final."""
-        for ranges, last, join in self._backward_gen(pred, actions, gscale):
-            done = self._run_deferred()
-            self._exchange(ranges, after_event=done)
-            if join:
-                self._join_grads()
-        self._join_grads()
+    # ---- update / capture ----------------------------------------------------------------------------------------------
+    def train_step(self, batch, lr: float, noise=None):
+        """One step, launched eagerly on the three streams (with a reducer: every gradient range goes to the exchange as soon as
+        it is final)."""
+        self._run(self._segments(batch, noise))
+        self.optimizer_step(lr)
         return self._loss3
 
-    # ---- update / capture (shared shape) ---------------------------------------------------------------------------
-    def train_step(self, batch, lr: float, noise=None):
-        pred = self.forward(batch, noise)
-        loss3 = self.backward(pred, batch["actions"])
-        self.optimizer_step(lr)
-        return loss3
-
     def capture(self, batch: Dict[str, torch.Tensor], noise: Optional[torch.Tensor] = None, warmup: int = 2):
-        """The step on the static ``batch`` / ``noise`` buffers (copy new data into them before each replay) as a CHAIN of linear
-        hipGraphs: forward + head backward, then one graph per backward piece (_backward_gen).  Between two replays the host hands
-        the piece's finished gradient ranges to the exchange stream, so the collectives of a captured multi-rank step run
-        underneath the remaining backward exactly as in the eager step (collectives themselves are not captured).  AdamW stays
-        outside (host-side bias corrections); the derived-operand rebuild is a last small graph.  A step is 3000-5000 launches:
-        issued from Python they cost more host time than GPU time."""
-        self._cap_stream = torch.cuda.Stream()
-        red, self.eng.reducer = self.eng.reducer, None            # warm-up passes exchange nothing
-        try:
-            for _ in range(warmup):
-                self.head.dirty = True
-                self.backward(self.forward(batch, noise), batch["actions"])
-        finally:
-            self.eng.reducer = red
+        """The step on the static ``batch`` / ``noise`` buffers (copy new data into them before each replay) as one linear hipGraph
+        per segment of the schedule (_segments), replayed on the segment's stream with plain events between them.  The host hands
+        a segment's finished gradient ranges to the exchange stream between two replays, so the collectives of a captured
+        multi-rank step run underneath the remaining backward exactly as in the eager step (collectives themselves are not
+        captured).  AdamW stays outside (host-side bias corrections); the derived-operand rebuild is a last small graph.  A step is
+        3000-5000 launches: issued from Python they cost more host time than GPU time."""
+        for _ in range(warmup):                      # allocate every buffer / set kernel attributes outside the capture
+            self.head.dirty = True
+            self._run(self._segments(batch, noise), exchange=False)
         torch.cuda.synchronize()
-        self.head.dirty = True                       # the head's own W^T / padded-operand refresh becomes part of the first graph
-        pool, gpool = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
-        self._gcap_stream = torch.cuda.Stream()
-        self._segs, gen, last = [], None, False
-        while not last:
+        self.head.dirty = True                       # the head's own W^T / padded-operand refresh becomes part of its graphs
+        self._segs = self._segments(batch, noise)
+        # one memory pool and one capture stream per stream kind: graphs sharing a pool are replayed strictly in capture order on
+        # ONE stream, so the allocator's reuse of freed capture-time temporaries stays race-free while the streams overlap
+        pools = {k: torch.cuda.graph_pool_handle() for k in "MHG"}
+        caps = {k: torch.cuda.Stream() for k in "MHG"}
+        self._graphs = []
+        for st, fn, _, _, _ in self._segs:
+            if fn is None:
+                self._graphs.append(None)
+                continue
+            kind = st if self._stream(st, None) is not None else "M"      # (single-stream mode: everything is an "M" graph)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool, stream=self._cap_stream, capture_error_mode="thread_local"):
-                if gen is None:
-                    gen = self._backward_gen(self.forward(batch, noise), batch["actions"], 1.0)
-                ranges, last, join = next(gen)
-            gg = None
-            if self._deferred:                       # the piece's gradient work: its own linear graph, replayed on the gradient stream
-                gg = torch.cuda.CUDAGraph()
-                work, self._deferred = self._deferred, []
-                with torch.cuda.graph(gg, pool=gpool, stream=self._gcap_stream, capture_error_mode="thread_local"):
-                    self._run_work(work)
-            self._segs.append((g, gg, ranges, join))
+            with torch.cuda.graph(g, pool=pools[kind], stream=caps[kind], capture_error_mode="thread_local"):
+                fn()
+            self._graphs.append(g)
         self._g_r = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_r, pool=pool, stream=self._cap_stream, capture_error_mode="thread_local"):
+        with torch.cuda.graph(self._g_r, pool=pools["M"], stream=caps["M"], capture_error_mode="thread_local"):
             self.refresh()
         torch.cuda.synchronize()
 
     def train_step_graphed(self, lr: float):
-        for g, gg, ranges, join in self._segs:
-            g.replay()
-            done = self._run_deferred(gg)            # the piece's gradient work, on the gradient stream behind the piece itself
-            self._exchange(ranges, after_event=done)
-            if join:                                 # (stream waits are not part of the captured graphs: issued between replays)
-                self._join_grads()
-        self._join_grads()
+        self._run(self._segs, self._graphs)
         self.optimizer_step(lr, refresh=False)
         self._g_r.replay()
         return self._loss3
