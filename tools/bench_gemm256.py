@@ -50,16 +50,16 @@ def main():
             fn = lambda: ops.gemm_nt(a, w, bias=bias, residual=res_t, out=out, split_k=0)
         else:
             fn = lambda: ops.gemm_nt(a, w, bias=bias, act=act, out=out, split_k=0)
-        variants = [("auto", "0"), ("128x128", "2"), ("256-8ph", "6"), ("256 1wg/tile", "6:0")]
+        variants = [("auto", "0"), ("128x128", "2"), ("256-8ph", "6"), ("256 xcd-blocked", "6:x")]
         res = {k: [] for k, _ in variants}
         res["vendor"] = []
         wt = w.t()
         def setv(v):
             os.environ["VLA_GEMM_TILE"] = v.split(":")[0]
-            if ":" in v:
-                os.environ["VLA_GEMM256_GRID"] = v.split(":")[1]
+            if v.endswith(":x"):
+                os.environ["VLA_GEMM256_XCD"] = "1"          # opt-in XCD-blocked tile order (gemm256.hip launch256)
             else:
-                os.environ.pop("VLA_GEMM256_GRID", None)
+                os.environ.pop("VLA_GEMM256_XCD", None)
         for k, v in variants:
             setv(v)
             fn()

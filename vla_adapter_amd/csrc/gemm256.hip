@@ -107,12 +107,21 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
   const int xcd = bid & 7;
   auto rstart = [&](int x) { return x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8; };
   int vt = bid;
+  // XCD-BLOCKED order (host: launch256, exact divisions only): the tile grid is cut into xpx x xpy = 8 equal rectangular blocks,
+  // enumerated one after the other, so that run x of the walk IS block x: XCD x works on an 11 x 19 patch of the 44 x 38 gate/up
+  // grid - 11 A panels + 19 B tiles through its private L2 instead of ~6 A panels and the whole of B twice (a run of the plain
+  // group-M order straddles two row groups).  xpx == 0: one block = the whole grid.
+  int bk_rows = p.ntiles / p.tiles_n, bk_cols = p.tiles_n, bk_r0 = 0, bk_c0 = 0, bk_start = 0;
+  if (p.xpx > 0) {
+    bk_rows /= p.xpx; bk_cols /= p.xpy;
+    bk_r0 = (xcd % p.xpx) * bk_rows; bk_c0 = (xcd / p.xpx) * bk_cols;
+    bk_start = xcd * bk_rows * bk_cols;
+  }
 
   // ---- tile identity + staging sources: this wave fills rows [16 wid, 16 wid + 16) of every half-tile (2 pieces of 8 rows)
   // group-M width of the tile order (A row panels an XCD keeps L2-resident while B tiles stream): 6, as for the 128-row tiles -
   // on the one-pipeline step 25.84-25.87 ms against 25.93-26.09 for 4 and 25.95-26.02 for 8 (same box, three alternating runs)
   const int GM = p.gm > 0 ? p.gm : 6;
-  const int tiles_m = p.ntiles / p.tiles_n, per_group = GM * p.tiles_n;
   int m0, n0, z;
   // sources as wave-uniform bases + 32-bit per-lane byte offsets (half the address registers of eight pointers)
   const char* Ab; const char* Bb;
@@ -124,14 +133,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
     const int lrow = sl >> 3;
     int gA = p.gA;
     asm volatile("" : "+s"(gA));       // (the same for the reciprocal of a divisor: recomputed per tile, not carried in VGPRs)
-    int ntl = p.ntiles, pg = per_group;
-    asm volatile("" : "+s"(ntl), "+s"(pg));
+    int ntl = p.ntiles;
+    asm volatile("" : "+s"(ntl));
     z = swz / ntl;
     const int tl = swz - z * ntl;
-    const int grp = tl / pg, rem = tl - grp * pg;
-    const int gmr = min(GM, tiles_m - grp * GM);
-    m0 = (grp * GM + rem % gmr) * 256;
-    n0 = (rem / gmr) * 256;
+    // group-M order inside this XCD's block of the tile grid (the whole grid when the order is not XCD-blocked)
+    int br = bk_rows, bc = bk_cols, r0b = bk_r0, c0b = bk_c0, t0 = bk_start;
+    asm volatile("" : "+s"(br), "+s"(bc), "+s"(r0b), "+s"(c0b), "+s"(t0));
+    const int tloc = tl - t0, pgb = GM * bc;
+    const int grp = tloc / pgb, rem = tloc - grp * pgb;
+    const int gmr = min(GM, br - grp * GM);
+    m0 = (r0b + grp * GM + rem % gmr) * 256;
+    n0 = (c0b + rem / gmr) * 256;
     Ab = reinterpret_cast<const char*>(p.A) + (long long)z * p.sA * EB;
     Bb = reinterpret_cast<const char*>(p.B) + (long long)z * p.sB * EB;
 #pragma unroll
@@ -694,8 +707,28 @@ int launch256(const GemmP& p0, int batch, hipStream_t st) {
   // one workgroup per CU walks the tiles (VLA_GEMM256_GRID overrides the workgroup count: 0 = one workgroup per tile)
   const char* ge = getenv("VLA_GEMM256_GRID");      // (read per launch: the A/B tool flips it in one process)
   const long long total = (long long)p.ntiles * batch;
+  // XCD-blocked tile order (setup()): px x py = 8 equal blocks of the tile grid (exact divisions only: the eight runs of the walk
+  // then coincide with the blocks), the smallest operand footprint per block (rows + columns) first.
+  p.xpx = p.xpy = 0;
+  // MEASURED AND NOT ADOPTED (round 3, same box): performance-neutral (step 25.28 vs 25.27 ms; gate/up, down, qkv, fc2 within 1 %)
+  // and the fabric-side fetch it was built to cut barely moves (gate/up 156 vs 160 MB raw FETCH_SIZE, down 134 vs 141, fc2 83 vs
+  // 110, ViT qkv 62 vs 56: profiles/r03_gemm256_traffic_order_ab.json) - the re-fetches are not the cross-XCD duplication the
+  // tile-order model predicts.  Opt-in through VLA_GEMM256_XCD=1; the default stays the plain group-M order.
+  const char* xe = getenv("VLA_GEMM256_XCD");                 // (read per launch: the A/B tool flips it in one process)
+  const bool xcd_on = xe != nullptr && atoi(xe) != 0;
+  if (xcd_on && batch == 1 && total >= 64) {
+    const int tm = p.ntiles / p.tiles_n, tn = p.tiles_n;
+    long long best = -1;
+    for (int px = 8; px >= 1; px >>= 1) {
+      const int py = 8 / px;
+      if (tm % px != 0 || tn % py != 0) continue;          // exact divisions only: the walk's eight equal runs must BE the blocks
+      const long long cost = tm / px + tn / py;            // operand footprint of a block (A panels + B tiles)
+      if (best < 0 || cost < best) { best = cost; p.xpx = px; p.xpy = py; }
+    }
+  }
   long long grid = ge ? atoll(ge) : num_cus();
   if (grid <= 0 || grid > total) grid = total;
+  if (grid % 8 != 0) p.xpx = p.xpy = 0;                    // (a workgroup must stay on its XCD's list: b and b + G share b & 7)
   hipLaunchKernelGGL((gemm256_kernel<EPI, F8>), dim3((unsigned)grid), dim3(512), LDS_BYTES, st, p);
   return 0;
 }
