@@ -125,3 +125,62 @@ def test_full_finetune_trains_and_updates_every_tensor():
     if v.mlp_pad != v.cfg.mlp:
         assert bool((v.blocks[0]["w1"][v.cfg.mlp:] == 0).all()) and bool((v.blocks[0]["w2"][:, v.cfg.mlp:] == 0).all())
     assert bool((v.wpe[:, 3 * v.cfg.patch ** 2:] == 0).all())
+
+
+@pytest.mark.parametrize("mode", ["full", "lora"])
+def test_llm_layers_above_the_heads_last_block_are_left_alone(mode):
+    """Qwen2.5-1.5B has 28 layers, the head 24 blocks (action_heads.py:117-118 reads hidden_states[1..24]): layers 25-28 and the
+    final norm never reach the loss.  The reference computes them anyway; autograd hands their parameters ALL-ZERO gradients (zeros
+    travel back through torch.cat / index_select of finetune.py:396-409), so AdamW moves them by the weight-decay factor 1 - lr wd
+    alone - which in bf16 rounds to 1 for lr wd < 2^-9: they never change.  Here (3 layers, 2 blocks) they are neither computed
+    nor touched: the gradients of the live layers still match the oracle's autograd through ALL layers, and after training steps
+    every parameter of the dead layer is bit-identical to its initial value."""
+    from vla_adapter_amd import engine as E, synthetic as S, ops
+    from vla_adapter_amd.trainers import FullFinetune, LoRAFinetune
+    cfg = E.tiny_config()
+    cfg.llm = E.LLMCfg(256, 3, 4, 2, 64, 512, 1e-6, 1e6, 1024)
+    cfg.num_blocks = 2
+    W = S.make_weights(cfg, DEV, seed=3, std=0.05)
+    batch = S.make_batch(cfg, 3, DEV, seed=4, P=20, ragged=True)
+    eng = E.VLAEngine(cfg, W, DEV)
+    tr = FullFinetune(eng) if mode == "full" else LoRAFinetune(eng, rank=8, seed=1)
+    assert tr.n_active == 2
+    if mode == "full":
+        pred = tr.forward(batch, None)
+        _, dpred = ops.l1_loss(pred, batch["actions"].to(BF), True)
+        tr.backward(pred, batch["actions"])
+        torch.cuda.synchronize()
+        res = {}
+        for emu in (True, False):
+            out, OW = _oracle_full(cfg, W, batch, emu)
+            out["pred"].backward(dpred.float().cpu())
+            res[emu] = (_ref_grads(OW, cfg), OW)
+        gdead = res[False][1]["llm"]["layers.2.mlp.down_proj.weight"].grad
+        assert gdead is None or gdead.abs().max().item() == 0.0, "autograd gives the dead layer an all-zero gradient"
+        got = tr.reference_named_gradients()
+        fam = [(k, got[k], res[True][0][k].reshape(got[k].shape), res[False][0][k].reshape(got[k].shape)) for k in got
+               if k in res[False][0] and "language_model.model.layers." in k and "layers.2." not in k and got[k].dim() >= 2]
+        assert len(fam) == 2 * 7
+        assert all(got[k].float().abs().max().item() == 0.0 for k in got if "layers.2." in k), "the dead layer's gradient is exactly zero"
+        budget_family(fam, "live LLM layers under a dead one: weight-matrix gradients", absfloor=1e-3 * max(t[3].norm().item() for t in fam))
+    p0 = tr.P.data.clone()
+    losses = [tr.train_step(batch, 1e-3)[0].item() for _ in range(4)]
+    torch.cuda.synchronize()
+    assert all(l == l for l in losses)
+    dead = [k for k in tr.P.offsets if ("llm.2." in k if mode == "full" else "layers.2." in k)] + (["llm.norm"] if mode == "full" else [])
+    live = [k for k in tr.P.offsets if ("llm.1." in k if mode == "full" else "layers.1." in k)]
+    assert dead and live
+    for k in dead:
+        off, shape = tr.P.offsets[k]
+        n = 1
+        for d in shape:
+            n *= d
+        assert torch.equal(tr.P.data[off:off + n], p0[off:off + n]), f"{k} must be left alone (no gradient, no weight decay)"
+    moved = 0
+    for k in live:
+        off, shape = tr.P.offsets[k]
+        n = 1
+        for d in shape:
+            n *= d
+        moved += int(not torch.equal(tr.P.data[off:off + n], p0[off:off + n]))
+    assert moved >= len(live) // 2, "the live layer below must train"

@@ -148,6 +148,7 @@ class BackboneTrainer:
         # granularity of the data-parallel exchange: gradient ranges are handed over every `exchange_layers` LLM layers (4 x 30 MB
         # of bf16 gradients at the 0.5B geometry: large messages for the point-to-point xGMI links) / `exchange_blocks` ViT blocks
         self.exchange_layers, self.exchange_blocks = 4, 7
+        self.n_active = min(cfg.llm.n_layers, cfg.num_blocks)      # LLM layers that reach the loss (see _segments)
         # Streams of the step schedule (_segments): the caller's stream carries the dX chain, `gstream` everything that only feeds a
         # parameter gradient, `hstream` the action head.  VLA_TRAINER_STREAMS=1: everything in line, 2: no separate head stream.
         import os
@@ -322,7 +323,9 @@ class BackboneTrainer:
         for i in range(hi - 1, lo - 1, -1):
             L, k = llm.layers[i], f"llm.{i}."
             d = self.G_res[i]
-            if i < n - 1:
+            if i == self.n_active - 1 and i < n - 1:       # top ACTIVE layer below dead ones: its output gradient is the head's alone
+                ops.copy2d(dHS[i + 1].view(M, D), d, M, D, D, D)
+            elif i < n - 1:
                 ops.add_(d, dHS[i + 1].view(M, D))
             tap = self.taps.get(("llm", i)) if self.taps is not None else None
             if tap is not None:
@@ -483,7 +486,11 @@ class BackboneTrainer:
     def _segments(self, batch, noise, gscale: float = 1.0, actions=None):
         eng, cfg, llm, head = self.eng, self.cfg, self.llm, self.head
         n, nb = cfg.llm.n_layers, cfg.num_blocks
-        lch = E.VLAEngine._chunks(n, [self.exchange_layers])
+        # LLM layers above the head's last block (Qwen2.5-1.5B: 28 layers, 24 head blocks - action_heads.py:117-118 reads
+        # hidden_states[1..24]) never reach the loss: the reference computes them and throws the result away; autograd hands their
+        # parameters all-zero gradients, so AdamW moves them by the weight-decay factor 1 - lr wd alone, which a bf16 parameter does
+        # not see (it rounds to 1 for lr wd < 2^-9).  Here they are neither computed nor touched (tests/test_full_finetune_gpu.py).
+        lch = E.VLAEngine._chunks(self.n_active, [self.exchange_layers])
         two = self.gstream is not None
         segs = []
 
@@ -716,6 +723,9 @@ class BackboneTrainer:
         self._g_r.replay()
         return self._loss3
 
+    def _adam_ranges(self):
+        return [(0, self.P.numel)]
+
     def _exchange_and_scale(self) -> float:
         """Join the data-parallel exchange the backward started range by range; returns the 1/N scale folded into AdamW."""
         red = self.eng.reducer
@@ -728,7 +738,8 @@ class BackboneTrainer:
         self.step_count += 1
         gscale = self._exchange_and_scale()
         P, HP = self.P, self.head.P
-        ops.adamw_(P.data, P.grad, P.m, P.v, self.step_count, lr, beta1, beta2, eps, wd, gscale=gscale)
+        for lo, hi in self._adam_ranges():            # (parameters of dead LLM layers: see _segments)
+            ops.adamw_(P.data[lo:hi], P.grad[lo:hi], P.m[lo:hi], P.v[lo:hi], self.step_count, lr, beta1, beta2, eps, wd, gscale=gscale)
         ops.adamw_(HP.data, HP.grad, HP.m, HP.v, self.step_count, lr, beta1, beta2, eps, wd, gscale=gscale)
         self.head.dirty = True
         if refresh:
@@ -835,6 +846,13 @@ class FullFinetune(BackboneTrainer):
         ids = self._batch["input_ids"]
         ops.N.check(ops._lib().vla_embed_grad(ops._st(), ops._p(dX0), ops._p(ids), ops._p(self.eng.qidx0), ops._p(self.G("llm.embed")),
                                               self.eng.B, ids.shape[1], self.eng.Np, self.cfg.llm.d, self.cfg.llm.vocab), "embed_grad")
+
+    def _adam_ranges(self):
+        na, n = self.n_active, self.cfg.llm.n_layers
+        if na == n:
+            return [(0, self.P.numel)]
+        off = lambda name: self.P.offsets[name][0]          # dead: matrices and vectors of layers na .. n-1, the final norm
+        return [(0, off(f"llm.{na}.wqkv")), (off("llm.embed"), off(f"llm.{na}.n1"))]
 
     def _begin_backward(self):
         ops.zero_(self.acc32)
@@ -980,6 +998,13 @@ class LoRAFinetune(BackboneTrainer):
         if swiglu_gu is not None:
             return ops.gemm_swiglu_bwd(dy, WT, swiglu_gu, out=out, ext=(dt, l.A_catT))
         return ops.gemm_nt(dy, WT, out=out, ext=(dt, l.A_catT))     # dx = dy W + dt A_cat
+
+    def _adam_ranges(self):
+        na = self.n_active
+        if na == self.cfg.llm.n_layers:
+            return [(0, self.P.numel)]
+        l = self.L[f"llm.{na}.qkv"]                          # the pairs of dead layers close the flat buffer
+        return [(0, self.P.offsets[f"{l.name}.{l.projs[0][0]}.lora_A"][0])]
 
     def _ranges(self, kind, lo=0, hi=0, j=0):
         first = lambda key: f"{self.L[key].name}.{self.L[key].projs[0][0]}.lora_A"
