@@ -282,6 +282,13 @@ int vla_resample_u8(void* stream, const void* src, void* dst, long long outer, i
 int vla_token_ce(void* stream, const void* logits, long long ld_logits, const long long* shifted_labels, int rows, int V,
                  float* loss_sum_and_count);
 
+/* Backward of vla_token_ce w.r.t. the logits (autograd of the HF loss on ``logits.float()``; the native trainer of
+ * prismatic/training/strategies/base_strategy.py:257-417 calls loss.backward()): valid rows get
+ * bf16((softmax(float(logits[row])) - onehot(label)) * gscale / count), ignored rows zeros; count = loss_sum_and_count[1] of the
+ * forward, read on the device.  dlogits may alias logits. */
+int vla_token_ce_bwd(void* stream, const void* logits, long long ld_logits, const long long* shifted_labels, int rows, int V,
+                     const float* loss_sum_and_count, float gscale, void* dlogits, long long ld_dlogits);
+
 /* ---------------------------------------------------------------- host-glue replacements
  * The reference's training step strings its ops together with dozens of small ATen index / cast / copy kernels
  * (finetune.py:331-343, 396-409; action_heads.py:53-72; modeling_prismatic.py:499-508); these entry points do the same

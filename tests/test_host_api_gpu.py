@@ -356,3 +356,49 @@ def test_finetune_picks_the_model_from_the_checkpoint(tmp_path):
     m = out["model"]
     assert [v["d"] for v in m["vit"]] == [192, 128] and m["vit"][0]["n_prefix"] == 5 and m["vit"][0]["layerscale"] and m["llm"]["d"] == 256
     assert all(l["loss_value"] == l["loss_value"] for l in out["log"])
+
+
+@pytest.mark.parametrize("mode", ["full", "lora"])
+def test_trainer_gradient_accumulation_matches_one_big_batch(mode):
+    """finetune.py:1039-1042 for the backbone trainers: two micro-batches of 2 with loss / 2 == one batch of 4, eager and captured;
+    one optimizer step per two micro-steps."""
+    from vla_adapter_amd import engine as E, synthetic as S
+    from vla_adapter_amd.trainers import FullFinetune, LoRAFinetune
+    cfg = E.tiny_config()
+    W = S.make_weights(cfg, "cuda", seed=3, std=0.05)
+    big = S.make_batch(cfg, 4, "cuda", seed=361, P=32)
+    halves = [{k: v[i:i + 2].contiguous() for k, v in big.items()} for i in (0, 2)]
+    mk = lambda: (FullFinetune(E.VLAEngine(cfg, W, "cuda")) if mode == "full" else LoRAFinetune(E.VLAEngine(cfg, W, "cuda"), rank=8, seed=3))
+    t_big, t_acc, t_gr = mk(), mk(), mk()
+    if mode == "lora":                               # B = 0 at initialisation gives the A matrices no gradient: start from a trained-looking B
+        g = torch.Generator(device="cuda").manual_seed(5)
+        for t in (t_big, t_acc, t_gr):
+            g.manual_seed(5)
+            for l in t.L.values():
+                for p_, _ in l.projs:
+                    Bv = t.P.view(f"{l.name}.{p_}.lora_B")
+                    Bv[:l.n_real, :l.r] = (torch.randn(min(l.n_real, Bv.shape[0]), l.r, generator=g, device="cuda") * 0.05).to(torch.bfloat16)
+            t.refresh()
+    t_big.train_step(big, 1e-3)
+    t_acc.set_grad_accumulation(2)
+    p0 = t_acc.P.data.clone()
+    t_acc.train_step(halves[0], 1e-3)
+    assert torch.equal(p0, t_acc.P.data) and t_acc.step_count == 0, "no optimizer step on the first micro-batch"
+    t_acc.train_step(halves[1], 1e-3)
+    torch.cuda.synchronize()
+    assert t_acc.step_count == 1
+    for a, b in ((t_big.P.grad, t_acc.P.grad), (t_big.head.P.grad, t_acc.head.P.grad)):
+        a, b = a.float(), b.float()
+        assert (a - b).norm() <= 2e-2 * a.norm(), ((a - b).norm() / a.norm()).item()
+    t_gr.set_grad_accumulation(2)
+    static = {k: v.clone() for k, v in halves[0].items()}
+    t_gr.capture(static, None)
+    t_gr.train_step_graphed(1e-3)
+    assert t_gr.step_count == 0
+    for k in static:
+        static[k].copy_(halves[1][k])
+    t_gr.train_step_graphed(1e-3)
+    torch.cuda.synchronize()
+    assert t_gr.step_count == 1
+    assert (t_gr.P.grad.float() - t_acc.P.grad.float()).norm() <= 2e-3 * t_acc.P.grad.float().norm()
+    assert (t_gr.P.data.float() - t_acc.P.data.float()).norm() <= 1e-3 * t_acc.P.data.float().norm()

@@ -941,6 +941,86 @@ extern "C" int vla_token_ce(void* stream, const void* logits, long long ld_logit
 }
 
 
+// Backward of the above w.r.t. the logits (autograd of HF's shifted CE on ``logits.float()``): for a valid row
+// dlogits[row, v] = bf16((softmax(float(logits[row]))[v] - [v == label]) * gscale / count), zeros for ignored rows; count is read from
+// the device (loss_sum_and_count[1] of the forward: no host sync).  May run in place (dlogits == logits).  One workgroup per row.
+__global__ __launch_bounds__(256) void token_ce_bwd_kernel(const bf16_t* __restrict__ logits, long long ldl, const long long* __restrict__ labels,
+                                                           int V, const float* __restrict__ out2, float gscale, bf16_t* __restrict__ dl, long long ldd) {
+  const long long row = blockIdx.x;
+  const long long lab = labels[row];
+  const bf16_t* x = logits + row * ldl;
+  bf16_t* y = dl + row * ldd;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (lab < 0 || lab >= V) {                       // IGNORE_INDEX: no gradient
+    for (int c = tid * 8; c < V; c += 256 * 8) {
+      if (c + 8 <= V) *reinterpret_cast<uint4*>(y + c) = uint4{0, 0, 0, 0};
+      else for (int k = c; k < V; ++k) y[k] = 0;
+    }
+    return;
+  }
+  __shared__ float red[8];
+  float m = -3.0e38f;
+  for (int c = tid * 8; c < V; c += 256 * 8) {
+    if (c + 8 <= V) {
+      const uint4 v = *reinterpret_cast<const uint4*>(x + c);
+      const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m = fmaxf(m, fmaxf(bf2f((bf16_t)(u[k] & 0xffff)), bf2f((bf16_t)(u[k] >> 16))));
+    } else {
+      for (int k = c; k < V; ++k) m = fmaxf(m, bf2f(x[k]));
+    }
+  }
+  m = wave_max(m);
+  if (lane == 0) red[w] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int c = tid * 8; c < V; c += 256 * 8) {
+    if (c + 8 <= V) {
+      const uint4 v = *reinterpret_cast<const uint4*>(x + c);
+      const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s += __expf(bf2f((bf16_t)(u[k] & 0xffff)) - m) + __expf(bf2f((bf16_t)(u[k] >> 16)) - m);
+    } else {
+      for (int k = c; k < V; ++k) s += __expf(bf2f(x[k]) - m);
+    }
+  }
+  s = wave_sum(s);
+  if (lane == 0) red[4 + w] = s;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  const float sc = gscale / out2[1];
+  for (int c = tid * 8; c < V; c += 256 * 8) {
+    if (c + 8 <= V) {
+      const uint4 v = *reinterpret_cast<const uint4*>(x + c);
+      const unsigned u[4] = {v.x, v.y, v.z, v.w};
+      unsigned o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float p0 = __expf(bf2f((bf16_t)(u[k] & 0xffff)) - m) * inv - (c + 2 * k == lab ? 1.f : 0.f);
+        const float p1 = __expf(bf2f((bf16_t)(u[k] >> 16)) - m) * inv - (c + 2 * k + 1 == lab ? 1.f : 0.f);
+        o[k] = pack2(p0 * sc, p1 * sc);
+      }
+      *reinterpret_cast<uint4*>(y + c) = uint4{o[0], o[1], o[2], o[3]};
+    } else {
+      for (int k = c; k < V; ++k) y[k] = f2bf((__expf(bf2f(x[k]) - m) * inv - (k == lab ? 1.f : 0.f)) * sc);
+    }
+  }
+}
+
+extern "C" int vla_token_ce_bwd(void* stream, const void* logits, long long ld_logits, const long long* shifted_labels, int rows, int V,
+                                const float* loss_sum_and_count, float gscale, void* dlogits, long long ld_dlogits) {
+  VLA_REQUIRE(logits && shifted_labels && loss_sum_and_count && dlogits && rows > 0 && V > 0 && ld_logits % 8 == 0 && ld_dlogits % 8 == 0 &&
+                  ((((uintptr_t)logits) | ((uintptr_t)dlogits)) & 15) == 0,
+              "token_ce_bwd: bad args (row strides % 8, 16-B aligned logits / dlogits)");
+  hipLaunchKernelGGL(token_ce_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, ld_logits, shifted_labels, V,
+                     loss_sum_and_count, gscale, (bf16_t*)dlogits, ld_dlogits);
+  VLA_CHECK_LAUNCH("token_ce_bwd");
+  return VLA_OK;
+}
+
+
 // ---------------------------------------------------------------- SwiGLU forward on interleaved pre-activations (LoRA path)
 // h[m, 16t + c] = bf16(bf16(silu(g)) * u), g = GU[m, 32t + c], u = GU[m, 32t + 16 + c]: the product the fused GEMM epilogue forms;
 // stand-alone because LoRA adds its low-rank deltas to the gate / up pre-activations BEFORE the activation (peft wraps each

@@ -127,8 +127,6 @@ def check_supported(cfg: FinetuneConfig, explicit=()) -> None:
         raise ValueError("grad_accumulation_steps must be >= 1")
     if cfg.use_lora and cfg.lora_dropout != 0.0:
         raise NotImplementedError("--lora_dropout > 0: the low-rank branch is built without dropout (every shipped script uses 0.0)")
-    if train_mode(cfg) != "adapter" and cfg.grad_accumulation_steps != 1:
-        raise NotImplementedError("grad_accumulation_steps > 1 is built for the adapter-only mode (--use_fz True) only")
     if cfg.backbone is not None:
         from .engine import NAMED_CONFIGS
         if cfg.backbone not in NAMED_CONFIGS:
@@ -331,7 +329,7 @@ def finetune(cfg: FinetuneConfig, batches=None, explicit=()) -> dict:
         from .trainers import FullFinetune
         trainer = FullFinetune(eng)
     use_graph = cfg.use_graph
-    eng.set_grad_accumulation(cfg.grad_accumulation_steps)
+    (trainer or eng).set_grad_accumulation(cfg.grad_accumulation_steps)
     stream = batch_stream(cfg, mcfg, dev, rank, batches)
     pad_id = min(S.PAD_ID, mcfg.llm.vocab - 1)
     cur = next(stream)

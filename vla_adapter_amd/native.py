@@ -111,6 +111,7 @@ _PROTOS = {
     "vla_embed_grad": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I], _I),
     "vla_resample_u8": ([_P, _P, _P, _L, _I, _I, _I, _P, _P, _I], _I),
     "vla_token_ce": ([_P, _P, _L, _P, _I, _I, _P], _I),
+    "vla_token_ce_bwd": ([_P, _P, _L, _P, _I, _I, _P, _F, _P, _L], _I),
     "vla_copy2d": ([_P, _P, _P, _L, _I, _L, _L, _I, _I, _I, _I, _L], _I),
     "vla_fill_zero": ([_P, _P, _L], _I),
     "vla_quant_fp8_rows": ([_P, _P, _P, _P, _I, _I, _I, _I], _I),

@@ -149,6 +149,8 @@ class BackboneTrainer:
         # of bf16 gradients at the 0.5B geometry: large messages for the point-to-point xGMI links) / `exchange_blocks` ViT blocks
         self.exchange_layers, self.exchange_blocks = 4, 7
         self.n_active = min(cfg.llm.n_layers, cfg.num_blocks)      # LLM layers that reach the loss (see _segments)
+        self.ga, self._micro, self._gacc = 1, 0, None             # gradient accumulation (set_grad_accumulation)
+        self.objective = "l1"
         # Streams of the step schedule (_segments): the caller's stream carries the dX chain, `gstream` everything that only feeds a
         # parameter gradient, `hstream` the action head.  VLA_TRAINER_STREAMS=1: everything in line, 2: no separate head stream.
         import os
@@ -484,6 +486,8 @@ class BackboneTrainer:
     # exchange of each starts right there, underneath the rest of the backward (vla-scripts/finetune.py:215-227, 869: DDP's
     # bucketed all-reduce overlapped with backward; BASELINE configs[3] "grad-bucket overlap").
     def _segments(self, batch, noise, gscale: float = 1.0, actions=None):
+        if self.objective == "token_ce":
+            return self._segments_ce(batch, gscale)
         eng, cfg, llm, head = self.eng, self.cfg, self.llm, self.head
         n, nb = cfg.llm.n_layers, cfg.num_blocks
         # LLM layers above the head's last block (Qwen2.5-1.5B: 28 layers, 24 head blocks - action_heads.py:117-118 reads
@@ -563,6 +567,113 @@ class BackboneTrainer:
         if self.trains_vectors:                     # the tail casts the ONE fp32 buffer every piece's bias / norm sums met in
             add("M", self._end_backward, [sg for sg in gsig if two], ("end", 0), self._ranges("tail"))
         return segs
+
+    # ---- token cross-entropy objective: the native trainer of prismatic/training/strategies/base_strategy.py:257-417 ----
+    # PrismaticVLM.forward(..., labels=) -> HF shifted causal-LM loss (prismatic/models/vlms/prismatic.py:312-481), loss.backward().
+    # No action queries, no action head: every LLM layer and the final norm are live, lm_head = the tied embedding table.  Only the
+    # rows that can carry a label are projected: the L - 1 text rows of every sequence (the patch rows' targets are IGNORE_INDEX by
+    # construction, :411-422) - 1520 of 5632 rows at batch 16 - so the three vocabulary-wide products (logits, d hidden, d lm_head)
+    # cost 27 % of their full-sequence form.  softmax - onehot is formed in place on the logits (vla_token_ce_bwd).
+    def _segments_ce(self, batch, gscale: float = 1.0):
+        eng, cfg, llm = self.eng, self.cfg, self.llm
+        n, D, V = cfg.llm.n_layers, cfg.llm.d, cfg.llm.vocab
+        assert getattr(llm, "lm_head", None) is None, "token-CE training: tied lm_head only (Qwen2.5-0.5B / 1.5B tie_word_embeddings)"
+        lch = E.VLAEngine._chunks(n, [self.exchange_layers])
+        two = self.gstream is not None
+        segs = []
+
+        def add(st, fn, wait=None, signal=None, ranges=None):
+            segs.append((st, fn, wait, signal, ranges))
+
+        def grads(after, signal, ranges):
+            if two:
+                add("G", self._flush_work, after, signal, ranges)
+            else:
+                add("M", None, None, signal, ranges)
+            return signal
+
+        def f_front():
+            eng._vision_begin(batch)
+            self._alloc(eng.B, eng.S)
+            for j in range(len(self.vits)):
+                self._vit_forward(j, batch["pixel_values"])
+            self._proj_forward()
+            self._mm = eng._embed(batch, action_queries=False)
+            self._batch = batch
+            llm.fwd_begin(eng.B, eng.S, self._mm, 0)
+            self._begin_backward()
+            self._dHS = eng._dhs(0)
+        add("M", f_front, None, ("front", 0))
+        for c, (lo, hi) in enumerate(lch):
+            add("M", lambda lo=lo, hi=hi: self._llm_fwd_layers(lo, hi), None, ("f", c))
+        self._n_forward = len(segs)
+
+        def f_ce():
+            B, S, Np = eng.B, eng.S, eng.Np
+            Lm = S - Np - 1                                          # text rows that predict a token: sequence rows Np .. S - 2
+            if getattr(self, "_ce_key", None) != (B, S):
+                e = lambda *sh, dt=BF16: torch.empty(*sh, device=self.dev, dtype=dt)
+                self.ce_h, self.ce_dh, self.ce_logits = e(B * Lm, D), e(B * Lm, D), e(B * Lm, V)
+                self.ce_out = torch.zeros(2, device=self.dev, dtype=torch.float32)
+                self._ce_key = (B, S)
+            ops.copy_rows3d(llm.HS[n][0, Np], self.ce_h, B, Lm, D, S * D, D, Lm * D, D)
+            ops.gemm_nt(self.ce_h, llm.embed, out=self.ce_logits, split_k=0)
+            tgt = self._ce_tgt = batch["labels"][:, 1:].contiguous().view(-1)
+            ops.zero_(self.ce_out)
+            lib, st, p = ops._lib(), ops._st, ops._p
+            ops.N.check(lib.vla_token_ce(st(), p(self.ce_logits), V, p(tgt), B * Lm, V, p(self.ce_out)), "token_ce")
+            loss = self.ce_out[0:1] / self.ce_out[1:2]
+            self._loss3 = torch.cat([loss, loss, loss])              # (same three-slot shape the L1 path logs)
+            ops.N.check(lib.vla_token_ce_bwd(st(), p(self.ce_logits), V, p(tgt), B * Lm, V, p(self.ce_out), gscale, p(self.ce_logits), V), "token_ce_bwd")
+            ops.gemm_nt(self.ce_logits, self.lmT, out=self.ce_dh, split_k=0)                      # d hidden = dlogits . W_lm
+            if self.trains_vectors:                                  # d lm_head = dlogits^T . hidden, added to the tied table's gradient in the tail
+                self._defer_tn(self.ce_logits, self.ce_h, self.g_lm)
+            ops.copy_rows3d(self.ce_dh, self._dHS[n][0, Np], B, Lm, D, Lm * D, D, S * D, D)
+        add("M", f_ce, None, ("ce", 0))
+        gsig = [grads(("ce", 0), ("gce", 0), [])] if self.trains_vectors else []       # (LoRA: lm_head is not adapted - nothing deferred here)
+        for k, (lo, hi) in enumerate(reversed(lch)):
+            add("M", lambda lo=lo, hi=hi: self._llm_bwd_layers(lo, hi), None, ("m", k))
+            gsig.append(grads(("m", k), ("g", k), self._ranges("llm", lo, hi - 1)))
+
+        def f_mid():
+            dX0 = self.d_last.view(eng.B, eng.S, D)
+            self._embed_backward(dX0)
+            self._proj_backward(dX0)
+        add("M", f_mid, None, ("mid", 0))
+        gsig.append(grads(("mid", 0), ("gmid", 0), self._ranges("proj")))
+        for j, v in enumerate(self.vits):
+            vch = E.VLAEngine._chunks(len(v.blocks), [self.exchange_blocks])
+            for q, (lo, hi) in enumerate(reversed(vch)):
+                def v_bwd(j=j, lo=lo, hi=hi, first=(q == 0)):
+                    if first:
+                        self._vit_bwd_begin(j)
+                    self._vit_bwd_blocks(j, lo, hi)
+                    if lo == 0 and self.trains_vectors:
+                        self._vit_bwd_end(j)
+                add("M", v_bwd, None, ("v", j, q))
+                gsig.append(grads(("v", j, q), ("gv", j, q), self._ranges("vit", lo, hi - 1, j)))
+        if self.trains_vectors:
+            def f_tail():
+                ops.add_(self.G("llm.embed"), self.g_lm)             # tied weights: lookup gradient + lm_head gradient (one bf16 add, as autograd accumulates)
+                self._end_backward()
+            add("M", f_tail, [sg for sg in gsig if two], ("end", 0), self._ranges("embed") + self._ranges("tail"))
+        return segs
+
+    def set_objective(self, objective: str):
+        """"l1" (default: action head + L1 regression, vla-scripts/finetune.py) or "token_ce" (the native VLM / VLA trainer's token
+        cross-entropy, base_strategy.py:257-417).  Before capture()."""
+        assert objective in ("l1", "token_ce") and getattr(self, "_graphs", None) is None
+        self.objective = objective
+        if objective == "token_ce":
+            self.n_active = self.cfg.llm.n_layers                    # every layer and the final norm reach this loss
+            V, D = self.llm.embed.shape
+            self.lmT = torch.empty(D, V, device=self.dev, dtype=BF16)
+            self.g_lm = torch.zeros(V, D, device=self.dev, dtype=BF16) if self.trains_vectors else None
+            self._refresh_objective()
+
+    def _refresh_objective(self):
+        if self.objective == "token_ce":
+            ops.transpose(self.llm.embed, out=self.lmT)              # W_lm^T operand of d hidden = dlogits . W_lm (the tied table moves every step)
 
     def _flush_work(self):
         work, self._deferred = self._deferred, []
@@ -678,11 +789,44 @@ class BackboneTrainer:
                     red.reduce_async(buf, lo, hi, after_event=after_event)
 
     # ---- update / capture ----------------------------------------------------------------------------------------------
+    def set_grad_accumulation(self, n: int):
+        """vla-scripts/finetune.py:1039-1042, 1078-1082: loss / n on every micro-batch, gradients summed over n micro-batches (in
+        bf16, as autograd accumulates ``.grad``), one optimizer step per n.  The data-parallel exchange then runs once, on the
+        summed gradient of the boundary micro-step (the reference's DDP all-reduces on every micro-step: same result).  Call
+        before capture(): the captured loss kernel carries the 1 / n."""
+        assert n >= 1 and getattr(self, "_graphs", None) is None, "set_grad_accumulation() before capture()"
+        self.ga, self._micro = int(n), 0
+        self._gacc = (torch.zeros_like(self.P.grad), torch.zeros_like(self.head.P.grad)) if n > 1 else None
+
+    def _accumulate(self) -> bool:
+        """Fold the micro-step's gradients into the accumulators; True on the boundary micro-step (the grad buffers then hold the sums)."""
+        if self.ga == 1:
+            return True
+        for acc, g in zip(self._gacc, (self.P.grad, self.head.P.grad)):
+            if self._micro == 0:
+                n = g.numel()
+                ops.copy2d(g, acc, 1, n, n, n)
+            else:
+                ops.add_(acc, g)
+        self._micro += 1
+        if self._micro < self.ga:
+            return False
+        self._micro = 0
+        for acc, g in zip(self._gacc, (self.P.grad, self.head.P.grad)):
+            n = g.numel()
+            ops.copy2d(acc, g, 1, n, n, n)
+        red = self.eng.reducer
+        if red is not None:                          # one exchange, of the sums
+            red.reduce_async(self.P.grad, 0, None)
+            red.reduce_async(self.head.P.grad, 0, None)
+        return True
+
     def train_step(self, batch, lr: float, noise=None):
-        """One step, launched eagerly on the three streams (with a reducer: every gradient range goes to the exchange as soon as
-        it is final)."""
-        self._run(self._segments(batch, noise))
-        self.optimizer_step(lr)
+        """One micro-step, launched eagerly on the three streams (with a reducer and no accumulation: every gradient range goes
+        to the exchange as soon as it is final); the optimizer steps on every ``ga``-th call."""
+        self._run(self._segments(batch, noise, 1.0 / self.ga), exchange=self.ga == 1)
+        if self._accumulate():
+            self.optimizer_step(lr)
         return self._loss3
 
     def capture(self, batch: Dict[str, torch.Tensor], noise: Optional[torch.Tensor] = None, warmup: int = 2):
@@ -694,10 +838,10 @@ class BackboneTrainer:
         3000-5000 launches: issued from Python they cost more host time than GPU time."""
         for _ in range(warmup):                      # allocate every buffer / set kernel attributes outside the capture
             self.head.dirty = True
-            self._run(self._segments(batch, noise), exchange=False)
+            self._run(self._segments(batch, noise, 1.0 / self.ga), exchange=False)
         torch.cuda.synchronize()
         self.head.dirty = True                       # the head's own W^T / padded-operand refresh becomes part of its graphs
-        self._segs = self._segments(batch, noise)
+        self._segs = self._segments(batch, noise, 1.0 / self.ga)
         # one memory pool and one capture stream per stream kind: graphs sharing a pool are replayed strictly in capture order on
         # ONE stream, so the allocator's reuse of freed capture-time temporaries stays race-free while the streams overlap
         pools = {k: torch.cuda.graph_pool_handle() for k in "MHG"}
@@ -718,9 +862,10 @@ class BackboneTrainer:
         torch.cuda.synchronize()
 
     def train_step_graphed(self, lr: float):
-        self._run(self._segs, self._graphs)
-        self.optimizer_step(lr, refresh=False)
-        self._g_r.replay()
+        self._run(self._segs, self._graphs, exchange=self.ga == 1)
+        if self._accumulate():
+            self.optimizer_step(lr, refresh=False)
+            self._g_r.replay()
         return self._loss3
 
     def _adam_ranges(self):
@@ -827,6 +972,7 @@ class FullFinetune(BackboneTrainer):
         for L in self.llm.layers:
             for k in ("wqkv", "wo", "wgu", "wd"):
                 ops.transpose(L[k], out=L[k + "T"])
+        self._refresh_objective()
 
     refresh_transposes = refresh
 
