@@ -30,6 +30,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -151,9 +152,9 @@ class BackboneTrainer:
         self.n_active = min(cfg.llm.n_layers, cfg.num_blocks)      # LLM layers that reach the loss (see _segments)
         self.ga, self._micro, self._gacc = 1, 0, None             # gradient accumulation (set_grad_accumulation)
         self.objective = "l1"
+        self.overlap_update = not os.environ.get("VLA_NO_UPDATE_OVERLAP")      # AdamW range by range under the backward (_run)
         # Streams of the step schedule (_segments): the caller's stream carries the dX chain, `gstream` everything that only feeds a
         # parameter gradient, `hstream` the action head.  VLA_TRAINER_STREAMS=1: everything in line, 2: no separate head stream.
-        import os
         nstreams = int(os.environ.get("VLA_TRAINER_STREAMS", "3"))
         self.gstream = torch.cuda.Stream() if nstreams > 1 else None
         self.hstream = torch.cuda.Stream() if nstreams > 2 else None
@@ -682,9 +683,13 @@ class BackboneTrainer:
     def _stream(self, name: str, main):
         return main if name == "M" else ((self.hstream or main) if name == "H" else (self.gstream or main))
 
-    def _run(self, segs, graphs=None, exchange: bool = True):
+    def _run(self, segs, graphs=None, exchange: bool = True, update=None):
         """Enqueue the segments in order (eagerly, or as replays of their captured graphs); events cross the streams; a segment's
-        finished gradient ranges go to the exchange behind an event of their own.  The caller's stream joins the others at the end."""
+        finished gradient ranges go to the exchange behind an event of their own.  The caller's stream joins the others at the end.
+        update=(lr, betas, eps, wd): AdamW runs RANGE BY RANGE on the gradient stream as soon as a range is final (and exchanged) -
+        the backward reads only the W^T copies of a weight, never the parameter itself, so the 15 GB of optimiser traffic of a full
+        fine-tune hides under the rest of the backward instead of trailing it (torch's optimizer.step() after loss.backward(),
+        vla-scripts/finetune.py:1078-1082: same arithmetic, every use of a parameter in the NEXT forward sees the updated value)."""
         main = torch.cuda.current_stream()
         for st in (self.hstream, self.gstream):
             if st is not None:
@@ -707,9 +712,26 @@ class BackboneTrainer:
                         ev[signal] = e
                     if ranges and exchange:
                         self._exchange(ranges, after_event=e)
+                    if ranges and update is not None:
+                        self._update_ranges(ranges, e, update)
         for st in (self.hstream, self.gstream):
             if st is not None:
                 main.wait_stream(st)
+
+    def _update_ranges(self, ranges, final_event, update):
+        lr, beta1, beta2, eps, wd = update
+        red = self.eng.reducer
+        st = self.gstream or torch.cuda.current_stream()
+        with torch.cuda.stream(st):
+            st.wait_event(final_event)
+            gscale = 1.0
+            if red is not None:                      # the range's collectives were just queued on the exchange stream: wait for them
+                st.wait_stream(red.stream)
+                gscale = red.grad_scale
+            for buf, lo, hi in ranges:
+                P = self.P if buf is self.P.grad else self.head.P
+                if hi > lo:
+                    ops.adamw_(P.data[lo:hi], P.grad[lo:hi], P.m[lo:hi], P.v[lo:hi], self.step_count, lr, beta1, beta2, eps, wd, gscale=gscale)
 
     def _run_inline(self, segs):
         """The same pieces one after the other on the current stream, gradient work in line (forward() / backward())."""
@@ -824,6 +846,11 @@ class BackboneTrainer:
     def train_step(self, batch, lr: float, noise=None):
         """One micro-step, launched eagerly on the three streams (with a reducer and no accumulation: every gradient range goes
         to the exchange as soon as it is final); the optimizer steps on every ``ga``-th call."""
+        if self.ga == 1 and self.overlap_update:
+            self.step_count += 1
+            self._run(self._segments(batch, noise), update=(lr, 0.9, 0.999, 1e-8, 0.01))
+            self._after_update(refresh=True)
+            return self._loss3
         self._run(self._segments(batch, noise, 1.0 / self.ga), exchange=self.ga == 1)
         if self._accumulate():
             self.optimizer_step(lr)
@@ -862,11 +889,24 @@ class BackboneTrainer:
         torch.cuda.synchronize()
 
     def train_step_graphed(self, lr: float):
+        if self.ga == 1 and self.overlap_update:
+            self.step_count += 1
+            self._run(self._segs, self._graphs, update=(lr, 0.9, 0.999, 1e-8, 0.01))
+            self._after_update(refresh=False)
+            self._g_r.replay()
+            return self._loss3
         self._run(self._segs, self._graphs, exchange=self.ga == 1)
         if self._accumulate():
             self.optimizer_step(lr, refresh=False)
             self._g_r.replay()
         return self._loss3
+
+    def _after_update(self, refresh: bool):
+        if self.eng.reducer is not None:
+            self.eng.reducer._pending = False        # every collective was joined range by range (_update_ranges)
+        self.head.dirty = True
+        if refresh:
+            self.refresh()
 
     def _adam_ranges(self):
         return [(0, self.P.numel)]
