@@ -565,8 +565,17 @@ inline bool use_256(int M, int N, int K, int batch, int act) {
   // first one's epilogue); on the step the two routings tie (25.25-25.34 vs 25.29-25.32 ms)
   const int ncu = vla_num_cus();
   if ((act == VLA_ACT_GELU || act == VLA_ACT_GELU_TANH) && tiles > ncu && (tiles % ncu) != 0 && (tiles % ncu) * 4 < ncu) return false;
-  static const int min_tiles = getenv("VLA_GEMM256_MIN_TILES") ? atoi(getenv("VLA_GEMM256_MIN_TILES")) : 96;      // (A/B aid)
-  return M >= 1024 && N >= 768 && K >= 256 && tiles >= min_tiles;
+  if (const char* mt = getenv("VLA_GEMM256_MIN_TILES"))      // (A/B aid: the round-2 rule, a plain tile-count threshold)
+    return M >= 1024 && N >= 768 && K >= 256 && tiles >= atoi(mt);
+  // Rounds model (round 3, tools/bench_tiles_b16.py): a 256 x 256 tile is four 128 x 128 tiles of work on one CU; the 128-row kernel
+  // keeps two workgroups per CU and reaches ~0.87 of the 256-row kernel's per-CU rate.  Cost in units of "one 128 x 128 tile at
+  // the 256-row kernel's rate":  rounds256 x 4  against  rounds128 x 2 / 0.87.  Reproduces every measured winner of the batch-32
+  // step (gate/up, down, o, q|k|v, ViT qkv / proj / fc2, task K/V -> 256) and of the batch-16 shapes of the LoRA / full steps, where
+  // the round-2 threshold (>= 96 tiles) sent two shapes the wrong way: LLM q|k|v 5632 x 1152 (110 tiles = 0.43 round: 25.2 vs
+  // 17.3 us) and ViT fc1 / dX fc2 4096 x 4352 (272 tiles = 1.06 rounds: 58.3 vs 47.8 us).
+  const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * batch;
+  const double est256 = (double)((tiles + ncu - 1) / ncu) * 4.0, est128 = (double)((t128 + 2 * ncu - 1) / (2 * ncu)) * (2.0 / 0.87);
+  return M >= 1024 && N >= 768 && K >= 256 && est256 < est128;
 }
 inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode, int batch = 1, int split = 1, int act = 0) {
   // rotate_half RoPE is fused in both kernels (bit-identical).  The LLM's q|k|v projection goes to the 256-row kernel when it
