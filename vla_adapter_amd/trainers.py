@@ -206,6 +206,8 @@ class BackboneTrainer:
         # per-layer dY of the four Linears (residual-stream gradient = dY of down_proj, d1 = dY of o_proj): 3.4 GB at batch 16
         self.G_res, self.G_d1, self.G_gu, self.G_qkv = e(n, M, D), e(n, M, D), e(n, M, 2 * I), e(n, M, W_)
         self.d_last = e(M, D)
+        if self.trains_vectors:       # dY of the two RMSNorms per layer: their weight gradients run on the gradient stream too (0.5 GB)
+            self.G_n1, self.G_n2 = e(n, M, D), e(n, M, D)
         self.dfeats = e(B * cfg.n_patches, cfg.vis_dim)
         self.dp = e(B * cfg.n_patches, D)
         self.pj = {}
@@ -334,9 +336,10 @@ class BackboneTrainer:
             if tap is not None:
                 tap["d_out"] = d.clone()
             d_gu = self._lin_bwd(k + "down", d, self.Hs[i], L["wdT"], out=self.G_gu[i], swiglu_gu=llm.GU[i])
-            d_n = self._lin_bwd(k + "gu", d_gu, self.N2[i], L["wguT"], out=llm.d_n[:M])
+            d_n = self._lin_bwd(k + "gu", d_gu, self.N2[i], L["wguT"], out=self.G_n2[i] if tv else llm.d_n[:M])
             if tv:
-                ops.N.check(lib.vla_rmsnorm_dw(st(), p(d_n), p(llm.X1[i]), p(llm.R2[i]), p(self.A(k + "n2")), M, D), "rmsnorm_dw")
+                self._defer(lambda dy=d_n, x=llm.X1[i], r=llm.R2[i], acc=self.A(k + "n2"):
+                            ops.N.check(ops._lib().vla_rmsnorm_dw(ops._st(), ops._p(dy), ops._p(x), ops._p(r), ops._p(acc), M, D), "rmsnorm_dw"))
             d1 = ops.rmsnorm_bwd(d_n, llm.X1[i], L["n2"], llm.R2[i], dres=d, out=self.G_d1[i])
             dao = self._lin_bwd(k + "o", d1, llm.AO[i], L["woT"], out=llm.d_n[:M])
             q, kk, v = llm._attn_views(llm.QKV[i].view(B, S, -1))
@@ -347,10 +350,11 @@ class BackboneTrainer:
             if dh != 64:
                 ops.rope_half_(d_qkv[:, :H * dh], llm.cos, llm.sin, S, H, dh, sign=-1)
                 ops.rope_half_(d_qkv[:, H * dh:(H + KV) * dh], llm.cos, llm.sin, S, KV, dh, sign=-1)
-            d_n = self._lin_bwd(k + "qkv", d_qkv, self.N1[i], L["wqkvT"], out=llm.d_n[:M])
+            d_n = self._lin_bwd(k + "qkv", d_qkv, self.N1[i], L["wqkvT"], out=self.G_n1[i] if tv else llm.d_n[:M])
             if tv:
                 self._defer(lambda dy=d_qkv, acc=self.A(k + "bqkv"): ops.colsum_(dy, acc))
-                ops.N.check(lib.vla_rmsnorm_dw(st(), p(d_n), p(llm.HS[i].view(M, D)), p(llm.R1[i]), p(self.A(k + "n1")), M, D), "rmsnorm_dw")
+                self._defer(lambda dy=d_n, x=llm.HS[i].view(M, D), r=llm.R1[i], acc=self.A(k + "n1"):
+                            ops.N.check(ops._lib().vla_rmsnorm_dw(ops._st(), ops._p(dy), ops._p(x), ops._p(r), ops._p(acc), M, D), "rmsnorm_dw"))
             d = ops.rmsnorm_bwd(d_n, llm.HS[i].view(M, D), L["n1"], llm.R1[i], dres=d1, out=self.G_res[i - 1] if i > 0 else self.d_last)
             if tap is not None:
                 tap["d_in"] = d.clone()
@@ -1029,9 +1033,9 @@ class FullFinetune(BackboneTrainer):
         return ops.gemm_nt(dy, WT, out=out)
 
     def _embed_backward(self, dX0):
-        ids = self._batch["input_ids"]
-        ops.N.check(ops._lib().vla_embed_grad(ops._st(), ops._p(dX0), ops._p(ids), ops._p(self.eng.qidx0), ops._p(self.G("llm.embed")),
-                                              self.eng.B, ids.shape[1], self.eng.Np, self.cfg.llm.d, self.cfg.llm.vocab), "embed_grad")
+        ids, q0, G, B, Np = self._batch["input_ids"], self.eng.qidx0, self.G("llm.embed"), self.eng.B, self.eng.Np
+        self._defer(lambda: ops.N.check(ops._lib().vla_embed_grad(ops._st(), ops._p(dX0), ops._p(ids), ops._p(q0), ops._p(G), B, ids.shape[1], Np,
+                                                                  self.cfg.llm.d, self.cfg.llm.vocab), "embed_grad"))      # gradient-only: off the dX chain
 
     def _adam_ranges(self):
         na, n = self.n_active, self.cfg.llm.n_layers
