@@ -82,6 +82,8 @@ class FinetuneConfig:
     max_seq_len: int = 0                  # static token length every batch is right-padded to (0: length of the first batch)
     conservative_rows: bool = False       # captured live-row window starts at the first text row instead of the first batch's action block
     dataset_statistics_file: Optional[str] = None   # JSON written next to every checkpoint (finetune.py:531)
+    objective: str = "l1"                 # "l1": action head + L1 regression (the reference's finetune.py); "token_ce": the native VLM / VLA trainer's
+                                          # token cross-entropy (base_strategy.py:257-417) - LoRA / full modes only, no action head in the loss
     backbone: Optional[str] = None        # model geometry: a name of engine.NAMED_CONFIGS ("config2", "dinosiglip-0_5b", "config5",
                                           # "tiny", "tiny_fused") - default: inferred from the --vlm_path state dict, else "config2"
     # fmt: on
@@ -127,6 +129,10 @@ def check_supported(cfg: FinetuneConfig, explicit=()) -> None:
         raise ValueError("grad_accumulation_steps must be >= 1")
     if cfg.use_lora and cfg.lora_dropout != 0.0:
         raise NotImplementedError("--lora_dropout > 0: the low-rank branch is built without dropout (every shipped script uses 0.0)")
+    if cfg.objective not in ("l1", "token_ce"):
+        raise ValueError("--objective is l1 or token_ce")
+    if cfg.objective == "token_ce" and train_mode(cfg) == "adapter":
+        raise NotImplementedError("--objective token_ce trains the VLM (LoRA or full fine-tune); --use_fz True freezes it")
     if cfg.backbone is not None:
         from .engine import NAMED_CONFIGS
         if cfg.backbone not in NAMED_CONFIGS:
@@ -330,6 +336,8 @@ def finetune(cfg: FinetuneConfig, batches=None, explicit=()) -> dict:
         trainer = FullFinetune(eng)
     use_graph = cfg.use_graph
     (trainer or eng).set_grad_accumulation(cfg.grad_accumulation_steps)
+    if cfg.objective != "l1":
+        trainer.set_objective(cfg.objective)
     stream = batch_stream(cfg, mcfg, dev, rank, batches)
     pad_id = min(S.PAD_ID, mcfg.llm.vocab - 1)
     cur = next(stream)
