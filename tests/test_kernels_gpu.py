@@ -932,6 +932,29 @@ def test_gemm256_bit_identical_to_128_tiles(ops, M, N, K, act, monkeypatch):
         check(out, O.rnd(y + f(r), True) if act != 1 else y, name=f"gemm256 vs oracle {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 1024, 64), (2048, 1024, 128), (2048, 1024, 192), (2048, 1024, 256), (4096, 2304, 896), (8192, 1152, 4352)])
+def test_gemm256_race_screen(ops, M, N, K, monkeypatch):
+    """The two-phase K loop is a sync structure of its own (segment-counted WAR / RAW distances, hand-counted vmcnt): screened by
+    repetition - every tile of 25 launches, run while a second stream keeps the memory system busy (the LDS-DMA's landing time
+    moves with the load), must equal the 128-row kernel's result bit for bit, with and without a residual; K = 64 ... 256 are the
+    one- to four-K-tile prologue / tail cases of the counted waits."""
+    a, b, bias, r = gen(M, K, seed=221).to(DEV), gen(N, K, seed=222, scale=0.05).to(DEV), gen(N, seed=223).to(DEV), gen(M, N, seed=224).to(DEV)
+    junk, side = torch.empty(64 << 20, dtype=torch.uint8, device=DEV), torch.cuda.Stream()
+    for res in (None, r):
+        monkeypatch.setenv("VLA_GEMM_TILE", "2")
+        ref = ops.gemm_nt(a, b, bias=bias, residual=res, split_k=0)
+        monkeypatch.setenv("VLA_GEMM_TILE", "6")
+        outs = []
+        for i in range(25):
+            with torch.cuda.stream(side):
+                junk.add_(1)
+            outs.append(ops.gemm_nt(a, b, bias=bias, residual=res, split_k=0))
+        torch.cuda.synchronize()
+        bad = [i for i, o in enumerate(outs) if not torch.equal(o, ref)]
+        assert not bad, f"gemm256 {M}x{N}x{K} residual={res is not None}: launches {bad} differ from the 128-row kernel"
+    monkeypatch.setenv("VLA_GEMM_TILE", "0")
+
+
 def test_gemm256_swiglu_forward_and_backward_bit_identical(ops, monkeypatch):
     M, D, I = 1100, 896, 1216
     x, wg, wu = gen(M, D, seed=211), gen(I, D, seed=212, scale=0.05), gen(I, D, seed=213, scale=0.05)

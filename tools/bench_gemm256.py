@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of the GEMM tile choices on the step's hot shapes (same process, interleaved rounds, random operands):
-auto (what the step runs) | 128x128 8-wave (VLA_GEMM_TILE=2) | 256x256 8-phase (VLA_GEMM_TILE=6) | vendor calibration (torch.matmul,
+auto (what the step runs) | 128x128 8-wave (VLA_GEMM_TILE=2) | 256x256 two-phase (VLA_GEMM_TILE=6) | vendor calibration (torch.matmul,
 never on the product path).  Prints TF/s per variant: median over rounds."""
 import os
 import statistics
@@ -50,16 +50,12 @@ def main():
             fn = lambda: ops.gemm_nt(a, w, bias=bias, residual=res_t, out=out, split_k=0)
         else:
             fn = lambda: ops.gemm_nt(a, w, bias=bias, act=act, out=out, split_k=0)
-        variants = [("auto", "0"), ("128x128", "2"), ("256-8ph", "6"), ("256 xcd-blocked", "6:x")]
+        variants = [("auto", "0"), ("128x128", "2"), ("256x256", "6")]
         res = {k: [] for k, _ in variants}
         res["vendor"] = []
         wt = w.t()
         def setv(v):
             os.environ["VLA_GEMM_TILE"] = v.split(":")[0]
-            if v.endswith(":x"):
-                os.environ["VLA_GEMM256_XCD"] = "1"          # opt-in XCD-blocked tile order (gemm256.hip launch256)
-            else:
-                os.environ.pop("VLA_GEMM256_XCD", None)
         for k, v in variants:
             setv(v)
             fn()

@@ -7,25 +7,31 @@
 // CU's global->LDS fill rate; this tile stages half the bytes per FLOP and keeps its LDS-DMA in flight
 // across barriers instead of relying on a second resident workgroup.
 //
-// Structure (cdna_hip_programming.md section 5, "The 256^2 8-phase template"):
-//   * 8 waves as 2 (M) x 4 (N); wave tile 128 x 64 = four 64 x 32 quadrants Q(mh, nh); one quadrant x K = 64 is a PHASE
-//     (16 MFMAs).  Quadrant order per K-tile: Q00, Q01, Q11, Q10 - the A fragments are read twice per K-tile (8 reads each),
-//     the B fragments twice (4 reads each), B0 stays in registers for Q10: 24 ds_read_b128 per 64 MFMAs.
+// Structure (after cdna_hip_programming.md section 5, "The 256^2 8-phase template", re-derived in round 3 as TWO phases per K-tile):
+//   * 8 waves as 2 (M) x 4 (N); wave tile 128 x 64 = four 64 x 32 quadrants Q(mh, nh), 16 MFMAs each per K-tile.
 //   * operands live in LDS as eight 16-KiB HALF-TILES (2 K-tile buffers x {B0, A0, B1, A1}); A-half h holds rows
-//     {wr*128 + h*64 + [0,64)} of the tile, B-half h columns {wc*64 + h*32 + [0,32)}: every wave needs exactly one A-half
-//     and one B-half per quadrant.  Half-tiles are filled by global_load_lds_dwordx4 (2 per wave per half-tile) with the
-//     16-B-chunk XOR swizzle on the SOURCE address and on the fragment read.
-//   * phase p issues half-tile p + 7 (seven half-tiles = almost two K-tiles ahead); ONE counted wait per K-tile
-//     (s_waitcnt vmcnt(6) in the Q10 phase: three half-tiles stay in flight), never vmcnt(0) before the last two K-tiles.
-//   * every phase is two segments separated by raw s_barriers: {fragment reads + DMA issue} | {16 MFMAs}.  The wr = 1 waves
-//     run ONE SEGMENT behind the wr = 0 waves (one extra barrier at the start), so on every SIMD one wave multiplies while
-//     its partner (waves w and w + 4 share a SIMD) reads LDS and issues DMA.
-//   * hazards, by barrier count (both wave groups take part in every barrier):
-//       RAW  a half-tile issued in phase p is retired by the counted wait of the next Q10 phase P >= p + 3 (in both groups, the
-//            later one a segment later) and read from phase P + 1 on;
-//       WAR  slot of half-tile h is refilled in phase h + 1: B0 is last read in phase h (its 4 reads are retired by the
-//            lgkmcnt(8) BEFORE that phase's first barrier), A0/B1/A1 are refilled >= 2 phases after their last read.
-//   * epilogue through the (now free) operand LDS: per wave two 64 x 64 passes, 16-B stores of whole row segments.
+//     {wr*128 + h*64 + [0,64)} of the tile, B-half h columns {wc*64 + h*32 + [0,32)}.  Half-tiles are filled by
+//     global_load_lds_dwordx4 (2 per wave per half-tile) with the 16-B-chunk XOR swizzle on the SOURCE address and on the
+//     fragment read.
+//   * a K-tile is two PHASES, each two SEGMENTS separated by raw s_barriers: {fragment reads + DMA issue + counted wait} |
+//     {32 MFMAs}.  Phase X reads B0, A0, B1 (16 ds_read_b128) and multiplies Q00, Q01; phase Y reads A1 (8) and multiplies Q11,
+//     Q10 (B0 / B1 stay in registers).  The wr = 1 waves run ONE SEGMENT behind the wr = 0 waves (one extra barrier at the
+//     start), so on every SIMD one wave multiplies while its partner (waves w and w + 4 share a SIMD) reads LDS and issues DMA.
+//     The template's four phases of 16 MFMAs (eight barriers per K-tile) measured 5 - 12 % slower on every shape of the step
+//     (tools/bench_gemm256.py, round 3): in-kernel stamps put this K loop at 2 090 - 2 130 cycles per K-tile against 2 048 for
+//     its 128 MFMAs per SIMD - what is left between it and the vendor kernel is the clock the chip holds under it, not cycles.
+//   * hazards, by segment count (segments of the wr = 0 waves: 4t X-read, 4t+1 X-mma, 4t+2 Y-read, 4t+3 Y-mma; wr = 1 one later;
+//     every read segment ends with lgkmcnt(0) BEFORE its closing barrier):
+//       WAR  B0/A0/B1 of K-tile t: last read in segment 4t+1, refilled (K-tile t+2) in Y-read(t) = 4t+2 / 4t+3;
+//            A1 of K-tile t: last read in 4t+3, refilled (K-tile t+2) in X-read(t+1) = 4t+4 / 4t+5;
+//       RAW  B0/A0/B1 of K-tile t+1 (issued in Y-read(t-1) / at the tile top) are retired by the counted wait of Y-read(t)
+//            (segments 4t+2, 4t+3; first read in 4t+4); A1 of K-tile t+1 (issued in X-read(t)) by the wait of X-read(t+1)
+//            (4t+4, 4t+5; first read in 4t+6).  Issue -> wait distance: four segments for every half-tile; never vmcnt(0)
+//            before the last two K-tiles.
+//   * epilogue through the (now free) operand LDS: per wave two 64 x 64 passes, 16-B stores of whole row segments; a pass requests
+//     its eight staged segments before the first store waits for one (eight serial LDS round trips per pass were the epilogue's
+//     largest single item on the stamped build: tools/diag/g256_stamps.py).  Residual segments are requested only by the
+//     instantiation that adds one (template flag RES).
 //   * PERSISTENT over tiles: at most one workgroup per CU walks the tile list.  K-tile 0 of the NEXT tile is issued (LDS-DMA
 //     into the K-tile buffer the epilogue does not stage through) before the epilogue of the current one, so the pipeline
 //     fill of every tile but a workgroup's first hides behind an epilogue; the epilogue's stores drain behind the next fill.
@@ -90,10 +96,11 @@ __device__ __forceinline__ v8i_f8 cat8(bf16x8 lo, bf16x8 hi) {          // two 1
 // F8: OCP e4m3 operands with per-row fp32 scales (gemm.hip's fp8 form, same conventions): a K-tile stays 128 B per row = 128
 // elements = ONE v_mfma_scale_f32_16x16x128_f8f6f4 per 16 x 16 tile instead of two bf16 MFMAs - identical staging, LDS image and
 // barrier structure, half the K-tiles per product.  The scales are applied to the accumulators at the start of the epilogue.
-template <int EPI, bool F8 = false>
+template <int EPI, bool F8 = false, bool RES = true>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int EB = F8 ? 1 : 2;      // bytes per operand element
+  constexpr bool HAS_RES = EPI == 0 && RES;   // residual segments are requested (always all sixteen: see below) only by launches that add one
   constexpr bool PRE = EPI != 2;      // next tile's K-tile 0 in flight during the epilogue (SwiGLU backward stages wider rows)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
     for (int t = 0; t < nt; ++t) {
       const char* kb = smem + d * 4 * HT;
       const int so = d * 4, sn = (d ^ 1) * 4;
-      // ================= phase Q00: reads B0 (4, first) + A0 (8); issues A1 of K-tile t+1
+      // ================= phase X: reads B0 (4), A0 (8), B1 (4); issues A1 of K-tile t+1; retires A1 of K-tile t
       {
         const char* sb = kb + 0 * HT + boff;
 #pragma unroll
@@ -251,43 +258,34 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
           fb0[ni][0] = *reinterpret_cast<const bf16x8*>(sb + ni * 2048 + fo0);
           fb0[ni][1] = *reinterpret_cast<const bf16x8*>(sb + ni * 2048 + fo1);
         }
-        __builtin_amdgcn_sched_barrier(0);
         const char* sa = kb + 1 * HT + aoff;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
           fa[mi][0] = *reinterpret_cast<const bf16x8*>(sa + mi * 2048 + fo0);
           fa[mi][1] = *reinterpret_cast<const bf16x8*>(sa + mi * 2048 + fo1);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < nt) stage_a(sn + 3, 1, (t + 1) * BK);
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");     // the B0 reads are done: its slot is refilled next phase
-        VLA_BARRIER();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-        VLA_MMA_QUADRANT(acc[0][0], fb0, fa);
-        __builtin_amdgcn_s_setprio(0);
-        VLA_BARRIER();
-      }
-      // ================= phase Q01: reads B1 (4); issues B0 of K-tile t+2
-      {
-        const char* sb = kb + 2 * HT + boff;
+        const char* sb1 = kb + 2 * HT + boff;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-          fb1[ni][0] = *reinterpret_cast<const bf16x8*>(sb + ni * 2048 + fo0);
-          fb1[ni][1] = *reinterpret_cast<const bf16x8*>(sb + ni * 2048 + fo1);
+          fb1[ni][0] = *reinterpret_cast<const bf16x8*>(sb1 + ni * 2048 + fo0);
+          fb1[ni][1] = *reinterpret_cast<const bf16x8*>(sb1 + ni * 2048 + fo1);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 2 < nt) stage_b(so + 0, 0, (t + 2) * BK);
-        VLA_BARRIER();
+        if (t + 1 < nt) {
+          stage_a(sn + 3, 1, (t + 1) * BK);
+          if (t > 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // A1 of K-tile t is in; B0/A0/B1 + A1 of t+1 in flight
+        } else if (t > 0) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+        VLA_BARRIER();
         __builtin_amdgcn_s_setprio(1);
+        VLA_MMA_QUADRANT(acc[0][0], fb0, fa);
         VLA_MMA_QUADRANT(acc[0][1], fb1, fa);
         __builtin_amdgcn_s_setprio(0);
         VLA_BARRIER();
       }
-      // ================= phase Q11: reads A1 (8); issues A0 of K-tile t+2
+      // ================= phase Y: reads A1 (8); issues B0, A0, B1 of K-tile t+2; retires B0, A0, B1 of K-tile t+1
       {
         const char* sa = kb + 3 * HT + aoff;
 #pragma unroll
@@ -296,25 +294,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
           fa[mi][1] = *reinterpret_cast<const bf16x8*>(sa + mi * 2048 + fo1);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 2 < nt) stage_a(so + 1, 0, (t + 2) * BK);
-        VLA_BARRIER();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-        VLA_MMA_QUADRANT(acc[1][1], fb1, fa);
-        __builtin_amdgcn_s_setprio(0);
-        VLA_BARRIER();
-      }
-      // ================= phase Q10: no reads (B0 kept in registers); issues B1 of K-tile t+2; the K-tile's counted wait
-      {
         if (t + 2 < nt) {
-          stage_b(so + 2, 1, (t + 2) * BK);
-          asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // K-tile t+1 has landed; three half-tiles of t+2 in flight
+          stage_b(so + 0, 0, (t + 2) * BK); stage_a(so + 1, 0, (t + 2) * BK); stage_b(so + 2, 1, (t + 2) * BK);
+          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // (t = 0: the four bias loads sit between K-tile 1 and these - retired too)
+        } else if (t + 1 < nt) {
+          asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // A1 of the last K-tile stays in flight
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         VLA_BARRIER();
         __builtin_amdgcn_s_setprio(1);
+        VLA_MMA_QUADRANT(acc[1][1], fb1, fa);
         VLA_MMA_QUADRANT(acc[1][0], fb0, fa);
         __builtin_amdgcn_s_setprio(0);
         VLA_BARRIER();
@@ -367,7 +358,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
     }
     // the two 64 x 64 halves of this wave: outside C / entirely inside / on its edge
     bf16_t* Cb = p.C + (long long)ez * p.sC;
-    const bf16_t* Rb = (EPI == 0 && p.R) ? p.R + (long long)ez * p.sR : nullptr;
+    const bf16_t* Rb = (HAS_RES && p.R) ? p.R + (long long)ez * p.sR : nullptr;
     const bool vec_ok = ((p.ldc & 7) == 0) && (!Rb || (p.ldr & 7) == 0);
     const bool plain_rows = (res_mod | gR | gC | c_live_mod) == 0;
     bool skip[2], inside[2], fastm[2];
@@ -386,7 +377,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
     u32x4 rv[2][8];
     int fres0 = 0, fres1 = 0;
     const char* rsrc = nullptr;
-    if constexpr (EPI == 0) {
+    if constexpr (HAS_RES) {
       long long rdist = Rb ? (long long)((uintptr_t)Rb - (uintptr_t)p.B) : 0;
       fres0 = __builtin_amdgcn_readfirstlane((fastm[0] && Rb) ? 1 : 0);
       fres1 = __builtin_amdgcn_readfirstlane((fastm[1] && Rb) ? 1 : 0);
@@ -407,7 +398,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
     // next tile: its K-tile 0 goes out now
     if (PRE && nxt >= 0) { setup(nxt); stage_k0(d); }
     char* const reg = PRE ? smem + (d ^ 1) * 4 * HT + wid * STG : smem + wid * STG;
-    if constexpr (EPI == 0) load_res(0, 0, 4); // the first segments: in flight under the activation math (16 registers: all 32
+    if constexpr (HAS_RES) load_res(0, 0, 4); // the first segments: in flight under the activation math (16 registers: all 32
                                                // of the half do not fit beside 128 accumulators)
 
     if constexpr (EPI == 2) {
@@ -559,12 +550,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
       //      - the half entirely inside C, 16-B aligned rows, plain row addressing - runs without a branch and with all its
       //      residual segments requested up front (in the general path every conditional load is followed by its own
       //      vmcnt(0): 16 serial round trips per tile).
-      if constexpr (EPI == 0) { load_res(0, 4, 8); load_res(1, 0, 8); }     // the rest: behind the first stores
+      if constexpr (HAS_RES) { load_res(0, 4, 8); load_res(1, 0, 8); }     // the rest: behind the first stores
 #pragma unroll
       for (int mh = 0; mh < 2; ++mh) {
         const int wm0 = em0 + wr * 128 + mh * 64;
         if (skip[mh]) {
-          if constexpr (EPI == 0) drop_res(mh);
+          if constexpr (HAS_RES) drop_res(mh);
           continue;
         }
         if constexpr (EPI == 1) {
@@ -577,11 +568,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
             for (int mi = 0; mi < 4; ++mi)
               *reinterpret_cast<uint2*>(reg + (mi * 16 + lr) * HSTR + (pr * 16 + lq * 4) * 2) = hp[mh][pr][mi];
           const bool hvec = ((p.ldc2 & 7) == 0) && (((size_t)C2 & 15) == 0);
+          uint4 hv[4];
+#pragma unroll
+          for (int it = 0; it < 4; ++it) hv[it] = *reinterpret_cast<const uint4*>(reg + (it * 16 + (el >> 2)) * HSTR + (el & 3) * 16);
+          __builtin_amdgcn_sched_barrier(0);                      // (the four staged segments in flight before the first store)
 #pragma unroll
           for (int it = 0; it < 4; ++it) {                        // 64 rows x 4 chunks of 16 B: 16 rows per pass
             const int row = it * 16 + (el >> 2), ch = el & 3;
             const int m = wm0 + row, hc = (wn0 >> 1) + ch * 8;
-            const uint4 v = *reinterpret_cast<const uint4*>(reg + row * HSTR + ch * 16);
+            const uint4 v = hv[it];
             if (hvec && inside[mh]) {                             // (wave-uniform) whole half inside: no per-lane test
               *reinterpret_cast<uint4*>(C2 + (long long)m * p.ldc2 + hc) = v;
               continue;
@@ -609,11 +604,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
             *reinterpret_cast<uint2*>(reg + row * 128 + (((t4 * 2 + (lq >> 1)) ^ ((row >> 1) & 7)) << 4) + (lq & 1) * 8) = pk[mh][t4][mi];
           }
         if (fastm[mh]) {
+          // all eight staged segments are requested before the first store waits for one (one LDS round trip per half instead
+          // of eight serial ones: 270 cycles each on the stamped build - the epilogue's stores are not what it waits for)
+          uint4 vv[8];
 #pragma unroll
           for (int it = 0; it < 8; ++it) {                       // 64 rows x 8 chunks of 16 B: 8 rows per pass
             const int row = it * 8 + (el >> 3), ch = el & 7;
-            uint4 v = *reinterpret_cast<const uint4*>(reg + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
-            if constexpr (EPI == 0) {
+            vv[it] = *reinterpret_cast<const uint4*>(reg + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            const int row = it * 8 + (el >> 3), ch = el & 7;
+            uint4 v = vv[it];
+            if constexpr (HAS_RES) {
               const u32x4 r = rv[mh][it];
               const unsigned a[4] = {v.x, v.y, v.z, v.w};
               unsigned o[4];
@@ -671,7 +675,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
             }
           }
         };
-        if constexpr (EPI == 0) drop_res(mh);
+        if constexpr (HAS_RES) drop_res(mh);
         if (plain_rows) store_rows(std::true_type{});
         else store_rows(std::false_type{});
       }
@@ -693,7 +697,7 @@ int num_cus() {
   return n;
 }
 
-template <int EPI, bool F8 = false>
+template <int EPI, bool F8 = false, bool RES = true>
 int launch256(const GemmP& p0, int batch, hipStream_t st) {
   GemmP p = p0;
   p.tiles_n = (p.N + 255) / 256;
@@ -701,7 +705,7 @@ int launch256(const GemmP& p0, int batch, hipStream_t st) {
   p.batch = batch;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, F8, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
   // one workgroup per CU walks the tiles (VLA_GEMM256_GRID overrides the workgroup count: 0 = one workgroup per tile)
@@ -729,7 +733,7 @@ int launch256(const GemmP& p0, int batch, hipStream_t st) {
   long long grid = ge ? atoll(ge) : num_cus();
   if (grid <= 0 || grid > total) grid = total;
   if (grid % 8 != 0) p.xpx = p.xpy = 0;                    // (a workgroup must stay on its XCD's list: b and b + G share b & 7)
-  hipLaunchKernelGGL((gemm256_kernel<EPI, F8>), dim3((unsigned)grid), dim3(512), LDS_BYTES, st, p);
+  hipLaunchKernelGGL((gemm256_kernel<EPI, F8, RES>), dim3((unsigned)grid), dim3(512), LDS_BYTES, st, p);
   return 0;
 }
 
@@ -741,5 +745,5 @@ int vla_gemm256_launch(const GemmP& p, int epi, int batch, hipStream_t st) {
   if (p.scaleA != nullptr) return epi == 1 ? launch256<1, true>(p, batch, st) : launch256<0, true>(p, batch, st);     // fp8 operands
   if (epi == 1) return launch256<1>(p, batch, st);
   if (epi == 2) return launch256<2>(p, batch, st);
-  return launch256<0>(p, batch, st);
+  return p.R ? launch256<0, false, true>(p, batch, st) : launch256<0, false, false>(p, batch, st);
 }
