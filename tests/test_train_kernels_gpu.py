@@ -16,10 +16,18 @@ from test_kernels_gpu import BF, DEV, check, gen, ops  # noqa: E402,F401
 
 
 # ------------------------------------------------------------------ TN GEMM
+@pytest.fixture(params=["128", "256"])
+def tn_tile(request, monkeypatch):
+    """Both tile geometries of the TN product on every case: the 128 x 128 kernel and the 256 x 256 two-phase kernel (forced through
+    VLA_TN_TILE; contraction splits always run on the 128-tile kernel)."""
+    monkeypatch.setenv("VLA_TN_TILE", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("M,N1,N2", [(64, 128, 128), (256, 2688, 896), (2080, 1792, 896), (300, 200, 136), (1000, 64, 896), (5000, 896, 64),
-                                     (31, 8, 8), (129, 264, 72)])
+                                     (31, 8, 8), (129, 264, 72), (128, 512, 512), (192, 256, 256), (5632, 1152, 896)])
 @pytest.mark.parametrize("split", [0, None, 3])
-def test_gemm_tn_matches_transposed_product(ops, M, N1, N2, split):
+def test_gemm_tn_matches_transposed_product(ops, M, N1, N2, split, tn_tile):
     a, b = gen(M, N1, seed=1), gen(M, N2, seed=2, scale=0.1)
     if split == 3 and M < 192:
         pytest.skip("three slices need three K-tiles")
@@ -27,7 +35,7 @@ def test_gemm_tn_matches_transposed_product(ops, M, N1, N2, split):
     check(out, O.rnd(a.float().t() @ b.float(), True), name=f"gemm_tn {M}x{N1}x{N2} split {split}")
 
 
-def test_gemm_tn_is_deterministic_and_matches_the_nt_kernel_on_transposes(ops):
+def test_gemm_tn_is_deterministic_and_matches_the_nt_kernel_on_transposes(ops, tn_tile):
     """Same fp32 sums in the same K order as the NT kernel on explicitly transposed operands (the round-2 form of dW): the
     two agree to the last bf16 bit up to fp32 summation order inside a K-tile (k permutation) - asserted at 1e-3, and the TN
     kernel itself is run-to-run identical."""
@@ -40,7 +48,27 @@ def test_gemm_tn_is_deterministic_and_matches_the_nt_kernel_on_transposes(ops):
     check(o1, nt.float().cpu(), rel=1e-3, name="tn vs nt-on-transposes")
 
 
-def test_gemm_tn_batched_alpha_accumulate(ops):
+@pytest.mark.parametrize("M,N1,N2", [(64, 256, 256), (128, 256, 512), (192, 512, 256), (2080, 1792, 896), (5632, 896, 4864), (1000, 640, 136), (333, 264, 200)])
+def test_gemm_tn256_bit_identical_to_the_128_tile_kernel(ops, M, N1, N2, monkeypatch):
+    """Same rows per K-tile, same m order inside a k-step, K-tiles added in the same order: the two tile geometries must agree
+    to the last bit - on one- to three-K-tile contractions (the prologue / tail cases of the counted waits), ragged contraction
+    tails and ragged outputs, and while a second stream keeps the memory system busy (race screen by repetition)."""
+    a, b = gen(M, N1, seed=41).to(DEV), gen(M, N2, seed=42, scale=0.1).to(DEV)
+    monkeypatch.setenv("VLA_TN_TILE", "128")
+    ref = ops.gemm_tn(a, b, split=0)
+    monkeypatch.setenv("VLA_TN_TILE", "256")
+    junk, side = torch.empty(64 << 20, dtype=torch.uint8, device=DEV), torch.cuda.Stream()
+    outs = []
+    for _ in range(10):
+        with torch.cuda.stream(side):
+            junk.add_(1)
+        outs.append(ops.gemm_tn(a, b, split=0))
+    torch.cuda.synchronize()
+    bad = [i for i, o in enumerate(outs) if not torch.equal(o, ref)]
+    assert not bad, f"gemm_tn 256 vs 128 tiles {M}x{N1}x{N2}: launches {bad} differ"
+
+
+def test_gemm_tn_batched_alpha_accumulate(ops, tn_tile):
     nb, M, N1, N2 = 3, 520, 256, 192
     a, b, c0 = gen(nb, M, N1, seed=5), gen(nb, M, N2, seed=6, scale=0.1), gen(nb, N1, N2, seed=7)
     out = c0.to(DEV).clone()
@@ -53,7 +81,7 @@ def test_gemm_tn_batched_alpha_accumulate(ops):
     check(out2, O.rnd(wide[:, N1:2 * N1].float().cpu().t() @ b[0].float(), True), name="gemm_tn column window")
 
 
-def test_gemm_tn_row_groups_and_column_groups(ops):
+def test_gemm_tn_row_groups_and_column_groups(ops, tn_tile):
     """Row groups on the contraction: X = the first Kt rows of every sequence of a [B, S, D] tensor, read in place.  Column groups
     on A: the gate (or up) columns of a gate/up-interleaved dY."""
     Bn, S, Kt, D, N1 = 5, 352, 256, 128, 192
@@ -149,7 +177,7 @@ def test_copy_rows3d(ops):
     assert torch.equal(dst[:, 1:8], src)
 
 
-def test_gemm_tn_grouped_equals_the_single_launches(ops):
+def test_gemm_tn_grouped_equals_the_single_launches(ops, tn_tile):
     """One grouped launch over several products (different shapes, a column-grouped operand, a ragged contraction) == the same
     products launched one by one, bit for bit (same tiles, same K order)."""
     M = 1000

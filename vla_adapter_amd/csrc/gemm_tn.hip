@@ -190,6 +190,233 @@ __device__ __forceinline__ void tn_tile(const TnP& p, const int swz, const int b
     }
 }
 
+// ================================================================================================ 256 x 256 tile (round 3)
+// The same product on gemm256.hip's skeleton: 256 (n1) x 256 (n2) output tile, 8 waves as 2 x 4, wave tile 128 x 64 = four
+// 64 x 32 quadrants, operands in LDS as eight 16-KiB half-tiles (2 K-tile buffers x {B0, A0, B1, A1}), each the [64 m][128
+// columns] image of the 128-tile kernel above (A-half h = columns {wr' 128 + h 64 + [0, 64)}, B-half h = columns {wc' 64 + h 32 +
+// [0, 32)}: a wave reads its columns of a half-tile exactly as it reads them of a 128-tile), the two-phase K loop with its
+// segment-counted LDS-DMA schedule (gemm256.hip, file header: phase X reads B0, A0, B1 and multiplies Q00, Q01; phase Y reads
+// A1 and multiplies Q11, Q10; every half-tile is issued four segments before the counted wait that retires it), one workgroup per
+// CU and per tile.  A weight gradient contracts over thousands of rows (88 K-tiles at batch 16), so what pays is the K loop:
+// half the staged bytes per FLOP of the 128-tile and no wait on the fill.  Plain, batched, row-grouped, column-grouped and
+// accumulating problems; the contraction split stays on the 128-tile kernel.
+constexpr int T2_HT = 16384;
+constexpr int T2_LDS = 8 * T2_HT;
+
+// LDS-DMA from inline asm (see gemm256.hip: a builtin global_load_lds makes hipcc drain vmcnt(0) around it; counted by hand below)
+__device__ __forceinline__ void glds16s(const char* base, unsigned voff, unsigned dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
+}
+
+#define TN_BARRIER()                       \
+  do {                                     \
+    __builtin_amdgcn_sched_barrier(0);     \
+    __builtin_amdgcn_s_barrier();          \
+    asm volatile("" ::: "memory");         \
+    __builtin_amdgcn_sched_barrier(0);     \
+  } while (0)
+
+#define TN_MMA_QUADRANT(Q, FN, FM)                                                                             \
+  do {                                                                                                         \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                           \
+      _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                         \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                       \
+          Q[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FN[ks][ni], FM[ks][mi], Q[ni][mi], 0, 0, 0);     \
+  } while (0)
+
+__device__ __forceinline__ void tn256_tile(const TnP& p, const int swz, const int zb, char* smem) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+  const int b1 = swz / p.tiles_n2, b2 = swz - b1 * p.tiles_n2;
+  const int n1_0 = b1 * 256, n2_0 = b2 * 256;
+  const int nt = (p.M + TBK - 1) / TBK;
+  const char* Ab = reinterpret_cast<const char*>(p.A + (long long)zb * p.sA);
+  const char* Bb = reinterpret_cast<const char*>(p.B + (long long)zb * p.sB);
+
+  // ---- staging: wave w fills pieces 2w, 2w + 1 (rows 8w .. 8w + 7) of every half-tile; lane -> row + (lane >> 4), LDS chunk
+  //      lane & 15 holds source chunk (lane & 15) ^ f(row) of the half-tile's 128 columns
+  const int r0 = wid * 8 + (lane >> 4);
+  unsigned ca[2][2], cb[2][2];                 // byte offset of this lane's source chunk inside a row: [half][piece]
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = r0 + 4 * j;
+    const int f = ((r & 3) << 2) | ((r >> 2) & 3);
+    const int lc = ((lane & 15) ^ f) << 3;     // first of this lane's 8 columns inside the half-tile
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int ga = n1_0 + (lc >> 6) * 128 + h * 64 + (lc & 63);
+      ga = min(ga, p.N1 - 8);                  // columns beyond the matrix: any valid chunk (those outputs are never stored)
+      if (p.cgA > 0) ga = (ga / p.cgA) * p.cgsA + ga % p.cgA;
+      ca[h][j] = (unsigned)ga * 2u;
+      const int gb = min(n2_0 + (lc >> 5) * 64 + h * 32 + (lc & 31), p.N2 - 8);
+      cb[h][j] = (unsigned)gb * 2u;
+    }
+  }
+  const unsigned wdst = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem) + wid * 2048;
+  auto row_base = [&](int mt, int grp, long long sgrp, int ld) -> long long {          // wave-uniform, elements
+    return grp > 0 ? (long long)(mt / grp) * sgrp + (long long)(mt % grp) * ld : (long long)mt * ld;
+  };
+  auto stage_a = [&](int slot, int h, int t) {
+    const int mt = t * TBK;
+    const char* base = Ab + row_base(mt, p.gA, p.sgA, p.lda) * 2;
+    const unsigned lim = (unsigned)(p.M - 1 - mt), ld2 = (unsigned)p.lda * 2u;          // contraction tail: clamped to the last valid row
+    glds16s(base, min((unsigned)r0, lim) * ld2 + ca[h][0], wdst + slot * T2_HT);
+    glds16s(base, min((unsigned)r0 + 4u, lim) * ld2 + ca[h][1], wdst + slot * T2_HT + 1024);
+  };
+  auto stage_b = [&](int slot, int h, int t) {
+    const int mt = t * TBK;
+    const char* base = Bb + row_base(mt, p.gB, p.sgB, p.ldb) * 2;
+    const unsigned lim = (unsigned)(p.M - 1 - mt), ld2 = (unsigned)p.ldb * 2u;
+    glds16s(base, min((unsigned)r0, lim) * ld2 + cb[h][0], wdst + slot * T2_HT);
+    glds16s(base, min((unsigned)r0 + 4u, lim) * ld2 + cb[h][1], wdst + slot * T2_HT + 1024);
+  };
+
+  // ---- transposed fragment reads (as tn_tile): byte offsets inside a half-tile, second k-step 8192 further
+  const int kq = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+  int fa[4][2], fb[2][2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int row = 8 * kq + qq + 4 * e, f = (qq << 2) | ((2 * kq + e) & 3);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i][e] = 256 * row + ((((wr * 64 + i * 16) >> 3) + (pp >> 1)) ^ f) * 16 + 8 * (pp & 1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fb[i][e] = 256 * row + ((((wc * 32 + i * 16) >> 3) + (pp >> 1)) ^ f) * 16 + 8 * (pp & 1);
+  }
+  auto read_a = [&](const char* sb, bf16x8 (&fm)[2][4]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16x4 lo = tr_read(sb + ks * 8192 + fa[i][0]), hi = tr_read(sb + ks * 8192 + fa[i][1]);
+        fm[ks][i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+  };
+  auto read_b = [&](const char* sb, bf16x8 (&fn)[2][2]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bf16x4 lo = tr_read(sb + ks * 8192 + fb[i][0]), hi = tr_read(sb + ks * 8192 + fb[i][1]);
+        fn[ks][i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+  };
+  auto mask_tail = [&](bf16x8 (&fn)[2][2], int valid) {      // rows >= valid of the last K-tile contribute nothing
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (ks * 32 + 8 * kq + e >= valid) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) fn[ks][i][e] = 0;
+        }
+  };
+
+  // ---- prologue: K-tile 0 (all four half-tiles) and B0, A0, B1 of K-tile 1
+  stage_b(0, 0, 0); stage_a(1, 0, 0); stage_b(2, 1, 0); stage_a(3, 1, 0);
+  if (nt > 1) {
+    stage_b(4, 0, 1); stage_a(5, 0, 1); stage_b(6, 1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  TN_BARRIER();
+  if (wr == 1) TN_BARRIER();         // stagger: the wr = 1 waves run one segment behind
+
+  f32x4 acc[2][2][2][4];             // [mh][nh][ni][mi]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[a][b][c][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  bf16x8 fm[2][4], fn0[2][2], fn1[2][2];
+  int d = 0;
+  for (int t = 0; t < nt; ++t) {
+    const char* kb = smem + d * 4 * T2_HT;
+    const int so = d * 4, sn = (d ^ 1) * 4;
+    const int valid = p.M - t * TBK;                         // rows of this K-tile inside the contraction (wave-uniform)
+    // ================= phase X: reads B0, A0, B1; issues A1 of K-tile t+1; retires A1 of K-tile t
+    {
+      read_b(kb + 0 * T2_HT, fn0);
+      read_a(kb + 1 * T2_HT, fm);
+      read_b(kb + 2 * T2_HT, fn1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < nt) {
+        stage_a(sn + 3, 1, t + 1);
+        if (t > 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else if (t > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (valid < TBK) { mask_tail(fn0, valid); mask_tail(fn1, valid); }
+      TN_BARRIER();
+      __builtin_amdgcn_s_setprio(1);
+      TN_MMA_QUADRANT(acc[0][0], fn0, fm);
+      TN_MMA_QUADRANT(acc[0][1], fn1, fm);
+      __builtin_amdgcn_s_setprio(0);
+      TN_BARRIER();
+    }
+    // ================= phase Y: reads A1; issues B0, A0, B1 of K-tile t+2; retires B0, A0, B1 of K-tile t+1
+    {
+      read_a(kb + 3 * T2_HT, fm);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 2 < nt) {
+        stage_b(so + 0, 0, t + 2); stage_a(so + 1, 0, t + 2); stage_b(so + 2, 1, t + 2);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else if (t + 1 < nt) {
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      TN_BARRIER();
+      __builtin_amdgcn_s_setprio(1);
+      TN_MMA_QUADRANT(acc[1][1], fn1, fm);
+      TN_MMA_QUADRANT(acc[1][0], fn0, fm);
+      __builtin_amdgcn_s_setprio(0);
+      TN_BARRIER();
+    }
+    d ^= 1;
+  }
+  if (wr == 0) TN_BARRIER();         // pairs with the last barrier of the wr = 1 waves
+
+  // ---- epilogue: lane owns, per (mh, nh, ni, mi): row n1 = 16 mi + (lane & 15), columns n2 = 16 ni + 4 (lane >> 4) + {0..3}
+  const int lq = lane >> 4, lr = lane & 15;
+  bf16_t* Cb = p.C + (long long)zb * p.sC;
+  const bf16_t* Rb = p.R ? p.R + (long long)zb * p.sR : nullptr;
+#pragma unroll
+  for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const int r = n1_0 + wr * 128 + mh * 64 + mi * 16 + lr, c = n2_0 + wc * 64 + nh * 32 + ni * 16 + lq * 4;
+          if (r >= p.N1 || c + 3 >= p.N2) continue;        // (N2 % 8 == 0: a lane's four columns are all inside or all outside)
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = acc[mh][nh][ni][mi][j] * p.alpha;
+          if (Rb) {
+            const uint2 rv = *reinterpret_cast<const uint2*>(Rb + (long long)r * p.ldr + c);
+            v[0] = rbf(v[0]) + bf2f((bf16_t)(rv.x & 0xffff)); v[1] = rbf(v[1]) + bf2f((bf16_t)(rv.x >> 16));
+            v[2] = rbf(v[2]) + bf2f((bf16_t)(rv.y & 0xffff)); v[3] = rbf(v[3]) + bf2f((bf16_t)(rv.y >> 16));
+          }
+          *reinterpret_cast<uint2*>(Cb + (long long)r * p.ldc + c) = uint2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+        }
+}
+
+__global__ __launch_bounds__(512) void gemm_tn256_kernel(TnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  tn256_tile(p, xcd_order(blockIdx.x, p.ntiles), blockIdx.z, smem);
+}
+
 __global__ __launch_bounds__(512) void gemm_tn_kernel(TnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   tn_tile(p, xcd_order(blockIdx.x, p.ntiles), blockIdx.z, smem);
@@ -222,6 +449,43 @@ __global__ __launch_bounds__(512) void gemm_tn_grouped_kernel(TnGroup G) {
   p.cgA = g.cgA; p.cgsA = g.cgsA;
   p.tiles_n2 = g.tiles_n2; p.ntiles = 0; p.split = 1; p.mslice = g.M;
   tn_tile(p, t - G.start[pi], 0, smem);
+}
+
+__global__ __launch_bounds__(512) void gemm_tn256_grouped_kernel(TnGroup G) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = xcd_order(blockIdx.x, G.total);
+  int pi = 0;
+  while (pi + 1 < G.count && t >= G.start[pi + 1]) ++pi;
+  const TnG& g = G.g[pi];
+  TnP p;
+  p.A = g.A; p.B = g.B; p.C = g.C; p.R = nullptr; p.ws = nullptr;
+  p.M = g.M; p.N1 = g.N1; p.N2 = g.N2; p.lda = g.lda; p.ldb = g.ldb; p.ldc = g.ldc; p.ldr = 0;
+  p.sA = p.sB = p.sC = p.sR = 0;
+  p.alpha = g.alpha;
+  p.gA = p.gB = 0; p.sgA = p.sgB = 0;
+  p.cgA = g.cgA; p.cgsA = g.cgsA;
+  p.tiles_n2 = g.tiles_n2; p.ntiles = 0; p.split = 1; p.mslice = g.M;
+  tn256_tile(p, t - G.start[pi], 0, smem);
+}
+
+// Which tile: the 256 x 256 kernel for products whose output holds whole big tiles and whose contraction is long enough to
+// amortise its prologue - when the launch (a batch, or a whole group) brings at least half a round of such tiles: one 256-tile
+// is ~130 us of K loop at 88 K-tiles, a launch of 20 of them leaves the chip to the tile's latency (tools/bench_tn.py: 5632 x
+// 1152 x 896 alone 86 us on 128-tiles, 142 us on 256-tiles; the four-layer group 848 -> 705 us).  VLA_TN_TILE=128 / 256 forces
+// one (read per launch for the A/B tools).
+constexpr int TN256_MIN_TILES = 128;
+int tn_forced() {
+  const char* e = getenv("VLA_TN_TILE");
+  return e != nullptr ? atoi(e) : 0;
+}
+bool tn_eligible_256(int M, int N1, int N2, int split) { return split <= 1 && M >= 1024 && N1 >= 192 && N2 >= 192; }
+long long tn_tiles_256(int N1, int N2) { return (long long)((N1 + 255) / 256) * ((N2 + 255) / 256); }
+bool tn_use_256(int M, int N1, int N2, int split, int batch) {
+  if (split > 1) return false;
+  const int f = tn_forced();
+  if (f == 128) return false;
+  if (f == 256) return true;
+  return tn_eligible_256(M, N1, N2, split) && tn_tiles_256(N1, N2) * batch >= TN256_MIN_TILES;
 }
 
 // second pass of the contraction split: C = bf16(bf16(alpha * sum_s ws[b][s]) + R); 4 columns per thread
@@ -282,7 +546,15 @@ extern "C" int vla_gemm_bf16_tn(void* stream, const vla_gemm_tn_desc* d) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS);
     attr_set = true;
+  }
+  if (tn_use_256(d->M, d->N1, d->N2, split, d->batch)) {
+    p.tiles_n2 = (d->N2 + 255) / 256;
+    p.ntiles = ((d->N1 + 255) / 256) * p.tiles_n2;
+    hipLaunchKernelGGL(gemm_tn256_kernel, dim3(p.ntiles, 1, d->batch), dim3(512), T2_LDS, st, p);
+    VLA_CHECK_LAUNCH("gemm_bf16_tn (256)");
+    return VLA_OK;
   }
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.ntiles, 1, d->batch * split), dim3(512), LDS_BYTES, st, p);
   VLA_CHECK_LAUNCH("gemm_bf16_tn");
@@ -298,8 +570,13 @@ extern "C" int vla_gemm_bf16_tn(void* stream, const vla_gemm_tn_desc* d) {
 
 extern "C" int vla_gemm_bf16_tn_grouped(void* stream, const vla_gemm_tn_desc* descs, int count) {
   VLA_REQUIRE(descs && count > 0 && count <= TN_GROUP_MAX, "gemm_tn_grouped: 1 .. 48 problems per launch");
-  TnGroup G;
-  int total = 0;
+  TnGroup G[2];                      // [0]: 128-tile kernel, [1]: 256-tile kernel
+  int total[2] = {0, 0}, cnt[2] = {0, 0};
+  const int forced = tn_forced();
+  long long big = 0;                 // 256-tiles of the group's eligible products: below half a round they all stay on the 128-tile kernel
+  for (int i = 0; i < count; ++i)
+    if (tn_eligible_256(descs[i].M, descs[i].N1, descs[i].N2, descs[i].split)) big += tn_tiles_256(descs[i].N1, descs[i].N2);
+  const bool any256 = forced == 256 || (forced != 128 && big >= TN256_MIN_TILES);
   for (int i = 0; i < count; ++i) {
     const vla_gemm_tn_desc* d = descs + i;
     VLA_REQUIRE(d->A && d->B && d->C && d->M > 0 && d->N1 > 0 && d->N2 > 0, "gemm_tn_grouped: null operand / empty problem");
@@ -309,23 +586,30 @@ extern "C" int vla_gemm_bf16_tn_grouped(void* stream, const vla_gemm_tn_desc* de
     VLA_REQUIRE(((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->B & 15) == 0 && ((uintptr_t)d->C & 7) == 0, "gemm_tn_grouped: alignment");
     VLA_REQUIRE(d->a_col_group >= 0 && d->a_col_group % 8 == 0 && d->a_col_group_stride % 8 == 0 &&
                     (d->a_col_group == 0 || d->a_col_group_stride >= d->a_col_group), "gemm_tn_grouped: bad column groups");
-    TnG& g = G.g[i];
+    const int k = (any256 && (forced == 256 || tn_eligible_256(d->M, d->N1, d->N2, d->split))) ? 1 : 0, tile = k ? 256 : 128;
+    TnG& g = G[k].g[cnt[k]];
     g.A = (const bf16_t*)d->A; g.B = (const bf16_t*)d->B; g.C = (bf16_t*)d->C;
     g.M = d->M; g.N1 = d->N1; g.N2 = d->N2; g.lda = d->lda; g.ldb = d->ldb; g.ldc = d->ldc;
     g.cgA = d->a_col_group; g.cgsA = d->a_col_group_stride;
     g.alpha = d->alpha == 0.f ? 1.f : d->alpha;
-    g.tiles_n2 = (d->N2 + 127) / 128;
-    G.start[i] = total;
-    total += ((d->N1 + 127) / 128) * g.tiles_n2;
+    g.tiles_n2 = (d->N2 + tile - 1) / tile;
+    G[k].start[cnt[k]] = total[k];
+    total[k] += ((d->N1 + tile - 1) / tile) * g.tiles_n2;
+    ++cnt[k];
   }
-  G.start[count] = total;
-  G.count = count; G.total = total;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_tn256_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(total), dim3(512), LDS_BYTES, (hipStream_t)stream, G);
-  VLA_CHECK_LAUNCH("gemm_bf16_tn_grouped");
+  for (int k = 1; k >= 0; --k) {       // the long 256-tile products first: the short ones fill their tail
+    if (cnt[k] == 0) continue;
+    G[k].start[cnt[k]] = total[k];
+    G[k].count = cnt[k]; G[k].total = total[k];
+    if (k == 1) hipLaunchKernelGGL(gemm_tn256_grouped_kernel, dim3(total[k]), dim3(512), T2_LDS, (hipStream_t)stream, G[k]);
+    else hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(total[k]), dim3(512), LDS_BYTES, (hipStream_t)stream, G[k]);
+    VLA_CHECK_LAUNCH("gemm_bf16_tn_grouped");
+  }
   return VLA_OK;
 }
