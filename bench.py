@@ -507,7 +507,7 @@ def main():
             "gflop_per_sample": {"executed": round(fl["step_live"] / 1e9, 1), "autograd_convention": round(fl["step"] / 1e9, 1)},
             "full_backward_variant": full_bwd,
             "fp8_frozen_forward_variant": fp8_var,
-            "roofline": {"bound": "mfma", "kernel": "gemm256_kernel + gemm_nt_kernel + gemm_tn_kernel (bf16 MFMA GEMMs, all launches of one step)",
+            "roofline": {"bound": "mfma", "kernel": "gemm256_kernel + gemm_nt_kernel + gemm_tn_kernel / gemm_tn256_kernel (bf16 MFMA GEMMs, all launches of one step)",
                          "achieved": round(roof["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(roof["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
                          "frac_in_situ": (in_situ_roofline(roof["flops"]) or {}).get("frac_in_situ"), "in_situ": in_situ_roofline(roof["flops"]),

@@ -20,7 +20,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RND = os.environ.get("VLA_ROUND", "r03")                       # profiles are named per round
 SRC, DST = os.path.join(ROOT, "gpurun_out", "prof_" + RND), os.path.join(ROOT, "profiles")
-GEMM_KERNELS = ("gemm_nt_kernel", "gemm256_kernel", "gemm_tn_kernel")
+GEMM_KERNELS = ("gemm_nt_kernel", "gemm256_kernel", "gemm_tn_kernel", "gemm_tn256_kernel", "gemm_tn_grouped_kernel", "gemm_tn256_grouped_kernel")
 
 
 def short(name: str) -> str:
