@@ -51,11 +51,14 @@ def budget(native, emu, truth, what, factor=1.25, floor=0.0):
     return dn, de
 
 
-def budget_family(items, what, each=4.0, total=1.5, floor=2e-3, absfloor=0.0):
+def budget_family(items, what, each=2.5, total=1.5, floor=2e-3, absfloor=0.0):
     """items: [(name, native, emu, truth)].  Per tensor: native <= each x emu + floor (or |err| <= absfloor: tensors orders of
     magnitude below the family's dominant ones sit on the absolute noise floor of the chain feeding them); aggregate
-    (root of summed squared relative distances) <= total x emu's + floor."""
+    (root of summed squared relative distances) <= total x emu's + floor.  `each`: 4.0 until round 3 (too loose); the
+    worst single-tensor ratios measured over every call site are 0.8 - 2.07 (LoRA A of one gate_proj: one ReLU / rounding flip
+    upstream of a rank-8 tensor) and 2.36 for the original block's shared k/v gradient (that call passes each=3), printed per run."""
     sn = se = 0.0
+    worst = (0.0, None, 0.0, 0.0)
     for name, native, emu, truth in items:
         n, e, t = (x.detach().float().cpu().reshape(-1) for x in (native, emu, truth))
         nt = t.norm().item() + 1e-30
@@ -63,8 +66,11 @@ def budget_family(items, what, each=4.0, total=1.5, floor=2e-3, absfloor=0.0):
         if dn * nt <= absfloor:
             continue
         sn, se = sn + dn * dn, se + de * de
+        if dn > floor and dn / (de + 1e-30) > worst[0]:
+            worst = (dn / (de + 1e-30), name, dn, de)
         assert dn <= each * de + floor, f"{what} / {name}: native-vs-fp32 {dn:.3e}, oracle(emu)-vs-fp32 {de:.3e}"
-    print(f"budget {what}: rms over {len(items)} tensors  native-vs-fp32 {sn ** 0.5:.3e}   oracle(emu)-vs-fp32 {se ** 0.5:.3e}")
+    print(f"budget {what}: rms over {len(items)} tensors  native-vs-fp32 {sn ** 0.5:.3e}   oracle(emu)-vs-fp32 {se ** 0.5:.3e}"
+          f"   worst single tensor above the floor: x{worst[0]:.2f} ({worst[1]}: {worst[2]:.2e} vs {worst[3]:.2e})")
     assert sn ** 0.5 <= total * se ** 0.5 + floor, f"{what}: aggregate {sn ** 0.5:.3e} vs {se ** 0.5:.3e}"
 
 
@@ -364,7 +370,8 @@ def test_original_head_block_end_to_end():
     gmax = max(v.grad.norm().item() for v in TW["head"].values() if v.grad is not None)
     keys = [f"model.mlp_resnet_blocks.{b}.{n}.weight" for b in (0, 1) for n in ("k_proj", "v_proj", "q_proj", "o_proj")]
     budget_family([(k, g[k], OW["head"][k].grad, TW["head"][k].grad) for k in keys], "original-block head: shared k/v gradients",
-                  total=2.0, absfloor=1e-3 * gmax)          # 8 small tensors of a 2-block head: the aggregate itself fluctuates
+                  each=3.0, total=2.0, absfloor=1e-3 * gmax)  # 8 small tensors of a 2-block head: the aggregate itself fluctuates
+                                                              # (worst single tensor measured x2.36: block 0's shared v_proj)
     e2 = E.VLAEngine(cfg, W, DEV)
     e2.capture(batch, None)
     losses = [e2.train_step_graphed(2e-3)[0].item() for _ in range(12)]
