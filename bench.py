@@ -238,6 +238,7 @@ def bench_full(args, cfg, W, eng, batch, noise, lr, rank, local, world, B, P):
     from vla_adapter_amd import flops
     from vla_adapter_amd.full_finetune import FullFinetune
     ft = FullFinetune(eng)
+    ft.set_objective(args.objective)
 
     def sync():
         if world > 1:
@@ -267,7 +268,8 @@ def bench_full(args, cfg, W, eng, batch, noise, lr, rank, local, world, B, P):
     if rank == 0:
         nparam = ft.P.numel + ft.head.P.numel
         print(json.dumps({
-            "metric": "fine-tune samples/sec (224px img + 32-tok prompt), FULL unfreeze (ViT + LLM + adapter), fwd+bwd+AdamW",
+            "metric": "fine-tune samples/sec (224px img + 32-tok prompt), FULL unfreeze (ViT + LLM + adapter), fwd+bwd+AdamW" +
+                      ("" if args.objective == "l1" else ", token cross-entropy objective (lm_head on the text rows)"),
             "value": round(world * B * args.steps / dt, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[3]: Prismatic SigLIP-224 + Qwen2.5-0.5B" if args.backbone == "config2" else args.backbone) +
@@ -293,6 +295,7 @@ def bench_lora(args, cfg, W, eng, batch, noise, lr, rank, local, world, B, P):
     from vla_adapter_amd import flops
     from vla_adapter_amd.lora_finetune import LoRAFinetune
     ft = LoRAFinetune(eng, rank=args.lora_rank)
+    ft.set_objective(args.objective)
     if args.eager:
         step = lambda: ft.train_step(batch, lr, noise)
     else:
@@ -313,7 +316,8 @@ def bench_lora(args, cfg, W, eng, batch, noise, lr, rank, local, world, B, P):
             "config5": "BASELINE configs[4] backbone: DINOv2-L + SigLIP-so400m fused + Qwen2.5-1.5B (bf16: the config's fp8 weight path is not part of this mode)"}[args.backbone]
     if rank == 0:
         print(json.dumps({
-            "metric": "fine-tune samples/sec (224px img + 32-tok prompt), LoRA rank %d on every Linear + adapter head, fwd+bwd+AdamW" % args.lora_rank,
+            "metric": "fine-tune samples/sec (224px img + 32-tok prompt), LoRA rank %d on every Linear + adapter head, fwd+bwd+AdamW" % args.lora_rank +
+                      ("" if args.objective == "l1" else ", token cross-entropy objective (lm_head on the text rows)"),
             "value": round(B * args.steps / dt, 2), "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{desc} + Pro action head, LoRA fine-tune (vla-scripts/finetune.py:832-844), {cfg.n_img} image(s) "
@@ -340,6 +344,9 @@ def main():
                     help="adapter: BASELINE configs[1]/[2] (the headline metric); full: configs[3], every VLM parameter trains; "
                          "lora: rank-r adapters on every Linear (the reference's --use_lora) on the 0.5B backbone")
     ap.add_argument("--lora-rank", type=int, default=64)
+    ap.add_argument("--objective", default="l1", choices=["l1", "token_ce"],
+                    help="--mode full / lora: L1 regression through the action head (the reference's finetune.py) or the token cross-entropy of its "
+                         "native trainer (SURVEY 8f-4: lm_head on the text rows, no action head)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=4, help="samples of the batch the CPU oracle is timed on (3 steps each: about 12 s of CPU work)")
     ap.add_argument("--no-full-backward", action="store_true", help="skip the extra timing of the reference-shaped full LLM backward")
