@@ -686,7 +686,7 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr;
   p.ldc2 = d->ldc2; p.res_mod = d->res_mod; p.act = d->act;
   p.sA = d->sA; p.sB = d->sB; p.sC = d->sC; p.sR = d->sR; p.sC2 = d->sC2; p.sBias = d->sBias;
-  p.tiles_n = p.ntiles = 0; p.batch = 1; p.xpx = p.xpy = 0;
+  p.tiles_n = p.ntiles = 0; p.batch = 1; p.xpx = p.xpy = 0; p.stagger = 0;
   p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
   p.gA = d->a_group; p.sgA = d->a_group_stride; p.gC = d->c_group; p.sgC = d->c_group_stride;
   p.gR = d->r_group; p.sgR = d->r_group_stride;

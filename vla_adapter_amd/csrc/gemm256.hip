@@ -207,6 +207,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
   const int aoff = wr * 64 * 128, boff = wc * 32 * 128;
 
   int cur = rstart(xcd) + (bid >> 3);
+  // Free de-phasing: when the last round of the walk is partial, the workgroups that walk one tile fewer would finish a tile early;
+  // they start late by a fraction of a tile instead, so that their epilogues' store bursts fall between those of the others.
+  if (p.stagger > 0 && (total - 1 - bid) / G + 1 < (total + G - 1) / G) {
+    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(16);       // ~1024 cycles each
+  }
   setup(cur);
   stage_k0(0);
   int d = 0;
@@ -730,8 +735,20 @@ int launch256(const GemmP& p0, int batch, hipStream_t st) {
       if (best < 0 || cost < best) { best = cost; p.xpx = px; p.xpy = py; }
     }
   }
+  // Free de-phasing of a partial last round (kernel: start of the walk).  Every workgroup has the same work per tile, so all 256
+  // epilogues burst their stores into the fabric in the same few microseconds and wait for it; the workgroups that walk one tile
+  // fewer have a tile's time to spare, and starting them late by half a tile puts their bursts between those of the others.
+  // Same box: gate/up 203 -> 196 us, d->dh 97 -> 95, exact-round launches unchanged, step -0.15 ... -0.2 ms.  (A delay for EVERY
+  // group of workgroups - not only those with slack - shortens the epilogues by what the delay costs: measured, no gain.)
+  // VLA_GEMM256_STAGGER = percent of the estimated tile time (default 50, 0 = off; read per launch for the A/B tools).
+  const char* se = getenv("VLA_GEMM256_STAGGER");
   long long grid = ge ? atoll(ge) : num_cus();
   if (grid <= 0 || grid > total) grid = total;
+  p.stagger = 0;
+  if (total > grid && total % grid != 0) {
+    const long long tile_cycles = (long long)(p.K / BK) * 2128 + 13000;       // K loop + what surrounds it (stamped: DESIGN section 4)
+    p.stagger = (int)(tile_cycles * (se != nullptr ? atoi(se) : 50) / 100 / 1024);
+  }
   if (grid % 8 != 0) p.xpx = p.xpy = 0;                    // (a workgroup must stay on its XCD's list: b and b + G share b & 7)
   hipLaunchKernelGGL((gemm256_kernel<EPI, F8, RES>), dim3((unsigned)grid), dim3(512), LDS_BYTES, st, p);
   return 0;
