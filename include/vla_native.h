@@ -29,8 +29,9 @@ extern "C" {
  *   1  rounds 1-2 (vla_gemm_desc ended at `bias_post_round`, later at `b_scale`);
  *   2  round 3: vla_gemm_desc gained the K extension (A2 .. ldb2), new entry points vla_gemm_bf16_tn (+ _grouped), vla_gemm256_extent_ok,
  *      vla_copy_rows3d, vla_layerscale_fwd / _bwd, vla_token_ce_bwd, vla_desc_size.
+ *   3  round 3: vla_head_attn_desc gained the optional backward workspace (ws, ws_floats).
  * A binder checks vla_version() AND vla_desc_size() against its own struct definitions before the first call. */
-#define VLA_ABI_VERSION 2
+#define VLA_ABI_VERSION 3
 int vla_version(void);
 /* sizeof() of the descriptor structs as this library was compiled: which = 0 vla_gemm_desc, 1 vla_attn_desc, 2 vla_head_attn_desc,
  * 3 vla_gemm_tn_desc; -1 for an unknown index.  A caller whose struct is shorter would make the library read past its end. */
@@ -334,6 +335,10 @@ typedef struct vla_head_attn_desc {
   /* backward, optional: tables f32 [>= max(T,Ka,Kt), dh] of vla_rope_interleaved; dq and the three dk are then
    * returned through the transpose of that RoPE map (positions restart per segment, action_heads.py:383-388) */
   const float* rope_cos; const float* rope_sin;
+  /* backward, optional (ABI 3): f32 workspace of >= B*H*ceil((T+Ka+Kt)/32)*(T*dh + 1) floats.  With it the MFMA backward runs
+   * in its tile-uniform form (one wave per (sample, head, 32-key tile); dq and dgate summed from per-tile partials in tile
+   * order); without it (NULL / too small) the combined kernel of ABI 2 runs.  Contents are scratch. */
+  float* ws; long long ws_floats;
 } vla_head_attn_desc;
 int vla_head_attn_fwd(void* stream, const vla_head_attn_desc* desc /* host */);
 int vla_head_attn_bwd(void* stream, const vla_head_attn_desc* desc /* host */);

@@ -498,6 +498,38 @@ def test_attention_bwd_fused_inverse_rope(ops):
     assert torch.equal(f(sl(g1)[2]), f(sl(g0)[2]))
 
 
+@pytest.mark.parametrize("B,T,Ka,Kt,D,rope", [(3, 8, 65, 256, 896, True), (2, 8, 65, 512, 896, False), (2, 8, 65, 40, 512, True), (2, 20, 65, 100, 1024, True),
+                                              (5, 8, 65, 16, 128, False), (1, 32, 33, 7, 256, True)])
+def test_head_attention_bwd_tile_uniform_equals_combined(ops, B, T, Ka, Kt, D, rope, monkeypatch):
+    """The tile-uniform MFMA backward (one wave per (sample, head, 32-key tile), dq / dgate from per-tile partials: ABI 3 workspace)
+    against the combined kernel it replaces (VLA_HEAD_BWD_COMBINED=1): dk / dv are the same MFMAs in the same order - bit for bit;
+    dq and dgate differ by fp32 summation order only.  T > 16 exercises the second k-step of the query contraction, Kt = 7 a ragged
+    last tile, Kt = 512 nineteen tiles (five workgroups per (sample, head), the last one partly idle)."""
+    H = 8
+    dh = D // H
+    x3, a2, t2 = gen(B, T, 3 * D, seed=60, scale=0.3), gen(B, Ka, 2 * D, seed=61, scale=0.3), gen(B, Kt, 2 * D, seed=62, scale=0.3)
+    gate, dout = torch.tensor([0.7]).to(BF).to(DEV), gen(B, T, D, seed=63).to(DEV)
+    dx3, da2, dt2 = x3.to(DEV), a2.to(DEV), t2.to(DEV)
+    args = (dx3[:, :, :D], dx3[:, :, D:2 * D], dx3[:, :, 2 * D:], da2[:, :, :D], da2[:, :, D:], dt2[:, :, :D], dt2[:, :, D:])
+    out, probs = ops.head_attn_fwd(*args, gate, H)
+    tabs = ops.rope_inter_tables(max(T, Ka, Kt), dh, DEV) if rope else None
+    res = []
+    for combined in (True, False):
+        if combined:
+            monkeypatch.setenv("VLA_HEAD_BWD_COMBINED", "1")
+        else:
+            monkeypatch.delenv("VLA_HEAD_BWD_COMBINED", raising=False)
+        g3, ga, gt = torch.zeros_like(dx3), torch.zeros_like(da2), torch.zeros_like(dt2)
+        dg = torch.zeros(1, device=DEV)
+        ops.head_attn_bwd(dout, out, *args, gate, probs, dg, g3[:, :, :D], g3[:, :, D:2 * D], g3[:, :, 2 * D:], ga[:, :, :D], ga[:, :, D:],
+                          gt[:, :, :D], gt[:, :, D:], H, rope=tabs)
+        res.append((g3, ga, gt, dg))
+    (c3, ca, ct, cg), (n3, na, nt, ng) = res
+    assert torch.equal(n3[:, :, D:], c3[:, :, D:]) and torch.equal(na, ca) and torch.equal(nt, ct), "dk / dv must be bit-identical"
+    check(n3[:, :, :D], f(c3[:, :, :D]), rel=4e-3, mx=2e-2, name="dq: tile-uniform vs combined")
+    assert abs(ng.item() - cg.item()) <= 2e-3 * abs(cg.item()) + 1e-4, f"dgate {ng.item()} vs {cg.item()}"
+
+
 @pytest.mark.parametrize("D", [896, 64])
 def test_head_attention_bwd_fused_rope_transpose(ops, D):
     """MFMA path (dh 112) and VALU fallback (dh 8): dq / dk returned through the transpose of the head's RoPE map."""

@@ -240,6 +240,8 @@ int fill(HP& p, const vla_head_attn_desc* d, bool bwd) {
     p.dka = (bf16_t*)d->dk_adp; p.dva = (bf16_t*)d->dv_adp; p.dkt = (bf16_t*)d->dk_task; p.dvt = (bf16_t*)d->dv_task;
     p.dgate = d->dgate;
     p.rope_cos = d->rope_cos; p.rope_sin = d->rope_sin;
+    p.ws = d->ws; p.ws_floats = d->ws ? d->ws_floats : 0;
+    if (d->ws) VLA_REQUIRE(((uintptr_t)d->ws & 15) == 0 && d->ws_floats >= 0, "head_attn_bwd: workspace must be 16-B aligned");
     if (d->rope_cos) VLA_REQUIRE(d->rope_sin && (((uintptr_t)d->rope_cos | (uintptr_t)d->rope_sin) & 15) == 0 && d->dh % 4 == 0, "head_attn_bwd: rope tables");
   }
   return VLA_OK;

@@ -405,38 +405,279 @@ __device__ __forceinline__ void head_dkv_body(const HP& p, const int blk, char* 
       S[r] = pr;
       dS[r] = gated ? ds * tg : ds;
     }
-    f32x16 dK[G::DT], dV[G::DT];
+    // One 32-column block of dV and dK at a time, stored before the next is formed: 2 x 16 live accumulator registers instead of
+    // DT x 2 x 16 (128 at head dim 112) - the kernel needed 380 registers and spilled under its 256-register cap.
+    const bf16x8 pf0 = pack_acc(S, 0), pf1 = pack_acc(S, 1), dsf0 = pack_acc(dS, 0), dsf1 = pack_acc(dS, 1);
+    const int pos = kc < p.T ? kc : (kc < p.T + p.Ka ? kc - p.T : kc - p.T - p.Ka);   // positions restart per segment
+    bf16_t* okp = const_cast<bf16_t*>(hrow(p.dks, p.dka, p.dkt, p, b, kc, hoff));
+    bf16_t* ovp = const_cast<bf16_t*>(hrow(p.dvs, p.dva, p.dvt, p, b, kc, hoff));
 #pragma unroll
-    for (int t = 0; t < G::DT; ++t) { dK[t] = zero16(); dV[t] = zero16(); }
+    for (int t = 0; t < G::DT; ++t) {
+      f32x16 dVt = zero16(), dKt = zero16();
+      dVt = mfma32(tr_frag(sdO, G::LD, 0, 32 * t, lane), pf0, dVt);    // dV^T[d x key] = dO^T . P
+      dVt = mfma32(tr_frag(sdO, G::LD, 1, 32 * t, lane), pf1, dVt);
+      dKt = mfma32(tr_frag(sQ, G::LD, 0, 32 * t, lane), dsf0, dKt);    // dK^T[d x key] = Q^T . dDot
+      dKt = mfma32(tr_frag(sQ, G::LD, 1, 32 * t, lane), dsf1, dKt);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const bf16x8 pf = pack_acc(S, s), dsf = pack_acc(dS, s);
-#pragma unroll
-      for (int t = 0; t < G::DT; ++t) {
-        dV[t] = mfma32(tr_frag(sdO, G::LD, s, 32 * t, lane), pf, dV[t]);   // dV^T[d x key] = dO^T . P
-        dK[t] = mfma32(tr_frag(sQ, G::LD, s, 32 * t, lane), dsf, dK[t]);   // dK^T[d x key] = Q^T . dDot
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * t + 8 * g + 4 * h;
+        if (d < D) {
+          float a0 = dKt[4 * g], b0 = dKt[4 * g + 1], a1 = dKt[4 * g + 2], b1 = dKt[4 * g + 3];
+          if (p.rope_cos) {                                              // inverse interleaved RoPE (rope_inter_bwd_acc, one block)
+            const float4 c = *reinterpret_cast<const float4*>(p.rope_cos + (long long)pos * D + d);
+            const float4 sn = *reinterpret_cast<const float4*>(p.rope_sin + (long long)pos * D + d);
+            const float x0 = a0 * c.x + b0 * sn.y, y0 = b0 * c.y - a0 * sn.x, x1 = a1 * c.z + b1 * sn.w, y1 = b1 * c.w - a1 * sn.z;
+            a0 = x0; b0 = y0; a1 = x1; b1 = y1;
+          }
+          if (key < N) {
+            *reinterpret_cast<uint2*>(okp + d) = uint2{pack2(a0, b0), pack2(a1, b1)};
+            *reinterpret_cast<uint2*>(ovp + d) = uint2{pack2(dVt[4 * g], dVt[4 * g + 1]), pack2(dVt[4 * g + 2], dVt[4 * g + 3])};
+          }
+        }
       }
     }
-    if (p.rope_cos) {
-      const int pos = kc < p.T ? kc : (kc < p.T + p.Ka ? kc - p.T : kc - p.T - p.Ka);   // positions restart per segment
-      rope_inter_bwd_acc<G::DT>(dK, p.rope_cos, p.rope_sin, pos, D, D, h);
-    }
-    if (key < N) {
-      bf16_t* okp = const_cast<bf16_t*>(hrow(p.dks, p.dka, p.dkt, p, b, key, hoff));
-      bf16_t* ovp = const_cast<bf16_t*>(hrow(p.dvs, p.dva, p.dvt, p, b, key, hoff));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward, tile-uniform form
+// (round 3) One WAVE per (sample, head, 32-key tile) does everything that tile contributes: dK and dV of its keys (complete),
+// its share of dQ and of the gate gradient (fp32 partials in a workspace, summed in tile order by head_dq_reduce).  The long dQ
+// waves of the combined kernel above (one per (sample, head): a serial loop over all key tiles with 64 accumulator + 112
+// operand / prefetch registers) set that kernel's register allocation at 380 (256 with spills) and its LDS at 17.6 KB per
+// wave; here every wave is the same short chain at <= 128 registers, and a workgroup = four consecutive key tiles of ONE
+// (sample, head) shares the staged Q / dO rows (T + 1 rows each: row T is the zero row every padded query row reads), so
+// four workgroups fit a CU.  Both score orientations are formed from the SAME fragments (S = Q.K^T with the key on the lane
+// for dK / dV, S^T = K.Q^T with the query on the lane for dQ: the operands of one are the swapped operands of the other).
+template <int D>
+__global__ __launch_bounds__(256) void head_bwd_tiles(HP p, float* __restrict__ ws_dq, float* __restrict__ ws_gate) {
+  using G = HG<D>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
+  const int N = p.T + p.Ka + p.Kt, ntile = (N + 31) / 32, nq = (ntile + 3) / 4;
+  const int gid = blockIdx.x / nq, tq = blockIdx.x - gid * nq;
+  const int b = gid / p.H, hd = gid - b * p.H, hoff = hd * D;
+  const int RQ = p.T + 1;                                   // staged query rows + the zero row
+  bf16_t* sQ = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* sdO = sQ + RQ * G::LD;
+  float* sLse = reinterpret_cast<float*>(sdO + RQ * G::LD);
+  float* sDelta = sLse + 32;
+  bf16_t* sK = reinterpret_cast<bf16_t*>(sDelta + 32) + w * G::TILE;
+  const int tile = tq * 4 + w;
+  const bool active = tile < ntile;
+  const int n0 = tile * 32;
+  const int key = n0 + (lane & 31), kc = min(key, N - 1);
+  const bool gated = key >= p.T + p.Ka;
+  // ---- ONE round of global latency: the tile's K and V rows as MFMA fragments (lane = key, 8 consecutive d) are requested first,
+  //      then the workgroup's query rows (shared by its four key tiles), LSE and delta = rowsum(dO * O) from global as well
+  bf16x8 kf[G::KS], vf[G::KS];
+  {
+    const bf16_t* kp = hrow(p.ks, p.ka, p.kt, p, b, kc, hoff);
+    const bf16_t* vp = hrow(p.vs, p.va, p.vt, p, b, kc, hoff);
 #pragma unroll
-      for (int t = 0; t < G::DT; ++t)
+    for (int ks = 0; ks < G::KS; ++ks) {
+      kf[ks] = *reinterpret_cast<const bf16x8*>(kp + 16 * ks + 8 * h);
+      vf[ks] = *reinterpret_cast<const bf16x8*>(vp + 16 * ks + 8 * h);
+    }
+  }
+  for (int c = tid; c < p.T * G::CPR; c += 256) {
+    const int r = c / G::CPR, ch = c - r * G::CPR;
+    const long long ro = ((long long)b * p.T + r);
+    *reinterpret_cast<u32x4*>(sQ + r * G::LD + ch * 8) = *reinterpret_cast<const u32x4*>(p.q + ro * p.ld_q + hoff + ch * 8);
+    *reinterpret_cast<u32x4*>(sdO + r * G::LD + ch * 8) = *reinterpret_cast<const u32x4*>(p.dout + ro * p.ld_out + hoff + ch * 8);
+  }
+  {                                                           // zero: pad columns [D, LD) of the T staged rows, and row T
+    constexpr int PADC = (G::LD - D) / 8;
+    for (int i = tid; i < 2 * p.T * PADC; i += 256) {
+      const int which = i / (p.T * PADC), j = i - which * p.T * PADC, r = j / PADC, c = D + 8 * (j - r * PADC);
+      *reinterpret_cast<u32x4*>((which ? sdO : sQ) + r * G::LD + c) = u32x4{0, 0, 0, 0};
+    }
+    for (int i = tid; i < 2 * G::LD / 8; i += 256) {
+      const int which = i / (G::LD / 8), c = 8 * (i - which * (G::LD / 8));
+      *reinterpret_cast<u32x4*>((which ? sdO : sQ) + p.T * G::LD + c) = u32x4{0, 0, 0, 0};
+    }
+  }
+  const float* slot = p.probs + (long long)gid * p.T * N;
+  if (tid < 32) sLse[tid] = tid < p.T ? slot[tid] * 1.4426950408889634f : 0.f;
+  for (int r0 = w * 8; r0 < 32; r0 += 32) {                   // 8 lanes per query row (wave w: rows 8w .. 8w + 7)
+    const int r = r0 + (lane >> 3), part = lane & 7;
+    float acc = 0.f;
+    if (r < p.T) {
+      const long long ro = ((long long)b * p.T + r);
+      for (int ch = part; ch < G::CPR; ch += 8) {
+        const bf16x8 ov = *reinterpret_cast<const bf16x8*>(p.out + ro * p.ld_out + hoff + ch * 8);
+        const bf16x8 dv = *reinterpret_cast<const bf16x8*>(p.dout + ro * p.ld_out + hoff + ch * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += bf2f((bf16_t)ov[j]) * bf2f((bf16_t)dv[j]);
+      }
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (part == 0) sDelta[r] = r < p.T ? acc : 0.f;
+  }
+  if (active) {
+    if (G::DV > D) {                                         // pad columns [D, DV) of the K tile: read by the last transposed block
+      for (int i = lane; i < 32 * (G::DV - D) / 8; i += 64) {
+        const int r = i / ((G::DV - D) / 8), c = D + 8 * (i - r * ((G::DV - D) / 8));
+        *reinterpret_cast<u32x4*>(sK + r * G::LD + c) = u32x4{0, 0, 0, 0};
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) *reinterpret_cast<bf16x8*>(sK + (lane & 31) * G::LD + 16 * ks + 8 * h) = kf[ks];
+  }
+  __syncthreads();
+  if (!active) return;                                       // (no workgroup barrier below)
+  const float tg = rbf(tanhf(bf2f(p.gate[0]))), rs = sqrtf((float)D), irs = 1.f / rs;
+  const bool two_steps = p.T > 16;                           // query rows 16 .. 31 exist: the second k-step of the q contraction
+  const int qrow = min(lane & 31, p.T);                      // padded query rows read the zero row
+  // ---- S[q x key], dP[q x key]: dK and dV
+  {
+    f32x16 S = zero16(), dP = zero16();
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+      S = mfma32(*reinterpret_cast<const bf16x8*>(sQ + qrow * G::LD + 16 * ks + 8 * h), kf[ks], S);
+      dP = mfma32(*reinterpret_cast<const bf16x8*>(sdO + qrow * G::LD + 16 * ks + 8 * h), vf[ks], dP);
+    }
+    f32x16 dS;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qr = acc_row(r, h);
+      const bool valid = key < N && qr < p.T;
+      const float pr = valid ? fexp2(score_chain(S[r], gated, tg, rs, true) - sLse[qr]) : 0.f;
+      const float ds = pr * (dP[r] - sDelta[qr]) * irs;
+      S[r] = pr;
+      dS[r] = gated ? ds * tg : ds;
+    }
+    const bf16x8 pf0 = pack_acc(S, 0), pf1 = pack_acc(S, 1), dsf0 = pack_acc(dS, 0), dsf1 = pack_acc(dS, 1);
+    const int pos = kc < p.T ? kc : (kc < p.T + p.Ka ? kc - p.T : kc - p.T - p.Ka);   // positions restart per segment
+    bf16_t* okp = const_cast<bf16_t*>(hrow(p.dks, p.dka, p.dkt, p, b, kc, hoff));
+    bf16_t* ovp = const_cast<bf16_t*>(hrow(p.dvs, p.dva, p.dvt, p, b, kc, hoff));
+    // transposed fragments of the staged Q / dO rows: rows >= T come from the zero row (tr_frag with clamped rows)
+    auto trq = [&](const bf16_t* tile, int s, int col0) {
+      const int gi = (lane >> 4) & 1, i = lane & 15;
+      const int r0 = 16 * s + 4 * h + (i >> 2);
+      const bf16_t* p0 = tile + min(r0, p.T) * G::LD + col0 + 16 * gi + 4 * (i & 3);
+      const bf16_t* p1 = tile + min(r0 + 8, p.T) * G::LD + col0 + 16 * gi + 4 * (i & 3);
+      const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)p0);
+      const bf16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)p1);
+      return bf16x8{a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+    };
+    // (the RoPE table rows of a block are requested BEFORE its MFMAs: an L2 round trip per block otherwise sits between the
+    //  accumulators and their stores; without RoPE the same loads read the head of the q tensor and are ignored)
+    const float* rc = p.rope_cos ? p.rope_cos + (long long)pos * D : reinterpret_cast<const float*>(p.q);
+    const float* rsn = p.rope_cos ? p.rope_sin + (long long)pos * D : reinterpret_cast<const float*>(p.q);
+#pragma unroll
+    for (int t = 0; t < G::DT; ++t) {
+      float4 rcv[4], rsv[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * t + 8 * g + 4 * h, dd = (p.rope_cos && d < D) ? d : 0;
+        rcv[g] = *reinterpret_cast<const float4*>(rc + dd);
+        rsv[g] = *reinterpret_cast<const float4*>(rsn + dd);
+      }
+      f32x16 dVt = zero16(), dKt = zero16();
+      dVt = mfma32(trq(sdO, 0, 32 * t), pf0, dVt);           // dV^T[d x key] = dO^T . P
+      dKt = mfma32(trq(sQ, 0, 32 * t), dsf0, dKt);           // dK^T[d x key] = Q^T . dDot
+      if (two_steps) {
+        dVt = mfma32(trq(sdO, 1, 32 * t), pf1, dVt);
+        dKt = mfma32(trq(sQ, 1, 32 * t), dsf1, dKt);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * t + 8 * g + 4 * h;
+        if (d < D) {
+          float a0 = dKt[4 * g], b0 = dKt[4 * g + 1], a1 = dKt[4 * g + 2], b1 = dKt[4 * g + 3];
+          if (p.rope_cos) {                                  // inverse interleaved RoPE (rope_inter_bwd_acc, one block)
+            const float4 c = rcv[g], sn = rsv[g];
+            const float x0 = a0 * c.x + b0 * sn.y, y0 = b0 * c.y - a0 * sn.x, x1 = a1 * c.z + b1 * sn.w, y1 = b1 * c.w - a1 * sn.z;
+            a0 = x0; b0 = y0; a1 = x1; b1 = y1;
+          }
+          if (key < N) {
+            *reinterpret_cast<uint2*>(okp + d) = uint2{pack2(a0, b0), pack2(a1, b1)};
+            *reinterpret_cast<uint2*>(ovp + d) = uint2{pack2(dVt[4 * g], dVt[4 * g + 1]), pack2(dVt[4 * g + 2], dVt[4 * g + 3])};
+          }
+        }
+      }
+    }
+  }
+  // ---- S^T[key x q], dP^T[key x q] (the same fragments, operands swapped): this tile's share of dQ and of the gate gradient
+  {
+    const int qi = lane & 31;
+    f32x16 S = zero16(), dP = zero16();
+    wave_lds_sync();                                         // the K tile written above: read back as rows here, transposed below
+    const bf16_t* vp2 = hrow(p.vs, p.va, p.vt, p, b, kc, hoff);
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {                     // (fragments re-read - LDS / L1-hot global - instead of 56 registers kept
+                                                             //  alive across the dK / dV phase)
+      const bf16x8 k2 = *reinterpret_cast<const bf16x8*>(sK + (lane & 31) * G::LD + 16 * ks + 8 * h);
+      const bf16x8 v2 = *reinterpret_cast<const bf16x8*>(vp2 + 16 * ks + 8 * h);
+      S = mfma32(k2, *reinterpret_cast<const bf16x8*>(sQ + qrow * G::LD + 16 * ks + 8 * h), S);
+      dP = mfma32(v2, *reinterpret_cast<const bf16x8*>(sdO + qrow * G::LD + 16 * ks + 8 * h), dP);
+    }
+    const float lse2 = sLse[qi], delta = sDelta[qi];
+    float gpart = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kk = n0 + acc_row(r, h);
+      const bool gk = kk >= p.T + p.Ka, valid = kk < N && qi < p.T;
+      const float dot = rbf(S[r]);
+      const float pr = valid ? fexp2(score_chain(S[r], gk, tg, rs, true) - lse2) : 0.f;
+      const float ds = pr * (dP[r] - delta) * irs;           // d(score before the /sqrt(dh))
+      if (gk) gpart += ds * dot;                             // d tanh(g)
+      S[r] = gk ? ds * tg : ds;                              // d(q.k)
+    }
+    const bf16x8 df0 = pack_acc(S, 0), df1 = pack_acc(S, 1);
+    float* wq = ws_dq + ((long long)(gid * ntile + tile) * p.T + qi) * D;
+#pragma unroll
+    for (int t = 0; t < G::DT; ++t) {
+      f32x16 dQt = zero16();
+      dQt = mfma32(tr_frag(sK, G::LD, 0, 32 * t, lane), df0, dQt);
+      dQt = mfma32(tr_frag(sK, G::LD, 1, 32 * t, lane), df1, dQt);
+      if (qi < p.T) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int d = 32 * t + 8 * g + 4 * h;
-          if (d < D) {
-            uint2 a = {pack2(dK[t][4 * g], dK[t][4 * g + 1]), pack2(dK[t][4 * g + 2], dK[t][4 * g + 3])};
-            uint2 c = {pack2(dV[t][4 * g], dV[t][4 * g + 1]), pack2(dV[t][4 * g + 2], dV[t][4 * g + 3])};
-            *reinterpret_cast<uint2*>(okp + d) = a;
-            *reinterpret_cast<uint2*>(ovp + d) = c;
-          }
+          if (d < D) *reinterpret_cast<float4*>(wq + d) = float4{dQt[4 * g], dQt[4 * g + 1], dQt[4 * g + 2], dQt[4 * g + 3]};
         }
+      }
     }
+    gpart = wave_sum(gpart);
+    if (lane == 0) ws_gate[gid * ntile + tile] = gpart;
+  }
+}
+
+// dq[b, q, head, :] = RoPE^T(sum over key tiles, in tile order, of the fp32 partials); dgate += (1 - tanh^2 g) * sum of the
+// gate partials (one atomic per (sample, head), as the combined kernel did).  One workgroup per (sample, head).
+template <int D>
+__global__ __launch_bounds__(256) void head_dq_reduce(HP p, const float* __restrict__ ws_dq, const float* __restrict__ ws_gate) {
+  const int gid = blockIdx.x, b = gid / p.H, hd = gid - b * p.H;
+  const int N = p.T + p.Ka + p.Kt, ntile = (N + 31) / 32;
+  for (int i = threadIdx.x; i < p.T * (D / 4); i += 256) {
+    const int q = i / (D / 4), d = 4 * (i - q * (D / 4));
+    float4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int t0 = 0; t0 < ntile; t0 += 12) {                 // twelve partials in flight (eleven tiles at 329 keys), added in tile order
+      float4 v[12];
+#pragma unroll
+      for (int j = 0; j < 12; ++j) {
+        const int t = min(t0 + j, ntile - 1);
+        v[j] = *reinterpret_cast<const float4*>(ws_dq + ((long long)(gid * ntile + t) * p.T + q) * D + d);
+      }
+#pragma unroll
+      for (int j = 0; j < 12; ++j)
+        if (t0 + j < ntile) { a.x += v[j].x; a.y += v[j].y; a.z += v[j].z; a.w += v[j].w; }
+    }
+    if (p.rope_cos) {
+      const float4 c = *reinterpret_cast<const float4*>(p.rope_cos + (long long)q * D + d);
+      const float4 s = *reinterpret_cast<const float4*>(p.rope_sin + (long long)q * D + d);
+      a = float4{a.x * c.x + a.y * s.y, a.y * c.y - a.x * s.x, a.z * c.z + a.w * s.w, a.w * c.w - a.z * s.z};
+    }
+    *reinterpret_cast<uint2*>(p.dq + ((long long)b * p.T + q) * p.ld_q + hd * D + d) = uint2{pack2(a.x, a.y), pack2(a.z, a.w)};
+  }
+  if (threadIdx.x == 0 && p.dgate) {
+    float g = 0.f;
+    for (int t = 0; t < ntile; ++t) g += ws_gate[gid * ntile + t];
+    const float th = tanhf(bf2f(p.gate[0]));
+    atomicAdd(p.dgate, g * (1.f - th * th));
   }
 }
 
@@ -459,8 +700,16 @@ void launch_fwd(const HP& p, hipStream_t st) {
 }
 template <int D>
 void launch_bwd(const HP& p, hipStream_t st) {
-  const size_t lds = 4 * HG<D>::WAVE_BYTES;
   const int ntile = (p.T + p.Ka + p.Kt + 31) / 32;
+  const long long need = (long long)p.B * p.H * ntile * ((long long)p.T * D + 1);
+  if (p.ws != nullptr && p.ws_floats >= need && !getenv("VLA_HEAD_BWD_COMBINED")) {     // tile-uniform form (needs the workspace)
+    float* ws_gate = p.ws + (long long)p.B * p.H * ntile * p.T * D;
+    const size_t lds2 = (size_t)4 * (p.T + 1) * HG<D>::LD + 256 + (size_t)4 * HG<D>::TILE * 2;
+    hipLaunchKernelGGL(head_bwd_tiles<D>, dim3(p.B * p.H * ((ntile + 3) / 4)), dim3(256), lds2, st, p, p.ws, ws_gate);
+    hipLaunchKernelGGL(head_dq_reduce<D>, dim3(p.B * p.H), dim3(256), 0, st, p, (const float*)p.ws, (const float*)ws_gate);
+    return;
+  }
+  const size_t lds = 4 * HG<D>::WAVE_BYTES;
   const int ndq = (p.B * p.H + 3) / 4, ndkv = (p.B * p.H * ntile + 3) / 4;
   hipLaunchKernelGGL(head_bwd_mfma<D>, dim3(ndq + ndkv), dim3(256), lds, st, p, ndq);
 }
@@ -468,6 +717,7 @@ template <int D>
 void set_attrs() {
   (void)hipFuncSetAttribute((const void*)head_fwd_mfma<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * HG<D>::WAVE_BYTES);
   (void)hipFuncSetAttribute((const void*)head_bwd_mfma<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * HG<D>::WAVE_BYTES);
+  (void)hipFuncSetAttribute((const void*)head_bwd_tiles<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 33 * HG<D>::LD + 256 + 4 * HG<D>::TILE * 2);
 }
 void set_all_attrs() {
   static bool done = false;

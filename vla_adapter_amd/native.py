@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = (os.environ.get("VLA_NATIVE_LIB") or None) or os.path.join(_HERE, "libvla_native.so")   # override: same-box A/B of two builds
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_TANH, ACT_SWIGLU, ACT_SWIGLU_BWD = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 2          # include/vla_native.h: VLA_ABI_VERSION
+ABI_VERSION = 3          # include/vla_native.h: VLA_ABI_VERSION
 
 
 class NativeLibraryMissing(ImportError):
@@ -67,7 +67,8 @@ class HeadAttnDesc(C.Structure):
                 ("gate_on_adapter", C.c_int),
                 ("dout", C.c_void_p), ("dq", C.c_void_p), ("dk_self", C.c_void_p), ("dv_self", C.c_void_p),
                 ("dk_adp", C.c_void_p), ("dv_adp", C.c_void_p), ("dk_task", C.c_void_p), ("dv_task", C.c_void_p),
-                ("dgate", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p)]
+                ("dgate", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
+                ("ws", C.c_void_p), ("ws_floats", C.c_longlong)]
 
 
 _P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double

@@ -621,6 +621,10 @@ def head_attn_bwd(dout, out, q, ks, vs, ka, va, kt, vt, gate, probs, dgate_f32, 
     if rope is not None:          # (cos, sin) f32 [>= max(T,Ka,Kt), dh]: dq / dk come back through the RoPE transpose
         assert rope[0].shape[0] >= max(q.shape[1], ka.shape[1], kt.shape[1]) and rope[0].shape[1] == d.dh
         d.rope_cos, d.rope_sin = rope[0].data_ptr(), rope[1].data_ptr()
+    # workspace of the tile-uniform MFMA backward (dQ / gate partials per 32-key tile): B*H*ceil(N/32)*(T*dh + 1) floats
+    ntile = (d.T + d.Ka + d.Kt + 31) // 32
+    ws = _splitk_ws(d.B * d.H * ntile * (d.T * d.dh + 1), q.device)
+    d.ws, d.ws_floats = ws.data_ptr(), ws.numel()
     N.check(_lib().vla_head_attn_bwd(_st(), C.byref(d)), "head_attn_bwd")
 
 
