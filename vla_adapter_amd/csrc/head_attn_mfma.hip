@@ -127,7 +127,7 @@ __device__ __forceinline__ float score_chain(float dot, bool gated, float tg, fl
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int D>
-__global__ __launch_bounds__(256) void head_fwd_mfma(HP p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void head_fwd_mfma(HP p) {
   using G = HG<D>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = lane >> 5;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void head_fwd_mfma(HP p) {
     for (int t = 0; t < G::DT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) O[t][r] *= a0;
-#pragma unroll
+#pragma nounroll                                              // (unrolled, the 3 x 64 partial values are all loaded up front: 244 registers, one wave per SIMD)
     for (int ww = 1; ww < HEAD_KV_WAVES; ++ww) {
       const float* oO = reinterpret_cast<const float*>(smem + ww * G::WAVE_BYTES);
       const float* oml = reinterpret_cast<const float*>(smem + ww * G::WAVE_BYTES + 2 * G::TILE * 2);
