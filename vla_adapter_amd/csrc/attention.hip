@@ -70,7 +70,7 @@ struct Geo {
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int D>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
+__global__ __launch_bounds__(256, (D <= 64 ? 4 : D <= 72 ? 3 : 2)) void attn_fwd_kernel(AttnP p) {
   using G = Geo<D>;
   __shared__ __attribute__((aligned(16))) bf16_t sK[32 * G::LD];
   __shared__ __attribute__((aligned(16))) bf16_t sV[32 * G::LD];
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
 
 // ------------------------------------------------------------------------------------------------ dQ
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
+__global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void attn_bwd_dq_kernel(AttnP p) {
   using G = Geo<D>;
   __shared__ __attribute__((aligned(16))) bf16_t sK[32 * G::LD];
   __shared__ __attribute__((aligned(16))) bf16_t sV[32 * G::LD];

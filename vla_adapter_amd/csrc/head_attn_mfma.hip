@@ -449,7 +449,7 @@ __device__ __forceinline__ void head_dkv_body(const HP& p, const int blk, char* 
 // four workgroups fit a CU.  Both score orientations are formed from the SAME fragments (S = Q.K^T with the key on the lane
 // for dK / dV, S^T = K.Q^T with the query on the lane for dQ: the operands of one are the swapped operands of the other).
 template <int D>
-__global__ __launch_bounds__(256) void head_bwd_tiles(HP p, float* __restrict__ ws_dq, float* __restrict__ ws_gate) {
+__global__ __launch_bounds__(256, 4) void head_bwd_tiles(HP p, float* __restrict__ ws_dq, float* __restrict__ ws_gate) {
   using G = HG<D>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
