@@ -30,8 +30,9 @@ extern "C" {
  *   2  round 3: vla_gemm_desc gained the K extension (A2 .. ldb2), new entry points vla_gemm_bf16_tn (+ _grouped), vla_gemm256_extent_ok,
  *      vla_copy_rows3d, vla_layerscale_fwd / _bwd, vla_token_ce_bwd, vla_desc_size.
  *   3  round 3: vla_head_attn_desc gained the optional backward workspace (ws, ws_floats).
+ *   4  round 3: vla_gemm_desc gained the RMSNorm fields (ssq_out .. rstd_out); new entry point vla_gemm_uses_256.
  * A binder checks vla_version() AND vla_desc_size() against its own struct definitions before the first call. */
-#define VLA_ABI_VERSION 3
+#define VLA_ABI_VERSION 4
 int vla_version(void);
 /* sizeof() of the descriptor structs as this library was compiled: which = 0 vla_gemm_desc, 1 vla_attn_desc, 2 vla_head_attn_desc,
  * 3 vla_gemm_tn_desc; -1 for an unknown index.  A caller whose struct is shorter would make the library read past its end. */
@@ -88,10 +89,19 @@ typedef struct vla_gemm_desc {
    * accumulator.  A LoRA-wrapped Linear (peft, vla-scripts/finetune.py:832-844) as one product: y = x W^T + (2 x A^T) B^T with the
    * base GEMM's epilogue intact; its backward dx = dy W + dt A likewise.  batch 1, no split-K / fp8 / interleaved RoPE. */
   const void* A2; const void* B2; int K2, lda2, ldb2;
+  /* ABI 4: RMSNorm folded into the neighbouring GEMMs (256-row kernel only: vla_gemm_uses_256 tells; the norm WEIGHT is folded into B by the
+   * caller, B' = B * w[None, :]).  Producer: ssq_out f32 [ceil(N/256)][M] receives, per 256-column tile, the sum of squares of the
+   * bf16 rows this GEMM stores (plain epilogue with a residual, batch 1, M and N multiples of 64).  Consumer: rowss = such partials
+   * of the rows of A (rowss_parts of them, <= 6); every accumulator row is multiplied by rstd[m] = rsqrt(sum_t rowss[t][m] / K + rows_eps)
+   * before alpha / bias / RoPE / SwiGLU; rstd_out f32 [M] (optional) receives rstd for the backward. */
+  float* ssq_out; const float* rowss; int rowss_parts; float rows_eps; float* rstd_out;
 } vla_gemm_desc;
 
 /* 1 when every operand row a 256-row tile of this problem can touch lies below 4 GiB from its base (the 256 x 256 kernel keeps
  * 32-bit per-lane byte offsets; larger operands are routed to the 128-row kernel, which uses 64-bit pointers).  Host arithmetic. */
+/* 1 when vla_gemm_bf16_nt would run this descriptor on the 256 x 256 kernel (the routing is shape- and device-dependent): callers that
+ * want the RMSNorm fields ask first and keep the stand-alone norm otherwise. */
+int vla_gemm_uses_256(const vla_gemm_desc* desc);
 int vla_gemm256_extent_ok(const vla_gemm_desc* desc /* host */);
 
 /* ---------------------------------------------------------------- TN GEMM (weight gradients) */

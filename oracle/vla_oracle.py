@@ -257,30 +257,53 @@ def qwen2_forward(x, mask, p: Dict[str, torch.Tensor], cfg: Dict, emu=False) -> 
     """
     S = x.shape[1]
     hs = [x]
+    fold = cfg.get("fold_llm_rmsnorm", False)     # native adapter-only forward: every RMSNorm but the first and the final one is folded
     for i in range(cfg["n_layers"]):
-        x = qwen2_layer(x, mask, p, f"layers.{i}.", cfg, emu)
+        x = qwen2_layer(x, mask, p, f"layers.{i}.", dict(cfg, fold_rmsnorm=(fold and i > 0, fold)), emu)
         hs.append(x)
     hs[-1] = rms_norm(x, p["norm.weight"], cfg["eps"], emu)
     return hs
 
 
+def folded_norm_linear(x, nw, eps, w, b, emu):
+    """RMSNorm folded into the Linear behind it (the native adapter-only forward, engine.LLM.fold_rmsnorm): the norm weight goes into
+    the weight matrix, W' = bf16(W * nw[None, :]), the row scale 1 / rms(x) onto the fp32 product - the normalised activations are never
+    rounded to bf16 (Qwen2RMSNorm rounds them twice).  A DIVERGENCE from the reference's rounding points, restated here so that the
+    native path is checked against its own arithmetic; emu=False is the same real-valued function as rms_norm -> linear."""
+    xf = x.float()
+    rstd = torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
+    y = (xf @ rnd(w.float() * nw.float()[None, :], emu).t()) * rstd
+    return rnd(y + b.float() if b is not None else y, emu)
+
+
 def qwen2_layer(x, mask, p: Dict[str, torch.Tensor], pre: str, cfg: Dict, emu=False):
-    """One Qwen2DecoderLayer (transformers): x + o(attn(rope(q, k), v)) ; x + down(silu(gate) * up)."""
+    """One Qwen2DecoderLayer (transformers): x + o(attn(rope(q, k), v)) ; x + down(silu(gate) * up).
+    cfg["fold_rmsnorm"] = (fold norm1, fold norm2) selects folded_norm_linear for the projections behind either norm."""
     B, S, D = x.shape
     H, KV, dh = cfg["heads"], cfg["kv_heads"], cfg["dh"]
     cos, sin = rope_half_tables(S, dh, cfg["theta"], emu)
-    h = rms_norm(x, p[pre + "input_layernorm.weight"], cfg["eps"], emu)
-    q = linear(h, p[pre + "self_attn.q_proj.weight"], p[pre + "self_attn.q_proj.bias"], emu)
-    k = linear(h, p[pre + "self_attn.k_proj.weight"], p[pre + "self_attn.k_proj.bias"], emu)
-    v = linear(h, p[pre + "self_attn.v_proj.weight"], p[pre + "self_attn.v_proj.bias"], emu)
+    f1, f2 = cfg.get("fold_rmsnorm", (False, False))
+    if f1:
+        nw = p[pre + "input_layernorm.weight"]
+        q, k, v = (folded_norm_linear(x, nw, cfg["eps"], p[pre + f"self_attn.{n}_proj.weight"], p[pre + f"self_attn.{n}_proj.bias"], emu) for n in "qkv")
+    else:
+        h = rms_norm(x, p[pre + "input_layernorm.weight"], cfg["eps"], emu)
+        q = linear(h, p[pre + "self_attn.q_proj.weight"], p[pre + "self_attn.q_proj.bias"], emu)
+        k = linear(h, p[pre + "self_attn.k_proj.weight"], p[pre + "self_attn.k_proj.bias"], emu)
+        v = linear(h, p[pre + "self_attn.v_proj.weight"], p[pre + "self_attn.v_proj.bias"], emu)
     q = rope_half(q.reshape(B, S, H, dh).transpose(1, 2), cos, sin, emu)
     k = rope_half(k.reshape(B, S, KV, dh).transpose(1, 2), cos, sin, emu)
     v = v.reshape(B, S, KV, dh).transpose(1, 2)
     a = attention(q, k, v, True, mask, dh ** -0.5, emu).transpose(1, 2).reshape(B, S, H * dh)
     x = rnd(x + linear(a, p[pre + "self_attn.o_proj.weight"], None, emu), emu)
-    h = rms_norm(x, p[pre + "post_attention_layernorm.weight"], cfg["eps"], emu)
-    g = linear(h, p[pre + "mlp.gate_proj.weight"], None, emu)
-    u = linear(h, p[pre + "mlp.up_proj.weight"], None, emu)
+    if f2:
+        nw = p[pre + "post_attention_layernorm.weight"]
+        g = folded_norm_linear(x, nw, cfg["eps"], p[pre + "mlp.gate_proj.weight"], None, emu)
+        u = folded_norm_linear(x, nw, cfg["eps"], p[pre + "mlp.up_proj.weight"], None, emu)
+    else:
+        h = rms_norm(x, p[pre + "post_attention_layernorm.weight"], cfg["eps"], emu)
+        g = linear(h, p[pre + "mlp.gate_proj.weight"], None, emu)
+        u = linear(h, p[pre + "mlp.up_proj.weight"], None, emu)
     m = rnd(rnd(g * torch.sigmoid(g), emu) * u, emu)
     return rnd(x + linear(m, p[pre + "mlp.down_proj.weight"], None, emu), emu)
 

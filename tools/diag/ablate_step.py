@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Diagnostic, timing only (results are WRONG by construction): the captured training step with one kernel family compiled out of
+the graphs.  CAUTION - NOT an upper bound as it stands: a skipped producer leaves its output buffer at zeros (or at whatever it held),
+and GEMMs on zero operands run the chip at a higher clock (MI355X_MICROARCH.md, DVFS): "no RMSNorm" read -1.2 ms this way while the
+real fold of those norms into their GEMMs measured +0.1 ms.  Fill the skipped outputs with random data before trusting a number.
+usage: ablate_step.py {none|rms|ln|attn|head_attn} [bench.py args]"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+what = sys.argv[1]
+sys.argv = [sys.argv[0]] + sys.argv[2:]
+from vla_adapter_amd import engine as E, ops  # noqa: E402
+
+_buf = {}
+
+
+def _like(key, shape, dtype, dev):
+    k = (key, tuple(shape), dtype)
+    if k not in _buf:
+        _buf[k] = torch.zeros(shape, dtype=dtype, device=dev)
+    return _buf[k]
+
+
+if what == "rms":
+    E.LLM._rms = lambda self, x, w, out, rstd: None
+elif what == "ln":
+    _ln = ops.layernorm_fwd
+
+    def ln(x, w, b, eps, want_stats=False, **kw):
+        if want_stats:
+            return _ln(x, w, b, eps, want_stats=True, **kw)
+        return x                                              # (ViT blocks: the GEMM reads the un-normalised rows)
+    ops.layernorm_fwd = ln
+elif what == "attn":
+    _af = ops.attn_fwd
+
+    def af(q, k, v, Hq, Hkv, dh, causal, kmask=None, want_lse=False, **kw):
+        o = _like("o", (q.shape[0], q.shape[1], Hq * dh), q.dtype, q.device)
+        if want_lse:
+            return o, _like("lse", (q.shape[0], Hq, q.shape[1]), torch.float32, q.device)
+        return o
+    ops.attn_fwd = af
+    E.LLM._attn_fwd = lambda self, q3, i, b0, b1, S: None     # (the LLM's attention output buffer keeps what it held)
+elif what == "head_attn":
+    ops.head_attn_bwd = lambda *a, **k: None
+import bench  # noqa: E402
+
+bench.main()

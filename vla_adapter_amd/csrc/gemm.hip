@@ -651,6 +651,21 @@ extern "C" int vla_gemm256_extent_ok(const vla_gemm_desc* d) {
   return (offA + d->K) * EB < lim && (offB + d->K) * EB < lim;
 }
 
+// The tile choice of vla_gemm_bf16_nt for a descriptor (shared with the predicate below).
+static TileChoice route(const vla_gemm_desc* d) {
+  const int split = d->split_k > 1 ? d->split_k : 1;
+  const char* e = getenv("VLA_GEMM_TILE");     // 0/unset auto, 1: 256x128, 2: 128x128, 3: 128x64  (benchmarking aid)
+  TileChoice tc = choose_tile(d->M, d->N, d->K / split, e ? atoi(e) : 0, d->rope_mode, split > 1 ? split : d->batch, split, d->act);
+  if (tc.bm == 256 && tc.bn == 257 && !vla_gemm256_extent_ok(d)) tc = TileChoice{128, 128};   // operands of 4 GiB and more: 64-bit-pointer kernel
+  return tc;
+}
+
+extern "C" int vla_gemm_uses_256(const vla_gemm_desc* d) {
+  if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->K2 > 0 || d->fp8 || d->split_k > 1 || getenv("VLA_COLPEEL") != nullptr) return 0;
+  const TileChoice tc = route(d);
+  return tc.bm == 256 && tc.bn == 257 ? 1 : 0;
+}
+
 extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   VLA_REQUIRE(d && d->A && d->B, "gemm: null operand");
   VLA_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->batch > 0, "gemm: empty problem");
@@ -687,6 +702,7 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   p.ldc2 = d->ldc2; p.res_mod = d->res_mod; p.act = d->act;
   p.sA = d->sA; p.sB = d->sB; p.sC = d->sC; p.sR = d->sR; p.sC2 = d->sC2; p.sBias = d->sBias;
   p.tiles_n = p.ntiles = 0; p.batch = 1; p.xpx = p.xpy = 0; p.stagger = 0;
+  p.ssq_out = d->ssq_out; p.rowss = d->rowss; p.rowss_parts = d->rowss_parts; p.rows_eps = d->rows_eps; p.rstd_out = d->rstd_out;
   p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
   p.gA = d->a_group; p.sgA = d->a_group_stride; p.gC = d->c_group; p.sgC = d->c_group_stride;
   p.gR = d->r_group; p.sgR = d->r_group_stride;
@@ -727,10 +743,22 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
                 "gemm: bad rope arguments");
     if (d->rope_mode == 1) VLA_REQUIRE(d->rope_dh == 64, "gemm: fused rotate_half RoPE needs head dim 64");
   }
-  const char* e = getenv("VLA_GEMM_TILE");     // 0/unset auto, 1: 256x128, 2: 128x128, 3: 128x64  (benchmarking aid)
-  TileChoice tc = choose_tile(d->M, d->N, d->K / split, e ? atoi(e) : 0, d->rope_mode, split > 1 ? split : d->batch, split, d->act);
-  const bool fits256 = vla_gemm256_extent_ok(d) != 0;          // operands of 4 GiB and more stay on the 64-bit-pointer kernel
-  if (tc.bm == 256 && tc.bn == 257 && !fits256) tc = TileChoice{128, 128};
+  const char* e = getenv("VLA_GEMM_TILE");
+  const TileChoice tc = route(d);
+  const bool fits256 = vla_gemm256_extent_ok(d) != 0;
+  if (d->ssq_out || d->rowss) {      // RMSNorm fields: the 256-row kernel's epilogue only (ask vla_gemm_uses_256 first)
+    VLA_REQUIRE(tc.bm == 256 && tc.bn == 257 && d->K2 == 0 && !d->fp8 && split == 1 && d->batch == 1 && getenv("VLA_COLPEEL") == nullptr,
+                "gemm: ssq_out / rowss need the 256-row kernel (vla_gemm_uses_256), batch 1, no split-K / K extension / fp8");
+    VLA_REQUIRE(!(d->ssq_out && d->rowss), "gemm: a GEMM is either the producer (ssq_out) or the consumer (rowss) of RMSNorm partials");
+    if (d->ssq_out)
+      VLA_REQUIRE(d->act == VLA_ACT_NONE && d->R && d->rope_mode == 0 && d->M % 64 == 0 && d->N % 64 == 0 && d->ldc % 8 == 0 && d->ldr % 8 == 0 &&
+                      d->c_group == 0 && d->r_group == 0 && d->res_mod == 0 && d->c_live_mod == 0 && ((uintptr_t)d->ssq_out & 3) == 0,
+                  "gemm: ssq_out needs the plain epilogue with a residual, M and N multiples of 64, plain row addressing");
+    if (d->rowss)
+      VLA_REQUIRE(d->rowss_parts >= 1 && d->rowss_parts <= 6 && d->rows_eps > 0.f && !d->R && d->act != VLA_ACT_SWIGLU_BWD && !d->bias_post_round &&
+                      d->a_group == 0 && ((uintptr_t)d->rowss & 3) == 0,
+                  "gemm: rowss needs 1..6 partials, eps > 0, no residual, plain A rows");
+  }
   if (d->K2 > 0) {                 // K extension: 128-row kernel (the 256-row kernel's hand-counted DMA schedule has one operand pair)
     if (d->act == VLA_ACT_SWIGLU_BWD) launch<128, 128, 2, 3, 4, false, true>(p, d->M, d->N, 1, (hipStream_t)stream);
     else if (d->rope_mode == 1) launch<128, 128, 2, 1, 4, false, true>(p, d->M, d->N, 1, (hipStream_t)stream);

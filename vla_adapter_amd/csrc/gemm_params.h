@@ -20,7 +20,10 @@ struct GemmP {
   const float* scaleA; const float* scaleB;   // fp8 operands (A, B point at OCP e4m3 bytes): per-row dequantisation scales [M], [N]
   int stagger;                              // gemm256.hip: start delay (units of 1024 cycles) of the workgroups that walk one tile fewer than the others (0 = none)
   int xpx, xpy;                             // gemm256.hip: XCD-blocked tile order (xpx * xpy = 8 blocks of the tile grid; 0 = plain group-M order)
-  const bf16_t* A2; const bf16_t* B2; int K2, lda2, ldb2;   // K extension (gemm.hip EXT): C = epilogue(A . B^T + A2 . B2^T)
+  const bf16_t* A2; const bf16_t* B2; int K2, lda2, ldb2;   // K extension (gemm.hip EXT): C = epilogue(A . B^T + A2 . B2^T)  // RMSNorm folded into neighbouring GEMMs (gemm256.hip only; the norm weight is folded into B by the caller):
+  float* ssq_out;                           // producer: [ceil(N / 256)][M] partial sums of squares of the bf16 OUTPUT rows, one per column tile
+  const float* rowss; int rowss_parts;      // consumer: such partials of the rows of A; every accumulator row is scaled by
+  float rows_eps; float* rstd_out;          //   rstd[m] = rsqrt(sum_t rowss[t][m] / K + eps) before alpha / bias; rstd_out [M] optional
 };
 
 // gemm256.hip: 256x256x64 tile, 8 waves, staggered 8-phase schedule.  epi: 0 plain, 1 SwiGLU forward, 2 SwiGLU backward.

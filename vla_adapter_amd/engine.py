@@ -310,6 +310,29 @@ class LLM:
         self.embed = g("embed_tokens.weight")
         self._buf_key = None
         self.gu_row0 = 0
+        self.folded = False
+        if os.environ.get("VLA_RMSNORM_FOLD"):                # opt-in: measured and NOT adopted (see fold_rmsnorm)
+            self.fold_rmsnorm(True)
+
+    def fold_rmsnorm(self, on: bool):
+        """RMSNorm folded into the GEMMs on either side of it (frozen weights: the adapter-only forward).  The norm weight goes into the
+        projection behind the norm (W' = bf16(W * w[None, :])), the GEMM in front of it also emits per-column-tile sums of squares of
+        the rows it stores, the GEMM behind scales its fp32 rows by 1 / rms before bias / RoPE / SwiGLU and saves that rstd for the
+        backward (vla_gemm_desc ssq_out / rowss, ABI 4).  47 launches fewer on the forward chain; one rounding point moves (the
+        normalised activations are never rounded to bf16: oracle.folded_norm_linear, tests/test_engine_gpu.py::
+        test_llm_rmsnorm_fold_matches_its_oracle).  Used only where all four GEMMs of a layer run on the 256-row kernel and the call
+        covers the whole batch (LLM._fold_ok); the first norm of layer 0 and the final norm stay kernels.
+        MEASURED AND NOT ADOPTED (round 3, opt-in through VLA_RMSNORM_FOLD=1): isolated the four GEMMs of a layer cost +9.9 us with the
+        extra fields (o +2.5: one more workgroup barrier and an LDS reduce; gate/up +6.8: 48 partial loads, 8 rsqrt and 128 multiplies
+        per lane and tile) against 2 x 7.7 us of norm kernels saved; on the step it measured 24.98 vs 24.88 ms (same box, three
+        alternating runs) - slower.  (A first "upper bound" of -1.2 ms came from an ablation that skipped the norm launches and thereby
+        fed the GEMMs a buffer of zeros: zero operands run the chip at a higher clock - tools/diag/ablate_step.py now refuses that.)"""
+        self.folded = bool(on)
+        for L in self.layers:
+            if on and "wqkv_n" not in L:
+                L["wqkv_n"] = (L["wqkv"].float() * L["n1"].float()[None, :]).to(BF16).contiguous()
+                L["wgu_n"] = (L["wgu"].float() * L["n2"].float()[None, :]).to(BF16).contiguous()
+        self._buf_key = None
 
     def _alloc(self, B: int, S: int):
         if self._buf_key == (B, S):
@@ -330,6 +353,18 @@ class LLM:
         self.d_a, self.d_b, self.d_h, self.d_gu, self.d_qkv, self.d_n = e(M, D), e(M, D), e(M, c.inter), e(M, 2 * c.inter), e(M, W), e(M, D)
         self.cos, self.sin = ops.rope_half_tables(S, c.dh, c.theta, dev)
         self._buf_key = (B, S)
+        # RMSNorm folding: partial sums of squares of the residual stream entering a layer (SSX) and of x1 (SSX1), one row per 256-column tile
+        parts = (D + 255) // 256
+        self.SSX, self.SSX1 = e(parts, M, dt=torch.float32), e(parts, M, dt=torch.float32)
+        self._fold_ok = False
+        if self.folded and not getattr(self, "fp8", False) and M % 64 == 0 and D % 64 == 0 and parts <= 6 and c.n_layers > 1:
+            L, H, KV, dh = self.layers[1], c.heads, c.kv_heads, c.dh
+            x, ao, x1, qkv, hb, gu = self.HS[1].view(-1, D), self.AO[1], self.X1[1], self.QKV[1], self.hbuf, self.GU[1]
+            rope = (1, self.cos, self.sin, S, dh, (H + KV) * dh) if dh == 64 else None
+            self._fold_ok = (ops.gemm_nt(x, L["wqkv_n"], bias=L["bqkv"], out=qkv, rope=rope, rownorm=(self.SSX, c.eps, self.R1[1]), query_256=True)
+                             and ops.gemm_nt(ao, L["wo"], residual=x, out=x1, ssq_out=self.SSX1, query_256=True)
+                             and ops.gemm_nt(x1, L["wgu_n"], act=ACT_SWIGLU, out=gu, out2=hb, rownorm=(self.SSX1, c.eps, self.R2[1]), query_256=True)
+                             and ops.gemm_nt(hb, L["wd"], residual=x1, out=x, ssq_out=self.SSX, query_256=True))
 
     def out_slot(self, i: int) -> int:
         """HS slot holding the output of layer i (0-based)."""
@@ -362,11 +397,23 @@ class LLM:
         fp8 = getattr(self, "fp8", False)
         q8, qs = self.q8[r0:r1], self.qs[r0:r1]
         qkv = self.QKV[i][r0:r1]
-        if fp8:
+        fold = self._fold_ok and not fp8 and b0 == 0 and b1 == self.B      # (the partial buffers are whole-batch, row-contiguous)
+        fold1 = fold and i > 0                                             # layer 0's input comes from the splice, not from a GEMM
+        if fold1:
+            pass
+        elif fp8:
             ops.rmsnorm_fwd_q8(x, L["n1"], c.eps, q8, qs, rstd=self.R1[i][r0:r1])
         else:
             self._rms(x, L["n1"], nbuf, self.R1[i][r0:r1])
-        if fp8 and dh == 64:
+        if fold1:
+            rn = (self.SSX, c.eps, self.R1[i])
+            if dh == 64:
+                ops.gemm_nt(x, L["wqkv_n"], bias=L["bqkv"], out=qkv, rope=(1, self.cos, self.sin, S, dh, (H + KV) * dh), rownorm=rn)
+            else:
+                ops.gemm_nt(x, L["wqkv_n"], bias=L["bqkv"], out=qkv, rownorm=rn)
+                ops.rope_half_(qkv[:, :H * dh], self.cos, self.sin, S, H, dh)
+                ops.rope_half_(qkv[:, H * dh:(H + KV) * dh], self.cos, self.sin, S, KV, dh)
+        elif fp8 and dh == 64:
             ops.gemm_nt(q8, L["wqkv_q"], bias=L["bqkv"], out=qkv, rope=(1, self.cos, self.sin, S, dh, (H + KV) * dh), fp8=(qs, L["wqkv_s"]))
         elif fp8:
             ops.gemm_nt(q8, L["wqkv_q"], bias=L["bqkv"], out=qkv, fp8=(qs, L["wqkv_s"]))
@@ -380,9 +427,12 @@ class LLM:
             ops.rope_half_(qkv[:, H * dh:(H + KV) * dh], self.cos, self.sin, S, KV, dh)
         self._attn_fwd(qkv.view(B, S, -1), i, b0, b1, S)
         x1 = self.X1[i][r0:r1]
-        ops.gemm_nt(self.AO[i][r0:r1], L["wo"], residual=x, out=x1)
+        ops.gemm_nt(self.AO[i][r0:r1], L["wo"], residual=x, out=x1, ssq_out=self.SSX1 if fold else None)
         # the pre-activations are kept for the backward only: rows below the live window are never read again
-        if fp8:
+        if fold:
+            ops.gemm_nt(x1, L["wgu_n"], act=ACT_SWIGLU, out=self.GU[i][r0:r1], out2=hbuf,
+                        c_live=(S, self.gu_row0) if self.gu_row0 else None, rownorm=(self.SSX1, c.eps, self.R2[i]))
+        elif fp8:
             ops.rmsnorm_fwd_q8(x1, L["n2"], c.eps, q8, qs, rstd=self.R2[i][r0:r1])
             ops.gemm_nt(q8, L["wgu_q"], act=ACT_SWIGLU, out=self.GU[i][r0:r1], out2=hbuf,
                         c_live=(S, self.gu_row0) if self.gu_row0 else None, fp8=(qs, L["wgu_s"]))
@@ -390,7 +440,8 @@ class LLM:
             self._rms(x1, L["n2"], nbuf, self.R2[i][r0:r1])
             ops.gemm_nt(nbuf, L["wgu"], act=ACT_SWIGLU, out=self.GU[i][r0:r1], out2=hbuf,
                         c_live=(S, self.gu_row0) if self.gu_row0 else None)
-        ops.gemm_nt(hbuf, L["wd"], residual=x1, out=self.HS[self.out_slot(i)].view(-1, D)[r0:r1])
+        ops.gemm_nt(hbuf, L["wd"], residual=x1, out=self.HS[self.out_slot(i)].view(-1, D)[r0:r1],
+                    ssq_out=self.SSX if (fold and i + 1 < c.n_layers) else None)
 
     def fwd_final(self, b0: int = 0, b1: Optional[int] = None):
         """hidden_states[n] = final RMSNorm of the last layer's output (HF convention)."""

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = (os.environ.get("VLA_NATIVE_LIB") or None) or os.path.join(_HERE, "libvla_native.so")   # override: same-box A/B of two builds
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_TANH, ACT_SWIGLU, ACT_SWIGLU_BWD = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 3          # include/vla_native.h: VLA_ABI_VERSION
+ABI_VERSION = 4          # include/vla_native.h: VLA_ABI_VERSION
 
 
 class NativeLibraryMissing(ImportError):
@@ -32,7 +32,8 @@ class GemmDesc(C.Structure):
                 ("r_group", C.c_int), ("r_group_stride", C.c_longlong), ("c_live_mod", C.c_int), ("c_live_from", C.c_int),
                 ("split_k", C.c_int), ("ws", C.c_void_p), ("bias_post_round", C.c_int),
                 ("fp8", C.c_int), ("a_scale", C.c_void_p), ("b_scale", C.c_void_p),
-                ("A2", C.c_void_p), ("B2", C.c_void_p), ("K2", C.c_int), ("lda2", C.c_int), ("ldb2", C.c_int)]
+                ("A2", C.c_void_p), ("B2", C.c_void_p), ("K2", C.c_int), ("lda2", C.c_int), ("ldb2", C.c_int),
+                ("ssq_out", C.c_void_p), ("rowss", C.c_void_p), ("rowss_parts", C.c_int), ("rows_eps", C.c_float), ("rstd_out", C.c_void_p)]
 
 
 class GemmTnDesc(C.Structure):
@@ -76,6 +77,7 @@ _PROTOS = {
     "vla_version": ([], _I),
     "vla_desc_size": ([_I], _I),
     "vla_gemm256_extent_ok": ([C.POINTER(GemmDesc)], _I),
+    "vla_gemm_uses_256": ([C.POINTER(GemmDesc)], _I),
     "vla_gemm_bf16_tn": ([_P, C.POINTER(GemmTnDesc)], _I),
     "vla_gemm_bf16_tn_grouped": ([_P, C.POINTER(GemmTnDesc), _I], _I),
     "vla_copy_rows3d": ([_P, _P, _P, _I, _I, _I, _L, _L, _L, _L], _I),

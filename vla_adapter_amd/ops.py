@@ -39,11 +39,16 @@ def _chk_bf16(*ts):
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_mod: int = 0, act: int = ACT_NONE,
             out: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, alpha: float = 1.0,
             want_pre: bool = True, a_group=None, c_group=None, r_group=None, rope=None, c_live=None,
-            split_k: Optional[int] = None, bias_post_round: bool = False, fp8=None, ext=None) -> torch.Tensor:
+            split_k: Optional[int] = None, bias_post_round: bool = False, fp8=None, ext=None, ssq_out=None, rownorm=None,
+            query_256: bool = False) -> torch.Tensor:
     """C = epilogue(A @ B^T).  a: [M,K] or [batch,M,K] (row stride = a.stride(-2)); b: [N,K] or [batch,N,K].
     SwiGLU: returns (pre [.., N] or None, h [.., N/2]).  split_k: None = automatic, 0/1 = off, k = forced.
     fp8=(a_scale [M] f32, b_scale [N] f32): a and b are uint8 tensors of OCP e4m3 codes (quant_fp8_rows).
-    ext=(a2 [M, K2], b2 [N, K2]): K extension, C = epilogue(A @ B^T + A2 @ B2^T) in one fp32 accumulator (LoRA branch)."""
+    ext=(a2 [M, K2], b2 [N, K2]): K extension, C = epilogue(A @ B^T + A2 @ B2^T) in one fp32 accumulator (LoRA branch).
+    RMSNorm folded into GEMMs (256-row kernel only; the norm weight folded into b by the caller): ssq_out f32 [ceil(N/256), M] = per
+    column tile, the sum of squares of the rows this GEMM stores (producer); rownorm=(partials f32 [parts, M], eps, rstd_out f32 [M] or
+    None): rows of the accumulator scaled by rsqrt(sum(partials) / K + eps) (consumer).  query_256=True: no launch, returns whether
+    this call would run on the 256-row kernel."""
     if fp8 is not None:
         assert a.dtype == torch.uint8 and b.dtype == torch.uint8 and a.dim() == 2 and split_k in (None, 0, 1)
         _chk_bf16(bias, residual, out, out2)
@@ -116,6 +121,18 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_m
         assert a2.stride(1) == 1 and b2.stride(1) == 1 and a2.shape[1] % 64 == 0 and split_k in (None, 0, 1)
         d.A2, d.B2, d.K2, d.lda2, d.ldb2 = a2.data_ptr(), b2.data_ptr(), a2.shape[1], a2.stride(0), b2.stride(0)
         split_k = 0
+    if ssq_out is not None:
+        assert ssq_out.dtype == torch.float32 and ssq_out.is_contiguous() and tuple(ssq_out.shape) == ((Nn + 255) // 256, M)
+        d.ssq_out = ssq_out.data_ptr()
+        split_k = 0
+    if rownorm is not None:
+        parts, eps, rstd_out = rownorm
+        assert parts.dtype == torch.float32 and parts.is_contiguous() and parts.dim() == 2 and parts.shape[1] == M
+        d.rowss, d.rowss_parts, d.rows_eps = parts.data_ptr(), parts.shape[0], eps
+        if rstd_out is not None:
+            assert rstd_out.dtype == torch.float32 and rstd_out.is_contiguous() and rstd_out.numel() == M
+            d.rstd_out = rstd_out.data_ptr()
+        split_k = 0
     if bias_post_round:          # C = bf16(bf16(A.B^T) + bias): torch CPU Linear on a strided bf16 input (vla_native.h)
         assert bias is not None
         d.bias_post_round = 1
@@ -133,6 +150,8 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_m
     if split_k > 1:
         assert plain and K % (64 * split_k) == 0, "split-K needs a plain epilogue and K divisible by 64 * split_k"
         d.split_k, d.ws = split_k, _splitk_ws(split_k * M * Nn, a.device).data_ptr()
+    if query_256:
+        return bool(_lib().vla_gemm_uses_256(C.byref(d)))
     N.check(_lib().vla_gemm_bf16_nt(_st(), C.byref(d)), "gemm_bf16_nt")
     if act == ACT_SWIGLU:
         return out, out2
