@@ -2,7 +2,8 @@
 """Diagnostic, timing only (results are WRONG by construction): the captured training step with one kernel family compiled out of
 the graphs.  CAUTION - NOT an upper bound as it stands: a skipped producer leaves its output buffer at zeros (or at whatever it held),
 and GEMMs on zero operands run the chip at a higher clock (MI355X_MICROARCH.md, DVFS): "no RMSNorm" read -1.2 ms this way while the
-real fold of those norms into their GEMMs measured +0.1 ms.  Fill the skipped outputs with random data before trusting a number.
+real fold of those norms into their GEMMs measured +0.1 ms.  The buffers of the skipped producers are therefore filled with random data
+once (rms, attn); head_attn still leaves zero gradients behind and is NOT a valid bound.
 usage: ablate_step.py {none|rms|ln|attn|head_attn} [bench.py args]"""
 import os
 import sys
@@ -21,8 +22,23 @@ _buf = {}
 def _like(key, shape, dtype, dev):
     k = (key, tuple(shape), dtype)
     if k not in _buf:
-        _buf[k] = torch.zeros(shape, dtype=dtype, device=dev)
+        _buf[k] = (torch.randn(shape, device=dev) * 0.5).to(dtype)      # never zeros: see the caution above
     return _buf[k]
+
+
+_alloc0 = E.LLM._alloc
+
+
+def _alloc_random(self, B, S):
+    fresh = self._buf_key != (B, S)
+    _alloc0(self, B, S)
+    if fresh:                                                            # buffers whose producer is skipped hold random data
+        self.nbuf.copy_((torch.randn(self.nbuf.shape, device=self.nbuf.device) * 0.5).to(self.nbuf.dtype))
+        self.AO.copy_((torch.randn(self.AO.shape, device=self.AO.device) * 0.5).to(self.AO.dtype))
+        self.R1.fill_(1.0); self.R2.fill_(1.0)
+
+
+E.LLM._alloc = _alloc_random
 
 
 if what == "rms":

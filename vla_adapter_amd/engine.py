@@ -326,7 +326,8 @@ class LLM:
         extra fields (o +2.5: one more workgroup barrier and an LDS reduce; gate/up +6.8: 48 partial loads, 8 rsqrt and 128 multiplies
         per lane and tile) against 2 x 7.7 us of norm kernels saved; on the step it measured 24.98 vs 24.88 ms (same box, three
         alternating runs) - slower.  (A first "upper bound" of -1.2 ms came from an ablation that skipped the norm launches and thereby
-        fed the GEMMs a buffer of zeros: zero operands run the chip at a higher clock - tools/diag/ablate_step.py now refuses that.)"""
+        fed the GEMMs a buffer of zeros: zero operands run the chip at a higher clock; with random data left in those buffers the same
+        ablation reads -0.46 ms - tools/diag/ablate_step.py.)"""
         self.folded = bool(on)
         for L in self.layers:
             if on and "wqkv_n" not in L:
