@@ -36,6 +36,9 @@ def _alloc_random(self, B, S):
         self.nbuf.copy_((torch.randn(self.nbuf.shape, device=self.nbuf.device) * 0.5).to(self.nbuf.dtype))
         self.AO.copy_((torch.randn(self.AO.shape, device=self.AO.device) * 0.5).to(self.AO.dtype))
         self.R1.fill_(1.0); self.R2.fill_(1.0)
+        if what == "nostore":                                             # (a library built without the 256-row kernel's stores, through VLA_NATIVE_LIB)
+            for t in (self.HS, self.X1, self.QKV, self.GU, self.hbuf):
+                t.copy_((torch.randn(t.shape, device=t.device) * 0.5).to(t.dtype))
 
 
 E.LLM._alloc = _alloc_random
