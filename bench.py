@@ -138,7 +138,7 @@ def measure_gemm_roofline(eng, batch, noise, lr, reps=10, record_only=False):
         total_b += cnt * nbytes
         n += cnt
         per.append((cnt * t, cnt, ("TN",) + tuple(sig[1]) if sig[0] == "tn" else sig[0], sig[2] if sig[0] == "tn" else sig[1], fl / t / 1e12))
-    per.sort(reverse=True)
+    per.sort(key=lambda x: x[0], reverse=True)      # (by time only: equal times must not fall through to comparing shape tuples with the "TN" tag)
     if os.environ.get("VLA_DUMP_GEMMS"):          # full per-signature table (tuning aid)
         with open(os.environ["VLA_DUMP_GEMMS"], "w") as fdump:
             for x in per:
