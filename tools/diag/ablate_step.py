@@ -3,8 +3,8 @@
 the graphs.  CAUTION - NOT an upper bound as it stands: a skipped producer leaves its output buffer at zeros (or at whatever it held),
 and GEMMs on zero operands run the chip at a higher clock (MI355X_MICROARCH.md, DVFS): "no RMSNorm" read -1.2 ms this way while the
 real fold of those norms into their GEMMs measured +0.1 ms.  The buffers of the skipped producers are therefore filled with random data
-once (rms, attn); head_attn still leaves zero gradients behind and is NOT a valid bound.
-usage: ablate_step.py {none|rms|ln|attn|head_attn} [bench.py args]"""
+once (rms, attn, head_fwd, head_bwd - the fills happen during the eager warm-up / capture pass, not in the timed replays).
+usage: ablate_step.py {none|rms|ln|attn|head_fwd|head_bwd|nostore} [bench.py args]"""
 import os
 import sys
 
@@ -64,8 +64,19 @@ elif what == "attn":
         return o
     ops.attn_fwd = af
     E.LLM._attn_fwd = lambda self, q3, i, b0, b1, S: None     # (the LLM's attention output buffer keeps what it held)
-elif what == "head_attn":
-    ops.head_attn_bwd = lambda *a, **k: None
+elif what in ("head_fwd", "head_bwd"):
+    _attn0 = E.Head._attn
+    _filled = set()
+
+    def _attn(self, i, fwd, dout=None):
+        if fwd != (what == "head_fwd"):
+            return _attn0(self, i, fwd, dout)
+        for name in (("AOx",) if fwd else ("dQKVx", "dKV_adp", "dKV_task")):      # the skipped kernel's outputs: random, once
+            t = getattr(self, name)[i]
+            if (name, i) not in _filled:
+                _filled.add((name, i))
+                t.copy_((torch.randn(t.shape, device=t.device) * 0.05).to(t.dtype))
+    E.Head._attn = _attn
 import bench  # noqa: E402
 
 bench.main()

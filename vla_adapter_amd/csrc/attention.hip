@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256, (D <= 64 ? 4 : D <= 72 ? 3 : 2)) void attn_fwd
   using G = Geo<D>;
   __shared__ __attribute__((aligned(16))) bf16_t sK[32 * G::LD];
   __shared__ __attribute__((aligned(16))) bf16_t sV[32 * G::LD];
+  __shared__ __attribute__((aligned(16))) bf16_t sO[4 * 32 * G::LD];     // per wave: the output tile as [query][d], for row-contiguous stores
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
   const int hq = blockIdx.y, b = blockIdx.z, hkv = hq / (p.Hq / p.Hkv);
   const int qblk = blockIdx.x * 128, q0 = qblk + w * 32;
@@ -164,23 +165,33 @@ __global__ __launch_bounds__(256, (D <= 64 ? 4 : D <= 72 ? 3 : 2)) void attn_fwd
       for (int t = 0; t < G::DT; ++t) O[t] = mfma32(tr_frag(sV, G::LD, s, 32 * t, lane), pf, O[t]);
     }
   }
-  // O^T accumulators: lane = query, registers = d
+  // O^T accumulators: lane = query, registers = d.  Stored directly, every lane wrote 8-B pieces of ITS OWN row (64 scattered pieces
+  // per store instruction: store-issue-bound, the same tail that cost the head's backward half its time); the wave's tile goes
+  // through its LDS region instead and leaves as whole 16-B row chunks.
   const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-  if (qi < p.Sq) {
-    bf16_t* op = p.o + (long long)b * p.o_sb + (long long)qi * p.o_ss + hq * D;
+  {
+    bf16_t* so = sO + w * 32 * G::LD;
 #pragma unroll
     for (int t = 0; t < G::DT; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d = 32 * t + 8 * g + 4 * h;
-        if (d < D) {
-          uint2 o = {pack2(O[t][4 * g] * inv, O[t][4 * g + 1] * inv), pack2(O[t][4 * g + 2] * inv, O[t][4 * g + 3] * inv)};
-          *reinterpret_cast<uint2*>(op + d) = o;
-        }
+        const uint2 o = {pack2(O[t][4 * g] * inv, O[t][4 * g + 1] * inv), pack2(O[t][4 * g + 2] * inv, O[t][4 * g + 3] * inv)};
+        *reinterpret_cast<uint2*>(so + (lane & 31) * G::LD + d) = o;
       }
-    if (p.lse && h == 0)
-      p.lse[((long long)b * p.Hq + hq) * p.lse_hs + qi] = l_run > 0.f ? (m_run + log2f(l_run)) * 0.6931471805599453f : -INFINITY;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    constexpr int CPR = D / 8;
+    bf16_t* ob = p.o + (long long)b * p.o_sb + hq * D;
+#pragma unroll
+    for (int i = 0; i < (32 * CPR + 63) / 64; ++i) {
+      const int c = lane + 64 * i, r = c / CPR, ch = c - r * CPR;
+      if (c < 32 * CPR && q0 + r < p.Sq)
+        *reinterpret_cast<u32x4*>(ob + (long long)(q0 + r) * p.o_ss + ch * 8) = *reinterpret_cast<const u32x4*>(so + r * G::LD + ch * 8);
+    }
   }
+  if (qi < p.Sq && p.lse && h == 0)
+    p.lse[((long long)b * p.Hq + hq) * p.lse_hs + qi] = l_run > 0.f ? (m_run + log2f(l_run)) * 0.6931471805599453f : -INFINITY;
 }
 
 // ------------------------------------------------------------------------------------------------ dQ
@@ -189,6 +200,7 @@ __global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void attn_bwd_dq_kernel(Att
   using G = Geo<D>;
   __shared__ __attribute__((aligned(16))) bf16_t sK[32 * G::LD];
   __shared__ __attribute__((aligned(16))) bf16_t sV[32 * G::LD];
+  __shared__ __attribute__((aligned(16))) bf16_t sO[4 * 32 * G::LD];     // per wave: dQ as [query][d] for row-contiguous stores
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
   const int hq = blockIdx.y, b = blockIdx.z, hkv = hq / (p.Hq / p.Hkv);
   const int qblk = blockIdx.x * 128, q0 = qblk + w * 32;
@@ -283,18 +295,26 @@ __global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void attn_bwd_dq_kernel(Att
         dQ[G::DT - 1][4 * g + j] = bb * c - a * sn;
       }
   }
-  if (qi < p.Sq) {
-    bf16_t* op = p.dq + (long long)b * p.dq_sb + (long long)qi * p.dq_ss + hq * D;
+  {                                     // row-contiguous stores through the wave's LDS region (as attn_fwd_kernel)
+    bf16_t* so = sO + w * 32 * G::LD;
 #pragma unroll
     for (int t = 0; t < G::DT; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d = 32 * t + 8 * g + 4 * h;
-        if (d < D) {
-          uint2 o = {pack2(dQ[t][4 * g], dQ[t][4 * g + 1]), pack2(dQ[t][4 * g + 2], dQ[t][4 * g + 3])};
-          *reinterpret_cast<uint2*>(op + d) = o;
-        }
+        const uint2 o = {pack2(dQ[t][4 * g], dQ[t][4 * g + 1]), pack2(dQ[t][4 * g + 2], dQ[t][4 * g + 3])};
+        *reinterpret_cast<uint2*>(so + (lane & 31) * G::LD + d) = o;
       }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    constexpr int CPR = D / 8;
+    bf16_t* ob = p.dq + (long long)b * p.dq_sb + hq * D;
+#pragma unroll
+    for (int i = 0; i < (32 * CPR + 63) / 64; ++i) {
+      const int c = lane + 64 * i, r = c / CPR, ch = c - r * CPR;
+      if (c < 32 * CPR && q0 + r < p.Sq)
+        *reinterpret_cast<u32x4*>(ob + (long long)(q0 + r) * p.dq_ss + ch * 8) = *reinterpret_cast<const u32x4*>(so + r * G::LD + ch * 8);
+    }
   }
 }
 

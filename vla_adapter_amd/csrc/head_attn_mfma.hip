@@ -449,7 +449,7 @@ __device__ __forceinline__ void head_dkv_body(const HP& p, const int blk, char* 
 // four workgroups fit a CU.  Both score orientations are formed from the SAME fragments (S = Q.K^T with the key on the lane
 // for dK / dV, S^T = K.Q^T with the query on the lane for dQ: the operands of one are the swapped operands of the other).
 template <int D>
-__global__ __launch_bounds__(256, 4) void head_bwd_tiles(HP p, float* __restrict__ ws_dq, float* __restrict__ ws_gate) {
+__global__ __launch_bounds__(256, 3) void head_bwd_tiles(HP p, float* __restrict__ ws_dq, float* __restrict__ ws_gate) {
   using G = HG<D>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
@@ -530,103 +530,47 @@ __global__ __launch_bounds__(256, 4) void head_bwd_tiles(HP p, float* __restrict
   const float tg = rbf(tanhf(bf2f(p.gate[0]))), rs = sqrtf((float)D), irs = 1.f / rs;
   const bool two_steps = p.T > 16;                           // query rows 16 .. 31 exist: the second k-step of the q contraction
   const int qrow = min(lane & 31, p.T);                      // padded query rows read the zero row
-  // ---- S[q x key], dP[q x key]: dK and dV
+  const int qi = lane & 31;
+  // ---- both score orientations while the K / V fragments are live: S[q x key], dP[q x key] (key on the lane: dK, dV) and
+  //      S^T[key x q], dP^T[key x q] (query on the lane: dQ) - the same fragments with the operands swapped
+  bf16x8 pf0, pf1, dsf0, dsf1, df0, df1;
+  float gpart = 0.f;
   {
-    f32x16 S = zero16(), dP = zero16();
+    f32x16 S = zero16(), dP = zero16(), St = zero16(), dPt = zero16();
 #pragma unroll
     for (int ks = 0; ks < G::KS; ++ks) {
-      S = mfma32(*reinterpret_cast<const bf16x8*>(sQ + qrow * G::LD + 16 * ks + 8 * h), kf[ks], S);
-      dP = mfma32(*reinterpret_cast<const bf16x8*>(sdO + qrow * G::LD + 16 * ks + 8 * h), vf[ks], dP);
+      const bf16x8 qa = *reinterpret_cast<const bf16x8*>(sQ + qrow * G::LD + 16 * ks + 8 * h);
+      const bf16x8 da = *reinterpret_cast<const bf16x8*>(sdO + qrow * G::LD + 16 * ks + 8 * h);
+      S = mfma32(qa, kf[ks], S);
+      dP = mfma32(da, vf[ks], dP);
+      St = mfma32(kf[ks], qa, St);
+      dPt = mfma32(vf[ks], da, dPt);
     }
-    f32x16 dS;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < 16; ++r) {                           // [q x key]: P and d(q.k)
       const int qr = acc_row(r, h);
       const bool valid = key < N && qr < p.T;
       const float pr = valid ? fexp2(score_chain(S[r], gated, tg, rs, true) - sLse[qr]) : 0.f;
       const float ds = pr * (dP[r] - sDelta[qr]) * irs;
       S[r] = pr;
-      dS[r] = gated ? ds * tg : ds;
+      dP[r] = gated ? ds * tg : ds;
     }
-    const bf16x8 pf0 = pack_acc(S, 0), pf1 = pack_acc(S, 1), dsf0 = pack_acc(dS, 0), dsf1 = pack_acc(dS, 1);
-    const int pos = kc < p.T ? kc : (kc < p.T + p.Ka ? kc - p.T : kc - p.T - p.Ka);   // positions restart per segment
-    bf16_t* okp = const_cast<bf16_t*>(hrow(p.dks, p.dka, p.dkt, p, b, kc, hoff));
-    bf16_t* ovp = const_cast<bf16_t*>(hrow(p.dvs, p.dva, p.dvt, p, b, kc, hoff));
-    // transposed fragments of the staged Q / dO rows: rows >= T come from the zero row (tr_frag with clamped rows)
-    auto trq = [&](const bf16_t* tile, int s, int col0) {
-      const int gi = (lane >> 4) & 1, i = lane & 15;
-      const int r0 = 16 * s + 4 * h + (i >> 2);
-      const bf16_t* p0 = tile + min(r0, p.T) * G::LD + col0 + 16 * gi + 4 * (i & 3);
-      const bf16_t* p1 = tile + min(r0 + 8, p.T) * G::LD + col0 + 16 * gi + 4 * (i & 3);
-      const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)p0);
-      const bf16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)p1);
-      return bf16x8{a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
-    };
-    // (the RoPE table rows of a block are requested BEFORE its MFMAs: an L2 round trip per block otherwise sits between the
-    //  accumulators and their stores; without RoPE the same loads read the head of the q tensor and are ignored)
-    const float* rc = p.rope_cos ? p.rope_cos + (long long)pos * D : reinterpret_cast<const float*>(p.q);
-    const float* rsn = p.rope_cos ? p.rope_sin + (long long)pos * D : reinterpret_cast<const float*>(p.q);
-#pragma unroll
-    for (int t = 0; t < G::DT; ++t) {
-      float4 rcv[4], rsv[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = 32 * t + 8 * g + 4 * h, dd = (p.rope_cos && d < D) ? d : 0;
-        rcv[g] = *reinterpret_cast<const float4*>(rc + dd);
-        rsv[g] = *reinterpret_cast<const float4*>(rsn + dd);
-      }
-      f32x16 dVt = zero16(), dKt = zero16();
-      dVt = mfma32(trq(sdO, 0, 32 * t), pf0, dVt);           // dV^T[d x key] = dO^T . P
-      dKt = mfma32(trq(sQ, 0, 32 * t), dsf0, dKt);           // dK^T[d x key] = Q^T . dDot
-      if (two_steps) {
-        dVt = mfma32(trq(sdO, 1, 32 * t), pf1, dVt);
-        dKt = mfma32(trq(sQ, 1, 32 * t), dsf1, dKt);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = 32 * t + 8 * g + 4 * h;
-        if (d < D) {
-          float a0 = dKt[4 * g], b0 = dKt[4 * g + 1], a1 = dKt[4 * g + 2], b1 = dKt[4 * g + 3];
-          if (p.rope_cos) {                                  // inverse interleaved RoPE (rope_inter_bwd_acc, one block)
-            const float4 c = rcv[g], sn = rsv[g];
-            const float x0 = a0 * c.x + b0 * sn.y, y0 = b0 * c.y - a0 * sn.x, x1 = a1 * c.z + b1 * sn.w, y1 = b1 * c.w - a1 * sn.z;
-            a0 = x0; b0 = y0; a1 = x1; b1 = y1;
-          }
-          if (key < N) {
-            *reinterpret_cast<uint2*>(okp + d) = uint2{pack2(a0, b0), pack2(a1, b1)};
-            *reinterpret_cast<uint2*>(ovp + d) = uint2{pack2(dVt[4 * g], dVt[4 * g + 1]), pack2(dVt[4 * g + 2], dVt[4 * g + 3])};
-          }
-        }
-      }
-    }
-  }
-  // ---- S^T[key x q], dP^T[key x q] (the same fragments, operands swapped): this tile's share of dQ and of the gate gradient
-  {
-    const int qi = lane & 31;
-    f32x16 S = zero16(), dP = zero16();
-    wave_lds_sync();                                         // the K tile written above: read back as rows here, transposed below
-    const bf16_t* vp2 = hrow(p.vs, p.va, p.vt, p, b, kc, hoff);
-#pragma unroll
-    for (int ks = 0; ks < G::KS; ++ks) {                     // (fragments re-read - LDS / L1-hot global - instead of 56 registers kept
-                                                             //  alive across the dK / dV phase)
-      const bf16x8 k2 = *reinterpret_cast<const bf16x8*>(sK + (lane & 31) * G::LD + 16 * ks + 8 * h);
-      const bf16x8 v2 = *reinterpret_cast<const bf16x8*>(vp2 + 16 * ks + 8 * h);
-      S = mfma32(k2, *reinterpret_cast<const bf16x8*>(sQ + qrow * G::LD + 16 * ks + 8 * h), S);
-      dP = mfma32(v2, *reinterpret_cast<const bf16x8*>(sdO + qrow * G::LD + 16 * ks + 8 * h), dP);
-    }
+    pf0 = pack_acc(S, 0); pf1 = pack_acc(S, 1); dsf0 = pack_acc(dP, 0); dsf1 = pack_acc(dP, 1);
     const float lse2 = sLse[qi], delta = sDelta[qi];
-    float gpart = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < 16; ++r) {                           // [key x q]: d(q.k) again, and the gate gradient
       const int kk = n0 + acc_row(r, h);
       const bool gk = kk >= p.T + p.Ka, valid = kk < N && qi < p.T;
-      const float dot = rbf(S[r]);
-      const float pr = valid ? fexp2(score_chain(S[r], gk, tg, rs, true) - lse2) : 0.f;
-      const float ds = pr * (dP[r] - delta) * irs;           // d(score before the /sqrt(dh))
+      const float dot = rbf(St[r]);
+      const float pr = valid ? fexp2(score_chain(St[r], gk, tg, rs, true) - lse2) : 0.f;
+      const float ds = pr * (dPt[r] - delta) * irs;          // d(score before the /sqrt(dh))
       if (gk) gpart += ds * dot;                             // d tanh(g)
-      S[r] = gk ? ds * tg : ds;                              // d(q.k)
+      St[r] = gk ? ds * tg : ds;                             // d(q.k)
     }
-    const bf16x8 df0 = pack_acc(S, 0), df1 = pack_acc(S, 1);
+    df0 = pack_acc(St, 0); df1 = pack_acc(St, 1);
+  }
+  // ---- this tile's share of dQ (K read transposed from LDS) and of the gate gradient
+  {
     float* wq = ws_dq + ((long long)(gid * ntile + tile) * p.T + qi) * D;
 #pragma unroll
     for (int t = 0; t < G::DT; ++t) {
@@ -643,6 +587,68 @@ __global__ __launch_bounds__(256, 4) void head_bwd_tiles(HP p, float* __restrict
     }
     gpart = wave_sum(gpart);
     if (lane == 0) ws_gate[gid * ntile + tile] = gpart;
+  }
+  // ---- dV, then dK: one 32-column block at a time into the (now free) K tile as [key][d] bf16, then whole 16-B row chunks to global.
+  //      The accumulators hold a key per LANE: stored directly, every lane wrote 8-B pieces of its own row - 64 scattered pieces per
+  //      store instruction, 33 of this kernel's 70 thousand cycles (stamped).
+  {
+    const int pos = kc < p.T ? kc : (kc < p.T + p.Ka ? kc - p.T : kc - p.T - p.Ka);   // positions restart per segment
+    // transposed fragments of the staged Q / dO rows: rows >= T come from the zero row (tr_frag with clamped rows)
+    auto trq = [&](const bf16_t* tile_, int s_, int col0) {
+      const int gi = (lane >> 4) & 1, i = lane & 15;
+      const int r0 = 16 * s_ + 4 * h + (i >> 2);
+      const bf16_t* p0 = tile_ + min(r0, p.T) * G::LD + col0 + 16 * gi + 4 * (i & 3);
+      const bf16_t* p1 = tile_ + min(r0 + 8, p.T) * G::LD + col0 + 16 * gi + 4 * (i & 3);
+      const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)p0);
+      const bf16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)p1);
+      return bf16x8{a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+    };
+    const float* rc = p.rope_cos ? p.rope_cos + (long long)pos * D : reinterpret_cast<const float*>(p.q);
+    const float* rsn = p.rope_cos ? p.rope_sin + (long long)pos * D : reinterpret_cast<const float*>(p.q);
+    bf16_t* stg = sK;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {                   // 0: dV, 1: dK
+      wave_lds_sync();                                       // the tile's previous readers (dQ's transposed reads / pass 0's row reads) are done
+#pragma unroll
+      for (int t = 0; t < G::DT; ++t) {
+        float4 rcv[4], rsv[4];
+        if (pass == 1) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {                      // (RoPE table rows of the block requested before its MFMAs)
+            const int d = 32 * t + 8 * g + 4 * h, dd = (p.rope_cos && d < D) ? d : 0;
+            rcv[g] = *reinterpret_cast<const float4*>(rc + dd);
+            rsv[g] = *reinterpret_cast<const float4*>(rsn + dd);
+          }
+        }
+        f32x16 acc = zero16();
+        acc = mfma32(trq(pass == 0 ? sdO : sQ, 0, 32 * t), pass == 0 ? pf0 : dsf0, acc);      // dV^T = dO^T . P   |   dK^T = Q^T . dDot
+        if (two_steps) acc = mfma32(trq(pass == 0 ? sdO : sQ, 1, 32 * t), pass == 0 ? pf1 : dsf1, acc);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = 32 * t + 8 * g + 4 * h;
+          float a0 = acc[4 * g], b0 = acc[4 * g + 1], a1 = acc[4 * g + 2], b1 = acc[4 * g + 3];
+          if (pass == 1 && p.rope_cos) {                     // inverse interleaved RoPE (rope_inter_bwd_acc, one block)
+            const float4 c = rcv[g], sn = rsv[g];
+            const float x0 = a0 * c.x + b0 * sn.y, y0 = b0 * c.y - a0 * sn.x, x1 = a1 * c.z + b1 * sn.w, y1 = b1 * c.w - a1 * sn.z;
+            a0 = x0; b0 = y0; a1 = x1; b1 = y1;
+          }
+          *reinterpret_cast<uint2*>(stg + (lane & 31) * G::LD + d) = uint2{pack2(a0, b0), pack2(a1, b1)};
+        }
+      }
+      wave_lds_sync();
+#pragma unroll
+      for (int i = 0; i < (32 * G::CPR + 63) / 64; ++i) {    // 32 rows x CPR chunks of 16 B
+        const int c = lane + 64 * i;
+        if (c < 32 * G::CPR) {
+          const int r = c / G::CPR, ch = c - r * G::CPR, kr = n0 + r;
+          if (kr < N) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(stg + r * G::LD + ch * 8);
+            bf16_t* dst = const_cast<bf16_t*>(pass == 0 ? hrow(p.dvs, p.dva, p.dvt, p, b, kr, hoff) : hrow(p.dks, p.dka, p.dkt, p, b, kr, hoff));
+            *reinterpret_cast<u32x4*>(dst + ch * 8) = v;
+          }
+        }
+      }
+    }
   }
 }
 
