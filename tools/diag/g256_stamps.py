@@ -52,11 +52,13 @@ def run(name, M, N, K, act, live=None, residual=False):
         med = np.median(d[ok], axis=0)
         tot = np.median(st[ok, it, 4] - st[ok, it, 0])
         nxt = np.median(st[ok, it + 1, 0] - st[ok, it, 0]) if it + 1 < 16 and (st[:, it + 1, 0] > 0).any() else float("nan")
-        print(f"  tile {it}: " + "  ".join(f"{n} {int(m):6d}" for n, m in zip(names, med)) + f"   | tile total {int(tot)} cycles, next top after {nxt}")
+        k10 = np.median(st[ok, it, 6] - st[ok, it, 1]) if (st[ok, it, 6] > 0).any() else float("nan")      # (deferred-h build: first ten K-tiles)
+        print(f"  tile {it}: " + "  ".join(f"{n} {int(m):6d}" for n, m in zip(names, med)) + f"   | tile total {int(tot)} cycles, next top after {nxt}  first-10-K-tiles {k10}")
 
 
-run("vit qkv", 32 * 256, 3456, 1152, 0)
-run("sq 8192 K1024", 8192, 8192, 1024, 0)
-run("sq 8192 K1024 +res", 8192, 8192, 1024, 0, residual=True)
+if not os.environ.get("ONLY_GATE_UP"):
+    run("vit qkv", 32 * 256, 3456, 1152, 0)
+    run("sq 8192 K1024", 8192, 8192, 1024, 0)
+    run("sq 8192 K1024 +res", 8192, 8192, 1024, 0, residual=True)
 run("llm gate_up live", 32 * 352, 9728, 896, 4, live=(352, 288))
 run("llm gate_up full", 32 * 352, 9728, 896, 4)

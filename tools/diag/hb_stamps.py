@@ -1,3 +1,10 @@
+"""Per-phase cycle medians of head_bwd_tiles from in-kernel s_memtime stamps.
+
+Needs a DIAGNOSTIC build of libvla_native.so that stamps the kernel and exports vla_hb_read_stamps (not part of the
+product ABI; the stamped kernel is not kept in the tree - add `s_memtime` reads at the phase boundaries of head_bwd_tiles
+into a __device__ array and a host entry that copies it out).  Used once in round 3: 33k of 70k cycles sat in the
+row-per-lane dK/dV stores, which is what moved them behind an LDS transpose.
+"""
 import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

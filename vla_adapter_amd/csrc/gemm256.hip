@@ -418,13 +418,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
     const bf16_t* Rb = (HAS_RES && p.R) ? p.R + (long long)ez * p.sR : nullptr;
     const bool vec_ok = ((p.ldc & 7) == 0) && (!Rb || (p.ldr & 7) == 0);
     const bool plain_rows = (res_mod | gR | gC | c_live_mod) == 0;
+    // a live-row filter alone (SwiGLU forward of the adapter-only step) keeps the fast path: the filter is a per-lane predicate on
+    // the stores (stamped build: the general path's eight serial read -> modulo -> store rounds per live half were 4.6k cycles of
+    // phase B and as much again at the closing barrier, of a 50k-cycle gate/up tile)
+    const bool live_rows = EPI == 1 && (res_mod | gR | gC) == 0 && c_live_mod >= 64;
     bool skip[2], inside[2], fastm[2];
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh) {
       const int wm0 = em0 + wr * 128 + mh * 64;
       skip[mh] = wm0 >= p.M || wn0 >= p.N;          // nothing of this half exists (N = 3.5 tiles: half the waves of the last column)
       inside[mh] = wm0 + 64 <= p.M && wn0 + 64 <= p.N;
-      fastm[mh] = EPI != 2 && plain_rows && vec_ok && inside[mh] && !skip[mh];
+      fastm[mh] = EPI != 2 && (plain_rows || live_rows) && vec_ok && inside[mh] && !skip[mh];
     }
     // Residual segments (plain epilogue): ALWAYS sixteen loads per lane, in two straight-line groups, read on every path - a
     // conditional load reaches its registers through a copy that waits for it, and a load that some path never reads leaves the
@@ -691,9 +695,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
             vv[it] = *reinterpret_cast<const uint4*>(reg + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
           }
           __builtin_amdgcn_sched_barrier(0);
+          auto store_fast = [&](auto live_t) {
+          constexpr bool LIVE = decltype(live_t)::value;         // live-row filter: a per-lane predicate on the stores
+          int lpos = 0;                                          // position of the half's first row in its row group
+          if constexpr (LIVE) lpos = __builtin_amdgcn_readfirstlane(wm0 % c_live_mod);
 #pragma unroll
           for (int it = 0; it < 8; ++it) {
             const int row = it * 8 + (el >> 3), ch = el & 7;
+            if constexpr (LIVE) {                                // (64 rows wrap at most once: c_live_mod >= 64)
+              int pos = lpos + row;
+              if (pos >= c_live_mod) pos -= c_live_mod;
+              if (pos < p.c_live_from) continue;
+            }
             uint4 v = vv[it];
             if constexpr (HAS_RES) {
               const u32x4 r = rv[mh][it];
@@ -715,6 +728,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
               if ((el & 7) == 0) reinterpret_cast<float*>(smem + LDS_BYTES)[((wr * 2 + mh) * 64 + row) * 4 + wc] = sq;
             }
           }
+          };
+          if (EPI == 1 && c_live_mod > 0) store_fast(std::true_type{});
+          else store_fast(std::false_type{});
           continue;
         }
         // Row addressing: the plain case (no row groups, no broadcast residual, no live-row filter) must not pay the four integer
