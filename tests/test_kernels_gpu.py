@@ -1137,6 +1137,26 @@ def test_gemm256_fused_rope_half_bit_identical(ops, grid, monkeypatch):
         assert torch.equal(out, ref), f"gemm256 rope {B}x{S}: {(out.float() - ref.float()).abs().max().item()}"
 
 
+@pytest.mark.parametrize("grid", [None, "5"])
+def test_gemm256_fused_rope_interleaved_bit_identical(ops, grid, monkeypatch):
+    """The interleaved RoPE epilogue of the 256-row kernel (the head's task-token K|V projection: K half rotated, V untouched; with
+    the strided-input rounding order of the reference's CPU Linear, read through row groups) against the 128-row kernel's, bit for
+    bit, and against the stand-alone pass on the plain projection - at the step's shape and on a ragged one."""
+    if grid:
+        monkeypatch.setenv("VLA_GEMM256_GRID", grid)
+    for B, Kt, S, H, dh, K, post in [(32, 256, 352, 8, 112, 896, True), (3, 100, 130, 4, 48, 320, False)]:
+        D = H * dh
+        hs = gen(B * S, K, seed=281).to(DEV)
+        w, bias = gen(2 * D, K, seed=282, scale=0.05).to(DEV), gen(2 * D, seed=283).to(DEV)
+        cos, sin = ops.rope_inter_tables(Kt + 3, dh, DEV)
+        run = lambda: ops.gemm_nt(hs[:B * Kt], w, bias=bias, a_group=(Kt, S * K), bias_post_round=post, rope=(2, cos, sin, Kt, dh, D))
+        out, ref = _both_tiles(monkeypatch, run)
+        assert torch.equal(out, ref), f"gemm256 interleaved rope {B}x{Kt}: {(out.float() - ref.float()).abs().max().item()}"
+        plain = ops.gemm_nt(hs[:B * Kt], w, bias=bias, a_group=(Kt, S * K), bias_post_round=post)
+        ops.rope_inter_(plain[:, :D], cos, sin, Kt, H, dh, 0)
+        assert torch.equal(out, plain), f"fused vs stand-alone {B}x{Kt}: {(out.float() - plain.float()).abs().max().item()}"
+
+
 def test_gemm_forced_tile_with_split_k(ops, monkeypatch):
     """Forced big tiles used to launch grid.z = batch instead of the K-slice count: every forced tile must agree
     with the automatic split-K result."""

@@ -583,7 +583,7 @@ inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode, int
   // same box); the half-batch launches of the two-pipeline forward (110 tiles) measured 26.10-26.20 vs 26.07-26.10 and stay
   // on the 128-row kernel.  VLA_NO_ROPE256 switches it off.
   static const bool no_rope256 = getenv("VLA_NO_ROPE256") != nullptr;
-  if ((rope_mode == 0 || rope_mode == 1) && split == 1) {     // (interleaved RoPE: 128-row kernel only)
+  if (split == 1) {     // (both RoPE conventions are fused in both kernels)
     if (force == 6 || force == 4) return {256, 257};   // 256 x 256 staggered 8-phase kernel (gemm256.hip); 4 = its round-1 predecessor
     const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256) * batch;
     if (force == 0 && (rope_mode == 0 || (!no_rope256 && t256 >= 192)) && use_256(M, N, K, batch, act)) return {256, 257};
@@ -657,6 +657,8 @@ static TileChoice route(const vla_gemm_desc* d) {
   const char* e = getenv("VLA_GEMM_TILE");     // 0/unset auto, 1: 256x128, 2: 128x128, 3: 128x64  (benchmarking aid)
   TileChoice tc = choose_tile(d->M, d->N, d->K / split, e ? atoi(e) : 0, d->rope_mode, split > 1 ? split : d->batch, split, d->act);
   if (tc.bm == 256 && tc.bn == 257 && !vla_gemm256_extent_ok(d)) tc = TileChoice{128, 128};   // operands of 4 GiB and more: 64-bit-pointer kernel
+  // interleaved RoPE on the 256-row kernel: the plain epilogue without residual (the head's K|V projections) - anything else keeps gemm.hip's
+  if (tc.bm == 256 && tc.bn == 257 && d->rope_mode == 2 && (d->R || d->act != VLA_ACT_NONE || d->fp8 || d->ssq_out || d->rowss)) tc = TileChoice{128, 128};
   return tc;
 }
 

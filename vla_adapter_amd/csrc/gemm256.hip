@@ -98,7 +98,7 @@ __device__ __forceinline__ v8i_f8 cat8(bf16x8 lo, bf16x8 hi) {          // two 1
 // F8: OCP e4m3 operands with per-row fp32 scales (gemm.hip's fp8 form, same conventions): a K-tile stays 128 B per row = 128
 // elements = ONE v_mfma_scale_f32_16x16x128_f8f6f4 per 16 x 16 tile instead of two bf16 MFMAs - identical staging, LDS image and
 // barrier structure, half the K-tiles per product.  The scales are applied to the accumulators at the start of the epilogue.
-template <int EPI, bool F8 = false, bool RES = true, bool SSQ = false, bool RN = false>
+template <int EPI, bool F8 = false, bool RES = true, bool SSQ = false, bool RN = false, bool R2 = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int EB = F8 ? 1 : 2;      // bytes per operand element
@@ -597,8 +597,42 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
               __builtin_amdgcn_sched_barrier(0);      // (one row block's table segments at a time)
             }
         };
+        // interleaved RoPE of the action head (action_heads.py:125-146: pairs (2i, 2i+1), tables of cat([f, f]); rope_mode 2): the
+        // rotation partners are neighbours inside a lane's four columns - gemm.hip's fused epilogue value for value, on the
+        // bf16-rounded projection, every product rounded.  (The head's task-token K|V projection, 8192 x 1792: fused it used to leave
+        // this kernel for the 128-row one - 76 us in situ against 39 + the stand-alone pass's 10-20.)
+        auto phase_a_rope2 = [&](auto post_t) {
+          constexpr bool POST = decltype(post_t)::value;
+          const float alpha = p.alpha;
+#pragma unroll
+          for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+              const int pos = min(em0 + wr * 128 + mh * 64 + mi * 16 + lr, p.M - 1) % p.rope_T;
+#pragma unroll
+              for (int t4 = 0; t4 < 4; ++t4) {
+                const int d = (wn0 + t4 * 16 + lq * 4) % p.rope_dh;
+                const f32x4 c = *reinterpret_cast<const f32x4*>(p.rope_cos + (long long)pos * p.rope_dh + d);
+                const f32x4 sn = *reinterpret_cast<const f32x4*>(p.rope_sin + (long long)pos * p.rope_dh + d);
+                const f32x4 a = acc[mh][t4 >> 1][t4 & 1][mi];
+                float x[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  const float aj = RN ? a[j] * rstd[mh][mi] : a[j];
+                  x[j] = rbf(POST ? rbf(aj * alpha) + bv[t4][j] : aj * alpha + bv[t4][j]);
+                }
+                const float y0 = rbf(x[0] * c[0]) + rbf(-x[1] * sn[0]), y1 = rbf(x[1] * c[1]) + rbf(x[0] * sn[1]);
+                const float y2 = rbf(x[2] * c[2]) + rbf(-x[3] * sn[2]), y3 = rbf(x[3] * c[3]) + rbf(x[2] * sn[3]);
+                pk[mh][t4][mi] = uint2{pack2(y0, y1), pack2(y2, y3)};
+                if (t4 & 1) __builtin_amdgcn_sched_barrier(0);      // (two n tiles' table segments at a time)
+              }
+            }
+        };
         if (p.rope_mode == 1 && wn0 < p.rope_cols) phase_a_rope();
-        else if (p.bias_post) phase_a([](float v) { return v; }, std::true_type{});       // (plain epilogue only: checked by the host)
+        else if (R2 && p.rope_mode == 2 && wn0 < p.rope_cols) {      // (its own instantiation: the table segments cost registers)
+          if (p.bias_post) phase_a_rope2(std::true_type{});
+          else phase_a_rope2(std::false_type{});
+        } else if (p.bias_post) phase_a([](float v) { return v; }, std::true_type{});       // (plain epilogue only: checked by the host)
         else if (p.act == VLA_ACT_GELU) phase_a([](float v) { return gelu_erf(rbf(v)); }, std::false_type{});
         else if (p.act == VLA_ACT_RELU) phase_a([](float v) { return fmaxf(v, 0.f); }, std::false_type{});
         else if (p.act == VLA_ACT_GELU_TANH) phase_a([](float v) { return gelu_tanh(rbf(v)); }, std::false_type{});
@@ -810,7 +844,7 @@ int num_cus() {
   return n;
 }
 
-template <int EPI, bool F8 = false, bool RES = true, bool SSQ = false, bool RN = false>
+template <int EPI, bool F8 = false, bool RES = true, bool SSQ = false, bool RN = false, bool R2 = false>
 int launch256(const GemmP& p0, int batch, hipStream_t st) {
   GemmP p = p0;
   p.tiles_n = (p.N + 255) / 256;
@@ -818,7 +852,7 @@ int launch256(const GemmP& p0, int batch, hipStream_t st) {
   p.batch = batch;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, F8, RES, SSQ, RN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + (SSQ ? SSQ_BYTES : 0));
+    (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, F8, RES, SSQ, RN, R2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + (SSQ ? SSQ_BYTES : 0));
     attr_set = true;
   }
   // one workgroup per CU walks the tiles (VLA_GEMM256_GRID overrides the workgroup count: 0 = one workgroup per tile)
@@ -858,7 +892,7 @@ int launch256(const GemmP& p0, int batch, hipStream_t st) {
     p.stagger = (int)(tile_cycles * (se != nullptr ? atoi(se) : 50) / 100 / 1024);
   }
   if (grid % 8 != 0) p.xpx = p.xpy = 0;                    // (a workgroup must stay on its XCD's list: b and b + G share b & 7)
-  hipLaunchKernelGGL((gemm256_kernel<EPI, F8, RES, SSQ, RN>), dim3((unsigned)grid), dim3(512), LDS_BYTES + (SSQ ? SSQ_BYTES : 0), st, p);
+  hipLaunchKernelGGL((gemm256_kernel<EPI, F8, RES, SSQ, RN, R2>), dim3((unsigned)grid), dim3(512), LDS_BYTES + (SSQ ? SSQ_BYTES : 0), st, p);
   return 0;
 }
 
@@ -870,6 +904,7 @@ int vla_gemm256_launch(const GemmP& p, int epi, int batch, hipStream_t st) {
   if (p.scaleA != nullptr) return epi == 1 ? launch256<1, true>(p, batch, st) : launch256<0, true>(p, batch, st);     // fp8 operands
   if (p.ssq_out != nullptr) return launch256<0, false, true, true, false>(p, batch, st);      // (host: plain epilogue with a residual, batch 1)
   if (p.rowss != nullptr) return epi == 1 ? launch256<1, false, true, false, true>(p, batch, st) : launch256<0, false, false, false, true>(p, batch, st);
+  if (p.rope_mode == 2) return launch256<0, false, false, false, false, true>(p, batch, st);     // (host: plain epilogue, no residual)
   if (epi == 1) return launch256<1>(p, batch, st);
   if (epi == 2) return launch256<2>(p, batch, st);
   return p.R ? launch256<0, false, true>(p, batch, st) : launch256<0, false, false>(p, batch, st);

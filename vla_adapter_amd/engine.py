@@ -794,14 +794,15 @@ class Head:
         wt, bt, _ = self._kv("task", i)
         # the reference feeds a STRIDED slice here: torch's CPU Linear then rounds the product before adding the bias, for B > 1
         # only (oracle.linear, vla_native.h bias_post_round) - reproduced so that the head tracks the reference's bf16 run
-        # (the task segment keeps the stand-alone RoPE: fused, its 8192 x 1792 product leaves the 256-row kernel for the 128-row
-        #  kernel's interleaved-RoPE epilogue - 76 us in situ against 39 + 10, profiles/r03_kernel_summary_steady.csv of the attempt)
-        ops.gemm_nt(hs2[:B * Kt], wt, bias=bt, out=self.KV_task[i], a_group=(Kt, S * D), bias_post_round=B > 1)
+        # (the task segment's RoPE rides in the 256-row kernel's epilogue since the end of round 3; before, fusing it sent the
+        #  8192 x 1792 product to the 128-row kernel: 76 us in situ against 39 + the stand-alone pass)
+        ops.gemm_nt(hs2[:B * Kt], wt, bias=bt, out=self.KV_task[i], a_group=(Kt, S * D), bias_post_round=B > 1,
+                    rope=(2, rc, rs_, Kt, dh, D) if fuse else None)
         x = self.X[i]
         if self.pro:
             if not fuse:
                 ops.rope_inter_(self.KV_adp[i][:, :D], rc, rs_, Ka, H, dh, 0)
-            ops.rope_inter_(self.KV_task[i][:, :D], rc, rs_, Kt, H, dh, 0)
+                ops.rope_inter_(self.KV_task[i][:, :D], rc, rs_, Kt, H, dh, 0)
             ops.gemm_nt(x, P.view("w_x")[i], bias=P.view("b_x")[i], out=self.QKVx[i], rope=(2, rc, rs_, T, dh, 2 * D))  # q, k_self
         else:
             ops.gemm_nt(x, P.view("w_x")[i], bias=P.view("b_x")[i], out=self.QKVx[i])
