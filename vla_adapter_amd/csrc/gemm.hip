@@ -605,18 +605,46 @@ inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode, int
 
 // split-K second pass: C = bf16(bf16(act(bf16(sum_z ws[z] * alpha + bias))) + R); 4 columns per thread
 __global__ void splitk_finalize_kernel(const float* __restrict__ ws, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ R,
-                                       bf16_t* __restrict__ C, int M, int N, int ldc, int ldr, int act, float alpha, int split) {
+                                       bf16_t* __restrict__ C, int M, int N, int ldc, int ldr, int act, float alpha, int split, int vec) {
   const long long total = (long long)M * N / 4, plane = (long long)M * N;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int m = (int)(i * 4 / N), n = (int)(i * 4 - (long long)m * N);
-    f32x4 a = *reinterpret_cast<const f32x4*>(ws + i * 4);
-    for (int z = 1; z < split; ++z) a += *reinterpret_cast<const f32x4*>(ws + z * plane + i * 4);
+    // every plane's segment (and the bias / residual segments) is requested before the first one is used: summed in a rolled
+    // loop, each plane paid its own dependent round trip (13 us in situ for 29 MB on the live-row backward's chain)
+    f32x4 pv[8];
+#pragma unroll
+    for (int z = 0; z < 8; ++z) pv[z] = z < split ? *reinterpret_cast<const f32x4*>(ws + z * plane + i * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // (vec: bias / R / C rows are 8-B aligned - host-checked; otherwise element accesses)
+    uint2 braw = {0, 0}, rraw = {0, 0};
+    if (vec) {
+      if (bias) braw = *reinterpret_cast<const uint2*>(bias + n);
+      if (R) rraw = *reinterpret_cast<const uint2*>(R + (long long)m * ldr + n);
+    } else {
+      if (bias) braw = uint2{(unsigned)bias[n] | ((unsigned)bias[n + 1] << 16), (unsigned)bias[n + 2] | ((unsigned)bias[n + 3] << 16)};
+      if (R) {
+        const bf16_t* rp = R + (long long)m * ldr + n;
+        rraw = uint2{(unsigned)rp[0] | ((unsigned)rp[1] << 16), (unsigned)rp[2] | ((unsigned)rp[3] << 16)};
+      }
+    }
+    f32x4 a = pv[0];
+#pragma unroll
+    for (int z = 1; z < 8; ++z) a += pv[z];                   // (same order as the rolled sum; absent planes add +0)
+    for (int z = 8; z < split; ++z) a += *reinterpret_cast<const f32x4*>(ws + z * plane + i * 4);
+    const float bb[4] = {bf2f((bf16_t)(braw.x & 0xffff)), bf2f((bf16_t)(braw.x >> 16)), bf2f((bf16_t)(braw.y & 0xffff)), bf2f((bf16_t)(braw.y >> 16))};
+    const float rr[4] = {bf2f((bf16_t)(rraw.x & 0xffff)), bf2f((bf16_t)(rraw.x >> 16)), bf2f((bf16_t)(rraw.y & 0xffff)), bf2f((bf16_t)(rraw.y >> 16))};
+    float o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float v = a[j] * alpha + (bias ? bf2f(bias[n + j]) : 0.f);
+      float v = a[j] * alpha + (bias ? bb[j] : 0.f);
       if (act != VLA_ACT_NONE) v = apply_act(rbf(v), act);
-      if (R) v = rbf(v) + bf2f(R[(long long)m * ldr + n + j]);
-      C[(long long)m * ldc + n + j] = f2bf(v);
+      if (R) v = rbf(v) + rr[j];
+      o[j] = v;
+    }
+    if (vec) {
+      *reinterpret_cast<uint2*>(C + (long long)m * ldc + n) = uint2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) C[(long long)m * ldc + n + j] = f2bf(o[j]);
     }
   }
 }
@@ -827,7 +855,9 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
     const long long total = (long long)d->M * d->N / 4;
     const unsigned nblk = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(splitk_finalize_kernel, dim3(nblk), dim3(256), 0, st, (const float*)d->ws, (const bf16_t*)d->bias,
-                       (const bf16_t*)d->R, (bf16_t*)d->C, d->M, d->N, d->ldc, d->ldr, d->act, d->alpha == 0.f ? 1.f : d->alpha, split);
+                       (const bf16_t*)d->R, (bf16_t*)d->C, d->M, d->N, d->ldc, d->ldr, d->act, d->alpha == 0.f ? 1.f : d->alpha, split,
+                       (d->ldc % 4 == 0 && ((uintptr_t)d->C & 7) == 0 && (!d->R || (d->ldr % 4 == 0 && ((uintptr_t)d->R & 7) == 0)) &&
+                        (!d->bias || ((uintptr_t)d->bias & 7) == 0)) ? 1 : 0);
     VLA_CHECK_LAUNCH("gemm_splitk_finalize");
   }
   return VLA_OK;
