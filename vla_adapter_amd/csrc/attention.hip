@@ -80,7 +80,8 @@ __global__ __launch_bounds__(256, (D <= 64 ? 4 : D <= 72 ? 3 : 2)) void attn_fwd
   const int qblk = blockIdx.x * 128, q0 = qblk + w * 32;
   const int qi = q0 + (lane & 31);
 
-  for (int i = tid; i < 32 * G::LD; i += 256) { sK[i] = 0; sV[i] = 0; }  // pad columns stay zero
+  lds_zero16(sK, 32 * G::LD * 2, tid, 256);   // pad columns stay zero
+  lds_zero16(sV, 32 * G::LD * 2, tid, 256);
 
   bf16x8 qf[G::KS];
   {
@@ -205,7 +206,8 @@ __global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void attn_bwd_dq_kernel(Att
   const int hq = blockIdx.y, b = blockIdx.z, hkv = hq / (p.Hq / p.Hkv);
   const int qblk = blockIdx.x * 128, q0 = qblk + w * 32;
   const int qi = q0 + (lane & 31), qc = min(qi, p.Sq - 1);
-  for (int i = tid; i < 32 * G::LD; i += 256) { sK[i] = 0; sV[i] = 0; }
+  lds_zero16(sK, 32 * G::LD * 2, tid, 256);
+  lds_zero16(sV, 32 * G::LD * 2, tid, 256);
 
   bf16x8 qf[G::KS], dof[G::KS];
   {
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int
   bf16_t* sdO = sQ + TILE;
   float* sLse = reinterpret_cast<float*>(sdO + TILE);
   float* sDelta = sLse + 32;
-  for (int i = lane; i < 2 * TILE; i += 64) sQ[i] = 0;   // pad columns stay zero (wave-private region)
+  lds_zero16(sQ, 2 * TILE * 2, lane, 64);   // pad columns stay zero (wave-private region)
 
   bf16x8 kf[G::KS], vf[G::KS];
   {

@@ -88,6 +88,13 @@ __device__ __forceinline__ float gelu_tanh(float x) {
 }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
+// Zero `bytes` (a multiple of 16, 16-B aligned) of LDS with 16-B stores, strided over `n` threads.  The attention kernels cleared
+// their tile images with one ds_write_b16 per element: 136 stores per lane and tile pair in the head kernels - 8.3k of
+// head_fwd_mfma's 32k cycles (tools/diag/hf_stamps.py, round 3).
+__device__ __forceinline__ void lds_zero16(void* p, int bytes, int idx, int n) {
+  for (int i = idx * 16; i < bytes; i += n * 16) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p) + i) = uint4{0, 0, 0, 0};
+}
+
 // async global -> LDS copy, 16 B per lane; LDS destination = wave-uniform base + lane*16
 __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,

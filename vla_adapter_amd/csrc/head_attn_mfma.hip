@@ -31,6 +31,7 @@ struct HG {
   static constexpr int WAVE_BYTES = 2 * TILE * 2 + 256;
   static constexpr int CPR = D / 8, NCH = (32 * CPR + 63) / 64;
   static_assert(D % 16 == 0, "head dim must be a multiple of 16");
+  static_assert((TILE * 2) % 16 == 0 && WAVE_BYTES % 16 == 0, "tile images are cleared and copied in 16-B pieces");
 };
 
 __device__ __forceinline__ const bf16_t* hrow(const bf16_t* s0, const bf16_t* s1, const bf16_t* s2, const HP& p, int b, int n,
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void h
   const int b = gid / p.H, hd = gid - b * p.H, hoff = hd * D, N = p.T + p.Ka + p.Kt;
   bf16_t* sK = reinterpret_cast<bf16_t*>(smem + w * G::WAVE_BYTES);
   bf16_t* sV = sK + G::TILE;
-  for (int i = lane; i < 2 * G::TILE; i += 64) sK[i] = 0;
+  lds_zero16(sK, 2 * G::TILE * 2, lane, 64);
   const int qi = lane & 31, qc = min(qi, p.T - 1);
   bf16x8 qf[G::KS];
 #pragma unroll
@@ -253,7 +254,7 @@ __device__ __forceinline__ void head_dq_body(const HP& p, const int blk, char* s
   const int b = gid / p.H, hd = gid - b * p.H, hoff = hd * D, N = p.T + p.Ka + p.Kt;
   bf16_t* sK = reinterpret_cast<bf16_t*>(smem + w * G::WAVE_BYTES);
   bf16_t* sV = sK + G::TILE;
-  for (int i = lane; i < 2 * G::TILE; i += 64) sK[i] = 0;
+  lds_zero16(sK, 2 * G::TILE * 2, lane, 64);
   const int qi = lane & 31, qc = min(qi, p.T - 1);
   bf16x8 qf[G::KS], dof[G::KS];
   float delta = 0.f;
@@ -346,7 +347,7 @@ __device__ __forceinline__ void head_dkv_body(const HP& p, const int blk, char* 
   bf16_t* sdO = sQ + G::TILE;
   float* sLse = reinterpret_cast<float*>(sdO + G::TILE);
   float* sDelta = sLse + 32;
-  for (int i = lane; i < 2 * G::TILE; i += 64) sQ[i] = 0;
+  lds_zero16(sQ, 2 * G::TILE * 2, lane, 64);
   wave_lds_sync();
   // the single query tile (rows >= T stay zero) and its row constants
   for (int c = lane; c < p.T * G::CPR; c += 64) {
