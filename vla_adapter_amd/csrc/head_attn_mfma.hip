@@ -142,13 +142,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void h
 #pragma unroll
   for (int ks = 0; ks < G::KS; ++ks)
     qf[ks] = *reinterpret_cast<const bf16x8*>(p.q + ((long long)b * p.T + qc) * p.ld_q + hoff + 16 * ks + 8 * h);
-  const float tg = rbf(tanhf(bf2f(p.gate[0]))), rs = sqrtf((float)D);
+  const bf16_t graw = p.gate[0];
   f32x16 O[G::DT];
 #pragma unroll
   for (int t = 0; t < G::DT; ++t) O[t] = zero16();
   float m_run = -INFINITY, l_run = 0.f;
   u32x4 rk[G::NCH], rv[G::NCH];
   seg_prefetch_kv<D, false>(rk, rv, p, b, hoff, 32 * w, N, lane);
+  __builtin_amdgcn_sched_barrier(0);          // the first tile's loads go out BEFORE anything waits for the gate (tanhf sat on its
+  const float tg = rbf(tanhf(bf2f(graw))), rs = sqrtf((float)D);      // load's round trip in front of the prefetch: hf_stamps.py)
   for (int n0 = 32 * w; n0 < N; n0 += 32 * HEAD_KV_WAVES) {
     tile_put<D>(rk, sK, lane);
     tile_put<D>(rv, sV, lane);
@@ -468,6 +470,7 @@ __global__ __launch_bounds__(256, 3) void head_bwd_tiles(HP p, float* __restrict
   const int n0 = tile * 32;
   const int key = n0 + (lane & 31), kc = min(key, N - 1);
   const bool gated = key >= p.T + p.Ka;
+  const bf16_t graw = p.gate[0];                            // (requested with the rest of the prologue: used behind the barrier)
   // ---- ONE round of global latency: the tile's K and V rows as MFMA fragments (lane = key, 8 consecutive d) are requested first,
   //      then the workgroup's query rows (shared by its four key tiles), LSE and delta = rowsum(dO * O) from global as well
   bf16x8 kf[G::KS], vf[G::KS];
@@ -528,7 +531,7 @@ __global__ __launch_bounds__(256, 3) void head_bwd_tiles(HP p, float* __restrict
   }
   __syncthreads();
   if (!active) return;                                       // (no workgroup barrier below)
-  const float tg = rbf(tanhf(bf2f(p.gate[0]))), rs = sqrtf((float)D), irs = 1.f / rs;
+  const float tg = rbf(tanhf(bf2f(graw))), rs = sqrtf((float)D), irs = 1.f / rs;
   const bool two_steps = p.T > 16;                           // query rows 16 .. 31 exist: the second k-step of the q contraction
   const int qrow = min(lane & 31, p.T);                      // padded query rows read the zero row
   const int qi = lane & 31;
