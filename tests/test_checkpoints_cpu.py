@@ -100,3 +100,22 @@ def test_offline_lora_merge_matches_w_plus_scaled_ba():
     import pytest
     with pytest.raises(KeyError):
         C.merge_lora_into_state_dict(base, {"base_model.model.nope.lora_A.weight": A, "base_model.model.nope.lora_B.weight": B})
+    # the scale is lora_alpha / r of adapter_config.json: alpha 3, r 2 -> 1.5; peft's in-memory key form carries the adapter name
+    live = {pre + "lora_A.default.weight": A, pre + "lora_B.default.weight": B}
+    m2 = C.merge_lora_into_state_dict(base, live, adapter_config=dict(r=2, lora_alpha=3))
+    assert torch.equal(m2[k], (base[k].float() + 1.5 * (B.float() @ A.float())).to(torch.bfloat16))
+    with pytest.raises(ValueError):
+        C.merge_lora_into_state_dict(base, live, scaling=2.0, adapter_config=dict(r=2, lora_alpha=3))
+    assert C.lora_scaling(None) == 2.0 and C.lora_scaling(dict(r=64, lora_alpha=128)) == 2.0 and C.lora_scaling({}, 4.0) == 4.0
+
+
+def test_load_lora_adapter_returns_the_config(tmp_path):
+    import json
+    from safetensors.torch import save_file
+    A = torch.ones(2, 8, dtype=torch.bfloat16)
+    save_file({"base_model.model.x.lora_A.weight": A}, str(tmp_path / "adapter_model.safetensors"))
+    sd, cfg = C.load_lora_adapter(str(tmp_path), with_config=True)
+    assert cfg == {} and torch.equal(sd["base_model.model.x.lora_A.weight"], A)
+    json.dump(dict(r=8, lora_alpha=4), open(tmp_path / "adapter_config.json", "w"))
+    _, cfg = C.load_lora_adapter(str(tmp_path), with_config=True)
+    assert C.lora_scaling(cfg) == 0.5

@@ -240,6 +240,44 @@ def test_head_only_parity_identical_inputs(setup, pro):
     budget(dHS[1:], dhe[1:], dht[1:], "head-only hidden-state gradients")
 
 
+@pytest.mark.parametrize("pd", [7, 14])
+def test_head_backward_other_proprio_widths(setup, pd):
+    """PROPRIO_DIM is 7 on BRIDGE and 14 on ALOHA (prismatic/vla/constants.py:38-52): neither is a multiple of the TN product's
+    8-element column chunk, so the proprio fc1 weight gradient contracts against the 64-column padded input."""
+    cfg0, _, batch, _ = setup
+    from vla_adapter_amd import ops, engine as E, synthetic as S
+    cfg = E.tiny_config()
+    cfg.proprio_dim = pd
+    W = S.make_weights(cfg, DEV, seed=3, std=0.05)
+    eng = E.VLAEngine(cfg, W, DEV)
+    B, L = batch["input_ids"].shape
+    Np, D, nb = cfg.n_patches, cfg.llm.d, cfg.num_blocks
+    Sq = L + Np
+    g = torch.Generator().manual_seed(22)
+    HS = (torch.randn(nb + 1, B, Sq, D, generator=g) * 0.5).to(BF)
+    proprio = (torch.rand(B, pd, generator=g) * 2 - 1).to(DEV)
+    _, pos1, _ = ops.action_mask(batch["labels"], 1)
+    head = eng.head
+    pred = head.forward(HS.to(DEV), pos1, proprio, Np, None)
+    dpred = (torch.randn(B, cfg.chunk, cfg.action_dim, generator=g) * 0.01).to(BF)
+    dHS = torch.zeros(nb + 1, B, Sq, D, dtype=BF, device=DEV)
+    head.backward(dpred.to(DEV), dHS)
+    torch.cuda.synchronize()
+    f = lambda sd: {k: v.float().cpu().clone().requires_grad_(True) for k, v in sd.items()}
+    res = {}
+    for emu in (True, False):
+        hp, pp = f(W["head"]), f(W["proprio"])
+        mlhs = O.regroup_hidden_states([HS[i].float() for i in range(nb + 1)], batch["labels"].cpu(), Np)
+        ref = O.head_predict_action(mlhs, proprio.cpu().to(BF).float(), hp, pp, Np, True, None, emu, nb)
+        ref.backward(dpred.float())
+        res[emu] = (ref.detach(), pp)
+    (re_, ppe), (rt, ppt) = res[True], res[False]
+    budget(pred, re_, rt, f"actions, proprio_dim {pd}")
+    gv = head.proprio_views(head.P.grad)
+    assert tuple(gv["fc1.weight"].shape) == (D, pd)
+    budget_family([("proprio." + k, v, ppe[k].grad, ppt[k].grad) for k, v in gv.items()], f"proprio projector gradients, proprio_dim {pd}")
+
+
 def test_llm_only_backward_identical_inputs(setup):
     """Frozen-LLM dX on identical inputs_embeds and an arbitrary gradient on every hidden state."""
     cfg, W, batch, eng = setup

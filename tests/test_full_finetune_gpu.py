@@ -184,3 +184,32 @@ def test_llm_layers_above_the_heads_last_block_are_left_alone(mode):
             n *= d
         moved += int(not torch.equal(tr.P.data[off:off + n], p0[off:off + n]))
     assert moved >= len(live) // 2, "the live layer below must train"
+
+
+def test_overlapped_and_plain_updates_cover_the_same_parameters(monkeypatch):
+    """the range-by-range update under the backward (_update_ranges over the 'tail' range) and the single update at the
+    end (_adam_ranges) must step the SAME parameters when LLM layers lie above the head's last block.  lr is chosen so large
+    that the weight-decay factor 1 - lr wd is visible in bf16 (0.995): a dead norm / bias / final norm that receives AdamW
+    moves, one that is skipped keeps its bits."""
+    from vla_adapter_amd import engine as E, synthetic as S
+    from vla_adapter_amd.trainers import FullFinetune
+    cfg = E.tiny_config()
+    cfg.llm = E.LLMCfg(256, 3, 4, 2, 64, 512, 1e-6, 1e6, 1024)
+    cfg.num_blocks = 2
+    batch = S.make_batch(cfg, 3, DEV, seed=4, P=20, ragged=True)
+    out = {}
+    for overlap in (True, False):
+        W = S.make_weights(cfg, DEV, seed=3, std=0.05)
+        tr = FullFinetune(E.VLAEngine(cfg, W, DEV))
+        tr.overlap_update = overlap
+        p0 = tr.P.data.clone()
+        tr.train_step(batch, 0.5)
+        torch.cuda.synchronize()
+        out[overlap] = tr.P.data.clone()
+        for k in [k for k in tr.P.offsets if "llm.2." in k] + ["llm.norm"]:
+            off, shape = tr.P.offsets[k]
+            n = 1
+            for d in shape:
+                n *= d
+            assert torch.equal(tr.P.data[off:off + n], p0[off:off + n]), f"{k} (dead) moved with overlap_update={overlap}"
+    assert torch.equal(out[True], out[False]), "the two update paths are the same arithmetic on the same parameters"

@@ -193,23 +193,54 @@ def infer_config(sd: Dict[str, torch.Tensor]) -> VLACfg:
     return cfg
 
 
-def load_lora_adapter(adapter_dir: str) -> Dict[str, torch.Tensor]:
+def load_lora_adapter(adapter_dir: str, with_config: bool = False):
     """``lora_adapter/adapter_model.safetensors`` (peft key names) of a run directory written by finetune.save_training_checkpoint
-    or by peft's ``save_pretrained`` (vla-scripts/finetune.py:553-554)."""
-    return load_file(os.path.join(adapter_dir, "adapter_model.safetensors"))
+    or by peft's ``save_pretrained`` (vla-scripts/finetune.py:553-554).  with_config: also return ``adapter_config.json`` as a dict
+    ({} when the file is absent) - ``r`` and ``lora_alpha`` decide the merge scale (lora_scaling)."""
+    sd = load_file(os.path.join(adapter_dir, "adapter_model.safetensors"))
+    if not with_config:
+        return sd
+    cfg_path = os.path.join(adapter_dir, "adapter_config.json")
+    cfg = {}
+    if os.path.exists(cfg_path):
+        import json
+        with open(cfg_path) as f:
+            cfg = json.load(f)
+    return sd, cfg
 
 
-def merge_lora_into_state_dict(base: Dict[str, torch.Tensor], adapter: Dict[str, torch.Tensor], scaling: float = 2.0) -> Dict[str, torch.Tensor]:
+def lora_scaling(adapter_config: Optional[Dict] = None, scaling: Optional[float] = None) -> float:
+    """lora_alpha / r of an adapter (peft's LoraLayer.scaling).  Every reference script uses lora_alpha = 2 r (finetune.py:835), which
+    is the fallback when no adapter_config.json came with the adapter; an explicit ``scaling`` that disagrees with the config is an
+    error rather than a silently wrong merge."""
+    from_cfg = None
+    if adapter_config and adapter_config.get("r") and adapter_config.get("lora_alpha") is not None:
+        from_cfg = float(adapter_config["lora_alpha"]) / float(adapter_config["r"])
+    if scaling is not None and from_cfg is not None and abs(scaling - from_cfg) > 1e-6 * max(1.0, abs(from_cfg)):
+        raise ValueError(f"merge scale {scaling} disagrees with adapter_config.json (lora_alpha / r = {from_cfg})")
+    return scaling if scaling is not None else from_cfg if from_cfg is not None else 2.0
+
+
+def merge_lora_into_state_dict(base: Dict[str, torch.Tensor], adapter: Dict[str, torch.Tensor], scaling: Optional[float] = None,
+                               adapter_config: Optional[Dict] = None) -> Dict[str, torch.Tensor]:
     """Offline merge of vla-scripts/merge_lora_weights_and_save.py:44-103 (PeftModel.from_pretrained(...).merge_and_unload()):
     W <- W + scaling * B @ A for every adapted Linear of an HF-style VLM state dict (fp32 product, one bf16 rounding); scaling =
-    lora_alpha / r = 2 in every reference script (finetune.py:835).  Keys: '<prefix>base_model.model.<module>.lora_A.weight'."""
+    lora_alpha / r from ``adapter_config`` (load_lora_adapter(..., with_config=True)), 2 when there is none (finetune.py:835).
+    Keys: '<prefix>base_model.model.<module>.lora_A.weight', or peft's in-memory form with the adapter name as an infix
+    ('....lora_A.default.weight')."""
+    scaling = lora_scaling(adapter_config, scaling)
     out = dict(base)
     pre = "base_model.model."
     for k, A in adapter.items():
-        if not k.endswith(".lora_A.weight"):
+        parts = k.split(".")
+        if "lora_A" not in parts or parts[-1] != "weight":
             continue
-        mod = k[:-len(".lora_A.weight")]
-        B = adapter[mod + ".lora_B.weight"]
+        ia = parts.index("lora_A")
+        mod, infix = ".".join(parts[:ia]), parts[ia + 1:-1]          # infix: [] on disk, [adapter name] in a live peft model
+        kb = ".".join(parts[:ia] + ["lora_B"] + infix + ["weight"])
+        if kb not in adapter:
+            raise KeyError(f"adapter holds {k} without its {kb}")
+        B = adapter[kb]
         name = (mod[len(pre):] if mod.startswith(pre) else mod) + ".weight"
         if name not in out:
             raise KeyError(f"adapter targets {name}, which the base state dict does not hold")

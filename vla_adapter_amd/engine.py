@@ -730,6 +730,7 @@ class Head:
         # (the dW products read dY and X as they lie: vla_gemm_bf16_tn contracts over their rows - no transposed operand copies)
         self.h_task_c = e(nb, B * Kt, D) if Kt % 64 else None      # plumbing sizes only: task rows compacted (row groups need Kt % 64 == 0)
         self.dfc2 = e(64, D)
+        self.dpfc1 = e(D, 64)                          # proprio fc1 weight gradient against the 64-column padded input (any proprio_dim)
         self.dh_adp = e(nb, B * Ka, D)
         self.dpad = z(R, 64)
         self.rope_tab = ops.rope_inter_tables(max(T, Ka, Kt), D // self.H, dev)
@@ -919,7 +920,11 @@ class Head:
         d_act = ops.gemm_nt(d_pf, self.T["p_fc2_w"])
         d_pre = ops.gelu_bwd(d_act, self.pp_pre)
         ops.colsum_(d_pre, self.b_f32["p_fc1_b"])
-        self._dw(d_pre, self.pr_in[:, :cfg.proprio_dim], out=G("p_fc1_w"))
+        # proprio_dim is 8 (LIBERO), 7 (BRIDGE) or 14 (ALOHA) - prismatic/vla/constants.py:38-52: the TN product wants 8-element
+        # column chunks, so it contracts against the zero-padded 64-column input (as the forward does) and the first proprio_dim
+        # columns are copied out (the fc2_w gradient above takes the same route for action_dim 7)
+        self._dw(d_pre, self.pr_in, out=self.dpfc1)
+        ops.copy2d(self.dpfc1, G("p_fc1_w"), D, cfg.proprio_dim, 64, cfg.proprio_dim)
         # batched dW products over the nb blocks: dW = dY^T . X as TN GEMMs on dY and X as they lie in memory (the contraction
         # runs over their rows); the task tokens are read in place from the hidden states (row groups: Kt rows of every sequence)
         Kt, S = self.Kt, self.S

@@ -1061,8 +1061,12 @@ class FullFinetune(BackboneTrainer):
         if kind == "proj":
             names = ["proj." + k for k in self.eng.proj if k.endswith("weight")]
             return [self._span(names[0], names[-1])]
-        # tail: the patch-embedding matrices (final after each backbone's last block) and the whole vector section
-        return [self._span(f"vit{j}.wpe", f"vit{j}.wpe") for j in range(len(self.vits))] + [(self.P.grad, self.vec_off, self.P.numel)]
+        # tail: the patch-embedding matrices (final after each backbone's last block) and the vector section - without the norms /
+        # biases of dead LLM layers and the final norm when layers lie above the head's last block (they close the section): the
+        # reference hands them all-zero gradients and never moves them, exactly what _adam_ranges does on the un-overlapped path
+        na, n = self.n_active, self.cfg.llm.n_layers
+        vec_end = self.P.numel if na == n else self.P.offsets[f"llm.{na}.n1"][0]
+        return [self._span(f"vit{j}.wpe", f"vit{j}.wpe") for j in range(len(self.vits))] + [(self.P.grad, self.vec_off, vec_end)]
 
     def reference_named_gradients(self) -> Dict[str, torch.Tensor]:
         """Gradients under the reference's state-dict names (fused layouts undone) - for parity tests / checkpoints."""
