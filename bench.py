@@ -25,13 +25,14 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+MFMA_FP8_PEAK_TFLOPS = 5000.0      # dense, same guide ("Peak FP8 MFMA"): the e4m3 base products of --mode lora --fp8
 
 
-def gemm_flops_of_call(a, b, batched):
+def gemm_flops_of_call(a, b, batched, ext=None):
     M, K = a.shape[-2:]
     N = b.shape[-2]
     nb = a.shape[0] if batched else 1
-    return 2.0 * nb * M * N * K
+    return 2.0 * nb * M * N * (K + (ext[0].shape[1] if ext is not None else 0))      # (K extension: the low-rank branch of a LoRA Linear)
 
 
 def gemm_bytes_of_call(a, b, batched, kw):
@@ -44,7 +45,10 @@ def gemm_bytes_of_call(a, b, batched, kw):
     if kw.get("c_live") is not None:
         period, first = kw["c_live"]
         c_rows = M * (period - first) // period
-    by = 2.0 * nb * (M * K + N * K + c_rows * N)
+    eb = 1.0 if kw.get("fp8") is not None else 2.0                      # e4m3 operands: one byte per element (+ the fp32 row scales)
+    by = eb * nb * (M * K + N * K) + 2.0 * nb * c_rows * N + (4.0 * (M + N) if kw.get("fp8") is not None else 0.0)
+    if kw.get("ext") is not None:
+        by += 2.0 * (M + N) * kw["ext"][0].shape[1]
     if kw.get("residual") is not None:
         by += 2.0 * nb * M * N
     if kw.get("act", 0) == 4:            # SwiGLU forward: h = [M, N/2]
@@ -54,37 +58,52 @@ def gemm_bytes_of_call(a, b, batched, kw):
     return by
 
 
-def measure_gemm_roofline(eng, batch, noise, lr, reps=10, record_only=False):
+def measure_gemm_roofline(eng, batch, noise, lr, reps=10, record_only=False, step_fn=None):
     """Live HIP-event timing of the dominant kernel (gemm_nt_kernel) on the stream it is launched on (torch's current
     stream == the stream handed to the C ABI).  One eager step records every GEMM launch of a training step (operands,
     epilogue, algorithmic FLOPs); each DISTINCT launch signature is then replayed `reps` times back-to-back between two
-    events (so the GPU, not the Python launcher, paces the interval) and weighted by its count per step."""
+    events (so the GPU, not the Python launcher, paces the interval) and weighted by its count per step.
+    step_fn: the eager step to record (default: the adapter-only engine step; --mode lora / full pass their trainer's)."""
     from vla_adapter_amd import ops
     calls = {}
     orig = ops.gemm_nt
 
     def rec(a, b, **kw):
         r = orig(a, b, **kw)
+        ext = kw.get("ext")
         sig = (tuple(a.shape), tuple(b.shape), a.stride(-2), b.stride(-2), kw.get("act", 0), kw.get("bias") is not None,
-               kw.get("residual") is not None)
+               kw.get("residual") is not None, ext[0].shape[1] if ext is not None else 0, kw.get("fp8") is not None)
         if sig not in calls:
             kw2 = dict(kw)
             if kw2.get("out") is None and kw2.get("act", 0) != 4:
                 kw2["out"] = r
-            calls[sig] = [0, gemm_flops_of_call(a, b, a.dim() == 3), a, b, kw2, gemm_bytes_of_call(a, b, a.dim() == 3, kw2)]
+            calls[sig] = [0, gemm_flops_of_call(a, b, a.dim() == 3, ext), a, b, kw2, gemm_bytes_of_call(a, b, a.dim() == 3, kw2)]
         calls[sig][0] += 1
         return r
 
     orig_sw = ops.gemm_swiglu_bwd
 
-    def rec_sw(d_, w_, gu_, out=None, gu_group=None, ext=None):        # the dH GEMM with the SwiGLU backward in its epilogue
-        assert ext is None
-        r = orig_sw(d_, w_, gu_, out=out, gu_group=gu_group)
-        sig = (tuple(d_.shape), tuple(w_.shape), d_.stride(-2), w_.stride(-2), 5, False, True)
+    def rec_sw(d_, w_, gu_, out=None, gu_group=None, ext=None, fp8=None):        # the dH GEMM with the SwiGLU backward in its epilogue
+        r = orig_sw(d_, w_, gu_, out=out, gu_group=gu_group, ext=ext, fp8=fp8)
+        sig = (tuple(d_.shape), tuple(w_.shape), d_.stride(-2), w_.stride(-2), 5, False, True, ext[0].shape[1] if ext is not None else 0, fp8 is not None)
         if sig not in calls:
-            kw_sw = dict(_swiglu_bwd=(gu_, r, gu_group))
-            calls[sig] = [0, gemm_flops_of_call(d_, w_, False), d_, w_, kw_sw, gemm_bytes_of_call(d_, w_, False, kw_sw)]
+            kw_sw = dict(_swiglu_bwd=(gu_, r, gu_group), ext=ext, fp8=fp8)
+            calls[sig] = [0, gemm_flops_of_call(d_, w_, False, ext), d_, w_, kw_sw, gemm_bytes_of_call(d_, w_, False, kw_sw)]
         calls[sig][0] += 1
+        return r
+
+    orig_tng = ops.gemm_tn_grouped
+
+    def rec_tng(problems):                                    # one launch over the tile lists of several dW products (<= 48 each)
+        r = orig_tng(problems)
+        for i in range(0, len(problems), ops.TN_GROUP_MAX):
+            chunk = problems[i:i + ops.TN_GROUP_MAX]
+            sig = ("tng",) + tuple((d.M, d.N1, d.N2) for d in chunk)
+            if sig not in calls:
+                fl = sum(2.0 * d.M * d.N1 * d.N2 for d in chunk)
+                by = sum(2.0 * (d.M * d.N1 + d.M * d.N2 + d.N1 * d.N2) for d in chunk)
+                calls[sig] = [0, fl, chunk, None, dict(_tng=True), by]
+            calls[sig][0] += 1
         return r
 
     orig_tn = ops.gemm_tn
@@ -104,23 +123,25 @@ def measure_gemm_roofline(eng, batch, noise, lr, reps=10, record_only=False):
     def replay(a, b, kw):
         if "_swiglu_bwd" in kw:
             gu_, out_, grp = kw["_swiglu_bwd"]
-            return orig_sw(a, b, gu_, out=out_, gu_group=grp)
+            return orig_sw(a, b, gu_, out=out_, gu_group=grp, ext=kw.get("ext"), fp8=kw.get("fp8"))
+        if kw.get("_tng"):
+            return orig_tng(a)
         if kw.get("_tn"):
             return orig_tn(a, b, **{k: v for k, v in kw.items() if k != "_tn"})
         return orig(a, b, **kw)
 
-    ops.gemm_nt, ops.gemm_swiglu_bwd, ops.gemm_tn = rec, rec_sw, rec_tn
+    ops.gemm_nt, ops.gemm_swiglu_bwd, ops.gemm_tn, ops.gemm_tn_grouped = rec, rec_sw, rec_tn, rec_tng
     reducer, eng.reducer = eng.reducer, None      # rank-0-only probe step: it must not issue collectives
     try:
-        eng.train_step(batch, lr, noise)
+        (step_fn or (lambda: eng.train_step(batch, lr, noise)))()
         torch.cuda.synchronize()
     finally:
-        ops.gemm_nt, ops.gemm_swiglu_bwd, ops.gemm_tn = orig, orig_sw, orig_tn
+        ops.gemm_nt, ops.gemm_swiglu_bwd, ops.gemm_tn, ops.gemm_tn_grouped = orig, orig_sw, orig_tn, orig_tng
         eng.reducer = reducer
     if record_only:
         return dict(launches=sum(c[0] for c in calls.values()), flops=sum(c[0] * c[1] for c in calls.values()),
                     bytes=sum(c[0] * c[5] for c in calls.values()))
-    total_t = total_f = total_b = 0.0
+    total_t = total_f = total_b = total_pk = 0.0
     n = 0
     per = []
     for sig, (cnt, fl, a, b, kw, nbytes) in calls.items():
@@ -136,15 +157,36 @@ def measure_gemm_roofline(eng, batch, noise, lr, reps=10, record_only=False):
         total_t += cnt * t
         total_f += cnt * fl
         total_b += cnt * nbytes
+        # seconds this launch would take at ITS peak: e4m3 base products against the fp8 MFMA peak (their bf16 extension is < 10 % of
+        # the contraction and is priced with them - optimistic for the launch, i.e. pessimistic for the fraction)
+        total_pk += cnt * fl / ((MFMA_FP8_PEAK_TFLOPS if kw.get("fp8") is not None else MFMA_BF16_PEAK_TFLOPS) * 1e12)
         n += cnt
-        per.append((cnt * t, cnt, ("TN",) + tuple(sig[1]) if sig[0] == "tn" else sig[0], sig[2] if sig[0] == "tn" else sig[1], fl / t / 1e12))
+        if sig[0] == "tng":
+            per.append((cnt * t, cnt, ("TN-grouped", len(sig) - 1), sig[1], fl / t / 1e12))
+        else:
+            per.append((cnt * t, cnt, ("TN",) + tuple(sig[1]) if sig[0] == "tn" else sig[0], sig[2] if sig[0] == "tn" else sig[1], fl / t / 1e12))
     per.sort(key=lambda x: x[0], reverse=True)      # (by time only: equal times must not fall through to comparing shape tuples with the "TN" tag)
     if os.environ.get("VLA_DUMP_GEMMS"):          # full per-signature table (tuning aid)
         with open(os.environ["VLA_DUMP_GEMMS"], "w") as fdump:
             for x in per:
                 fdump.write(f"{x[0] * 1e3:8.3f} ms/step  count {x[1]:4d}  A {list(x[2])}  B {list(x[3])}  {x[4]:7.1f} TF/s\n")
     top = [dict(ms_per_step=round(x[0] * 1e3, 3), count=x[1], A=list(x[2]), B=list(x[3]), tflops=round(x[4], 1)) for x in per[:8]]
-    return dict(launches=n, seconds=total_t, flops=total_f, tflops=total_f / total_t / 1e12, top=top, bytes=total_b)
+    return dict(launches=n, seconds=total_t, flops=total_f, tflops=total_f / total_t / 1e12, top=top, bytes=total_b,
+                frac_of_own_peaks=total_pk / total_t)
+
+
+def roofline_block(roof, convention):
+    """The `roofline` object of a --mode lora / full line: every GEMM launch of one eager step replayed in isolation (see
+    measure_gemm_roofline).  `frac` prices bf16 launches against the bf16 MFMA peak and e4m3-operand launches against the fp8 peak."""
+    return {"bound": "mfma", "kernel": "gemm256_kernel + gemm_nt_kernel (+ K extension) + gemm_tn*_kernel: all GEMM launches of one step",
+            "achieved": round(roof["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(roof["frac_of_own_peaks"], 4), "frac_vs_bf16_peak": round(roof["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
+            "peak_fp8_launches": MFMA_FP8_PEAK_TFLOPS, "traffic": None, "flop_convention": convention,
+            "timing": "isolated: each distinct launch signature of one eager step replayed back-to-back between two HIP events on its launch "
+                      "stream, weighted by its count per step",
+            "launches_per_step": roof["launches"], "gemm_ms_per_step": round(roof["seconds"] * 1e3, 3), "gemm_flops_per_step": roof["flops"],
+            "algorithmic_bytes_per_launch": round(roof["bytes"] / roof["launches"]), "avg_launch_us": round(roof["seconds"] / roof["launches"] * 1e6, 1),
+            "top_launches": roof["top"]}
 
 
 def pmc_traffic():
@@ -265,6 +307,10 @@ def bench_full(args, cfg, W, eng, batch, noise, lr, rank, local, world, B, P):
     ms = dt / args.steps * 1e3
     fl = flops.step_flops_per_sample(cfg, L=P + 64, row0=0)
     full = 3.0 * fl["forward"]                               # config 4 ~ 3 x forward (dX + dW for every op)
+    roof = None
+    if rank == 0 and not args.no_probe:
+        roof = roofline_block(measure_gemm_roofline(eng, batch, noise, lr, step_fn=lambda: ft.train_step(batch, lr, noise)),
+                              "executed GEMM FLOPs of one step: forward, dX and dW = dY^T X of every Linear (attention products are not GEMM launches)")
     if rank == 0:
         nparam = ft.P.numel + ft.head.P.numel
         print(json.dumps({
@@ -282,6 +328,7 @@ def bench_full(args, cfg, W, eng, batch, noise, lr, rank, local, world, B, P):
             "step_tflops_per_gpu": round(full * B / (ms * 1e-3) / 1e12, 1),
             "step_frac_of_bf16_mfma_peak": round(full * B / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
             "gflop_per_sample": {"autograd_convention": round(full / 1e9, 1)},
+            "roofline": roof,
         }), flush=True)
     if world > 1:
         dist.barrier()
@@ -289,45 +336,74 @@ def bench_full(args, cfg, W, eng, batch, noise, lr, rank, local, world, B, P):
 
 
 def bench_lora(args, cfg, W, eng, batch, noise, lr, rank, local, world, B, P):
-    """LoRA fine-tune step (reference --use_lora, rank 64, all Linears of the ViT / projector / LLM + the adapter head), the 0.5B
-    backbone of BASELINE configs[1]: forward with the low-rank terms, full-sequence dX chain, dA / dB, AdamW over adapters + head.
-    Not the headline metric; same JSON contract."""
+    """LoRA fine-tune step (reference --use_lora, rank 64, all Linears of the ViT / projector / LLM + the adapter head): forward with the
+    low-rank terms, full-sequence dX chain, dA / dB, AdamW over adapters + head.  --fp8: the same step a second time with the frozen
+    base weights' products on e4m3 operands (BASELINE configs[4]: "LoRA-adapter fine-tune, fp8 MFMA weight path"), reported BESIDE
+    the bf16 line (reduced precision: never `value`).  Not the headline metric; same JSON contract."""
+    import gc
     from vla_adapter_amd import flops
     from vla_adapter_amd.lora_finetune import LoRAFinetune
-    ft = LoRAFinetune(eng, rank=args.lora_rank)
-    ft.set_objective(args.objective)
-    if args.eager:
-        step = lambda: ft.train_step(batch, lr, noise)
-    else:
-        ft.capture(batch, noise)
-        step = lambda: ft.train_step_graphed(lr)
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss3 = step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    ms = dt / args.steps * 1e3
     fl = flops.step_flops_per_sample(cfg, L=P + 64, row0=0)
     work = 2.0 * fl["forward"] + fl["head_fwd"]                # forward + dX of every op + the head's dW (base dW is not computed; rank terms ~2-10 %)
+    conv = ("executed GEMM FLOPs of one step: base products of forward and dX incl. their rank-r K extension, the skinny t = 2 x A^T / dt = 2 dy B "
+            "products, dA / dB as TN products, the action head's forward / dX / dW")
+
+    def run(fp8):
+        ft = LoRAFinetune(eng, rank=args.lora_rank, fp8=fp8)
+        ft.set_objective(args.objective)
+        if args.eager:
+            step = lambda: ft.train_step(batch, lr, noise)
+        else:
+            ft.capture(batch, noise)
+            step = lambda: ft.train_step_graphed(lr)
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss3 = step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        roof = None
+        if not args.no_probe:
+            roof = roofline_block(measure_gemm_roofline(eng, batch, noise, lr, step_fn=lambda: ft.train_step(batch, lr, noise)), conv)
+        out = dict(dt=dt, ms=dt / args.steps * 1e3, loss=round(float(loss3[0]), 5), roof=roof, nparam=ft.P.numel + ft.head.P.numel,
+                   nseg=None if args.eager else len(ft._segs), fp8_keys=(len(ft.Q), len(ft.QT), len(ft.L)))
+        del ft, step
+        gc.collect()
+        torch.cuda.empty_cache()
+        return out
+
+    r16 = run(False)
+    r8 = run(True) if args.fp8 else None
     desc = {"config2": "Prismatic SigLIP-224 + Qwen2.5-0.5B", "dinosiglip-0_5b": "DINOv2-L + SigLIP-so400m fused + Qwen2.5-0.5B (the reference's documented recipe)",
-            "config5": "BASELINE configs[4] backbone: DINOv2-L + SigLIP-so400m fused + Qwen2.5-1.5B (bf16: the config's fp8 weight path is not part of this mode)"}[args.backbone]
+            "config5": "BASELINE configs[4]: DINOv2-L + SigLIP-so400m fused + Qwen2.5-1.5B"}[args.backbone]
     if rank == 0:
+        fp8_line = None
+        if r8 is not None:
+            fp8_line = {"value": round(B * args.steps / r8["dt"], 2), "unit": "samples/s", "ms_per_step": round(r8["ms"], 3), "steps": args.steps,
+                        "dtype": "fp8 (OCP e4m3) base-weight products with fp32 accumulation + bf16 rank-r branch, activations / gradients / adapters bf16",
+                        "final_loss": r8["loss"], "linears_on_fp8_forward_backward_of": list(r8["fp8_keys"]),
+                        "step_tflops_per_gpu": round(work * B / (r8["ms"] * 1e-3) / 1e12, 1), "roofline": r8["roof"],
+                        "what": "every base product x W^T (forward) and dy W (dX) of the LoRA-wrapped Linears on e4m3 operands: weights quantised once "
+                                "(one scale per output / input channel), activations per row inside the norm that produces them or by one pass over "
+                                "the producer's output, dy per row; the low-rank branch adds in bf16 to the dequantised product in the same "
+                                "accumulator (GEMM K extension).  The reference has no fp8 code: parity unpinned, never the headline"}
         print(json.dumps({
             "metric": "fine-tune samples/sec (224px img + 32-tok prompt), LoRA rank %d on every Linear + adapter head, fwd+bwd+AdamW" % args.lora_rank +
                       ("" if args.objective == "l1" else ", token cross-entropy objective (lm_head on the text rows)"),
-            "value": round(B * args.steps / dt, 2), "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "value": round(B * args.steps / r16["dt"], 2), "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(r16["ms"], 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{desc} + Pro action head, LoRA fine-tune (vla-scripts/finetune.py:832-844), {cfg.n_img} image(s) "
                                    f"({cfg.n_patches} patches) + 32-token prompt + 64 action queries (S={cfg.n_patches + P + 64})",
                        "global_batch": B, "per_gpu_batch": B, "seq_len": cfg.n_patches + P + 64, "parallelism": "dp1", "weights": "random-init",
-                       "trainable_parameters": ft.P.numel + ft.head.P.numel, "captured_segment_graphs": None if args.eager else len(ft._segs),
-                       "launch": "eager" if args.eager else "hipGraph replay", "final_loss": round(float(loss3[0]), 5)},
-            "step_tflops_per_gpu": round(work * B / (ms * 1e-3) / 1e12, 1),
-            "step_frac_of_bf16_mfma_peak": round(work * B / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                       "trainable_parameters": r16["nparam"], "captured_segment_graphs": r16["nseg"],
+                       "launch": "eager" if args.eager else "hipGraph replay", "final_loss": r16["loss"]},
+            "step_tflops_per_gpu": round(work * B / (r16["ms"] * 1e-3) / 1e12, 1),
+            "step_frac_of_bf16_mfma_peak": round(work * B / (r16["ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
             "gflop_per_sample": {"forward": round(fl["forward"] / 1e9, 1), "counted": round(work / 1e9, 1)},
+            "roofline": r16["roof"],
+            "fp8_base_weights_variant": fp8_line,
         }), flush=True)
 
 
@@ -344,6 +420,10 @@ def main():
                     help="adapter: BASELINE configs[1]/[2] (the headline metric); full: configs[3], every VLM parameter trains; "
                          "lora: rank-r adapters on every Linear (the reference's --use_lora) on the 0.5B backbone")
     ap.add_argument("--lora-rank", type=int, default=64)
+    ap.add_argument("--fp8", action="store_true", help="--mode lora: also time the step with the frozen base weights' products on OCP e4m3 operands "
+                                                       "(BASELINE configs[4]'s fp8 MFMA weight path), printed beside the bf16 line")
+    ap.add_argument("--ddp-algo", default=os.environ.get("VLA_DDP_ALGO", "allreduce"), choices=["allreduce", "rs_ag"],
+                    help="gradient exchange per bucket: one all-reduce, or reduce-scatter + all-gather (all xGMI links of the node at once)")
     ap.add_argument("--objective", default="l1", choices=["l1", "token_ce"],
                     help="--mode full / lora: L1 regression through the action head (the reference's finetune.py) or the token cross-entropy of its "
                          "native trainer (SURVEY 8f-4: lm_head on the text rows, no action head)")
@@ -376,7 +456,7 @@ def main():
     batch["pixel_values"] = batch["pixel_values"].to(torch.bfloat16)   # finetune.py:339
     noise = (torch.randn(cfg.chunk, cfg.action_dim * cfg.llm.d, device=dev) * 0.02).to(torch.bfloat16)  # phase="Training"
     if world > 1:
-        eng.reducer = ddp.FlatGradReducer()
+        eng.reducer = ddp.FlatGradReducer(algo=args.ddp_algo)
     elif args.rehearse_exchange:
         # one-GPU rehearsal of the RCCL exchange: a ONE-rank "nccl" group and a reducer that issues its collectives as an
         # N-rank job would (a one-rank all-reduce is the identity; grad scale stays 1).  Costs what the exchange machinery
@@ -384,7 +464,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
         dist.init_process_group(backend="nccl", rank=0, world_size=1)
-        eng.reducer = ddp.FlatGradReducer()
+        eng.reducer = ddp.FlatGradReducer(algo=args.ddp_algo)
         eng.reducer.world = 2
         type(eng.reducer).grad_scale = property(lambda self: 1.0)
     lr = 5e-4
@@ -503,6 +583,7 @@ def main():
                                     "fine-tune (not the config's LoRA + fp8 mode), 1 image + 32-token prompt + 64 action queries"),
                        "global_batch": world * B, "per_gpu_batch": B, "seq_len": cfg.n_patches + P + 64,
                        "parallelism": f"dp{world}", "weights": "random-init", "launch": "eager" if args.eager else "hipGraph replay",
+                       "gradient_exchange": None if world == 1 else f"{dist.get_backend()} {args.ddp_algo}, bucketed, under the backward / the next step's vision stage",
                        "prompts": "ragged 24..32 tokens, right-padded" if args.ragged else "32 tokens",
                        "llm_backward": (f"live rows >= {row0} of {cfg.n_patches + P + 64} (gradient rows that only reach frozen inputs are "
                                         "not computed; parameter gradients identical)") if row0 else "all rows",

@@ -31,8 +31,10 @@ extern "C" {
  *      vla_copy_rows3d, vla_layerscale_fwd / _bwd, vla_token_ce_bwd, vla_desc_size.
  *   3  round 3: vla_head_attn_desc gained the optional backward workspace (ws, ws_floats).
  *   4  round 3: vla_gemm_desc gained the RMSNorm fields (ssq_out .. rstd_out); new entry point vla_gemm_uses_256.
+ *   5  round 4: the RMSNorm fields are gone again (the fold measured slower and left the tree: tools/diag/gemm256_pruned_paths.patch);
+ *      fp8 = 1 may be combined with the K extension (and, in that form, with the SwiGLU-backward epilogue).
  * A binder checks vla_version() AND vla_desc_size() against its own struct definitions before the first call. */
-#define VLA_ABI_VERSION 4
+#define VLA_ABI_VERSION 5
 int vla_version(void);
 /* sizeof() of the descriptor structs as this library was compiled: which = 0 vla_gemm_desc, 1 vla_attn_desc, 2 vla_head_attn_desc,
  * 3 vla_gemm_tn_desc; -1 for an unknown index.  A caller whose struct is shorter would make the library read past its end. */
@@ -82,25 +84,20 @@ typedef struct vla_gemm_desc {
   /* optional (round 2; BASELINE configs[4]'s "fp8 MFMA weight path" - the reference has no fp8 code, parity unpinned):
    * fp8 = 1: A and B point at OCP e4m3 bytes (lda / ldb in elements, multiples of 16; K % 128 == 0), a_scale[M] / b_scale[N]
    * are the per-row dequantisation factors (vla_quant_fp8_rows): C = epilogue(a_scale[m] b_scale[n] (A . B^T)[m, n]).
-   * Plain / activation / residual / SwiGLU-forward / rotate_half epilogues; no split-K, no batch. */
+   * Plain / activation / residual / SwiGLU-forward / rotate_half epilogues; no split-K, no batch.  With a K extension: see A2. */
   int fp8; const float* a_scale; const float* b_scale;
   /* optional K extension (ABI 2; K2 = 0: off): the contraction continues over a second operand pair,
    * C = epilogue(A . B^T + A2 . B2^T) with A2 bf16 [M, K2] (row stride lda2) and B2 bf16 [N, K2] (ldb2), K2 % 64 == 0, in ONE fp32
    * accumulator.  A LoRA-wrapped Linear (peft, vla-scripts/finetune.py:832-844) as one product: y = x W^T + (2 x A^T) B^T with the
-   * base GEMM's epilogue intact; its backward dx = dy W + dt A likewise.  batch 1, no split-K / fp8 / interleaved RoPE. */
+   * base GEMM's epilogue intact; its backward dx = dy W + dt A likewise.  batch 1, no split-K / interleaved RoPE.  With fp8 = 1 (ABI 5)
+   * the base operands A / B are e4m3 bytes and A2 / B2 stay bf16: C = epilogue(a_scale[m] b_scale[n] (A . B^T)[m, n] + (A2 . B2^T)[m, n]) -
+   * the frozen base weights of a LoRA fine-tune on the fp8 MFMA path (BASELINE configs[4]); SwiGLU backward is allowed in this form. */
   const void* A2; const void* B2; int K2, lda2, ldb2;
-  /* ABI 4: RMSNorm folded into the neighbouring GEMMs (256-row kernel only: vla_gemm_uses_256 tells; the norm WEIGHT is folded into B by the
-   * caller, B' = B * w[None, :]).  Producer: ssq_out f32 [ceil(N/256)][M] receives, per 256-column tile, the sum of squares of the
-   * bf16 rows this GEMM stores (plain epilogue with a residual, batch 1, M and N multiples of 64).  Consumer: rowss = such partials
-   * of the rows of A (rowss_parts of them, <= 6); every accumulator row is multiplied by rstd[m] = rsqrt(sum_t rowss[t][m] / K + rows_eps)
-   * before alpha / bias / RoPE / SwiGLU; rstd_out f32 [M] (optional) receives rstd for the backward. */
-  float* ssq_out; const float* rowss; int rowss_parts; float rows_eps; float* rstd_out;
 } vla_gemm_desc;
 
 /* 1 when every operand row a 256-row tile of this problem can touch lies below 4 GiB from its base (the 256 x 256 kernel keeps
  * 32-bit per-lane byte offsets; larger operands are routed to the 128-row kernel, which uses 64-bit pointers).  Host arithmetic. */
-/* 1 when vla_gemm_bf16_nt would run this descriptor on the 256 x 256 kernel (the routing is shape- and device-dependent): callers that
- * want the RMSNorm fields ask first and keep the stand-alone norm otherwise. */
+/* 1 when vla_gemm_bf16_nt would run this descriptor on the 256 x 256 kernel (the routing is shape- and device-dependent). */
 int vla_gemm_uses_256(const vla_gemm_desc* desc);
 int vla_gemm256_extent_ok(const vla_gemm_desc* desc /* host */);
 

@@ -52,8 +52,10 @@ def linear(x, w, b=None, emu=False, strided_input=False):
     dimensions are ignored) and the fused path is taken (batch-1 inference!).  Verified op by op against the reference module in this container and pinned by
     tests/golden/head_bf16_*.npz; every other Linear of the head sees a contiguous input (cat / view outputs)."""
     if id(w) in FP8:             # opt-in fp8 weight path: both operands fake-quantised per row (e4m3, scale amax / 448)
-        x, w = fake_quant_e4m3_rows(x), fake_quant_e4m3_rows(w)
-    y = x @ w.t()
+        base = lambda: _Fp8Product.apply(x, w, FP8_BWD)      # (the low-rank branch below reads the UN-quantised input)
+    else:
+        base = lambda: x @ w.t()
+    y = base()
     if b is not None:
         y = (rnd(y, emu) if strided_input else y) + b
     y = rnd(y, emu)
@@ -62,7 +64,7 @@ def linear(x, w, b=None, emu=False, strided_input=False):
         # the native build's form (vla_adapter_amd/trainers.py): the low-rank branch inside the base product's fp32 accumulator -
         # t = bf16(scale x A^T), y = bf16(x W^T + t B^T + b): ONE rounding of y where peft's module-by-module evaluation has three
         A, Bm, scale = l
-        y = x @ w.t() + rnd(scale * (x @ A.t()), emu) @ Bm.t()
+        y = base() + rnd(scale * (x @ A.t()), emu) @ Bm.t()
         return rnd(y + b, emu) if b is not None else rnd(y, emu)
     if l is not None:            # peft Linear.forward: result = base(x) + lora_B(lora_A(x)) * scaling, every step a bf16 tensor
         A, Bm, scale = l
@@ -70,10 +72,53 @@ def linear(x, w, b=None, emu=False, strided_input=False):
     return y
 
 
+def linear_group(x, wbs, emu=False):
+    """Several Linears on the SAME input (q / k / v; gate / up): one ``linear`` each - except when their base products run on fp8
+    operands INCLUDING the backward (FP8_BWD): the native build forms them as one product on a fused weight, so the gradient row
+    that is quantised for dx = Q(dy) Q(W^T)^T is the CONCATENATION of their output gradients (one scale per row over q | k | v),
+    and a row of W^T spans all of their output channels.  Forward values are the same either way (per-output-channel weight
+    scales, shared input).  The fused LoRA form only (LORA_FUSED) or no LoRA."""
+    ws = [w for w, _ in wbs]
+    if not (FP8_BWD and all(id(w) in FP8 for w in ws)):
+        return [linear(x, w, b, emu) for w, b in wbs]
+    base = _Fp8Product.apply(x, torch.cat([w.detach() for w in ws], 0), True)
+    outs, o = [], 0
+    for w, b in wbs:
+        y = base[..., o:o + w.shape[0]]
+        o += w.shape[0]
+        l = LORA.get(id(w))
+        if l is not None:
+            assert LORA_FUSED, "fp8 base products: the fused single-rounding LoRA form"
+            A, Bm, scale = l
+            y = y + rnd(scale * (x @ A.t()), emu) @ Bm.t()
+        outs.append(rnd(y + b, emu) if b is not None else rnd(y, emu))
+    return outs
+
+
 # fp8 registry (BASELINE configs[4] "fp8 MFMA weight path"; the reference has no fp8 code: PARITY UNPINNED): ids of the weight
 # tensors whose Linear runs on e4m3 operands in the native build (vla_quant_fp8_rows semantics: per-row dynamic scale for the
 # input, per-output-channel scale for the weight, fp32 accumulation of the dequantised values).
 FP8: set = set()
+FP8_BWD = False       # True: the dX product of a registered Linear runs on e4m3 operands too (LoRAFinetune(fp8_backward=True))
+
+
+class _Fp8Product(torch.autograd.Function):
+    """y = Q(x) Q(W)^T with rows of x and rows of W (output channels) quantised to e4m3; the weight is frozen (no dW).  Backward:
+    dx = dy W through the un-quantised weight (the engine's adapter-only step: bf16 W^T), or - bwd_fp8 - dx = Q(dy) Q(W^T)^T with
+    rows of dy and rows of W^T (INPUT channels) quantised: the arithmetic of trainers.LoRAFinetune._lin_bwd on fp8 operands."""
+
+    @staticmethod
+    def forward(ctx, x, w, bwd_fp8):
+        ctx.save_for_backward(w)
+        ctx.bwd_fp8 = bool(bwd_fp8)
+        return fake_quant_e4m3_rows(x) @ fake_quant_e4m3_rows(w).t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        (w,) = ctx.saved_tensors
+        if ctx.bwd_fp8:
+            return fake_quant_e4m3_rows(dy) @ fake_quant_e4m3_rows(w.detach().t().contiguous()).t(), None, None
+        return dy @ w.detach(), None, None
 
 
 def fake_quant_e4m3_rows(t):
@@ -257,53 +302,27 @@ def qwen2_forward(x, mask, p: Dict[str, torch.Tensor], cfg: Dict, emu=False) -> 
     """
     S = x.shape[1]
     hs = [x]
-    fold = cfg.get("fold_llm_rmsnorm", False)     # native adapter-only forward: every RMSNorm but the first and the final one is folded
     for i in range(cfg["n_layers"]):
-        x = qwen2_layer(x, mask, p, f"layers.{i}.", dict(cfg, fold_rmsnorm=(fold and i > 0, fold)), emu)
+        x = qwen2_layer(x, mask, p, f"layers.{i}.", cfg, emu)
         hs.append(x)
     hs[-1] = rms_norm(x, p["norm.weight"], cfg["eps"], emu)
     return hs
 
 
-def folded_norm_linear(x, nw, eps, w, b, emu):
-    """RMSNorm folded into the Linear behind it (the native adapter-only forward, engine.LLM.fold_rmsnorm): the norm weight goes into
-    the weight matrix, W' = bf16(W * nw[None, :]), the row scale 1 / rms(x) onto the fp32 product - the normalised activations are never
-    rounded to bf16 (Qwen2RMSNorm rounds them twice).  A DIVERGENCE from the reference's rounding points, restated here so that the
-    native path is checked against its own arithmetic; emu=False is the same real-valued function as rms_norm -> linear."""
-    xf = x.float()
-    rstd = torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
-    y = (xf @ rnd(w.float() * nw.float()[None, :], emu).t()) * rstd
-    return rnd(y + b.float() if b is not None else y, emu)
-
-
 def qwen2_layer(x, mask, p: Dict[str, torch.Tensor], pre: str, cfg: Dict, emu=False):
-    """One Qwen2DecoderLayer (transformers): x + o(attn(rope(q, k), v)) ; x + down(silu(gate) * up).
-    cfg["fold_rmsnorm"] = (fold norm1, fold norm2) selects folded_norm_linear for the projections behind either norm."""
+    """One Qwen2DecoderLayer (transformers): x + o(attn(rope(q, k), v)) ; x + down(silu(gate) * up)."""
     B, S, D = x.shape
     H, KV, dh = cfg["heads"], cfg["kv_heads"], cfg["dh"]
     cos, sin = rope_half_tables(S, dh, cfg["theta"], emu)
-    f1, f2 = cfg.get("fold_rmsnorm", (False, False))
-    if f1:
-        nw = p[pre + "input_layernorm.weight"]
-        q, k, v = (folded_norm_linear(x, nw, cfg["eps"], p[pre + f"self_attn.{n}_proj.weight"], p[pre + f"self_attn.{n}_proj.bias"], emu) for n in "qkv")
-    else:
-        h = rms_norm(x, p[pre + "input_layernorm.weight"], cfg["eps"], emu)
-        q = linear(h, p[pre + "self_attn.q_proj.weight"], p[pre + "self_attn.q_proj.bias"], emu)
-        k = linear(h, p[pre + "self_attn.k_proj.weight"], p[pre + "self_attn.k_proj.bias"], emu)
-        v = linear(h, p[pre + "self_attn.v_proj.weight"], p[pre + "self_attn.v_proj.bias"], emu)
+    h = rms_norm(x, p[pre + "input_layernorm.weight"], cfg["eps"], emu)
+    q, k, v = linear_group(h, [(p[pre + f"self_attn.{n}_proj.weight"], p[pre + f"self_attn.{n}_proj.bias"]) for n in "qkv"], emu)
     q = rope_half(q.reshape(B, S, H, dh).transpose(1, 2), cos, sin, emu)
     k = rope_half(k.reshape(B, S, KV, dh).transpose(1, 2), cos, sin, emu)
     v = v.reshape(B, S, KV, dh).transpose(1, 2)
     a = attention(q, k, v, True, mask, dh ** -0.5, emu).transpose(1, 2).reshape(B, S, H * dh)
     x = rnd(x + linear(a, p[pre + "self_attn.o_proj.weight"], None, emu), emu)
-    if f2:
-        nw = p[pre + "post_attention_layernorm.weight"]
-        g = folded_norm_linear(x, nw, cfg["eps"], p[pre + "mlp.gate_proj.weight"], None, emu)
-        u = folded_norm_linear(x, nw, cfg["eps"], p[pre + "mlp.up_proj.weight"], None, emu)
-    else:
-        h = rms_norm(x, p[pre + "post_attention_layernorm.weight"], cfg["eps"], emu)
-        g = linear(h, p[pre + "mlp.gate_proj.weight"], None, emu)
-        u = linear(h, p[pre + "mlp.up_proj.weight"], None, emu)
+    h = rms_norm(x, p[pre + "post_attention_layernorm.weight"], cfg["eps"], emu)
+    g, u = linear_group(h, [(p[pre + "mlp.gate_proj.weight"], None), (p[pre + "mlp.up_proj.weight"], None)], emu)
     m = rnd(rnd(g * torch.sigmoid(g), emu) * u, emu)
     return rnd(x + linear(m, p[pre + "mlp.down_proj.weight"], None, emu), emu)
 

@@ -88,10 +88,10 @@ def test_gemm_plain_bias(ops, M, N, K):
     check(out, O.linear(a.float(), b.float(), bias.float(), emu=True), name=f"gemm {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", [2, 3, 6])
 @pytest.mark.parametrize("M,N,K", [(300, 200, 192), (1000, 896, 896), (512, 384, 64), (2080, 1792, 896), (64, 7, 128)])
 def test_gemm_every_tile_config(ops, tile, M, N, K, monkeypatch):
-    """The three kernel instantiations (256x128x3-stage, 128x128x2, 128x64x3) must agree with the oracle on ragged
+    """The three tile geometries (128x128 8 waves, 128x64 4 waves, 256x256 two-phase) must agree with the oracle on ragged
     edges, K=64 (shorter than the pipeline depth) and long K; VLA_GEMM_TILE forces the choice."""
     monkeypatch.setenv("VLA_GEMM_TILE", str(tile))
     a, b, bias, r = gen(M, K, seed=1), gen(N, K, seed=2, scale=0.05), gen(N, seed=3), gen(M, N, seed=4)
@@ -100,7 +100,7 @@ def test_gemm_every_tile_config(ops, tile, M, N, K, monkeypatch):
     check(out, O.rnd(y + r.float(), True), name=f"gemm tile{tile} {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("tile", [1, 3, 6])
+@pytest.mark.parametrize("tile", [2, 3, 6])
 def test_gemm_swiglu_tile_configs(ops, tile, monkeypatch):
     monkeypatch.setenv("VLA_GEMM_TILE", str(tile))
     M, I, K = 330, 320, 256
@@ -1163,7 +1163,7 @@ def test_gemm_forced_tile_with_split_k(ops, monkeypatch):
     M, N, K = 512, 896, 4096
     a, w, bias = gen(M, K, seed=241).to(DEV), gen(N, K, seed=242, scale=0.05).to(DEV), gen(N, seed=243).to(DEV)
     ref = ops.gemm_nt(a, w, bias=bias, split_k=4)
-    for tile in (1, 4, 5, 6):
+    for tile in (2, 3, 6):
         monkeypatch.setenv("VLA_GEMM_TILE", str(tile))
         out = ops.gemm_nt(a, w, bias=bias, split_k=4)
         check(out, f(ref), rel=2e-3, name=f"split-K 4 with forced tile {tile}")

@@ -147,6 +147,66 @@ def test_gemm_k_extension_keeps_the_fused_epilogues(ops):
         del os.environ["VLA_GEMM_TILE"]
 
 
+def _deq(q, s):
+    return q.cpu().view(torch.float8_e4m3fn).float() * s.cpu()[:, None]
+
+
+@pytest.mark.parametrize("M,N,K,K2", [(300, 200, 256, 64), (1000, 896, 896, 128), (2048, 1152, 1152, 192), (64, 8, 128, 64), (640, 1536, 8960, 64)])
+def test_gemm_fp8_base_with_bf16_k_extension(ops, M, N, K, K2):
+    """ABI 5: e4m3 base operands + bf16 extension in ONE accumulator (a LoRA-wrapped Linear whose frozen base weight runs on the fp8
+    MFMA): C = epilogue(sa[m] sb[n] (Aq . Bq^T) + A2 . B2^T) against the fp32 product of the DEQUANTISED base operands plus the bf16
+    extension.  The reference has no fp8 code: parity unpinned, the kernel is held to the arithmetic it claims."""
+    a, b, a2, b2 = gen(M, K, seed=31), gen(N, K, seed=32, scale=0.05), gen(M, K2, seed=33), gen(N, K2, seed=34, scale=0.05)
+    bias, r = gen(N, seed=35), gen(M, N, seed=36)
+    qa, sa = ops.quant_fp8_rows(a.to(DEV))
+    qb, sb = ops.quant_fp8_rows(b.to(DEV))
+    out = ops.gemm_nt(qa, qb, bias=bias.to(DEV), residual=r.to(DEV), fp8=(sa, sb), ext=(a2.to(DEV), b2.to(DEV)))
+    y = O.rnd(_deq(qa, sa) @ _deq(qb, sb).t() + a2.float() @ b2.float().t() + bias.float(), True)
+    check(out, O.rnd(y + r.float(), True), name=f"fp8 gemm + bf16 ext {M}x{N}x{K}+{K2}")
+    # the extension really adds to the DEQUANTISED product: with unit scales forced, the result must differ
+    wrong = ops.gemm_nt(qa, qb, bias=bias.to(DEV), residual=r.to(DEV), fp8=(torch.ones_like(sa), torch.ones_like(sb)), ext=(a2.to(DEV), b2.to(DEV)))
+    assert not torch.equal(out, wrong)
+
+
+def test_gemm_fp8_k_extension_keeps_the_fused_epilogues(ops):
+    """SwiGLU forward, rotate_half RoPE and the SwiGLU-backward epilogue on the fp8 + extension form."""
+    M, I, K, K2 = 330, 320, 256, 128
+    x, w, x2, w2 = gen(M, K, seed=42), gen(2 * I, K, seed=43, scale=0.1), gen(M, K2, seed=44), gen(2 * I, K2, seed=45, scale=0.1)
+    d = lambda t: t.to(DEV)
+    qa, sa = ops.quant_fp8_rows(d(x))
+    qb, sb = ops.quant_fp8_rows(d(w))
+    pre, h = ops.gemm_nt(qa, qb, act=ops.ACT_SWIGLU, fp8=(sa, sb), ext=(d(x2), d(w2)))
+    y = O.rnd(_deq(qa, sa) @ _deq(qb, sb).t() + x2.float() @ w2.float().t(), True)
+    check(pre, y, name="fp8 + ext swiglu pre-activations")
+    g, u = y.view(M, I // 16, 2, 16)[:, :, 0].reshape(M, I), y.view(M, I // 16, 2, 16)[:, :, 1].reshape(M, I)
+    check(h, O.rnd(O.rnd(g * torch.sigmoid(g), True) * u, True), rel=6e-3, name="fp8 + ext swiglu h")
+    S, H, dh = 33, 5, 64
+    cos, sin = ops.rope_half_tables(S, dh, 1e6, DEV)
+    Bq = 10
+    Mr, N = Bq * S, (H + 2) * dh
+    a, b, a2, b2 = gen(Mr, K, seed=46), gen(N, K, seed=47, scale=0.1), gen(Mr, K2, seed=48), gen(N, K2, seed=49, scale=0.1)
+    bias = gen(N, seed=50)
+    qa, sa = ops.quant_fp8_rows(d(a))
+    qb, sb = ops.quant_fp8_rows(d(b))
+    o = ops.gemm_nt(qa, qb, bias=d(bias), rope=(1, cos, sin, S, dh, (H + 1) * dh), fp8=(sa, sb), ext=(d(a2), d(b2)))
+    y = O.rnd(_deq(qa, sa) @ _deq(qb, sb).t() + a2.float() @ b2.float().t() + bias.float(), True)
+    c, s_ = O.rope_half_tables(S, dh, 1e6, True)
+    rot = O.rope_half(y[:, :(H + 1) * dh].view(Bq, S, H + 1, dh).transpose(1, 2), c, s_, True).transpose(1, 2).reshape(Mr, (H + 1) * dh)
+    check(o, torch.cat([rot, y[:, (H + 1) * dh:]], 1), name="fp8 + ext gemm + rope_half")
+    gu = gen(M, 2 * I, seed=51)
+    dy, wdT, dt, AT = gen(M, K, seed=52), gen(I, K, seed=53, scale=0.1), gen(M, K2, seed=54), gen(I, K2, seed=55, scale=0.1)
+    qd, sd = ops.quant_fp8_rows(d(dy))
+    qw, sw = ops.quant_fp8_rows(d(wdT))
+    g1 = ops.gemm_swiglu_bwd(qd, qw, d(gu), ext=(d(dt), d(AT)), fp8=(sd, sw))
+    dh_ = O.rnd(_deq(qd, sd) @ _deq(qw, sw).t() + dt.float() @ AT.float().t(), True)          # dH [M, I], rounded as the epilogue does
+    gg = gu.float().view(M, I // 16, 2, 16)
+    gate, up = gg[:, :, 0].reshape(M, I), gg[:, :, 1].reshape(M, I)
+    sg = torch.sigmoid(gate)
+    dgate, dup = dh_ * up * (sg * (1 + gate * (1 - sg))), dh_ * gate * sg
+    ref = torch.stack([dgate.view(M, I // 16, 16), dup.view(M, I // 16, 16)], 2).reshape(M, 2 * I)
+    check(g1, O.rnd(ref, True), rel=6e-3, name="fp8 + ext swiglu backward")
+
+
 # ------------------------------------------------------------------ LayerScale, row copies
 @pytest.mark.parametrize("rows,cols", [(261 * 3, 1024), (40, 192), (1000, 8)])
 def test_layerscale_forward_backward(ops, rows, cols):

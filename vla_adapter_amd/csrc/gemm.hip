@@ -41,6 +41,13 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
+typedef int v8i_f8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ v8i_f8 cat8(bf16x8 lo, bf16x8 hi) {          // two 16-B fragment reads -> the 32-byte fp8 operand
+  typedef float f32x8 __attribute__((ext_vector_type(8)));
+  const f32x4 l = __builtin_bit_cast(f32x4, lo), h = __builtin_bit_cast(f32x4, hi);
+  return __builtin_bit_cast(v8i_f8, f32x8{l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]});
+}
+
 template <int BM, int BN, int STAGES, int WN = 2>
 struct Cfg {
   static constexpr int NW = (BM / 64) * WN;              // waves: (BM/64) along M x WN along N
@@ -72,7 +79,8 @@ struct Cfg {
 // branch inside the base GEMM's fp32 accumulator - the base product keeps its bias / RoPE / SwiGLU epilogue and no
 // read-modify-write pass over y exists (backward alike: dx = dy W + dt A).
 template <int BM, int BN, int STAGES, int ROPE, int WN = 2, bool F8 = false, bool EXT = false>
-__global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
+__global__ __launch_bounds__((BM / 64) * 64 * WN) __attribute__((amdgpu_waves_per_eu((F8 && EXT) ? 4 : 1)))   // (fp8 + extension: two
+void gemm_nt_kernel(GemmP p) {                                   //  workgroups per CU like every other form: 128 registers, no spill)
   using C = Cfg<BM, BN, STAGES, WN>;
   constexpr int EB = F8 ? 1 : 2;                           // bytes per operand element
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -90,8 +98,8 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
   // (row-major order re-streamed every B tile from beyond L2 for every row panel: 44 x 17 MB for the gate/up GEMM).
   // 6 for the 128-row tiles: in the two/three-stream step the XCD's L2 is shared with the other streams' kernels and the
   // smaller patch wins (same-box sweep: 8 -> 31.55 ms/step, 6 -> 30.85, 5 -> 30.8, 4 -> 31.0, 3 -> 30.85, 12 -> 32.3;
-  // isolated launches are indifferent between 4 and 8).  VLA_GEMM_GM overrides.
-  const int GM = p.gm > 0 ? p.gm : (BM == 256 ? 4 : 6);   // A panels kept L2-resident per XCD
+  // isolated launches are indifferent between 4 and 8).
+  constexpr int GM = 6;                                    // A panels kept L2-resident per XCD
   const int tiles_m = p.ntiles / p.tiles_n, per_group = GM * p.tiles_n;
   const int grp = swz / per_group, rem = swz - grp * per_group;
   const int gm = min(GM, tiles_m - grp * GM);
@@ -145,10 +153,12 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
 
   // fragment read offsets (bytes) inside an operand tile, per k-step s: row*128 + ((4s + (lane>>4)) ^ (lane&7))*16
   const int frow = lane & 15;
-  int foff[2];
+  int foff[2], foff2[2];                      // foff2: the bf16 K-extension tiles of an fp8 product (F8 && EXT)
 #pragma unroll
-  for (int s = 0; s < 2; ++s)                 // (fp8: the lane's 32 contiguous bytes = chunks 2q and 2q + 1, q = lane >> 4)
+  for (int s = 0; s < 2; ++s) {               // (fp8: the lane's 32 contiguous bytes = chunks 2q and 2q + 1, q = lane >> 4)
     foff[s] = frow * 128 + (((F8 ? 2 * (lane >> 4) + s : 4 * s + (lane >> 4)) ^ (lane & 7)) << 4);
+    foff2[s] = frow * 128 + (((4 * s + (lane >> 4)) ^ (lane & 7)) << 4);
+  }
 
   // epilogue coordinates: lane owns, for tile (ni, mi): m = 16mi + (lane&15), n = 16ni + 4(lane>>4) + {0..3}.
   // The bias slice is fetched HERE (one 8-B load per n-tile) so its latency hides under the main loop; fetched in the
@@ -178,81 +188,77 @@ __global__ __launch_bounds__((BM / 64) * 64 * WN) void gemm_nt_kernel(GemmP p) {
     }
   }
 
+  // (fp8 base product with a bf16 K extension - a LoRA-wrapped Linear on e4m3 base operands: the dequantisation scales are applied
+  //  to the accumulator BETWEEN the two contractions, so the low-rank branch adds to the dequantised base product)
   const int nt = nt1 + (EXT ? p.K2 / BK : 0);
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < nt) stage(s, s);
   int buf = 0;
-  for (int t = 0; t < nt; ++t) {
-    // retire this wave's pieces of tile t; up to STAGES-2 younger tiles stay in flight
-    if (STAGES == 3 && t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PPW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // tile t visible to every wave; every wave is done reading tile t-1's buffer
-    asm volatile("" ::: "memory");
-    if (t + STAGES - 1 < nt) {
-      int nb = buf + STAGES - 1;
-      if (nb >= STAGES) nb -= STAGES;
-      stage(nb, t + STAGES - 1);
+  static_assert(C::NT <= 4, "wave tiles are 64 x 32 or 64 x 64");
+  // One K-tile (written as a macro so that the fp8 product with a bf16 extension can run it as TWO loops - e4m3 tiles, then bf16
+  // tiles - each with one MFMA form and one set of fragment offsets: as one loop with a per-tile branch the kernel needed 200
+  // registers and lost its second resident workgroup).  All fragment reads of the K-tile (both 32-deep k-steps) are issued up
+  // front: the second k-step's LDS latency hides under the first k-step's MFMAs instead of stalling between them.
+#define VLA_KTILE(F8T, FO)                                                                                                           \
+  do {                                                                                                                               \
+    /* retire this wave's pieces of tile t; up to STAGES-2 younger tiles stay in flight */                                           \
+    if (STAGES == 3 && t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PPW) : "memory");                                      \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                            \
+    __builtin_amdgcn_s_barrier(); /* tile t visible to every wave; every wave is done reading tile t-1's buffer */                    \
+    asm volatile("" ::: "memory");                                                                                                   \
+    if (t + STAGES - 1 < nt) {                                                                                                       \
+      int nb = buf + STAGES - 1;                                                                                                     \
+      if (nb >= STAGES) nb -= STAGES;                                                                                                \
+      stage(nb, t + STAGES - 1);                                                                                                     \
+    }                                                                                                                                \
+    const char* sa = smem + buf * C::STAGE_BYTES + wr * 64 * 128;                                                                    \
+    const char* sb = smem + buf * C::STAGE_BYTES + C::A_BYTES; /* B tile; n tile i of this wave starts at row cbase(i) */             \
+    bf16x8 fm[2][4], fn[2][C::NT];                                                                                                   \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                                                  \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) fm[s][i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + FO[s]);          \
+      _Pragma("unroll") for (int i = 0; i < C::NT; ++i) fn[s][i] = *reinterpret_cast<const bf16x8*>(sb + cbase(i) * 128 + FO[s]);    \
+    }                                                                                                                                \
+    if constexpr (F8T) {                                                                                                             \
+      _Pragma("unroll") for (int ni = 0; ni < C::NT; ++ni)                                                                           \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                                             \
+          acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(cat8(fn[0][ni], fn[1][ni]), cat8(fm[0][mi], fm[1][mi]),     \
+                                                                         acc[ni][mi], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);            \
+    } else {                                                                                                                         \
+      _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                                  \
+        _Pragma("unroll") for (int ni = 0; ni < C::NT; ++ni)                                                                         \
+          _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                                           \
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[s][ni], fm[s][mi], acc[ni][mi], 0, 0, 0);                       \
+    }                                                                                                                                \
+    if (++buf == STAGES) buf = 0;                                                                                                    \
+  } while (0)
+  if constexpr (F8 && EXT) {
+    for (int t = 0; t < nt1; ++t) VLA_KTILE(true, foff);
+    // dequantisation of the base product, then the bf16 extension adds to it
+    {
+      float fsa[4];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) fsa[mi] = p.scaleA[min(wm0 + mi * 16 + lr, p.M - 1)];
+#pragma unroll
+      for (int ni = 0; ni < C::NT; ++ni)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float sbv = p.scaleB[min(n0 + cbase(ni) + lq * 4 + j, p.N - 1)];
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) acc[ni][mi][j] *= fsa[mi] * sbv;
+        }
     }
-    const char* sa = smem + buf * C::STAGE_BYTES + wr * 64 * 128;
-    const char* sb = smem + buf * C::STAGE_BYTES + C::A_BYTES;     // B tile; n tile i of this wave starts at row cbase(i)
-    if constexpr (C::NT <= 4) {
-      // all fragment reads of the K-tile (both 32-deep k-steps) are issued up front: the second k-step's LDS latency
-      // hides under the first k-step's MFMAs instead of stalling between them
-      bf16x8 fm[2][4], fn[2][C::NT];
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fm[s][i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + foff[s]);
-#pragma unroll
-        for (int i = 0; i < C::NT; ++i) fn[s][i] = *reinterpret_cast<const bf16x8*>(sb + cbase(i) * 128 + foff[s]);
-      }
-      if constexpr (F8) {
-        typedef int v8i __attribute__((ext_vector_type(8)));
-        auto cat = [](bf16x8 lo, bf16x8 hi) {
-          const f32x4 l = __builtin_bit_cast(f32x4, lo), h = __builtin_bit_cast(f32x4, hi);
-          typedef float f32x8 __attribute__((ext_vector_type(8)));
-          return __builtin_bit_cast(v8i, f32x8{l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]});
-        };
-#pragma unroll
-        for (int ni = 0; ni < C::NT; ++ni)
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
-            acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(cat(fn[0][ni], fn[1][ni]), cat(fm[0][mi], fm[1][mi]), acc[ni][mi],
-                                                                            0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-      } else {
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-          for (int ni = 0; ni < C::NT; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-              acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[s][ni], fm[s][mi], acc[ni][mi], 0, 0, 0);
-      }
-    } else {
-      // 64 x 128 wave tile (128 accumulator registers): fragments per k-step, 12 reads feed 32 MFMAs
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        bf16x8 fm[4], fn[C::NT];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fm[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + foff[s]);
-#pragma unroll
-        for (int i = 0; i < C::NT; ++i) fn[i] = *reinterpret_cast<const bf16x8*>(sb + cbase(i) * 128 + foff[s]);
-#pragma unroll
-        for (int ni = 0; ni < C::NT; ++ni)
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
-            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[ni], fm[mi], acc[ni][mi], 0, 0, 0);
-      }
-    }
-    if (++buf == STAGES) buf = 0;
+    for (int t = nt1; t < nt; ++t) VLA_KTILE(false, foff2);
+  } else {
+    for (int t = 0; t < nt; ++t) VLA_KTILE(F8, foff);
   }
+#undef VLA_KTILE
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // all waves done with the operand tiles before the staging regions are overwritten
   asm volatile("" ::: "memory");
 
   // ---------------- epilogue ----------------
-  if constexpr (F8) {
+  if constexpr (F8 && !EXT) {
     // dequantisation: acc[m][n] *= scaleA[m] * scaleB[n] (fp32, before alpha / bias / activation)
     float sa[4];
 #pragma unroll
@@ -565,8 +571,6 @@ inline bool use_256(int M, int N, int K, int batch, int act) {
   // first one's epilogue); on the step the two routings tie (25.25-25.34 vs 25.29-25.32 ms)
   const int ncu = vla_num_cus();
   if ((act == VLA_ACT_GELU || act == VLA_ACT_GELU_TANH) && tiles > ncu && (tiles % ncu) != 0 && (tiles % ncu) * 4 < ncu) return false;
-  if (const char* mt = getenv("VLA_GEMM256_MIN_TILES"))      // (A/B aid: the round-2 rule, a plain tile-count threshold)
-    return M >= 1024 && N >= 768 && K >= 256 && tiles >= atoi(mt);
   // Rounds model (round 3, tools/bench_tiles_b16.py): a 256 x 256 tile is four 128 x 128 tiles of work on one CU; the 128-row kernel
   // keeps two workgroups per CU and reaches ~0.87 of the 256-row kernel's per-CU rate.  Cost in units of "one 128 x 128 tile at
   // the 256-row kernel's rate":  rounds256 x 4  against  rounds128 x 2 / 0.87.  Reproduces every measured winner of the batch-32
@@ -584,22 +588,20 @@ inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode, int
   // on the 128-row kernel.  VLA_NO_ROPE256 switches it off.
   static const bool no_rope256 = getenv("VLA_NO_ROPE256") != nullptr;
   if (split == 1) {     // (both RoPE conventions are fused in both kernels)
-    if (force == 6 || force == 4) return {256, 257};   // 256 x 256 staggered 8-phase kernel (gemm256.hip); 4 = its round-1 predecessor
+    if (force == 6) return {256, 257};   // 256 x 256 two-phase kernel (gemm256.hip)
     const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256) * batch;
     if (force == 0 && (rope_mode == 0 || (!no_rope256 && t256 >= 192)) && use_256(M, N, K, batch, act)) return {256, 257};
   }
   if (rope_mode == 1) return {128, 128};   // rotate_half: 8 waves, each owning 16 columns of both halves of one head
-  if (force == 1 && rope_mode == 0) return {256, 128};
   if (force == 2) return {128, 128};
   if (force == 3) return {128, 64};
-  if (force == 5 && rope_mode == 0) return {128, 129};   // 128x128 with 4 waves of 64x64 (the round-1 v1 geometry)
   // In situ (whole training step, same-box A/B) the 8-wave 128x128 geometry beats the narrow tile on every shape of
   // the step, including the M=256 head GEMMs that overlap the LLM on the side stream (48.5 vs 49.5 vs 52.0 ms/step
   // for always-square / mixed / always-narrow); the narrow tile stays available through VLA_GEMM_TILE=3.
   // Exception: long-K problems that fill less than half the chip with square tiles (the live-row gate/up dX GEMM:
   // M 2048, N 896, K 9728 -> 112 tiles): the narrow tile doubles the number of K loops in flight.
   const long long tiles = (long long)((M + 127) / 128) * ((N + 127) / 128) * batch;
-  if (tiles <= 128 && K >= 4096 && N % 64 == 0 && !getenv("VLA_NO_NARROW_LONGK")) return TileChoice{128, 64};
+  if (tiles <= 128 && K >= 4096 && N % 64 == 0) return TileChoice{128, 64};
   return TileChoice{128, 128};
 }
 
@@ -682,16 +684,16 @@ extern "C" int vla_gemm256_extent_ok(const vla_gemm_desc* d) {
 // The tile choice of vla_gemm_bf16_nt for a descriptor (shared with the predicate below).
 static TileChoice route(const vla_gemm_desc* d) {
   const int split = d->split_k > 1 ? d->split_k : 1;
-  const char* e = getenv("VLA_GEMM_TILE");     // 0/unset auto, 1: 256x128, 2: 128x128, 3: 128x64  (benchmarking aid)
+  const char* e = getenv("VLA_GEMM_TILE");     // 0/unset auto, 2: 128x128, 3: 128x64, 6: 256x256  (test / benchmarking aid)
   TileChoice tc = choose_tile(d->M, d->N, d->K / split, e ? atoi(e) : 0, d->rope_mode, split > 1 ? split : d->batch, split, d->act);
   if (tc.bm == 256 && tc.bn == 257 && !vla_gemm256_extent_ok(d)) tc = TileChoice{128, 128};   // operands of 4 GiB and more: 64-bit-pointer kernel
   // interleaved RoPE on the 256-row kernel: the plain epilogue without residual (the head's K|V projections) - anything else keeps gemm.hip's
-  if (tc.bm == 256 && tc.bn == 257 && d->rope_mode == 2 && (d->R || d->act != VLA_ACT_NONE || d->fp8 || d->ssq_out || d->rowss)) tc = TileChoice{128, 128};
+  if (tc.bm == 256 && tc.bn == 257 && d->rope_mode == 2 && (d->R || d->act != VLA_ACT_NONE || d->fp8)) tc = TileChoice{128, 128};
   return tc;
 }
 
 extern "C" int vla_gemm_uses_256(const vla_gemm_desc* d) {
-  if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->K2 > 0 || d->fp8 || d->split_k > 1 || getenv("VLA_COLPEEL") != nullptr) return 0;
+  if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->K2 > 0 || d->fp8 || d->split_k > 1) return 0;
   const TileChoice tc = route(d);
   return tc.bm == 256 && tc.bn == 257 ? 1 : 0;
 }
@@ -703,8 +705,8 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   VLA_REQUIRE(d->lda % 8 == 0 && d->ldb % 8 == 0, "gemm: lda/ldb must be multiples of 8 elements (16-B rows)");
   if (d->fp8)
     VLA_REQUIRE(d->fp8 == 1 && d->a_scale && d->b_scale && d->K % 128 == 0 && d->lda % 16 == 0 && d->ldb % 16 == 0 && d->batch == 1 &&
-                    d->split_k <= 1 && d->rope_mode != 2 && d->act != VLA_ACT_SWIGLU_BWD && d->a_group == 0,
-                "gemm: fp8 needs scales, K % 128 == 0, 16-B rows, batch 1, no split-K / interleaved RoPE / SwiGLU backward / row groups on A");
+                    d->split_k <= 1 && d->rope_mode != 2 && d->a_group == 0 && (d->act != VLA_ACT_SWIGLU_BWD || d->K2 > 0),
+                "gemm: fp8 needs scales, K % 128 == 0, 16-B rows, batch 1, no split-K / interleaved RoPE / row groups on A (SwiGLU backward: with a K extension only)");
   VLA_REQUIRE(((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->B & 15) == 0, "gemm: A/B must be 16-B aligned");
   VLA_REQUIRE(d->sA % 8 == 0 && d->sB % 8 == 0, "gemm: batch strides of A/B must keep 16-B alignment");
   if (d->act == VLA_ACT_SWIGLU_BWD) {
@@ -731,8 +733,7 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   p.M = d->M; p.N = d->N; p.K = d->K; p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr;
   p.ldc2 = d->ldc2; p.res_mod = d->res_mod; p.act = d->act;
   p.sA = d->sA; p.sB = d->sB; p.sC = d->sC; p.sR = d->sR; p.sC2 = d->sC2; p.sBias = d->sBias;
-  p.tiles_n = p.ntiles = 0; p.batch = 1; p.xpx = p.xpy = 0; p.stagger = 0;
-  p.ssq_out = d->ssq_out; p.rowss = d->rowss; p.rowss_parts = d->rowss_parts; p.rows_eps = d->rows_eps; p.rstd_out = d->rstd_out;
+  p.tiles_n = p.ntiles = 0; p.batch = 1; p.stagger = 0;
   p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
   p.gA = d->a_group; p.sgA = d->a_group_stride; p.gC = d->c_group; p.sgC = d->c_group_stride;
   p.gR = d->r_group; p.sgR = d->r_group_stride;
@@ -741,7 +742,6 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   p.bias_post = d->bias_post_round;
   VLA_REQUIRE(d->bias_post_round == 0 || (d->bias_post_round == 1 && d->bias && d->rope_mode != 1 && split == 1 && d->act == VLA_ACT_NONE),
               "gemm: bias_post_round needs a bias and a plain epilogue (no rotate_half rope / split-K / activation)");
-  { const char* ge = getenv("VLA_GEMM_GM"); p.gm = ge ? atoi(ge) : 0; }
   p.ws = nullptr;
   if (split > 1) {
     VLA_REQUIRE(d->ws && d->batch == 1 && d->K % (BK * split) == 0 && d->rope_mode == 0 && d->c_group == 0 && d->r_group == 0 &&
@@ -764,8 +764,8 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   p.A2 = (const bf16_t*)d->A2; p.B2 = (const bf16_t*)d->B2; p.K2 = d->K2; p.lda2 = d->lda2; p.ldb2 = d->ldb2;
   if (d->K2 != 0)
     VLA_REQUIRE(d->K2 > 0 && d->K2 % BK == 0 && d->A2 && d->B2 && d->lda2 % 8 == 0 && d->ldb2 % 8 == 0 && (((uintptr_t)d->A2 | (uintptr_t)d->B2) & 15) == 0 &&
-                    d->batch == 1 && split == 1 && !d->fp8 && d->rope_mode != 2,
-                "gemm: the K extension needs A2 / B2 (16-B aligned rows, K2 % 64 == 0), batch 1, no split-K / fp8 / interleaved RoPE");
+                    d->batch == 1 && split == 1 && d->rope_mode != 2,
+                "gemm: the K extension needs A2 / B2 (bf16, 16-B aligned rows, K2 % 64 == 0), batch 1, no split-K / interleaved RoPE");
   if (d->rope_mode != 0) {
     VLA_REQUIRE(d->rope_mode == 1 || d->rope_mode == 2, "gemm: rope_mode 0/1/2");
     VLA_REQUIRE(d->rope_cos && d->rope_sin && d->rope_T > 0 && d->rope_dh > 0 && d->rope_dh % 4 == 0 && d->rope_cols % 64 == 0 &&
@@ -776,23 +776,15 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   const char* e = getenv("VLA_GEMM_TILE");
   const TileChoice tc = route(d);
   const bool fits256 = vla_gemm256_extent_ok(d) != 0;
-  if (d->ssq_out || d->rowss) {      // RMSNorm fields: the 256-row kernel's epilogue only (ask vla_gemm_uses_256 first)
-    VLA_REQUIRE(tc.bm == 256 && tc.bn == 257 && d->K2 == 0 && !d->fp8 && split == 1 && d->batch == 1 && getenv("VLA_COLPEEL") == nullptr,
-                "gemm: ssq_out / rowss need the 256-row kernel (vla_gemm_uses_256), batch 1, no split-K / K extension / fp8");
-    VLA_REQUIRE(!(d->ssq_out && d->rowss), "gemm: a GEMM is either the producer (ssq_out) or the consumer (rowss) of RMSNorm partials");
-    if (d->ssq_out)
-      VLA_REQUIRE(d->act == VLA_ACT_NONE && d->R && d->rope_mode == 0 && d->M % 64 == 0 && d->N % 64 == 0 && d->ldc % 8 == 0 && d->ldr % 8 == 0 &&
-                      d->c_group == 0 && d->r_group == 0 && d->res_mod == 0 && d->c_live_mod == 0 && ((uintptr_t)d->ssq_out & 3) == 0,
-                  "gemm: ssq_out needs the plain epilogue with a residual, M and N multiples of 64, plain row addressing");
-    if (d->rowss)
-      VLA_REQUIRE(d->rowss_parts >= 1 && d->rowss_parts <= 6 && d->rows_eps > 0.f && !d->R && d->act != VLA_ACT_SWIGLU_BWD && !d->bias_post_round &&
-                      d->a_group == 0 && ((uintptr_t)d->rowss & 3) == 0,
-                  "gemm: rowss needs 1..6 partials, eps > 0, no residual, plain A rows");
-  }
   if (d->K2 > 0) {                 // K extension: 128-row kernel (the 256-row kernel's hand-counted DMA schedule has one operand pair)
-    if (d->act == VLA_ACT_SWIGLU_BWD) launch<128, 128, 2, 3, 4, false, true>(p, d->M, d->N, 1, (hipStream_t)stream);
-    else if (d->rope_mode == 1) launch<128, 128, 2, 1, 4, false, true>(p, d->M, d->N, 1, (hipStream_t)stream);
-    else launch<128, 128, 2, 0, 4, false, true>(p, d->M, d->N, 1, (hipStream_t)stream);
+    hipStream_t sx = (hipStream_t)stream;
+    if (d->fp8) {                  // e4m3 base operands, bf16 extension: the scales meet the accumulator between the two contractions
+      if (d->act == VLA_ACT_SWIGLU_BWD) launch<128, 128, 2, 3, 4, true, true>(p, d->M, d->N, 1, sx);
+      else if (d->rope_mode == 1) launch<128, 128, 2, 1, 4, true, true>(p, d->M, d->N, 1, sx);
+      else launch<128, 128, 2, 0, 4, true, true>(p, d->M, d->N, 1, sx);
+    } else if (d->act == VLA_ACT_SWIGLU_BWD) launch<128, 128, 2, 3, 4, false, true>(p, d->M, d->N, 1, sx);
+    else if (d->rope_mode == 1) launch<128, 128, 2, 1, 4, false, true>(p, d->M, d->N, 1, sx);
+    else launch<128, 128, 2, 0, 4, false, true>(p, d->M, d->N, 1, sx);
     VLA_CHECK_LAUNCH("gemm_bf16_nt(ext)");
     return VLA_OK;
   }
@@ -811,44 +803,15 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   }
   if (tc.bm == 256 && tc.bn == 257) {          // 256 x 256 staggered 8-phase kernel (gemm256.hip)
     const int epi = d->act == VLA_ACT_SWIGLU ? 1 : d->act == VLA_ACT_SWIGLU_BWD ? 2 : 0;
-    // Tail round.  A launch of r full rounds of tiles plus a few more (ViT fc1: 32 x 17 = 544 tiles on 256 CUs = two rounds
-    // and 32 tiles, which cost a third tile time on every CU's clock: 105 us instead of ~70) is cut along N: the leading
-    // column tiles that make exactly r rounds stay here, the last column tile(s) go to the 128-row kernel behind it (same
-    // stream, ~a quarter of the chip for ~20 us).  Every epilogue option addresses rows and columns independently, so the
-    // second launch is the same problem on shifted column pointers.  OFF unless VLA_COLPEEL is set: isolated it turns fc1's
-    // 105 us into ~80, on the whole step it measured 24.85-24.94 ms against 24.75-24.81 without (same box, three alternating
-    // runs; round-2a's Python-side version of the same cut: 26.9 vs 26.8) - the other streams already fill the tail round.
-    static const bool no_peel = getenv("VLA_COLPEEL") == nullptr;
-    const int ncu = vla_num_cus();
-    const int tm = (p.M + 255) / 256, tn = (p.N + 255) / 256;
-    int peel = 0;
-    if (!no_peel && e == nullptr && d->batch == 1 && epi != 2 && d->rope_mode == 0 && (long long)tm * tn > ncu) {
-      for (int c = 1; c <= 2 && c < tn; ++c)
-        if (((long long)tm * (tn - c)) % ncu == 0 && (long long)tm * c * 4 <= 2 * ncu) { peel = c; break; }   // tail <= one round of 128-row tiles
-    }
-    if (peel == 0) {
-      vla_gemm256_launch(p, epi, d->batch, st);
-    } else {
-      const int n1 = (tn - peel) * 256;          // columns of the main launch; the tail takes [n1, N)
-      GemmP a = p, b = p;
-      a.N = n1;
-      b.N = p.N - n1;
-      b.B = p.B + (long long)n1 * p.ldb;
-      if (p.bias) b.bias = p.bias + n1;
-      if (p.C) b.C = p.C + n1;
-      if (p.R) b.R = p.R + n1;
-      if (p.C2) b.C2 = p.C2 + n1 / 2;             // SwiGLU: h columns are half the interleaved gate/up columns
-      vla_gemm256_launch(a, epi, 1, st);
-      launch<128, 128, 2, 0, 4>(b, b.M, b.N, 1, st);
-    }
+    // (a column peel of the tail round - the last column tiles on the 128-row kernel behind this launch - turned ViT fc1's 105 us into
+    //  ~80 isolated and cost 0.1 ms on the step: the other streams already fill the tail round.  tools/diag/gemm256_pruned_paths.patch)
+    vla_gemm256_launch(p, epi, d->batch, st);
   } else if (d->act == VLA_ACT_SWIGLU_BWD) launch<128, 128, 2, 3, 4>(p, d->M, d->N, d->batch, st);
   else if (d->rope_mode == 1) launch<128, 128, 2, 1, 4>(p, d->M, d->N, d->batch, st);   // 8 waves, rotation pairs inside a lane
   else if (d->rope_mode == 2) {
     if (tc.bn == 128) launch<128, 128, 2, 2, 4>(p, d->M, d->N, d->batch, st);
     else launch<128, 64, 2, 2>(p, d->M, d->N, d->batch, st);
-  } else if (tc.bm == 256) launch<256, 128, 3, 0, 4>(p, d->M, d->N, split > 1 ? split : d->batch, st);   // 16 waves, loads two K-tiles ahead
-  else if (tc.bn == 129) launch<128, 128, 2, 0>(p, d->M, d->N, split > 1 ? split : d->batch, st);      // 4 waves of 64x64 (forced only)
-  else if (tc.bn == 128) launch<128, 128, 2, 0, 4>(p, d->M, d->N, split > 1 ? split : d->batch, st);   // 8 waves (2x4) of 64x32
+  } else if (tc.bn == 128) launch<128, 128, 2, 0, 4>(p, d->M, d->N, split > 1 ? split : d->batch, st);   // 8 waves (2x4) of 64x32
   else launch<128, 64, 2, 0>(p, d->M, d->N, split > 1 ? split : d->batch, st);
   VLA_CHECK_LAUNCH("gemm_bf16_nt");
   if (split > 1) {

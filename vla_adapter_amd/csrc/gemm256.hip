@@ -47,8 +47,6 @@ namespace {
 constexpr int BK = 64;
 constexpr int HT = 16384;            // bytes per half-tile (128 rows x 64 k x 2 B)
 constexpr int LDS_BYTES = 8 * HT;    // 128 KiB of operands: one workgroup per CU
-constexpr int SSQ_BYTES = 4096;      // producer of RMSNorm partials: [wr][mh][64 rows][wc] floats behind the operand buffers
-constexpr int RN_MAXP = 6;           // consumer: at most this many partials per row (N of the producer <= 1536)
 constexpr int STG = 8192;            // epilogue staging per wave: 64 rows x 128 B, 16-B chunk c of row r at c ^ ((r >> 1) & 7)
 
 // LDS-DMA issued from inline asm: 16 B per lane from (wave-uniform base + per-lane 32-bit byte offset) to LDS address `dst`
@@ -98,7 +96,7 @@ __device__ __forceinline__ v8i_f8 cat8(bf16x8 lo, bf16x8 hi) {          // two 1
 // F8: OCP e4m3 operands with per-row fp32 scales (gemm.hip's fp8 form, same conventions): a K-tile stays 128 B per row = 128
 // elements = ONE v_mfma_scale_f32_16x16x128_f8f6f4 per 16 x 16 tile instead of two bf16 MFMAs - identical staging, LDS image and
 // barrier structure, half the K-tiles per product.  The scales are applied to the accumulators at the start of the epilogue.
-template <int EPI, bool F8 = false, bool RES = true, bool SSQ = false, bool RN = false, bool R2 = false>
+template <int EPI, bool F8 = false, bool RES = true, bool R2 = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int EB = F8 ? 1 : 2;      // bytes per operand element
@@ -116,21 +114,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
   const int xcd = bid & 7;
   auto rstart = [&](int x) { return x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8; };
   int vt = bid;
-  // XCD-BLOCKED order (host: launch256, exact divisions only): the tile grid is cut into xpx x xpy = 8 equal rectangular blocks,
-  // enumerated one after the other, so that run x of the walk IS block x: XCD x works on an 11 x 19 patch of the 44 x 38 gate/up
-  // grid - 11 A panels + 19 B tiles through its private L2 instead of ~6 A panels and the whole of B twice (a run of the plain
-  // group-M order straddles two row groups).  xpx == 0: one block = the whole grid.
-  int bk_rows = p.ntiles / p.tiles_n, bk_cols = p.tiles_n, bk_r0 = 0, bk_c0 = 0, bk_start = 0;
-  if (p.xpx > 0) {
-    bk_rows /= p.xpx; bk_cols /= p.xpy;
-    bk_r0 = (xcd % p.xpx) * bk_rows; bk_c0 = (xcd / p.xpx) * bk_cols;
-    bk_start = xcd * bk_rows * bk_cols;
-  }
-
   // ---- tile identity + staging sources: this wave fills rows [16 wid, 16 wid + 16) of every half-tile (2 pieces of 8 rows)
   // group-M width of the tile order (A row panels an XCD keeps L2-resident while B tiles stream): 6, as for the 128-row tiles -
   // on the one-pipeline step 25.84-25.87 ms against 25.93-26.09 for 4 and 25.95-26.02 for 8 (same box, three alternating runs)
-  const int GM = p.gm > 0 ? p.gm : 6;
+  constexpr int GM = 6;
   int m0, n0, z;
   // sources as wave-uniform bases + 32-bit per-lane byte offsets (half the address registers of eight pointers)
   const char* Ab; const char* Bb;
@@ -146,14 +133,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
     asm volatile("" : "+s"(ntl));
     z = swz / ntl;
     const int tl = swz - z * ntl;
-    // group-M order inside this XCD's block of the tile grid (the whole grid when the order is not XCD-blocked)
-    int br = bk_rows, bc = bk_cols, r0b = bk_r0, c0b = bk_c0, t0 = bk_start;
-    asm volatile("" : "+s"(br), "+s"(bc), "+s"(r0b), "+s"(c0b), "+s"(t0));
-    const int tloc = tl - t0, pgb = GM * bc;
-    const int grp = tloc / pgb, rem = tloc - grp * pgb;
+    // group-M order (an XCD-blocked order - every XCD on a compact block of the tile grid - cut the fabric fetch of fc2 by 25 %
+    // and changed no launch duration by more than 1 %: profiles/r03_gemm256_traffic_order_ab.json; tools/diag/gemm256_pruned_paths.patch)
+    int br = ntl / p.tiles_n, bc = p.tiles_n;
+    asm volatile("" : "+s"(br), "+s"(bc));
+    const int pgb = GM * bc;
+    const int grp = tl / pgb, rem = tl - grp * pgb;
     const int gmr = min(GM, br - grp * GM);
-    m0 = (r0b + grp * GM + rem % gmr) * 256;
-    n0 = (c0b + rem / gmr) * 256;
+    m0 = (grp * GM + rem % gmr) * 256;
+    n0 = (rem / gmr) * 256;
     Ab = reinterpret_cast<const char*>(p.A) + (long long)z * p.sA * EB;
     Bb = reinterpret_cast<const char*>(p.B) + (long long)z * p.sB * EB;
 #pragma unroll
@@ -208,38 +196,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
 
   const int aoff = wr * 64 * 128, boff = wc * 32 * 128;
 
-  // RMSNorm consumer (RN): sum of squares of this lane's eight A rows (tile rows wr*128 + mh*64 + mi*16 + (lane & 15)), summed from the
-  // producer's per-column-tile partials.  The partials of the NEXT tile are requested in the epilogue of the current one (behind its
-  // K-tile 0, in front of its stores: retired by the next top's counted wait without changing any count) and added up at the
-  // epilogue's end; only the eight sums cross the K loop.
-  float rsum[2][4];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) rsum[a][b] = 0.f;
-  auto rn_issue = [&](int tm0, float (&rl)[2][4][RN_MAXP]) {
-    int sl = lane;
-    asm volatile("" : "+v"(sl));
-#pragma unroll
-    for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        const int m = min(tm0 + wr * 128 + mh * 64 + mi * 16 + (sl & 15), p.M - 1);
-#pragma unroll
-        for (int t = 0; t < RN_MAXP; ++t) rl[mh][mi][t] = p.rowss[(long long)(t < p.rowss_parts ? t : 0) * p.M + m];
-      }
-  };
-  auto rn_sum = [&](const float (&rl)[2][4][RN_MAXP]) {
-#pragma unroll
-    for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        float a = 0.f;
-#pragma unroll
-        for (int t = 0; t < RN_MAXP; ++t) a += t < p.rowss_parts ? rl[mh][mi][t] : 0.f;
-        rsum[mh][mi] = a;
-      }
-  };
   int cur = rstart(xcd) + (bid >> 3);
   // Free de-phasing: when the last round of the walk is partial, the workgroups that walk one tile fewer would finish a tile early;
   // they start late by a fraction of a tile instead, so that their epilogues' store bursts fall between those of the others.
@@ -248,11 +204,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
   }
   setup(cur);
   stage_k0(0);
-  if constexpr (RN) {
-    float rl[2][4][RN_MAXP];
-    rn_issue(m0, rl);
-    rn_sum(rl);
-  }
   int d = 0;
 
   for (;;) {
@@ -362,7 +313,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
     // ---------------- epilogue of tile (em0, en0, ez): two 64 x 64 passes per wave through its private staging region,
     //                  in the K-tile buffer that the next tile's K-tile 0 (issued first) does not occupy
     const int em0 = m0, en0 = n0, ez = z;
-    const int m0e = m0, n0e = n0;          // (copies that stay valid behind setup(nxt))
     int el = lane;
     asm volatile("" : "+v"(el));       // (see setup: nothing of the epilogue's addressing may live across the K loop)
     const int lq = el >> 4, lr = el & 15;
@@ -386,18 +336,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
           }
       }
     }
-    float rstd[2][4];                      // RN: 1 / rms of this lane's eight A rows (1 otherwise)
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        rstd[a][b] = 1.f;
-        if constexpr (RN) {
-          rstd[a][b] = rsqrtf(rsum[a][b] / (float)p.K + p.rows_eps);
-          const int m = em0 + wr * 128 + a * 64 + b * 16 + lr;
-          if (p.rstd_out != nullptr && en0 == 0 && wc == 0 && lq == 0 && m < p.M) p.rstd_out[m] = rstd[a][b];
-        }
-      }
     float bv[4][4];
     int ebvec = __builtin_amdgcn_readfirstlane(bias_vec() ? 1 : 0);
     asm volatile("" : "+s"(ebvec));      // (opaque: the four loads of the top are read on every path, so that nothing stays pending)
@@ -530,10 +468,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
               f32x4 ga = acc[mh][pr][0][mi], ua = acc[mh][pr][1][mi];
-              if constexpr (RN) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { ga[j] *= rstd[mh][mi]; ua[j] *= rstd[mh][mi]; }
-              }
               if (!plain) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { ga[j] = ga[j] * p.alpha + bv[2 * pr][j]; ua[j] = ua[j] * p.alpha + bv[2 * pr + 1][j]; }
@@ -561,8 +495,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
                 float x[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                  const float aj = RN ? a[j] * rstd[mh][mi] : a[j];
-                  x[j] = fn(POST ? rbf(aj * alpha) + bv[t4][j] : aj * alpha + bv[t4][j]);
+                  x[j] = fn(POST ? rbf(a[j] * alpha) + bv[t4][j] : a[j] * alpha + bv[t4][j]);
                 }
                 pk[mh][t4][mi] = uint2{pack2(x[0], x[1]), pack2(x[2], x[3])};
               }
@@ -586,8 +519,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
                 float ya[4], yb[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                  const float sc = RN ? alpha * rstd[mh][mi] : alpha;
-                  const float a = rbf(xa[j] * sc + bv[ni][j]), b = rbf(xb[j] * sc + bv[ni + 2][j]);
+                  const float a = rbf(xa[j] * alpha + bv[ni][j]), b = rbf(xb[j] * alpha + bv[ni + 2][j]);
                   ya[j] = rbf(a * c[j]) + rbf(-b * sn[j]);
                   yb[j] = rbf(b * c[j]) + rbf(a * sn[j]);
                 }
@@ -618,8 +550,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
                 float x[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                  const float aj = RN ? a[j] * rstd[mh][mi] : a[j];
-                  x[j] = rbf(POST ? rbf(aj * alpha) + bv[t4][j] : aj * alpha + bv[t4][j]);
+                  x[j] = rbf(POST ? rbf(a[j] * alpha) + bv[t4][j] : a[j] * alpha + bv[t4][j]);
                 }
                 const float y0 = rbf(x[0] * c[0]) + rbf(-x[1] * sn[0]), y1 = rbf(x[1] * c[1]) + rbf(x[0] * sn[1]);
                 const float y2 = rbf(x[2] * c[2]) + rbf(-x[3] * sn[2]), y3 = rbf(x[3] * c[3]) + rbf(x[2] * sn[3]);
@@ -648,19 +579,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
           asm volatile("" : "+v"(pk[mh][t4][0].x), "+v"(pk[mh][t4][0].y), "+v"(pk[mh][t4][1].x), "+v"(pk[mh][t4][1].y),
                             "+v"(pk[mh][t4][2].x), "+v"(pk[mh][t4][2].y), "+v"(pk[mh][t4][3].x), "+v"(pk[mh][t4][3].y));
       asm volatile("" : "+v"(el));
-      float rl[2][4][RN_MAXP];
-      if constexpr (RN) {                  // the partials of the NEXT tile's rows (m0 is the next tile's since setup(nxt) above)
-        if (nxt >= 0) rn_issue(m0, rl);
-        else {
-#pragma unroll
-          for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-#pragma unroll
-              for (int t = 0; t < RN_MAXP; ++t) rl[a][b][t] = 0.f;
-        }
-      }
-
       // ---- phase B: per 64 x 64 half, through the wave's staging region, 16-B stores of whole row segments.  The common case
       //      - the half entirely inside C, 16-B aligned rows, plain row addressing - runs without a branch and with all its
       //      residual segments requested up front (in the general path every conditional load is followed by its own
@@ -671,7 +589,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
         const int wm0 = em0 + wr * 128 + mh * 64;
         if (skip[mh]) {
           if constexpr (HAS_RES) drop_res(mh);
-          if constexpr (SSQ) reinterpret_cast<float*>(smem + LDS_BYTES)[((wr * 2 + mh) * 64 + el) * 4 + wc] = 0.f;   // columns beyond N
           continue;
         }
         if constexpr (EPI == 1) {
@@ -751,16 +668,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
               v = uint4{o[0], o[1], o[2], o[3]};
             }
             *reinterpret_cast<uint4*>(Cb + (long long)(wm0 + row) * p.ldc + wn0 + ch * 8) = v;
-            if constexpr (SSQ) {             // sum of squares of the STORED bf16 values: 8 per lane, the row's 64 columns over 8 lanes
-              const unsigned w4[4] = {v.x, v.y, v.z, v.w};
-              float sq = 0.f;
-#pragma unroll
-              for (int k = 0; k < 4; ++k) sq += flo(w4[k]) * flo(w4[k]) + fhi(w4[k]) * fhi(w4[k]);
-              sq += __shfl_xor(sq, 1, 64);
-              sq += __shfl_xor(sq, 2, 64);
-              sq += __shfl_xor(sq, 4, 64);
-              if ((el & 7) == 0) reinterpret_cast<float*>(smem + LDS_BYTES)[((wr * 2 + mh) * 64 + row) * 4 + wc] = sq;
-            }
           }
           };
           if (EPI == 1 && c_live_mod > 0) store_fast(std::true_type{});
@@ -817,17 +724,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
         if (plain_rows) store_rows(std::true_type{});
         else store_rows(std::false_type{});
       }
-      if constexpr (RN) rn_sum(rl);          // (requested before phase B: landed by now; older than every store of this epilogue)
     }
 
-    if constexpr (SSQ) {                     // producer of RMSNorm partials: the four column waves' sums of a row -> one value per row and tile
-      VLA_BARRIER();
-      if (tid < 256) {
-        const float* sq = reinterpret_cast<const float*>(smem + LDS_BYTES) + tid * 4;     // row tid = wr*128 + mh*64 + r: [row][wc]
-        const int m = m0e + tid;
-        if (m < p.M) p.ssq_out[(long long)(n0e >> 8) * p.M + m] = (sq[0] + sq[1]) + (sq[2] + sq[3]);
-      }
-    }
     if (nxt < 0) break;
     VLA_BARRIER();                   // every wave is done with its staging region: K-tile 1 may land there
     if (!PRE) { setup(nxt); stage_k0(d); }
@@ -844,7 +742,7 @@ int num_cus() {
   return n;
 }
 
-template <int EPI, bool F8 = false, bool RES = true, bool SSQ = false, bool RN = false, bool R2 = false>
+template <int EPI, bool F8 = false, bool RES = true, bool R2 = false>
 int launch256(const GemmP& p0, int batch, hipStream_t st) {
   GemmP p = p0;
   p.tiles_n = (p.N + 255) / 256;
@@ -852,31 +750,12 @@ int launch256(const GemmP& p0, int batch, hipStream_t st) {
   p.batch = batch;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, F8, RES, SSQ, RN, R2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + (SSQ ? SSQ_BYTES : 0));
+    (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, F8, RES, R2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
   // one workgroup per CU walks the tiles (VLA_GEMM256_GRID overrides the workgroup count: 0 = one workgroup per tile)
   const char* ge = getenv("VLA_GEMM256_GRID");      // (read per launch: the A/B tool flips it in one process)
   const long long total = (long long)p.ntiles * batch;
-  // XCD-blocked tile order (setup()): px x py = 8 equal blocks of the tile grid (exact divisions only: the eight runs of the walk
-  // then coincide with the blocks), the smallest operand footprint per block (rows + columns) first.
-  p.xpx = p.xpy = 0;
-  // MEASURED AND NOT ADOPTED (round 3, same box): performance-neutral (step 25.28 vs 25.27 ms; gate/up, down, qkv, fc2 within 1 %)
-  // and the fabric-side fetch it was built to cut barely moves (gate/up 156 vs 160 MB raw FETCH_SIZE, down 134 vs 141, fc2 83 vs
-  // 110, ViT qkv 62 vs 56: profiles/r03_gemm256_traffic_order_ab.json) - the re-fetches are not the cross-XCD duplication the
-  // tile-order model predicts.  Opt-in through VLA_GEMM256_XCD=1; the default stays the plain group-M order.
-  const char* xe = getenv("VLA_GEMM256_XCD");                 // (read per launch: the A/B tool flips it in one process)
-  const bool xcd_on = xe != nullptr && atoi(xe) != 0;
-  if (xcd_on && batch == 1 && total >= 64) {
-    const int tm = p.ntiles / p.tiles_n, tn = p.tiles_n;
-    long long best = -1;
-    for (int px = 8; px >= 1; px >>= 1) {
-      const int py = 8 / px;
-      if (tm % px != 0 || tn % py != 0) continue;          // exact divisions only: the walk's eight equal runs must BE the blocks
-      const long long cost = tm / px + tn / py;            // operand footprint of a block (A panels + B tiles)
-      if (best < 0 || cost < best) { best = cost; p.xpx = px; p.xpy = py; }
-    }
-  }
   // Free de-phasing of a partial last round (kernel: start of the walk).  Every workgroup has the same work per tile, so all 256
   // epilogues burst their stores into the fabric in the same few microseconds and wait for it; the workgroups that walk one tile
   // fewer have a tile's time to spare, and starting them late by half a tile puts their bursts between those of the others.
@@ -891,8 +770,7 @@ int launch256(const GemmP& p0, int batch, hipStream_t st) {
     const long long tile_cycles = (long long)(p.K / BK) * 2128 + 13000;       // K loop + what surrounds it (stamped: DESIGN section 4)
     p.stagger = (int)(tile_cycles * (se != nullptr ? atoi(se) : 50) / 100 / 1024);
   }
-  if (grid % 8 != 0) p.xpx = p.xpy = 0;                    // (a workgroup must stay on its XCD's list: b and b + G share b & 7)
-  hipLaunchKernelGGL((gemm256_kernel<EPI, F8, RES, SSQ, RN, R2>), dim3((unsigned)grid), dim3(512), LDS_BYTES + (SSQ ? SSQ_BYTES : 0), st, p);
+  hipLaunchKernelGGL((gemm256_kernel<EPI, F8, RES, R2>), dim3((unsigned)grid), dim3(512), LDS_BYTES, st, p);
   return 0;
 }
 
@@ -902,9 +780,7 @@ int vla_num_cus() { return num_cus(); }
 
 int vla_gemm256_launch(const GemmP& p, int epi, int batch, hipStream_t st) {
   if (p.scaleA != nullptr) return epi == 1 ? launch256<1, true>(p, batch, st) : launch256<0, true>(p, batch, st);     // fp8 operands
-  if (p.ssq_out != nullptr) return launch256<0, false, true, true, false>(p, batch, st);      // (host: plain epilogue with a residual, batch 1)
-  if (p.rowss != nullptr) return epi == 1 ? launch256<1, false, true, false, true>(p, batch, st) : launch256<0, false, false, false, true>(p, batch, st);
-  if (p.rope_mode == 2) return launch256<0, false, false, false, false, true>(p, batch, st);     // (host: plain epilogue, no residual)
+  if (p.rope_mode == 2) return launch256<0, false, false, true>(p, batch, st);     // (host: plain epilogue, no residual)
   if (epi == 1) return launch256<1>(p, batch, st);
   if (epi == 2) return launch256<2>(p, batch, st);
   return p.R ? launch256<0, false, true>(p, batch, st) : launch256<0, false, false>(p, batch, st);

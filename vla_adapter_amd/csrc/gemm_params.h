@@ -13,17 +13,12 @@ struct GemmP {
   float alpha;
   int gA, gC, gR; long long sgA, sgC, sgR;  // row-group addressing: row r -> (r / g) * sg + (r % g) * ld
   int c_live_mod, c_live_from;              // C rows with (m % c_live_mod) < c_live_from are not stored
-  int gm;                                   // group-M override (0 = default)
   float* ws;                                // split-K: fp32 [M, N] accumulator (blockIdx.z = K slice), finalised by a second kernel
   int bias_post;                            // 1: round alpha * acc to bf16 before adding the bias (torch CPU Linear on a strided input)
   int rope_mode, rope_T, rope_dh, rope_cols; const float* rope_cos; const float* rope_sin;
   const float* scaleA; const float* scaleB;   // fp8 operands (A, B point at OCP e4m3 bytes): per-row dequantisation scales [M], [N]
   int stagger;                              // gemm256.hip: start delay (units of 1024 cycles) of the workgroups that walk one tile fewer than the others (0 = none)
-  int xpx, xpy;                             // gemm256.hip: XCD-blocked tile order (xpx * xpy = 8 blocks of the tile grid; 0 = plain group-M order)
-  const bf16_t* A2; const bf16_t* B2; int K2, lda2, ldb2;   // K extension (gemm.hip EXT): C = epilogue(A . B^T + A2 . B2^T)  // RMSNorm folded into neighbouring GEMMs (gemm256.hip only; the norm weight is folded into B by the caller):
-  float* ssq_out;                           // producer: [ceil(N / 256)][M] partial sums of squares of the bf16 OUTPUT rows, one per column tile
-  const float* rowss; int rowss_parts;      // consumer: such partials of the rows of A; every accumulator row is scaled by
-  float rows_eps; float* rstd_out;          //   rstd[m] = rsqrt(sum_t rowss[t][m] / K + eps) before alpha / bias; rstd_out [M] optional
+  const bf16_t* A2; const bf16_t* B2; int K2, lda2, ldb2;   // K extension (gemm.hip EXT): C = epilogue(A . B^T + A2 . B2^T)
 };
 
 // gemm256.hip: 256x256x64 tile, 8 waves, staggered 8-phase schedule.  epi: 0 plain, 1 SwiGLU forward, 2 SwiGLU backward.

@@ -118,3 +118,33 @@ class FlatGradReducer:
     @property
     def grad_scale(self) -> float:
         return 1.0 / self.world
+
+
+def params_checksum(flats) -> torch.Tensor:
+    """int64 [2]: (sum of the 16-bit patterns of every parameter, number of parameters) over the given flat bf16 buffers.  An
+    integer sum: exact, order-independent - two ranks holding the same parameters produce the same pair."""
+    dev = flats[0].device
+    acc = torch.zeros(2, dtype=torch.int64, device=dev)
+    for t in flats:
+        assert t.dtype == torch.bfloat16 and t.is_contiguous()
+        acc[0] += t.view(torch.int16).to(torch.int32).sum(dtype=torch.int64)
+        acc[1] += t.numel()
+    return acc
+
+
+def assert_ranks_in_sync(flats, what: str = "parameters", group=None) -> None:
+    """Desync guard of a data-parallel run (every rank must hold the same replica after every update: the reference relies on
+    DDP's construction-time broadcast and identical all-reduced gradients, vla-scripts/finetune.py:869).  The ranks exchange the
+    MIN and the MAX of a parameter checksum (two 16-byte all-reduces); any difference raises on every rank.  Off the hot path:
+    called every --sync_check_freq optimizer steps (one host sync)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    c = params_checksum(flats)
+    if dist.get_backend(group) == "gloo":
+        c = c.cpu()
+    lo, hi = c.clone(), c.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    if not torch.equal(lo, hi):
+        raise RuntimeError(f"data-parallel ranks diverged: {what} differ between ranks (checksum min {lo.tolist()} != max {hi.tolist()}, "
+                           f"this rank {c.tolist()})")

@@ -310,30 +310,6 @@ class LLM:
         self.embed = g("embed_tokens.weight")
         self._buf_key = None
         self.gu_row0 = 0
-        self.folded = False
-        if os.environ.get("VLA_RMSNORM_FOLD"):                # opt-in: measured and NOT adopted (see fold_rmsnorm)
-            self.fold_rmsnorm(True)
-
-    def fold_rmsnorm(self, on: bool):
-        """RMSNorm folded into the GEMMs on either side of it (frozen weights: the adapter-only forward).  The norm weight goes into the
-        projection behind the norm (W' = bf16(W * w[None, :])), the GEMM in front of it also emits per-column-tile sums of squares of
-        the rows it stores, the GEMM behind scales its fp32 rows by 1 / rms before bias / RoPE / SwiGLU and saves that rstd for the
-        backward (vla_gemm_desc ssq_out / rowss, ABI 4).  47 launches fewer on the forward chain; one rounding point moves (the
-        normalised activations are never rounded to bf16: oracle.folded_norm_linear, tests/test_engine_gpu.py::
-        test_llm_rmsnorm_fold_matches_its_oracle).  Used only where all four GEMMs of a layer run on the 256-row kernel and the call
-        covers the whole batch (LLM._fold_ok); the first norm of layer 0 and the final norm stay kernels.
-        MEASURED AND NOT ADOPTED (round 3, opt-in through VLA_RMSNORM_FOLD=1): isolated the four GEMMs of a layer cost +9.9 us with the
-        extra fields (o +2.5: one more workgroup barrier and an LDS reduce; gate/up +6.8: 48 partial loads, 8 rsqrt and 128 multiplies
-        per lane and tile) against 2 x 7.7 us of norm kernels saved; on the step it measured 24.98 vs 24.88 ms (same box, three
-        alternating runs) - slower.  (A first "upper bound" of -1.2 ms came from an ablation that skipped the norm launches and thereby
-        fed the GEMMs a buffer of zeros: zero operands run the chip at a higher clock; with random data left in those buffers the same
-        ablation reads -0.46 ms - tools/diag/ablate_step.py.)"""
-        self.folded = bool(on)
-        for L in self.layers:
-            if on and "wqkv_n" not in L:
-                L["wqkv_n"] = (L["wqkv"].float() * L["n1"].float()[None, :]).to(BF16).contiguous()
-                L["wgu_n"] = (L["wgu"].float() * L["n2"].float()[None, :]).to(BF16).contiguous()
-        self._buf_key = None
 
     def _alloc(self, B: int, S: int):
         if self._buf_key == (B, S):
@@ -354,18 +330,6 @@ class LLM:
         self.d_a, self.d_b, self.d_h, self.d_gu, self.d_qkv, self.d_n = e(M, D), e(M, D), e(M, c.inter), e(M, 2 * c.inter), e(M, W), e(M, D)
         self.cos, self.sin = ops.rope_half_tables(S, c.dh, c.theta, dev)
         self._buf_key = (B, S)
-        # RMSNorm folding: partial sums of squares of the residual stream entering a layer (SSX) and of x1 (SSX1), one row per 256-column tile
-        parts = (D + 255) // 256
-        self.SSX, self.SSX1 = e(parts, M, dt=torch.float32), e(parts, M, dt=torch.float32)
-        self._fold_ok = False
-        if self.folded and not getattr(self, "fp8", False) and M % 64 == 0 and D % 64 == 0 and parts <= 6 and c.n_layers > 1:
-            L, H, KV, dh = self.layers[1], c.heads, c.kv_heads, c.dh
-            x, ao, x1, qkv, hb, gu = self.HS[1].view(-1, D), self.AO[1], self.X1[1], self.QKV[1], self.hbuf, self.GU[1]
-            rope = (1, self.cos, self.sin, S, dh, (H + KV) * dh) if dh == 64 else None
-            self._fold_ok = (ops.gemm_nt(x, L["wqkv_n"], bias=L["bqkv"], out=qkv, rope=rope, rownorm=(self.SSX, c.eps, self.R1[1]), query_256=True)
-                             and ops.gemm_nt(ao, L["wo"], residual=x, out=x1, ssq_out=self.SSX1, query_256=True)
-                             and ops.gemm_nt(x1, L["wgu_n"], act=ACT_SWIGLU, out=gu, out2=hb, rownorm=(self.SSX1, c.eps, self.R2[1]), query_256=True)
-                             and ops.gemm_nt(hb, L["wd"], residual=x1, out=x, ssq_out=self.SSX, query_256=True))
 
     def out_slot(self, i: int) -> int:
         """HS slot holding the output of layer i (0-based)."""
@@ -398,23 +362,13 @@ class LLM:
         fp8 = getattr(self, "fp8", False)
         q8, qs = self.q8[r0:r1], self.qs[r0:r1]
         qkv = self.QKV[i][r0:r1]
-        fold = self._fold_ok and not fp8 and b0 == 0 and b1 == self.B      # (the partial buffers are whole-batch, row-contiguous)
-        fold1 = fold and i > 0                                             # layer 0's input comes from the splice, not from a GEMM
-        if fold1:
-            pass
-        elif fp8:
+        # (RMSNorm folded into the neighbouring GEMMs - 47 launches fewer, built and measured SLOWER in round 3 - left the tree in
+        #  round 4: DESIGN section 4, tools/diag/gemm256_pruned_paths.patch)
+        if fp8:
             ops.rmsnorm_fwd_q8(x, L["n1"], c.eps, q8, qs, rstd=self.R1[i][r0:r1])
         else:
             self._rms(x, L["n1"], nbuf, self.R1[i][r0:r1])
-        if fold1:
-            rn = (self.SSX, c.eps, self.R1[i])
-            if dh == 64:
-                ops.gemm_nt(x, L["wqkv_n"], bias=L["bqkv"], out=qkv, rope=(1, self.cos, self.sin, S, dh, (H + KV) * dh), rownorm=rn)
-            else:
-                ops.gemm_nt(x, L["wqkv_n"], bias=L["bqkv"], out=qkv, rownorm=rn)
-                ops.rope_half_(qkv[:, :H * dh], self.cos, self.sin, S, H, dh)
-                ops.rope_half_(qkv[:, H * dh:(H + KV) * dh], self.cos, self.sin, S, KV, dh)
-        elif fp8 and dh == 64:
+        if fp8 and dh == 64:
             ops.gemm_nt(q8, L["wqkv_q"], bias=L["bqkv"], out=qkv, rope=(1, self.cos, self.sin, S, dh, (H + KV) * dh), fp8=(qs, L["wqkv_s"]))
         elif fp8:
             ops.gemm_nt(q8, L["wqkv_q"], bias=L["bqkv"], out=qkv, fp8=(qs, L["wqkv_s"]))
@@ -428,12 +382,9 @@ class LLM:
             ops.rope_half_(qkv[:, H * dh:(H + KV) * dh], self.cos, self.sin, S, KV, dh)
         self._attn_fwd(qkv.view(B, S, -1), i, b0, b1, S)
         x1 = self.X1[i][r0:r1]
-        ops.gemm_nt(self.AO[i][r0:r1], L["wo"], residual=x, out=x1, ssq_out=self.SSX1 if fold else None)
+        ops.gemm_nt(self.AO[i][r0:r1], L["wo"], residual=x, out=x1)
         # the pre-activations are kept for the backward only: rows below the live window are never read again
-        if fold:
-            ops.gemm_nt(x1, L["wgu_n"], act=ACT_SWIGLU, out=self.GU[i][r0:r1], out2=hbuf,
-                        c_live=(S, self.gu_row0) if self.gu_row0 else None, rownorm=(self.SSX1, c.eps, self.R2[i]))
-        elif fp8:
+        if fp8:
             ops.rmsnorm_fwd_q8(x1, L["n2"], c.eps, q8, qs, rstd=self.R2[i][r0:r1])
             ops.gemm_nt(q8, L["wgu_q"], act=ACT_SWIGLU, out=self.GU[i][r0:r1], out2=hbuf,
                         c_live=(S, self.gu_row0) if self.gu_row0 else None, fp8=(qs, L["wgu_s"]))
@@ -441,8 +392,7 @@ class LLM:
             self._rms(x1, L["n2"], nbuf, self.R2[i][r0:r1])
             ops.gemm_nt(nbuf, L["wgu"], act=ACT_SWIGLU, out=self.GU[i][r0:r1], out2=hbuf,
                         c_live=(S, self.gu_row0) if self.gu_row0 else None)
-        ops.gemm_nt(hbuf, L["wd"], residual=x1, out=self.HS[self.out_slot(i)].view(-1, D)[r0:r1],
-                    ssq_out=self.SSX if (fold and i + 1 < c.n_layers) else None)
+        ops.gemm_nt(hbuf, L["wd"], residual=x1, out=self.HS[self.out_slot(i)].view(-1, D)[r0:r1])
 
     def fwd_final(self, b0: int = 0, b1: Optional[int] = None):
         """hidden_states[n] = final RMSNorm of the last layer's output (HF convention)."""
@@ -1286,11 +1236,8 @@ class VLAEngine:
     # forward->backward turn-around (little pipeline fill/drain) and longer elsewhere (fewer graph launches).
     def _ensure_streams(self):
         if getattr(self, "side", None) is None:
-            # head stream (a high-priority stream measured 0.7 % slower on the step in round 1; VLA_PRIO=h: A/B knob)
-            prio = os.environ.get("VLA_PRIO", "")
-            self.side = torch.cuda.Stream(priority=-1) if "h" in prio else torch.cuda.Stream()
+            self.side = torch.cuda.Stream()            # head stream (a high-priority stream measured 0.7 % slower on the step in round 1)
             self._cap_main = torch.cuda.Stream()       # capture stream of the "M" graphs (replayed on the current stream)
-            self.llm_streams = [torch.cuda.Stream()]   # further LLM forward pipelines (the other parts of the batch)
             self.vis_stream = torch.cuda.Stream()      # vision stage of the NEXT step (fills the backward's idle CUs)
             self._vstreams = [self.vis_stream] + [torch.cuda.Stream() for _ in range(max(0, len(self.vits) - 1))]   # one per backbone
 
@@ -1331,14 +1278,14 @@ class VLAEngine:
             self._prep_backward(batch)
             llm.fwd_begin(self.B, self.S, mm, self._row0_used)
 
-        def m_fwd(c, lo, hi, b0=0, b1=None, begin=False):
+        def m_fwd(c, lo, hi, begin=False):
             def fn():
                 if begin:
                     m_begin()
                 for i in range(lo, hi):
-                    llm.fwd_layer(i, b0, b1)
+                    llm.fwd_layer(i)
                 if hi == n:
-                    llm.fwd_final(b0, b1)
+                    llm.fwd_final()
             return fn
 
         def h_fwd(c, lo, hi, last):
@@ -1372,28 +1319,13 @@ class VLAEngine:
                     ops.cast_f32_bf16(dq, out=head.P.g("action_queries"))
             return fn
 
-        # The LLM forward runs as TWO pipelines over the halves of the batch ("M" = current stream, "N" = a second LLM
-        # stream): every op is sample-wise, and with one stream the chain qkv -> attention -> o -> norm -> gate/up -> down
-        # leaves the chip idle in every kernel's tail and at every kernel boundary; two half-batch chains fill each other's
-        # gaps (the backward phase already has three streams and is bound by total GEMM throughput instead).
-        # (three and four pipelines measured 33-34.6 ms against 27.9 for two and 28.4 for one, same box)
-        # Round 2: that was the 128-row GEMM (two workgroups per CU: a half-batch launch is 1.6 rounds of tiles and its tail
-        # is filled by the other pipeline).  With the persistent 256 x 256 kernel (one workgroup per CU, whole-batch launches =
-        # 6.5 rounds of gate/up tiles instead of 3.3 twice, half the launches) ONE pipeline is faster: 25.27-25.34 vs
-        # 25.61-25.75 ms, 25.96-26.01 vs 26.59 on a second box.  VLA_LLM_PIPES=2 restores the two pipelines.
-        npipe = int(os.environ.get("VLA_LLM_PIPES", "1")) if self.B >= 8 and not os.environ.get("VLA_NO_LLM_SPLIT") else 1
-        if npipe > 1:
-            cuts = [self.B * j // npipe for j in range(npipe + 1)]
-            segs.append(("M", m_begin, None, ("e", 0)))
-            for c, (lo, hi) in enumerate(fch):
-                segs.append(("M", m_fwd(c, lo, hi, 0, cuts[1]), None, ("f", c)))
-                for j in range(1, npipe):
-                    segs.append((f"N{j}", m_fwd(c, lo, hi, cuts[j], cuts[j + 1]), ("e", 0) if c == 0 else None, (f"g{j}", c)))
-                segs.append(("H", h_fwd(c, lo, hi, c == len(fch) - 1), [("f", c)] + [(f"g{j}", c) for j in range(1, npipe)], None))
-        else:
-            for c, (lo, hi) in enumerate(fch):
-                segs.append(("M", m_fwd(c, lo, hi, begin=c == 0), None, ("f", c)))
-                segs.append(("H", h_fwd(c, lo, hi, c == len(fch) - 1), ("f", c), None))
+        # ONE whole-batch forward pipeline.  (Round 1 ran the forward as two half-batch pipelines on two streams - with the 128-row
+        # GEMM, two workgroups per CU, the chains filled each other's tail rounds: -0.5 ms.  With the persistent 256 x 256 kernel,
+        # one workgroup per CU and 6.5 rounds of gate/up tiles per whole-batch launch, one pipeline measured 25.27-25.34 against
+        # 25.61-25.75 ms and the two-pipeline form left the tree in round 4: DESIGN section 5b.)
+        for c, (lo, hi) in enumerate(fch):
+            segs.append(("M", m_fwd(c, lo, hi, begin=c == 0), None, ("f", c)))
+            segs.append(("H", h_fwd(c, lo, hi, c == len(fch) - 1), ("f", c), None))
         for k, (lo, hi) in enumerate(reversed(fch)):
             segs.append(("H", h_bwd(lo, hi), None, ("b", k)))
             segs.append(("M", m_bwd(lo, hi, k == 0, k == len(fch) - 1), ("b", k), None))
@@ -1401,10 +1333,6 @@ class VLAEngine:
         return segs
 
     def _stream_of(self, name: str, main):
-        if name[0] == "N":                       # further LLM forward pipelines (N1, N2, ...)
-            while len(self.llm_streams) < int(name[1:]):
-                self.llm_streams.append(torch.cuda.Stream())
-            return self.llm_streams[int(name[1:]) - 1]
         return main if name == "M" else self.side if name == "H" else self._vstreams[int(name[1:])]
 
     def _run_segments(self, segs, graphs=None, timeline=None, hooks=None):
@@ -1610,9 +1538,7 @@ class VLAEngine:
             gscale = self.reducer.grad_scale
         if self.ga > 1:                                # accumulated gradient was assembled on the current stream
             self.side.wait_event(self._h_end)
-        if os.environ.get("VLA_UPDATE_ON_MAIN"):       # A/B knob: the whole update in front of the step, on the current stream
-            cur.wait_event(self._h_end)
-        with torch.cuda.stream(cur if os.environ.get("VLA_UPDATE_ON_MAIN") else self.side):
+        with torch.cuda.stream(self.side):
             ops.adamw_(P.data[:aq_off], P.grad[:aq_off], P.m[:aq_off], P.v[:aq_off], self.step_count, lr, gscale=gscale)
             side_done = torch.cuda.Event()
             side_done.record()

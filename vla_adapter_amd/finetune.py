@@ -84,6 +84,12 @@ class FinetuneConfig:
     dataset_statistics_file: Optional[str] = None   # JSON written next to every checkpoint (finetune.py:531)
     objective: str = "l1"                 # "l1": action head + L1 regression (the reference's finetune.py); "token_ce": the native VLM / VLA trainer's
                                           # token cross-entropy (base_strategy.py:257-417) - LoRA / full modes only, no action head in the loss
+    fp8_base_weights: bool = False        # --use_lora: the frozen base weights' products (forward and dX) on OCP e4m3 operands, the rank-r branch in
+                                          # bf16 inside the same accumulator (BASELINE configs[4] "fp8 MFMA weight path"; parity unpinned: the reference is bf16)
+    ddp_algo: str = "allreduce"           # data-parallel exchange per gradient bucket: "allreduce", or "rs_ag" = reduce-scatter + all-gather
+                                          # (every rank talks to every peer directly: all 7 xGMI links instead of a ring)
+    sync_check_freq: int = 0              # > 0: every that many optimizer steps the ranks compare a checksum of their parameters (one 8-byte
+                                          # all-reduce) and the run stops on a mismatch; 0 = off
     backbone: Optional[str] = None        # model geometry: a name of engine.NAMED_CONFIGS ("config2", "dinosiglip-0_5b", "config5",
                                           # "tiny", "tiny_fused") - default: inferred from the --vlm_path state dict, else "config2"
     # fmt: on
@@ -129,6 +135,10 @@ def check_supported(cfg: FinetuneConfig, explicit=()) -> None:
         raise ValueError("grad_accumulation_steps must be >= 1")
     if cfg.use_lora and cfg.lora_dropout != 0.0:
         raise NotImplementedError("--lora_dropout > 0: the low-rank branch is built without dropout (every shipped script uses 0.0)")
+    if cfg.fp8_base_weights and not cfg.use_lora:
+        raise NotImplementedError("--fp8_base_weights needs --use_lora True (frozen base weights); the adapter-only forward has engine.enable_fp8_frozen()")
+    if cfg.ddp_algo not in ("allreduce", "rs_ag"):
+        raise ValueError("--ddp_algo is allreduce or rs_ag")
     if cfg.objective not in ("l1", "token_ce"):
         raise ValueError("--objective is l1 or token_ce")
     if cfg.objective == "token_ce" and train_mode(cfg) == "adapter":
@@ -324,11 +334,11 @@ def finetune(cfg: FinetuneConfig, batches=None, explicit=()) -> dict:
             lora_sd = CK.load_file(str(f))
     eng = E.VLAEngine(mcfg, W, dev)
     if world > 1:
-        eng.reducer = ddp.FlatGradReducer()
+        eng.reducer = ddp.FlatGradReducer(algo=cfg.ddp_algo)
     trainer = None
     if mode == "lora":
         from .trainers import LoRAFinetune
-        trainer = LoRAFinetune(eng, rank=cfg.lora_rank, seed=cfg.seed)
+        trainer = LoRAFinetune(eng, rank=cfg.lora_rank, seed=cfg.seed, fp8=cfg.fp8_base_weights)
         if lora_sd is not None:
             trainer.load_lora_state_dict(lora_sd)
     elif mode == "full":
@@ -376,6 +386,10 @@ def finetune(cfg: FinetuneConfig, batches=None, explicit=()) -> dict:
         else:
             loss3 = eng.train_step(cur, lr, noise if training else None)
         steps_done += int(boundary)
+        if boundary and world > 1 and cfg.sync_check_freq > 0 and steps_done % cfg.sync_check_freq == 0:
+            eng.flush()                      # (the captured adapter step leaves its update pending: compare what the ranks really hold)
+            flats = [eng.head.P.data] + ([trainer.P.data] if trainer is not None else [])
+            ddp.assert_ranks_in_sync(flats, what=f"parameters after optimizer step {steps_done}")
         if boundary and (log_step % cfg.wandb_log_freq == 0 or last):          # the only host sync, every log_freq gradient steps
             l = loss3.tolist()
             if not all(x == x for x in l):

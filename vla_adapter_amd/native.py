@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = (os.environ.get("VLA_NATIVE_LIB") or None) or os.path.join(_HERE, "libvla_native.so")   # override: same-box A/B of two builds
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_TANH, ACT_SWIGLU, ACT_SWIGLU_BWD = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 4          # include/vla_native.h: VLA_ABI_VERSION
+ABI_VERSION = 5          # include/vla_native.h: VLA_ABI_VERSION
 
 
 class NativeLibraryMissing(ImportError):
@@ -32,8 +32,7 @@ class GemmDesc(C.Structure):
                 ("r_group", C.c_int), ("r_group_stride", C.c_longlong), ("c_live_mod", C.c_int), ("c_live_from", C.c_int),
                 ("split_k", C.c_int), ("ws", C.c_void_p), ("bias_post_round", C.c_int),
                 ("fp8", C.c_int), ("a_scale", C.c_void_p), ("b_scale", C.c_void_p),
-                ("A2", C.c_void_p), ("B2", C.c_void_p), ("K2", C.c_int), ("lda2", C.c_int), ("ldb2", C.c_int),
-                ("ssq_out", C.c_void_p), ("rowss", C.c_void_p), ("rowss_parts", C.c_int), ("rows_eps", C.c_float), ("rstd_out", C.c_void_p)]
+                ("A2", C.c_void_p), ("B2", C.c_void_p), ("K2", C.c_int), ("lda2", C.c_int), ("ldb2", C.c_int)]
 
 
 class GemmTnDesc(C.Structure):

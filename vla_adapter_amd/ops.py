@@ -39,16 +39,13 @@ def _chk_bf16(*ts):
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_mod: int = 0, act: int = ACT_NONE,
             out: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, alpha: float = 1.0,
             want_pre: bool = True, a_group=None, c_group=None, r_group=None, rope=None, c_live=None,
-            split_k: Optional[int] = None, bias_post_round: bool = False, fp8=None, ext=None, ssq_out=None, rownorm=None,
-            query_256: bool = False) -> torch.Tensor:
+            split_k: Optional[int] = None, bias_post_round: bool = False, fp8=None, ext=None, query_256: bool = False) -> torch.Tensor:
     """C = epilogue(A @ B^T).  a: [M,K] or [batch,M,K] (row stride = a.stride(-2)); b: [N,K] or [batch,N,K].
     SwiGLU: returns (pre [.., N] or None, h [.., N/2]).  split_k: None = automatic, 0/1 = off, k = forced.
     fp8=(a_scale [M] f32, b_scale [N] f32): a and b are uint8 tensors of OCP e4m3 codes (quant_fp8_rows).
-    ext=(a2 [M, K2], b2 [N, K2]): K extension, C = epilogue(A @ B^T + A2 @ B2^T) in one fp32 accumulator (LoRA branch).
-    RMSNorm folded into GEMMs (256-row kernel only; the norm weight folded into b by the caller): ssq_out f32 [ceil(N/256), M] = per
-    column tile, the sum of squares of the rows this GEMM stores (producer); rownorm=(partials f32 [parts, M], eps, rstd_out f32 [M] or
-    None): rows of the accumulator scaled by rsqrt(sum(partials) / K + eps) (consumer).  query_256=True: no launch, returns whether
-    this call would run on the 256-row kernel."""
+    ext=(a2 [M, K2], b2 [N, K2]) bf16: K extension, C = epilogue(A @ B^T + A2 @ B2^T) in one fp32 accumulator (LoRA branch); with fp8
+    the base pair is e4m3 and dequantised before the extension adds to it.  query_256=True: no launch, returns whether this call
+    would run on the 256-row kernel."""
     if fp8 is not None:
         assert a.dtype == torch.uint8 and b.dtype == torch.uint8 and a.dim() == 2 and split_k in (None, 0, 1)
         _chk_bf16(bias, residual, out, out2)
@@ -121,18 +118,6 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_m
         assert a2.stride(1) == 1 and b2.stride(1) == 1 and a2.shape[1] % 64 == 0 and split_k in (None, 0, 1)
         d.A2, d.B2, d.K2, d.lda2, d.ldb2 = a2.data_ptr(), b2.data_ptr(), a2.shape[1], a2.stride(0), b2.stride(0)
         split_k = 0
-    if ssq_out is not None:
-        assert ssq_out.dtype == torch.float32 and ssq_out.is_contiguous() and tuple(ssq_out.shape) == ((Nn + 255) // 256, M)
-        d.ssq_out = ssq_out.data_ptr()
-        split_k = 0
-    if rownorm is not None:
-        parts, eps, rstd_out = rownorm
-        assert parts.dtype == torch.float32 and parts.is_contiguous() and parts.dim() == 2 and parts.shape[1] == M
-        d.rowss, d.rowss_parts, d.rows_eps = parts.data_ptr(), parts.shape[0], eps
-        if rstd_out is not None:
-            assert rstd_out.dtype == torch.float32 and rstd_out.is_contiguous() and rstd_out.numel() == M
-            d.rstd_out = rstd_out.data_ptr()
-        split_k = 0
     if bias_post_round:          # C = bf16(bf16(A.B^T) + bias): torch CPU Linear on a strided bf16 input (vla_native.h)
         assert bias is not None
         d.bias_post_round = 1
@@ -142,7 +127,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_m
         split_k = 0
         tiles = ((M + 127) // 128) * ((Nn + 127) // 128)
         if plain and K >= 2048 and tiles <= 256 and not os.environ.get("VLA_NO_SPLITK"):
-            cap = int(os.environ.get("VLA_SPLITK_WGS", "512"))          # workgroup slots a split may fill (A/B aid; 512 = two per CU)
+            cap = 512                                                   # workgroup slots a split may fill (two per CU)
             for sk in (8, 4, 2):
                 if tiles * sk <= cap and K % (64 * sk) == 0 and K // sk >= 512:
                     split_k = sk
@@ -171,11 +156,16 @@ def _splitk_ws(numel: int, device) -> torch.Tensor:
 
 
 def gemm_swiglu_bwd(d: torch.Tensor, w_downT: torch.Tensor, gu: torch.Tensor, out: Optional[torch.Tensor] = None,
-                    gu_group=None, ext=None) -> torch.Tensor:
+                    gu_group=None, ext=None, fp8=None) -> torch.Tensor:
     """dGU[M, 2I] = swiglu'(GU) * (d[M, D] @ w_downT[I, D]^T): the dH GEMM with the SwiGLU backward in its epilogue.
     gu_group=(rows per group, element stride between groups): ``gu`` is then the first row-group window of a larger
-    tensor (row m of the product reads gu row (m // g) * stride + (m % g) * ld)."""
-    _chk_bf16(d, w_downT, gu, out)
+    tensor (row m of the product reads gu row (m // g) * stride + (m % g) * ld).
+    fp8=(d_scale [M], w_scale [I]) (with ext only): d and w_downT are uint8 e4m3 codes (quant_fp8_rows)."""
+    if fp8 is not None:
+        assert ext is not None and d.dtype == torch.uint8 and w_downT.dtype == torch.uint8
+        _chk_bf16(gu, out)
+    else:
+        _chk_bf16(d, w_downT, gu, out)
     M, K = d.shape
     I = w_downT.shape[0]
     assert gu.shape[-1] == 2 * I and gu.stride(-1) == 1 and w_downT.shape[1] == K
@@ -194,6 +184,10 @@ def gemm_swiglu_bwd(d: torch.Tensor, w_downT: torch.Tensor, gu: torch.Tensor, ou
         _chk_bf16(a2, b2)
         assert a2.shape == (M, b2.shape[1]) and b2.shape[0] == I and a2.stride(1) == 1 and b2.stride(1) == 1 and a2.shape[1] % 64 == 0
         desc.A2, desc.B2, desc.K2, desc.lda2, desc.ldb2 = a2.data_ptr(), b2.data_ptr(), a2.shape[1], a2.stride(0), b2.stride(0)
+    if fp8 is not None:
+        sa, sb = fp8
+        assert sa.dtype == torch.float32 and sb.dtype == torch.float32 and sa.numel() == M and sb.numel() == I and sa.is_contiguous() and sb.is_contiguous()
+        desc.fp8, desc.a_scale, desc.b_scale = 1, sa.data_ptr(), sb.data_ptr()
     N.check(_lib().vla_gemm_bf16_nt(_st(), C.byref(desc)), "gemm_bf16_nt(swiglu_bwd)")
     return out
 

@@ -133,7 +133,7 @@ class BackboneTrainer:
 
     def __init__(self, eng: E.VLAEngine):
         cfg = eng.cfg
-        assert not getattr(eng, "fp8_frozen", False), "the backbone weights train: the fp8 frozen-weight path does not apply"
+        assert not getattr(eng, "fp8_frozen", False), "engine.enable_fp8_frozen() is the adapter-only forward's opt-in; LoRA has its own (LoRAFinetune(fp8=True))"
         self.eng, self.cfg, self.dev = eng, cfg, eng.device
         self.vits, self.llm, self.head = eng.vits, eng.llm, eng.head
         for v in self.vits:
@@ -218,6 +218,9 @@ class BackboneTrainer:
         d = x.shape[1]
         ops.N.check(ops._lib().vla_layernorm_fwd(ops._st(), ops._p(x), ops._p(w), ops._p(b), ops._p(y), ops._p(st), x.shape[0], d, d, d, eps), "layernorm_fwd")
 
+    def _rms(self, x, w, out, rstd):
+        self.llm._rms(x, w, out, rstd)
+
     def _ln_bwd(self, dy, x, w, st, dx, dw, db):
         d = x.shape[1]
         ops.N.check(ops._lib().vla_layernorm_bwd(ops._st(), ops._p(dy), ops._p(x), ops._p(w), ops._p(st), ops._p(dx), ops._p(dw), ops._p(db),
@@ -295,7 +298,7 @@ class BackboneTrainer:
         for i in range(lo, hi):
             L = llm.layers[i]
             x, k = llm.HS[i].view(-1, D), f"llm.{i}."
-            llm._rms(x, L["n1"], self.N1[i], llm.R1[i])
+            self._rms(x, L["n1"], self.N1[i], llm.R1[i])
             qkv = llm.QKV[i]
             if dh == 64:          # RoPE in the projection's epilogue (the LoRA delta is already inside the accumulator)
                 self._lin(k + "qkv", self.N1[i], L["wqkv"], L["bqkv"], out=qkv, rope=(1, llm.cos, llm.sin, S, dh, (H + KV) * dh))
@@ -306,7 +309,7 @@ class BackboneTrainer:
             llm._attn_fwd(qkv.view(B, S, -1), i, 0, B, S)
             x1 = llm.X1[i]
             self._lin(k + "o", llm.AO[i], L["wo"], None, out=x1, residual=x)
-            llm._rms(x1, L["n2"], self.N2[i], llm.R2[i])
+            self._rms(x1, L["n2"], self.N2[i], llm.R2[i])
             self._lin(k + "gu", self.N2[i], L["wgu"], None, act=ACT_SWIGLU, out=llm.GU[i], out2=self.Hs[i])
             self._lin(k + "down", self.Hs[i], L["wd"], None, out=llm.HS[llm.out_slot(i)].view(-1, D), residual=x1)
         if hi == c.n_layers:
@@ -1115,9 +1118,19 @@ class LoRAFinetune(BackboneTrainer):
     mode = "lora"
     trains_vectors = False
 
-    def __init__(self, eng: E.VLAEngine, rank: int = 32, seed: int = 0):
+    def __init__(self, eng: E.VLAEngine, rank: int = 32, seed: int = 0, fp8: bool = False, fp8_backward: Optional[bool] = None):
+        """fp8: BASELINE configs[4]'s "fp8 MFMA weight path" where it belongs - under LoRA every base weight is frozen, so every base
+        product runs on OCP e4m3 operands (weights quantised once, one scale per output channel; activations per row: inside the
+        norm that produces them, or by one pass over the producer's output) while the rank-r branch stays bf16 INSIDE the same
+        accumulator (the GEMM's K extension on the dequantised base product).  fp8_backward (default: as fp8): the dX products
+        dy W likewise, on e4m3 W^T (one scale per input channel) and row-quantised dy; the adapter gradients dA / dB read the bf16
+        activations and bf16 dy as before.  The reference has no fp8 code (it runs bf16 everywhere): PARITY UNPINNED; the oracle
+        restates this arithmetic (oracle.FP8 registry + FP8_BWD).  A Linear whose contraction length is not a multiple of 128
+        (plumbing-size configs) keeps bf16."""
         super().__init__(eng)
         cfg, self.rank = self.cfg, rank
+        self.fp8 = bool(fp8)
+        self.fp8_backward = self.fp8 if fp8_backward is None else (bool(fp8_backward) and self.fp8)
         c = cfg.llm
         H, KV, dh, I, D = c.heads, c.kv_heads, c.dh, c.inter, c.d
         L: Dict[str, LoraLinear] = {}
@@ -1159,6 +1172,16 @@ class LoRAFinetune(BackboneTrainer):
                     b[k + "T"] = ops.transpose(b[k])
         self.projT = {k: ops.transpose(w) for k, w in eng.proj.items() if k.endswith("weight")}
         self.T, self.DT = {}, {}              # t = 2 x A^T per LoRA Linear (kept for dB), dt = 2 dy B scratch per shape
+        self.Q, self.QT = {}, {}              # fp8: key -> (e4m3 codes, fp32 scales) of W [out, in] / of W^T [in, out]
+        self._qbuf, self._xq = {}, None       # row-quantised activations: scratch per shape; (data_ptr, codes, scales) of the last norm output
+        if self.fp8:
+            for key in L:
+                holder, wk = self._base(key)
+                W, WT = holder[wk], self._baseT(key)
+                if W.shape[1] % 128 == 0:
+                    self.Q[key] = ops.quant_fp8_rows(W)
+                if self.fp8_backward and WT.shape[1] % 128 == 0:
+                    self.QT[key] = ops.quant_fp8_rows(WT)
         self.refresh()
 
     vit = property(lambda self: self.vits[0])
@@ -1166,6 +1189,48 @@ class LoRAFinetune(BackboneTrainer):
     def refresh(self):
         for l in self.L.values():
             l.refresh()
+
+    def fp8_keys(self):
+        """(forward keys, backward keys) of the Linears that run on e4m3 base operands (tests register the same set with the oracle)."""
+        return sorted(self.Q), sorted(self.QT)
+
+    def _baseT(self, key: str):
+        part, *rest = key.split(".")
+        if part.startswith("vit"):
+            return self.vits[int(part[3:])].blocks[int(rest[0])][{"qkv": "wqkvT", "proj": "wprojT", "fc1": "w1T", "fc2": "w2T"}[rest[1]]]
+        if part == "proj":
+            return self.projT[rest[0] + ".weight"]
+        return self.llm.layers[int(rest[0])][{"qkv": "wqkvT", "o": "woT", "gu": "wguT", "down": "wdT"}[rest[1]]]
+
+    # ---- fp8: row-quantised activations
+    def _qscratch(self, rows: int, cols: int, slot: str):
+        k = (rows, cols, slot)
+        b = self._qbuf.get(k)
+        if b is None:
+            b = self._qbuf[k] = (torch.empty(rows, cols, device=self.dev, dtype=torch.uint8), torch.empty(rows, device=self.dev, dtype=torch.float32))
+        return b
+
+    def _quant(self, x, slot: str):
+        """(codes, scales) of the rows of x: taken from the norm that just produced x, else one pass over x (vla_quant_fp8_rows)."""
+        if self._xq is not None and self._xq[0] == (x.data_ptr(), tuple(x.shape)):
+            hit, self._xq = self._xq, None               # (consumed: the scratch is overwritten by the next norm of this shape)
+            return hit[1], hit[2]
+        q, s_ = self._qscratch(x.shape[0], x.shape[1], slot)
+        return ops.quant_fp8_rows(x, q, s_)
+
+    def _ln(self, x, w, b, y, st, eps):
+        if not self.fp8 or x.shape[1] % 128:
+            return super()._ln(x, w, b, y, st, eps)
+        q, s_ = self._qscratch(x.shape[0], x.shape[1], "n")
+        ops.layernorm_fwd_q8(x, w, b, eps, q, s_, y=y, stats=st)          # the row is still in registers: bit-identical to norm + quantise
+        self._xq = ((y.data_ptr(), tuple(y.shape)), q, s_)
+
+    def _rms(self, x, w, out, rstd):
+        if not self.fp8 or x.shape[1] % 128:
+            return super()._rms(x, w, out, rstd)
+        q, s_ = self._qscratch(x.shape[0], x.shape[1], "n")
+        ops.rmsnorm_fwd_q8(x, w, self.cfg.llm.eps, q, s_, rstd=rstd, y=out)
+        self._xq = ((out.data_ptr(), tuple(out.shape)), q, s_)
 
     def _alloc(self, B, S):
         if self._key != (B, S):
@@ -1179,6 +1244,10 @@ class LoRAFinetune(BackboneTrainer):
         if t is None or t.shape[0] != x.shape[0]:
             t = self.T[key] = torch.empty(x.shape[0], l.Rr, device=self.dev, dtype=BF16)
         ops.gemm_nt(x, l.A_cat, alpha=2.0, out=t)                   # t = 2 x A_cat^T   (alpha / r = 2)
+        wq = self.Q.get(key)
+        if wq is not None:                                          # e4m3 base operands, bf16 low-rank branch, one accumulator
+            xq, xs = self._quant(x, "f")
+            return ops.gemm_nt(xq, wq[0], bias=bias, fp8=(xs, wq[1]), ext=(t, l.B_blk), **kw)
         return ops.gemm_nt(x, W, bias=bias, ext=(t, l.B_blk), **kw)
 
     def _lin_bwd(self, key, dy, x, WT, out=None, swiglu_gu=None):
@@ -1189,6 +1258,12 @@ class LoRAFinetune(BackboneTrainer):
             dt = self.DT[key] = torch.empty(M, l.Rr, device=self.dev, dtype=BF16)
         ops.gemm_nt(dy, l.B_blkT, alpha=2.0, out=dt)                # dt = 2 dy B_blk
         l.grads(dy, x, self.T[key], dt, self._defer_tn)             # dA_cat, dB_j: gradient-only work
+        wq = self.QT.get(key)
+        if wq is not None:                                          # dx = Q(dy) Q(W^T)^T + dt A_cat
+            dq, ds = self._quant(dy, "b")
+            if swiglu_gu is not None:
+                return ops.gemm_swiglu_bwd(dq, wq[0], swiglu_gu, out=out, ext=(dt, l.A_catT), fp8=(ds, wq[1]))
+            return ops.gemm_nt(dq, wq[0], out=out, fp8=(ds, wq[1]), ext=(dt, l.A_catT))
         if swiglu_gu is not None:
             return ops.gemm_swiglu_bwd(dy, WT, swiglu_gu, out=out, ext=(dt, l.A_catT))
         return ops.gemm_nt(dy, WT, out=out, ext=(dt, l.A_catT))     # dx = dy W + dt A_cat
