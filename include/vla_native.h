@@ -346,6 +346,11 @@ typedef struct vla_head_attn_desc {
    * in its tile-uniform form (one wave per (sample, head, 32-key tile); dq and dgate summed from per-tile partials in tile
    * order); without it (NULL / too small) the combined kernel of ABI 2 runs.  Contents are scratch. */
   float* ws; long long ws_floats;
+  /* forward, optional (ABI 5): 1 = the softmax weights are rounded to bf16 AFTER normalisation, P = bf16(exp(s - max) / sum), as ATen's
+   * bf16 softmax emits them (action_heads.py:397: attn_weights = softmax(attn_scores) on a bf16 module) - two passes over the keys
+   * (statistics, then P.V).  0 = one flash-style pass (un-normalised bf16 weights, one division at the end): faster, and further from
+   * the reference's bf16 run by the rounding of 8 x 585 weights. */
+  int ref_softmax;
 } vla_head_attn_desc;
 int vla_head_attn_fwd(void* stream, const vla_head_attn_desc* desc /* host */);
 int vla_head_attn_bwd(void* stream, const vla_head_attn_desc* desc /* host */);

@@ -19,14 +19,21 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.dirname(__file__))
 
 from oracle import vla_oracle as O  # noqa: E402
-from test_layer_gradients_gpu import Checker, TOL_DW, TOL_DX, llm_layer_oracle  # noqa: E402
+from test_layer_gradients_gpu import Checker, TOL_BIAS, llm_layer_oracle  # noqa: E402
 
 DEV, BF = "cuda", torch.bfloat16
 LLM_NAMES = ["self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj"]
-# e4m3 operands: native and oracle quantise the same bf16 tensors, but a value that differs by one bf16 ulp between the two runs
-# (the layer's own intermediate activations) can fall on the other side of an e4m3 rounding boundary (a 6 % step on that element).
-# Measured on the MI355X (round 4, gpurun_out/t_r4_config5.log): see the printed table; bound = measured + 50 %.
-TOL_F8 = 2.0e-2
+# e4m3 operands: native and oracle quantise bf16 tensors that agree to ~5e-3 (the layer's own intermediates: the bf16 test above),
+# and a value that moves by 0.5 % crosses an e4m3 rounding boundary (6-12 % apart) in ~5 % of the elements, each flip a FULL e4m3 step
+# (3.5 x the rms quantisation error): two valid evaluations of the same fp8 arithmetic sit about as far from each other as either sits
+# from the un-rounded truth.  Measured on the MI355X (round 4, gpurun_out/t_r4_b.log): native-vs-emu 1.3e-2 ... 4.2e-2 per tensor with
+# native-vs-fp32 = emu-vs-fp32 to within 5 % on every one of the 15 tensors.  The criterion is therefore the error budget of the
+# end-to-end tests - native no further from the truth, and from the emulation, than 1.25 x the emulation is from the truth - and the
+# self-test scales a gradient by 1.10 (a 1.05 error drowns in e4m3 noise on the tensors that sit 5e-2 from the truth).
+F8_BUDGET = 1.25
+# bf16 at this geometry (d 1536, head dim 128, the plumbing-size batch of 3 x 136 rows, weights N(0, 0.03)): dX sits 5.0e-3 from the
+# emulating oracle with BOTH 5.0e-3 from fp32 (gpurun_out/t_r4_all.log) - two valid bf16 evaluations apart; bound = measured + 50 %
+TOL_DX_15B = 7.5e-3
 
 
 def _geometry_setup(seed=5):
@@ -55,10 +62,11 @@ def test_full_finetune_one_llm_layer_at_the_15b_geometry():
     t = ft.taps[("llm", kl)]
     res = {emu: llm_layer_oracle(W["llm"], kl, eng.llm.HS[kl], eng.llm.kmask.bool().cpu(), t["d_out"].view(B, S_, D), cfg, emu) for emu in (True, False)}
     ck = Checker(f"full fine-tune, Qwen2.5-1.5B geometry: LLM layer {kl}")
-    ck.add("dX", t["d_in"].view(B, S_, D), res[True][0], res[False][0], TOL_DX)
+    ck.add("dX", t["d_in"].view(B, S_, D), res[True][0], res[False][0], TOL_DX_15B)
     for k in sorted(res[True][1]):
-        ck.add(k, G["language_model.model." + k], res[True][1][k].grad, res[False][1][k].grad, TOL_DW)
+        ck.add(k, G["language_model.model." + k], res[True][1][k].grad, res[False][1][k].grad, TOL_BIAS if k.endswith(".bias") else TOL_DX_15B)
     ck.run()
+    ck.must_catch_a_wrong_scale("dX")
     ck.must_catch_a_wrong_scale(f"layers.{kl}.mlp.down_proj.weight")
     ck.must_catch_a_wrong_scale(f"layers.{kl}.self_attn.k_proj.weight")
 
@@ -115,15 +123,32 @@ def test_lora_one_llm_layer_at_the_15b_geometry(fp8):
             stores[emu] = {}
             O.FP8.clear()
             res[emu] = llm_layer_oracle(W["llm"], kl, eng.llm.HS[kl], eng.llm.kmask.bool().cpu(), t["d_out"].view(B, S_, D), cfg, emu, lora=registrar(stores[emu]))
-        tol_x, tol_w = (TOL_F8, TOL_F8) if fp8 else (TOL_DX, TOL_DW)
-        ck = Checker(f"LoRA{' + fp8 base products' if fp8 else ''}, Qwen2.5-1.5B geometry: LLM layer {kl}")
-        ck.add("dX", t["d_in"].view(B, S_, D), res[True][0], res[False][0], tol_x)
+        rows = [("dX", t["d_in"].view(B, S_, D), res[True][0], res[False][0])]
         for n in LLM_NAMES:
             for w, idx in (("lora_A", 0), ("lora_B", 1)):
-                ck.add(f"{n}.{w}", gsd[f"{pre}{n}.{w}.weight"], stores[True][n][idx].grad, stores[False][n][idx].grad, tol_w)
-        ck.run()
-        ck.must_catch_a_wrong_scale("mlp.up_proj.lora_B")
-        ck.must_catch_a_wrong_scale("self_attn.k_proj.lora_A")
+                rows.append((f"{n}.{w}", gsd[f"{pre}{n}.{w}.weight"], stores[True][n][idx].grad, stores[False][n][idx].grad))
+        if not fp8:
+            ck = Checker(f"LoRA, Qwen2.5-1.5B geometry: LLM layer {kl}")
+            for r_ in rows:
+                ck.add(*r_, TOL_DX_15B)
+            ck.run()
+            ck.must_catch_a_wrong_scale("mlp.up_proj.lora_B")
+            ck.must_catch_a_wrong_scale("self_attn.k_proj.lora_A")
+        else:
+            from test_layer_gradients_gpu import rel
+
+            def f8_check(rows_, verbose):
+                for name, nat, emu_, tru in rows_:
+                    emu_, tru = emu_.reshape(nat.shape), tru.reshape(nat.shape)
+                    r_ne, r_nt, r_et = rel(nat, emu_), rel(nat, tru), rel(emu_, tru)
+                    if verbose:
+                        print(f"  LoRA + fp8 base products, 1.5B geometry / {name}: native-vs-emu {r_ne:.2e}  native-vs-fp32 {r_nt:.2e}  emu-vs-fp32 {r_et:.2e}")
+                    assert r_nt <= F8_BUDGET * r_et + 2e-3 and r_ne <= F8_BUDGET * r_et + 2e-3, (name, r_ne, r_nt, r_et)
+
+            f8_check(rows, True)
+            for bad in ("dX", "mlp.up_proj.lora_B", "self_attn.k_proj.lora_A", "self_attn.o_proj.lora_B"):      # discriminating power: one gradient x 1.10
+                with pytest.raises(AssertionError):
+                    f8_check([(n_, a_ * 1.10 if n_ == bad else a_, e_, t_) for n_, a_, e_, t_ in rows], False)
         if fp8:          # the e4m3 products really ran: against the bf16 oracle (same LoRA pairs, no FP8 registry) the distance is the quantisation's
             from test_layer_gradients_gpu import rel
             O.FP8.clear()
@@ -181,9 +206,11 @@ def test_config5_full_size_lora_step(fp8):
     assert dead == 4 * 7 * 2 and fed > 500, (dead, fed)
     l0 = loss3[0].item()
     lo.optimizer_step(1e-4)
-    ls = [lo.train_step(batch, 1e-4)[0].item() for _ in range(4)]
+    ls = [lo.train_step(batch, 1e-4)[0].item() for _ in range(5)]
     torch.cuda.synchronize()
-    assert all(v == v for v in ls) and min(ls) < l0, (l0, ls)
+    # AdamW's first update moves every one of the head's ~640 M random-init parameters by lr at once (the loss jumps, as in the
+    # reference's optimizer); from there the steps must bring it down steadily (measured 2.68 -> 1.69 -> 1.29 -> 1.00 -> ...)
+    assert all(v == v for v in ls) and all(b_ < a_ for a_, b_ in zip(ls, ls[1:])) and ls[-1] < 0.5 * ls[0], (l0, ls)
     first_dead = lo.P.offsets[f"{lo.L['llm.24.qkv'].name}.q_proj.lora_A"][0]
     assert torch.equal(lo.P.data[first_dead:], p0[first_dead:]), "the adapters of the four dead layers are left alone"
     assert not torch.equal(lo.P.data[:first_dead], p0[:first_dead])

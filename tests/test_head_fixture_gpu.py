@@ -29,7 +29,7 @@ def rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
-def _run_native(case):
+def _run_native(case, ref_softmax=False):
     from vla_adapter_amd import engine as E
     z = np.load(os.path.join(G, f"head_bf16_{case}.npz"))
     inp = GG.case_inputs(case)
@@ -37,6 +37,7 @@ def _run_native(case):
     pro, D, Kt, B, phase, nb = GG.case_cfg(case)
     cfg = E.VLACfg(llm=E.LLMCfg(d=D), num_blocks=nb, pro=pro)
     head = E.Head(cfg, DEV)
+    head.ref_softmax = ref_softmax
     head.load_state_dicts({k: v.to(DEV) for k, v in inp["head"].items()}, {k: v.to(DEV) for k, v in inp["proprio"].items()})
     hs = inp["mlhs"].to(BF).permute(1, 0, 2, 3).contiguous().to(DEV)                 # [nb+1, B, Kt+64, D]: per-layer "sequences"
     pos1 = torch.arange(GG.NUM_TOKENS, device=DEV, dtype=torch.int32)[None].expand(B, -1).contiguous()
@@ -52,13 +53,35 @@ def _run_native(case):
     return z, pred, grads, taps, dx
 
 
+# one-block bounds against the reference's own bf16 run: (block output, actions).  Default forward = flash-style softmax (weights
+# rounded before normalisation); ref_softmax = weights rounded where ATen rounds them (vla_head_attn_desc.ref_softmax).
+# Measured on the MI355X (round 4, gpurun_out/t_r4_fixture.log) - bounds = measured + 25 %, see the table printed by the test.
+#   case              flash-style softmax (default)              ref_softmax
+#   pro1_d128_kt64    block 1.31e-3 (9.5 % of elements)  actions 2.22e-3     block 0 (BIT-IDENTICAL: 0 % of elements differ)  actions 0
+#   orig1_d128_kt64   block 1.55e-3 (9.4 %)               actions 2.06e-3     block 0 (BIT-IDENTICAL)                          actions 0
+#   pro1_d896_kt256   block 1.87e-3 (15 %)                actions 3.04e-3     block 1.24e-3 (8.3 %: one-ulp flips of 896-long   actions 2.32e-3
+#                                                                             fp32 dot products summed in another order)
+ONE_BLOCK_BOUNDS = {False: (2.4e-3, 3.8e-3), True: (1.6e-3, 2.9e-3)}
+
+
+@pytest.mark.parametrize("ref_softmax", [False, True])
 @pytest.mark.parametrize("case", ["pro1_d128_kt64", "orig1_d128_kt64", "pro1_d896_kt256"])
-def test_one_block_head_tracks_the_reference_bf16_run(case):
-    z, pred, grads, taps, dx = _run_native(case)
+def test_one_block_head_tracks_the_reference_bf16_run(case, ref_softmax):
+    z, pred, grads, taps, dx = _run_native(case, ref_softmax)
     rb, rp = rel(taps[0], z["xblk_bf16"][0]), rel(pred, z["out_bf16"])
     gap = rel(torch.as_tensor(z["out_bf16"]), z["out_fp32"])
-    print(f"{case}: native-vs-reference-bf16  block output {rb:.2e}  actions {rp:.2e}   (reference bf16-vs-fp32 actions {gap:.2e})")
-    assert rb <= 4e-3 and rp <= 6e-3
+    nflip = (taps[0].float().cpu() != torch.as_tensor(z["xblk_bf16"][0]).float()).float().mean().item()
+    print(f"{case} ref_softmax={ref_softmax}: native-vs-reference-bf16  block output {rb:.2e} ({100 * nflip:.2f} % of its elements differ)  "
+          f"actions {rp:.2e}   (reference bf16-vs-fp32 actions {gap:.2e})")
+    bb, ba = ONE_BLOCK_BOUNDS[ref_softmax]
+    assert rb <= bb and rp <= ba, (rb, rp)
+    if ref_softmax and "d128" in case:
+        # north_star: "action-head logits within 1e-3 of reference".  With the attention weights rounded where ATen rounds them, the HIP
+        # head reproduces the reference's own bf16 run of this block BIT FOR BIT (fc1, q/k/v projections with RoPE, attention over the
+        # three segments with the tanh gate, o-proj, LayerNorm, ffn, the output layers): every hidden unit and every action
+        assert nflip == 0.0 and rb == 0.0 and rp == 0.0, (nflip, rb, rp)
+    if ref_softmax:
+        assert rb <= 1.6e-3, "north_star's 1e-3-class bound on the block output (1.24e-3 measured at D = 896: summation-order flips)"
     worst = (0.0, "")
     gmax = max(np.linalg.norm(z[f"g_bf16.{k}"]) for k in GG.grad_keys(case))
     for k in GG.grad_keys(case) + GG.weight_grad_rows(case) + ["proprio.fc2.bias"]:
@@ -75,17 +98,19 @@ def test_one_block_head_tracks_the_reference_bf16_run(case):
     assert rdx <= 3e-2
 
 
+@pytest.mark.parametrize("ref_softmax", [False, True])
 @pytest.mark.parametrize("case", ["pro_d128_kt64", "pro_d128_kt64_train", "orig_d128_kt64", "pro_d896_kt256", "pro_d896_kt256_train",
                                   "pro_d896_kt512"])
-def test_full_head_within_the_reference_bf16_error_budget(case):
-    z, pred, grads, taps, dx = _run_native(case)
+def test_full_head_within_the_reference_bf16_error_budget(case, ref_softmax):
+    z, pred, grads, taps, dx = _run_native(case, ref_softmax)
     for j, i in enumerate(GG.block_taps(case)[:3]):
         r = rel(taps[i], z["xblk_bf16"][j])
-        print(f"{case}: block {i} output native-vs-reference-bf16 {r:.2e}")
+        nfl = (taps[i].float().cpu() != torch.as_tensor(z["xblk_bf16"][j]).float()).float().mean().item()
+        print(f"{case} ref_softmax={ref_softmax}: block {i} output native-vs-reference-bf16 {r:.2e} ({100 * nfl:.2f} % of its elements differ)")
         assert r <= 4e-3 * (i + 1)
     gap = rel(torch.as_tensor(z["out_bf16"]), z["out_fp32"])
     r_ref, r_truth = rel(pred, z["out_bf16"]), rel(pred, z["out_fp32"])
-    print(f"{case}: actions  native-vs-ref_bf16 {r_ref:.3e}  native-vs-ref_fp32 {r_truth:.3e}  ref_bf16-vs-ref_fp32 {gap:.3e}")
+    print(f"{case} ref_softmax={ref_softmax}: actions  native-vs-ref_bf16 {r_ref:.3e}  native-vs-ref_fp32 {r_truth:.3e}  ref_bf16-vs-ref_fp32 {gap:.3e}")
     # the actions are a 112-element tensor at the end of the chain: one realisation's distance fluctuates by ~ +-20 % around the
     # expected one (measured spread over the six cases: 0.67 .. 1.25 x the reference's own), hence 1.5 here; the large tensors
     # (hidden states, tests/test_engine_gpu.py) get the 1.25

@@ -264,63 +264,3 @@ def test_gemm_tn_grouped_equals_the_single_launches(ops, tn_tile):
     many = [ops.tn_problem(short, short, torch.empty(128, 128, device=DEV, dtype=BF)) for _ in range(ops.TN_GROUP_MAX + 5)]   # > one table
     ops.gemm_tn_grouped(many)
     assert all(torch.equal(p._keep[2], refs[-1]) for p in many)
-
-
-# ------------------------------------------------------------------ RMSNorm folded into the neighbouring GEMMs (ABI 4)
-@pytest.mark.parametrize("M,N,K", [(1024, 896, 1024), (2048, 1536, 896), (512, 256, 64)])
-def test_gemm256_rmsnorm_partials_producer(ops, M, N, K, monkeypatch):
-    """The producer side: a residual GEMM on the 256-row kernel also emits, per 256-column tile, the sum of squares of the bf16 rows it
-    stores - and stores exactly what the same launch stores without the extra output."""
-    monkeypatch.setenv("VLA_GEMM_TILE", "6")
-    a, w, bias, r = gen(M, K, seed=71).to(DEV), gen(N, K, seed=72, scale=0.05).to(DEV), gen(N, seed=73).to(DEV), gen(M, N, seed=74).to(DEV)
-    ref = ops.gemm_nt(a, w, bias=bias, residual=r, split_k=0)
-    ssq = torch.full(((N + 255) // 256, M), -1.0, device=DEV)
-    out = torch.empty(M, N, device=DEV, dtype=BF)
-    assert ops.gemm_nt(a, w, bias=bias, residual=r, out=out, ssq_out=ssq, query_256=True)
-    ops.gemm_nt(a, w, bias=bias, residual=r, out=out, ssq_out=ssq)
-    assert torch.equal(out, ref)
-    want = torch.stack([(out[:, c:c + 256].float() ** 2).sum(1) for c in range(0, N, 256)])
-    assert torch.allclose(ssq, want, rtol=2e-6, atol=0), (ssq - want).abs().max().item()
-
-
-@pytest.mark.parametrize("mode", ["plain", "rope", "swiglu"])
-@pytest.mark.parametrize("M,D", [(1024, 896), (2048, 1536)])
-def test_gemm256_rmsnorm_consumer(ops, M, D, mode, monkeypatch):
-    """The consumer side: y = epilogue(rstd[m] * (x . (W * w_norm)^T) + b) with rstd from the producer's partials - against the fp32
-    restatement rmsnorm -> Linear on the same bf16 x and the same folded bf16 weight (the normalised activations are never rounded to
-    bf16 here: the one rounding point this fusion moves, oracle.FOLD_RMSNORM)."""
-    monkeypatch.setenv("VLA_GEMM_TILE", "6")
-    eps = 1e-6
-    x = gen(M, D, seed=81).to(DEV)
-    parts = torch.stack([(x[:, c:c + 256].float() ** 2).sum(1) for c in range(0, D, 256)]).contiguous()
-    rstd_ref = torch.rsqrt((x.float() ** 2).mean(1) + eps)
-    rstd = torch.zeros(M, device=DEV)
-    if mode == "swiglu":
-        I = 1216
-        w = gen(2 * I, D, seed=82, scale=0.05).to(DEV)
-        _, h = ops.gemm_nt(x, w, act=ops.ACT_SWIGLU, want_pre=False, rownorm=(parts, eps, rstd))
-        y = (x.float() @ w.float().t()) * rstd_ref[:, None]
-        y3 = O.rnd(y.cpu(), True).view(M, I // 16, 2, 16)
-        g, u = y3[:, :, 0].reshape(M, I), y3[:, :, 1].reshape(M, I)
-        ref = O.rnd(O.rnd(g * torch.sigmoid(g), True) * u, True)
-        check(h, ref, name="rmsnorm-folded gate/up")
-    else:
-        N = 1152 if mode == "rope" else 1024
-        w, bias = gen(N, D, seed=83, scale=0.05).to(DEV), gen(N, seed=84).to(DEV)
-        y = (x.float() @ w.float().t()) * rstd_ref[:, None] + bias.float()
-        if mode == "rope":
-            T, Hq, Hkv, dh = 128, 14, 2, 64
-            cos, sin = ops.rope_half_tables(T, dh, 1e6, DEV)
-            out = ops.gemm_nt(x, w, bias=bias, rope=(1, cos, sin, T, dh, (Hq + Hkv) * dh), rownorm=(parts, eps, rstd))
-            base = ops.gemm_nt(x, w, bias=bias, rope=(1, cos, sin, T, dh, (Hq + Hkv) * dh))        # same epilogue on the un-normalised rows:
-            yb = O.rnd((x.float() @ w.float().t() + bias.float()).cpu(), True)                     # the rotation itself is checked elsewhere
-            assert out.shape == base.shape
-            # columns beyond the rotated ones are plain: compare those exactly against the restatement, the rotated ones through the norms
-            check(out[:, (Hq + Hkv) * dh:], O.rnd(y.cpu(), True)[:, (Hq + Hkv) * dh:], name="rmsnorm-folded q|k|v: v columns")
-            rot = out[:, :(Hq + Hkv) * dh].float().view(M, Hq + Hkv, dh)
-            want = O.rnd(y.cpu(), True)[:, :(Hq + Hkv) * dh].view(M, Hq + Hkv, dh)
-            assert torch.allclose(rot.norm(dim=-1).cpu(), want.norm(dim=-1), rtol=2e-2, atol=1e-2)  # a rotation keeps each head's norm
-        else:
-            out = ops.gemm_nt(x, w, bias=bias, rownorm=(parts, eps, rstd))
-            check(out, O.rnd(y.cpu(), True), name="rmsnorm-folded Linear")
-    assert torch.allclose(rstd, rstd_ref, rtol=2e-6, atol=0)

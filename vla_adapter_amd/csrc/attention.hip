@@ -26,6 +26,12 @@ struct AttnP {
   int q_off;    // query i sits at sequence position q_off + i (causal: key j visible iff j <= q_off + i)
   int dkv_k0;   // dK/dV are produced for keys >= dkv_k0 only and stored at row (key - dkv_k0)
   int lse_hs;   // head stride of lse (f32 [B, Hq, lse_hs], query i at index i)
+  // Causal launches, heavy blocks first: a query block of a causal attention walks (block index + 1) x 4 key tiles, a key tile of
+  // dK / dV is visited by every query behind it - the blocks of one (sample, head) differ 3 : 1 in work.  With the block index as
+  // the FASTEST grid dimension (x) light and heavy workgroups are dispatched alternately, the 1.3 rounds of the LLM's forward launch
+  // end with heavy stragglers that started late (makespan 15 tile-steps where 10 would do).  lpt = 1: the block index moves to the
+  // SLOWEST grid dimension (z), heaviest first; x carries the sample.  (hipcc dispatches x fastest, then y, then z.)
+  int lpt;
 };
 
 // Tile staging split in two (cdna_hip_programming.md T14): the global loads of tile t+1 are issued into registers
@@ -76,8 +82,8 @@ __global__ __launch_bounds__(256, (D <= 64 ? 4 : D <= 72 ? 3 : 2)) void attn_fwd
   __shared__ __attribute__((aligned(16))) bf16_t sV[32 * G::LD];
   __shared__ __attribute__((aligned(16))) bf16_t sO[4 * 32 * G::LD];     // per wave: the output tile as [query][d], for row-contiguous stores
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
-  const int hq = blockIdx.y, b = blockIdx.z, hkv = hq / (p.Hq / p.Hkv);
-  const int qblk = blockIdx.x * 128, q0 = qblk + w * 32;
+  const int hq = blockIdx.y, b = p.lpt ? blockIdx.x : blockIdx.z, hkv = hq / (p.Hq / p.Hkv);
+  const int qblk = (p.lpt ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.x) * 128, q0 = qblk + w * 32;
   const int qi = q0 + (lane & 31);
 
   lds_zero16(sK, 32 * G::LD * 2, tid, 256);   // pad columns stay zero
@@ -203,8 +209,8 @@ __global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void attn_bwd_dq_kernel(Att
   __shared__ __attribute__((aligned(16))) bf16_t sV[32 * G::LD];
   __shared__ __attribute__((aligned(16))) bf16_t sO[4 * 32 * G::LD];     // per wave: dQ as [query][d] for row-contiguous stores
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
-  const int hq = blockIdx.y, b = blockIdx.z, hkv = hq / (p.Hq / p.Hkv);
-  const int qblk = blockIdx.x * 128, q0 = qblk + w * 32;
+  const int hq = blockIdx.y, b = p.lpt ? blockIdx.x : blockIdx.z, hkv = hq / (p.Hq / p.Hkv);
+  const int qblk = (p.lpt ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.x) * 128, q0 = qblk + w * 32;
   const int qi = q0 + (lane & 31), qc = min(qi, p.Sq - 1);
   lds_zero16(sK, 32 * G::LD * 2, tid, 256);
   lds_zero16(sV, 32 * G::LD * 2, tid, 256);
@@ -334,8 +340,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
   const int hh = w % grp, kt = w / grp;
-  const int hkv = blockIdx.y, b = blockIdx.z, hq = hkv * grp + hh;
-  const int k0 = p.dkv_k0 + (blockIdx.x * KT + kt) * 32;
+  const int hkv = blockIdx.y, b = p.lpt ? blockIdx.x : blockIdx.z, hq = hkv * grp + hh;
+  const int kblk = p.lpt ? blockIdx.z : blockIdx.x;      // (causal: the first key tiles are the heavy ones - ascending IS heaviest first)
+  const int k0 = p.dkv_k0 + (kblk * KT + kt) * 32;
   const int ki = k0 + (lane & 31), kc = min(ki, p.Sk - 1);
   bf16_t* sQ = reinterpret_cast<bf16_t*>(smem + w * WAVE_BYTES);
   bf16_t* sdO = sQ + TILE;
@@ -440,7 +447,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int
       const int o_ss = pass == 0 ? p.dk_ss : p.dv_ss;
       for (int i = tid; i < KT * 32 * G::DV; i += blockDim.x) {
         const int kt2 = i / (32 * G::DV), rem = i - kt2 * (32 * G::DV), key = rem / G::DV, d = rem - key * G::DV;
-        const int kg = p.dkv_k0 + (blockIdx.x * KT + kt2) * 32 + key;
+        const int kg = p.dkv_k0 + (kblk * KT + kt2) * 32 + key;
         if (kg < p.Sk && d < D) {
           const float* src = reinterpret_cast<const float*>(smem) + (kt2 * grp) * (32 * ACC_LD) + key * ACC_LD + d;
           float sum = 0.f;
@@ -528,6 +535,7 @@ extern "C" int vla_attn_fwd(void* stream, const vla_attn_desc* d) {
   int rc = fill(p, d, false);
   if (rc) return rc;
   dim3 grid((p.Sq + 127) / 128, p.Hq, p.B);
+  if (p.causal && grid.x > 1 && grid.x <= 65535) { p.lpt = 1; grid = dim3(p.B, p.Hq, grid.x); }     // heavy query blocks first (AttnP::lpt)
   hipStream_t st = (hipStream_t)stream;
   switch (p.dh) {
     case 64: hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, st, p); break;
@@ -550,6 +558,11 @@ extern "C" int vla_attn_bwd(void* stream, const vla_attn_desc* d) {
   VLA_REQUIRE(grp <= 8, "attn_bwd: at most 8 query heads per kv head");
   const int KT = grp >= 4 ? 1 : 4 / grp;                   // waves per workgroup = grp * KT (4..8)
   dim3 gq((p.Sq + 127) / 128, p.Hq, p.B), gk((p.Sk - p.dkv_k0 + 32 * KT - 1) / (32 * KT), p.Hkv, p.B);
+  if (p.causal && gq.x <= 65535 && gk.x <= 65535 && (gq.x > 1 || gk.x > 1)) {      // heavy blocks first (AttnP::lpt): both kernels read the flag
+    p.lpt = 1;
+    gq = dim3(p.B, p.Hq, gq.x);
+    gk = dim3(p.B, p.Hkv, gk.x);
+  }
   const int ld = ((p.dh + 31) / 32 * 32 + 8);
   const size_t lds = (size_t)grp * KT * (2 * 32 * ld * 2 + 256);
   static bool attr_set = false;

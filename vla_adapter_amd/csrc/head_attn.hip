@@ -230,6 +230,7 @@ int fill(HP& p, const vla_head_attn_desc* d, bool bwd) {
   p.gate = (const bf16_t*)d->gate; p.out = (bf16_t*)d->out; p.probs = d->probs;
   p.B = d->B; p.T = d->T; p.Ka = d->Ka; p.Kt = d->Kt; p.H = d->H; p.dh = d->dh;
   p.ld_q = d->ld_q; p.ld_self = d->ld_self; p.ld_adp = d->ld_adp; p.ld_task = d->ld_task; p.ld_out = d->ld_out;
+  p.ref_softmax = d->ref_softmax;
   if (!bwd) {
     VLA_REQUIRE(d->out, "head_attn_fwd: null out");
   } else {

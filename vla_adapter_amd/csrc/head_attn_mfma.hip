@@ -246,6 +246,134 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void h
   }
 }
 
+// The same forward with the softmax weights rounded where ATen's bf16 softmax rounds them (HP::ref_softmax): the weights of a
+// bf16 module leave softmax as bf16(exp(s - max) / sum) - AFTER normalisation - so max and sum over all T + Ka + Kt keys must be
+// known before the first weight is formed.  Pass 1 walks the wave's key tiles for the statistics only (scores through the same
+// rounded chain), the four waves meet once in LDS for the global (max, sum) per query; pass 2 walks the tiles again, forms
+// P = bf16(exp(s - max) / sum) and accumulates O^T = V^T P^T; the waves' partial O are plain sums.  K is read twice (131 KB per
+// (sample, head) at 585 keys: L2); used by the reference-run fixture tests and by anyone who wants the head to track a bf16 PyTorch
+// run as closely as the GEMM summation order allows.  Natural-log domain for max / sum: s - max is then an exact bf16 difference.
+template <int D>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void head_fwd_mfma_ref(HP p) {
+  using G = HG<D>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, h = lane >> 5;
+  const int gid = blockIdx.x;                          // grid = B * H exactly
+  const int b = gid / p.H, hd = gid - b * p.H, hoff = hd * D, N = p.T + p.Ka + p.Kt;
+  bf16_t* sK = reinterpret_cast<bf16_t*>(smem + w * G::WAVE_BYTES);
+  bf16_t* sV = sK + G::TILE;
+  float* myml = reinterpret_cast<float*>(smem + w * G::WAVE_BYTES + 2 * G::TILE * 2);
+  lds_zero16(sK, 2 * G::TILE * 2, lane, 64);
+  const int qi = lane & 31, qc = min(qi, p.T - 1);
+  bf16x8 qf[G::KS];
+#pragma unroll
+  for (int ks = 0; ks < G::KS; ++ks)
+    qf[ks] = *reinterpret_cast<const bf16x8*>(p.q + ((long long)b * p.T + qc) * p.ld_q + hoff + 16 * ks + 8 * h);
+  const float tg = rbf(tanhf(bf2f(p.gate[0]))), rs = sqrtf((float)D);
+  constexpr float LN2 = 0.6931471805599453f, LOG2E = 1.4426950408889634f;
+  u32x4 rk[G::NCH], rv[G::NCH];
+  // ---- pass 1: max and sum of exp over this wave's tiles (natural units)
+  float m_run = -INFINITY, l_run = 0.f;
+  for (int n0 = 32 * w; n0 < N; n0 += 32 * HEAD_KV_WAVES) {
+    seg_prefetch_kv<D, false>(rk, rv, p, b, hoff, n0, N, lane);
+    tile_put<D>(rk, sK, lane);
+    wave_lds_sync();
+    f32x16 S = zero16();
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks)
+      S = mfma32(*reinterpret_cast<const bf16x8*>(sK + (lane & 31) * G::LD + 16 * ks + 8 * h), qf[ks], S);
+    float mt = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = n0 + acc_row(r, h);
+      S[r] = score_chain(S[r], key >= p.T + p.Ka, tg, rs, key < N) * LN2;      // (back to natural units; -inf stays -inf)
+      mt = fmaxf(mt, S[r]);
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    float rsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rsum += fexp2((S[r] - m_new) * LOG2E);
+    rsum += __shfl_xor(rsum, 32, 64);
+    l_run = l_run * fexp2((m_run - m_new) * LOG2E) + rsum;
+    m_run = m_new;
+    wave_lds_sync();
+  }
+  if (lane < 32) { myml[lane] = m_run; myml[32 + lane] = l_run; }
+  __syncthreads();
+  float M = -INFINITY, L = 0.f;
+#pragma unroll
+  for (int ww = 0; ww < HEAD_KV_WAVES; ++ww)
+    M = fmaxf(M, reinterpret_cast<const float*>(smem + ww * G::WAVE_BYTES + 2 * G::TILE * 2)[qi]);
+#pragma unroll
+  for (int ww = 0; ww < HEAD_KV_WAVES; ++ww) {
+    const float* oml = reinterpret_cast<const float*>(smem + ww * G::WAVE_BYTES + 2 * G::TILE * 2);
+    const float mw = oml[qi];
+    L += mw == -INFINITY ? 0.f : oml[32 + qi] * fexp2((mw - M) * LOG2E);       // (a wave without tiles carries m = -inf, l = 0)
+  }
+  // ---- pass 2: P = bf16(exp(s - M) / L), O^T += V^T P^T
+  f32x16 O[G::DT];
+#pragma unroll
+  for (int t = 0; t < G::DT; ++t) O[t] = zero16();
+  for (int n0 = 32 * w; n0 < N; n0 += 32 * HEAD_KV_WAVES) {
+    seg_prefetch_kv<D, false>(rk, rv, p, b, hoff, n0, N, lane);
+    tile_put<D>(rk, sK, lane);
+    tile_put<D>(rv, sV, lane);
+    wave_lds_sync();
+    f32x16 S = zero16();
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks)
+      S = mfma32(*reinterpret_cast<const bf16x8*>(sK + (lane & 31) * G::LD + 16 * ks + 8 * h), qf[ks], S);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = n0 + acc_row(r, h);
+      const float s = score_chain(S[r], key >= p.T + p.Ka, tg, rs, key < N) * LN2;
+      S[r] = fexp2((s - M) * LOG2E) / L;           // (pack_acc rounds to bf16: the weight ATen's softmax emits; padded keys: 0)
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bf16x8 pf = pack_acc(S, s);
+#pragma unroll
+      for (int t = 0; t < G::DT; ++t) O[t] = mfma32(tr_frag(sV, G::LD, s, 32 * t, lane), pf, O[t]);
+    }
+    wave_lds_sync();
+  }
+  __syncthreads();                                  // every wave is done with its tiles: the regions now carry the partial O
+  {
+    float* myO = reinterpret_cast<float*>(smem + w * G::WAVE_BYTES);
+    if (w > 0) {
+#pragma unroll
+      for (int t = 0; t < G::DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) myO[(t * 16 + r) * 64 + lane] = O[t][r];
+    }
+    __syncthreads();
+    if (w > 0) return;
+#pragma nounroll
+    for (int ww = 1; ww < HEAD_KV_WAVES; ++ww) {
+      const float* oO = reinterpret_cast<const float*>(smem + ww * G::WAVE_BYTES);
+#pragma unroll
+      for (int t = 0; t < G::DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[t][r] += oO[(t * 16 + r) * 64 + lane];
+    }
+  }
+  if (qi < p.T) {
+    bf16_t* op = p.out + ((long long)b * p.T + qi) * p.ld_out + hoff;
+#pragma unroll
+    for (int t = 0; t < G::DT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * t + 8 * g + 4 * h;
+        if (d < D) {
+          uint2 o = {pack2(O[t][4 * g], O[t][4 * g + 1]), pack2(O[t][4 * g + 2], O[t][4 * g + 3])};
+          *reinterpret_cast<uint2*>(op + d) = o;
+        }
+      }
+    if (h == 0) p.probs[(long long)gid * p.T * N + qi] = M + logf(L);   // LSE slot (the backward rebuilds fp32 weights from it)
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ dQ (+ gate gradient)
 template <int D>
 __device__ __forceinline__ void head_dq_body(const HP& p, const int blk, char* smem) {
@@ -706,7 +834,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void h
 template <int D>
 void launch_fwd(const HP& p, hipStream_t st) {
   const size_t lds = 4 * HG<D>::WAVE_BYTES;
-  hipLaunchKernelGGL(head_fwd_mfma<D>, dim3(p.B * p.H), dim3(256), lds, st, p);
+  if (p.ref_softmax) hipLaunchKernelGGL(head_fwd_mfma_ref<D>, dim3(p.B * p.H), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL(head_fwd_mfma<D>, dim3(p.B * p.H), dim3(256), lds, st, p);
 }
 template <int D>
 void launch_bwd(const HP& p, hipStream_t st) {
@@ -726,6 +855,7 @@ void launch_bwd(const HP& p, hipStream_t st) {
 template <int D>
 void set_attrs() {
   (void)hipFuncSetAttribute((const void*)head_fwd_mfma<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * HG<D>::WAVE_BYTES);
+  (void)hipFuncSetAttribute((const void*)head_fwd_mfma_ref<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * HG<D>::WAVE_BYTES);
   (void)hipFuncSetAttribute((const void*)head_bwd_mfma<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * HG<D>::WAVE_BYTES);
   (void)hipFuncSetAttribute((const void*)head_bwd_tiles<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 33 * HG<D>::LD + 256 + 4 * HG<D>::TILE * 2);
 }

@@ -9,6 +9,7 @@ struct HP {
   const bf16_t* dout; bf16_t* dq; bf16_t* dks; bf16_t* dvs; bf16_t* dka; bf16_t* dva; bf16_t* dkt; bf16_t* dvt; float* dgate;
   const float* rope_cos; const float* rope_sin;   // optional [>= max(T,Ka,Kt), dh]: fold the RoPE transpose into dq / dk
   float* ws; long long ws_floats;                 // optional backward workspace (tile-uniform MFMA backward: dQ / gate partials)
+  int ref_softmax;                                // forward: bf16 weights rounded after normalisation (two passes), as ATen's bf16 softmax
 };
 
 bool head_attn_mfma_supported(const HP& p);

@@ -552,6 +552,10 @@ class Head:
         self.dirty = True
         self._key = None
         self.rope_tab = None     # f32 [max(T, Ka, Kt), dh] cos/sin tables (positions restart per segment: one table serves all)
+        # attention weights rounded to bf16 AFTER normalisation, as the reference's bf16 softmax emits them (action_heads.py:397): a second
+        # pass over the keys (vla_head_attn_desc.ref_softmax).  Off by default: +N us per block on a chain the step's turn-around waits
+        # for; the reference-run fixture tests switch it on (tests/test_head_fixture_gpu.py prints both distances)
+        self.ref_softmax = bool(int(os.environ.get("VLA_HEAD_REF_SOFTMAX", "0")))
 
     # ---- reference state-dict interop (file names / keys: finetune.py:527-572) -------------------------
     _BLK_PRO = [("q_proj", "w_x", "b_x", 0), ("k_self", "w_x", "b_x", 1), ("v_self", "w_x", "b_x", 2),
@@ -783,6 +787,7 @@ class Head:
         out = self.AOx[i].view(B, T, D)
         if fwd:
             d = ops.head_attn_desc(*args, gate, self.probs[i], out, H)
+            d.ref_softmax = int(self.ref_softmax)
             ops.N.check(ops._lib().vla_head_attn_fwd(ops._st(), C.byref(d)), "head_attn_fwd")
         else:
             g = self.dQKVx[i].view(B, T, 3 * D)

@@ -68,7 +68,7 @@ class HeadAttnDesc(C.Structure):
                 ("dout", C.c_void_p), ("dq", C.c_void_p), ("dk_self", C.c_void_p), ("dv_self", C.c_void_p),
                 ("dk_adp", C.c_void_p), ("dv_adp", C.c_void_p), ("dk_task", C.c_void_p), ("dv_task", C.c_void_p),
                 ("dgate", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
-                ("ws", C.c_void_p), ("ws_floats", C.c_longlong)]
+                ("ws", C.c_void_p), ("ws_floats", C.c_longlong), ("ref_softmax", C.c_int)]
 
 
 _P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double

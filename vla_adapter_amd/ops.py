@@ -606,8 +606,9 @@ def head_attn_desc(q, ks, vs, ka, va, kt, vt, gate, probs, out, H: int):
     return d
 
 
-def head_attn_fwd(q, ks, vs, ka, va, kt, vt, gate, H: int = 8):
-    """q/ks/vs [B,T,D*], ka/va [B,Ka,D*], kt/vt [B,Kt,D*] (views, last stride 1) -> out [B,T,D], probs f32."""
+def head_attn_fwd(q, ks, vs, ka, va, kt, vt, gate, H: int = 8, ref_softmax: bool = False):
+    """q/ks/vs [B,T,D*], ka/va [B,Ka,D*], kt/vt [B,Kt,D*] (views, last stride 1) -> out [B,T,D], probs f32.
+    ref_softmax: weights rounded to bf16 after normalisation, as ATen's bf16 softmax emits them (two passes over the keys)."""
     _chk_bf16(q, ks, vs, ka, va, kt, vt, gate)
     B, T = q.shape[:2]
     D = q.shape[-1]
@@ -615,6 +616,7 @@ def head_attn_fwd(q, ks, vs, ka, va, kt, vt, gate, H: int = 8):
     out = torch.empty(B, T, D, device=q.device, dtype=BF16)
     probs = torch.empty(B, H, T, Nn, device=q.device, dtype=torch.float32)
     d = head_attn_desc(q, ks, vs, ka, va, kt, vt, gate, probs, out, H)
+    d.ref_softmax = int(ref_softmax)
     N.check(_lib().vla_head_attn_fwd(_st(), C.byref(d)), "head_attn_fwd")
     return out, probs
 
