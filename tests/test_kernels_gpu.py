@@ -956,13 +956,10 @@ def _both_tiles(monkeypatch, fn):
     return out, ref
 
 
-@pytest.mark.parametrize("rows", ["256", "192"])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (256, 256, 192), (512, 768, 320), (1300, 900, 896), (5632, 1152, 1152),
-                                   (2048, 1000, 4864), (300, 77, 448), (11264, 1792, 896), (192, 256, 64), (11264, 896, 896), (400, 264, 256)])
+                                   (2048, 1000, 4864), (300, 77, 448), (11264, 1792, 896)])
 @pytest.mark.parametrize("act", [0, 1, 2])
-def test_gemm256_bit_identical_to_128_tiles(ops, rows, M, N, K, act, monkeypatch):
-    """rows: the 256-row tile, or its 192-row form (three m tiles per quadrant: sub-round launches - LLM down / o-proj, ViT proj / fc2)."""
-    monkeypatch.setenv("VLA_GEMM256_ROWS", rows)
+def test_gemm256_bit_identical_to_128_tiles(ops, M, N, K, act, monkeypatch):
     a, b, bias, r = gen(M, K, seed=201).to(DEV), gen(N, K, seed=202, scale=0.05).to(DEV), gen(N, seed=203).to(DEV), gen(M, N, seed=204).to(DEV)
     out, ref = _both_tiles(monkeypatch, lambda: ops.gemm_nt(a, b, bias=bias, residual=r if act != 1 else None, act=act, split_k=0))
     assert torch.equal(out, ref), f"gemm256 {M}x{N}x{K} act {act}: {(out.float() - ref.float()).abs().max().item()}"
@@ -972,14 +969,12 @@ def test_gemm256_bit_identical_to_128_tiles(ops, rows, M, N, K, act, monkeypatch
         check(out, O.rnd(y + f(r), True) if act != 1 else y, name=f"gemm256 vs oracle {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("rows", ["256", "192"])
 @pytest.mark.parametrize("M,N,K", [(2048, 1024, 64), (2048, 1024, 128), (2048, 1024, 192), (2048, 1024, 256), (4096, 2304, 896), (8192, 1152, 4352)])
-def test_gemm256_race_screen(ops, rows, M, N, K, monkeypatch):
+def test_gemm256_race_screen(ops, M, N, K, monkeypatch):
     """The two-phase K loop is a sync structure of its own (segment-counted WAR / RAW distances, hand-counted vmcnt): screened by
     repetition - every tile of 25 launches, run while a second stream keeps the memory system busy (the LDS-DMA's landing time
     moves with the load), must equal the 128-row kernel's result bit for bit, with and without a residual; K = 64 ... 256 are the
     one- to four-K-tile prologue / tail cases of the counted waits."""
-    monkeypatch.setenv("VLA_GEMM256_ROWS", rows)
     a, b, bias, r = gen(M, K, seed=221).to(DEV), gen(N, K, seed=222, scale=0.05).to(DEV), gen(N, seed=223).to(DEV), gen(M, N, seed=224).to(DEV)
     junk, side = torch.empty(64 << 20, dtype=torch.uint8, device=DEV), torch.cuda.Stream()
     for res in (None, r):

@@ -558,17 +558,7 @@ void gemm_nt_kernel(GemmP p) {                                   //  workgroups 
 struct TileChoice { int bm, bn; };
 // When the 256 x 256 8-phase kernel (one workgroup per CU) is chosen automatically: problems with at least a chip-full of
 // its tiles' worth of work in both dimensions.  VLA_GEMM_TILE=6 forces it, VLA_NO_GEMM256 disables it.
-// Rows of the 256-column tile: 256, or 192 where that is faster by the rounds model (a launch runs for rounds x tile time; a 192-row
-// tile is 3/4 of a 256-row tile's K loop): sub-round launches - LLM down / o-proj (176 tiles of 256 rows on 256 CUs -> 236 of 192),
-// ViT proj / fc2 (160 -> 215).  Plain epilogues only (gemm256.hip MH = 3).  VLA_GEMM256_ROWS = 192 / 256 forces (tests, A/B).
-inline int rows_256(int M, int N, int batch, int act, int rope_mode, int fp8) {
-  if (act == VLA_ACT_SWIGLU || act == VLA_ACT_SWIGLU_BWD || rope_mode != 0 || fp8) return 256;
-  if (const char* e = getenv("VLA_GEMM256_ROWS")) return atoi(e) == 192 ? 192 : 256;
-  const int ncu = vla_num_cus();
-  const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256) * batch, t192 = (long long)((M + 191) / 192) * ((N + 255) / 256) * batch;
-  return ((t192 + ncu - 1) / ncu) * 3 < ((t256 + ncu - 1) / ncu) * 4 ? 192 : 256;
-}
-inline bool use_256(int M, int N, int K, int batch, int act, int rope_mode = 0, int fp8 = 0) {
+inline bool use_256(int M, int N, int K, int batch, int act) {
   static const bool off = getenv("VLA_NO_GEMM256") != nullptr;
   if (off) return false;
   const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256) * batch;
@@ -588,8 +578,7 @@ inline bool use_256(int M, int N, int K, int batch, int act, int rope_mode = 0, 
   // the round-2 threshold (>= 96 tiles) sent two shapes the wrong way: LLM q|k|v 5632 x 1152 (110 tiles = 0.43 round: 25.2 vs
   // 17.3 us) and ViT fc1 / dX fc2 4096 x 4352 (272 tiles = 1.06 rounds: 58.3 vs 47.8 us).
   const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * batch;
-  const long long t192 = (long long)((M + 191) / 192) * ((N + 255) / 256) * batch;
-  const double est256 = rows_256(M, N, batch, act, rope_mode, fp8) == 192 ? (double)((t192 + ncu - 1) / ncu) * 3.0 : (double)((tiles + ncu - 1) / ncu) * 4.0, est128 = (double)((t128 + 2 * ncu - 1) / (2 * ncu)) * (2.0 / 0.87);
+  const double est256 = (double)((tiles + ncu - 1) / ncu) * 4.0, est128 = (double)((t128 + 2 * ncu - 1) / (2 * ncu)) * (2.0 / 0.87);
   return M >= 1024 && N >= 768 && K >= 256 && est256 < est128;
 }
 inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode, int batch = 1, int split = 1, int act = 0) {
@@ -601,7 +590,7 @@ inline TileChoice choose_tile(int M, int N, int K, int force, int rope_mode, int
   if (split == 1) {     // (both RoPE conventions are fused in both kernels)
     if (force == 6) return {256, 257};   // 256 x 256 two-phase kernel (gemm256.hip)
     const long long t256 = (long long)((M + 255) / 256) * ((N + 255) / 256) * batch;
-    if (force == 0 && (rope_mode == 0 || (!no_rope256 && t256 >= 192)) && use_256(M, N, K, batch, act, rope_mode)) return {256, 257};
+    if (force == 0 && (rope_mode == 0 || (!no_rope256 && t256 >= 192)) && use_256(M, N, K, batch, act)) return {256, 257};
   }
   if (rope_mode == 1) return {128, 128};   // rotate_half: 8 waves, each owning 16 columns of both halves of one head
   if (force == 2) return {128, 128};
@@ -745,7 +734,6 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   p.ldc2 = d->ldc2; p.res_mod = d->res_mod; p.act = d->act;
   p.sA = d->sA; p.sB = d->sB; p.sC = d->sC; p.sR = d->sR; p.sC2 = d->sC2; p.sBias = d->sBias;
   p.tiles_n = p.ntiles = 0; p.batch = 1; p.stagger = 0;
-  p.tile_rows = rows_256(d->M, d->N, d->batch, d->act, d->rope_mode, d->fp8);
   p.alpha = d->alpha == 0.f ? 1.f : d->alpha;
   p.gA = d->a_group; p.sgA = d->a_group_stride; p.gC = d->c_group; p.sgC = d->c_group_stride;
   p.gR = d->r_group; p.sgR = d->r_group_stride;

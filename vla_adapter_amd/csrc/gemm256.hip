@@ -67,13 +67,13 @@ __device__ __forceinline__ void glds16s(const char* base, unsigned voff, unsigne
   do {                                                                                                                                \
     if constexpr (F8) {                                                                                                               \
       _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                                                \
-        _Pragma("unroll") for (int mi = 0; mi < MH; ++mi)                                                                             \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                                              \
           Q[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(cat8(FB[ni][0], FB[ni][1]), cat8(FA[mi][0], FA[mi][1]), Q[ni][mi], \
                                                                        0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);                            \
     } else {                                                                                                                          \
       _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                                   \
         _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                                              \
-          _Pragma("unroll") for (int mi = 0; mi < MH; ++mi)                                                                           \
+          _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                                            \
             Q[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[ni][s], FA[mi][s], Q[ni][mi], 0, 0, 0);                            \
     }                                                                                                                                 \
   } while (0)
@@ -96,20 +96,12 @@ __device__ __forceinline__ v8i_f8 cat8(bf16x8 lo, bf16x8 hi) {          // two 1
 // F8: OCP e4m3 operands with per-row fp32 scales (gemm.hip's fp8 form, same conventions): a K-tile stays 128 B per row = 128
 // elements = ONE v_mfma_scale_f32_16x16x128_f8f6f4 per 16 x 16 tile instead of two bf16 MFMAs - identical staging, LDS image and
 // barrier structure, half the K-tiles per product.  The scales are applied to the accumulators at the start of the epilogue.
-// MH: 16-row m tiles per A half-tile.  4 = the 256-row tile.  3 = a 192-ROW tile (wave tile 96 x 64, quadrants 48 x 32, 12 MFMAs each) for
-// launches that fill LESS than one round of 256-row tiles: a sub-round launch runs for one tile's K loop however few tiles it has, so
-// 176 tiles on 256 CUs (LLM down / o-proj: 44 x 3.5) waste a third of the chip - as 59 x 4 = 236 tiles of 192 rows the same product
-// needs 3/4 of the K-loop time on 92 % of the CUs.  Same LDS image (an A half-tile slot holds 96 rows instead of 128), same DMA
-// schedule and hand-counted waits: every wave still issues two 8-row pieces per A half-tile (the 4 waves of a row group cover the 6
-// pieces of 48 rows; the last wave repeats pieces 4 and 5 - identical bytes to identical addresses), plain epilogues only.
-template <int EPI, bool F8 = false, bool RES = true, bool R2 = false, int MH = 4>
+template <int EPI, bool F8 = false, bool RES = true, bool R2 = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int EB = F8 ? 1 : 2;      // bytes per operand element
   constexpr bool HAS_RES = EPI == 0 && RES;   // residual segments are requested (always all sixteen: see below) only by launches that add one
   constexpr bool PRE = EPI != 2;      // next tile's K-tile 0 in flight during the epilogue (SwiGLU backward stages wider rows)
-  constexpr int HR = 16 * MH, TM = 4 * HR;      // rows of one (wave row, half) = one quadrant's height; rows of the tile
-  static_assert(MH == 4 || (MH == 3 && EPI == 0 && !R2), "the 192-row form: plain epilogues");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;
@@ -148,7 +140,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
     const int pgb = GM * bc;
     const int grp = tl / pgb, rem = tl - grp * pgb;
     const int gmr = min(GM, br - grp * GM);
-    m0 = (grp * GM + rem % gmr) * TM;
+    m0 = (grp * GM + rem % gmr) * 256;
     n0 = (rem / gmr) * 256;
     Ab = reinterpret_cast<const char*>(p.A) + (long long)z * p.sA * EB;
     Bb = reinterpret_cast<const char*>(p.B) + (long long)z * p.sB * EB;
@@ -156,21 +148,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        int pj = (wid & 3) * 2 + j;                      // 8-row piece of the (wave row, half)'s HR rows
-        if (MH == 3 && pj >= 6) pj -= 2;                 // (48 rows = 6 pieces: the fourth wave repeats pieces 4, 5)
-        const int ra = min(m0 + wr * 2 * HR + h * HR + pj * 8 + lrow, p.M - 1);
+        const int ra = min(m0 + wr * 128 + h * 64 + (wid & 3) * 16 + j * 8 + lrow, p.M - 1);
         oa[h][j] = (unsigned)((gA > 0 ? (long long)(ra / gA) * p.sgA + (long long)(ra % gA) * p.lda : (long long)ra * p.lda) * EB + kc);
         const int rb = min(n0 + (wid >> 1) * 64 + h * 32 + (wid & 1) * 16 + j * 8 + lrow, p.N - 1);
         ob[h][j] = (unsigned)((long long)rb * p.ldb * EB + kc);
       }
   };
   const unsigned wdst = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem) + wid * 2048;
-  // A pieces land at LDS row wr * HR + 8 * piece of their half-tile slot (MH = 4: rows 16 wid, 16 wid + 8 - the same as wdst)
-  const unsigned adst0 = MH == 4 ? wdst : (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem) + (wr * HR + (wid & 3) * 16 - ((wid & 3) == 3 ? 16 : 0)) * 128;
   // half-tile kinds inside a K-tile buffer: 0 = B0, 1 = A0, 2 = B1, 3 = A1 (the order of first use)
   auto stage_a = [&](int slot, int h, int k0) {
-    glds16s(Ab + k0 * 2, oa[h][0], adst0 + slot * HT);
-    glds16s(Ab + k0 * 2, oa[h][1], adst0 + slot * HT + 1024);
+    glds16s(Ab + k0 * 2, oa[h][0], wdst + slot * HT);
+    glds16s(Ab + k0 * 2, oa[h][1], wdst + slot * HT + 1024);
   };
   auto stage_b = [&](int slot, int h, int k0) {
     glds16s(Bb + k0 * 2, ob[h][0], wdst + slot * HT);
@@ -206,7 +194,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
 
   const int nt = p.K / (F8 ? 2 * BK : BK);      // K-tiles of 128 B per row
 
-  const int aoff = wr * HR * 128, boff = wc * 32 * 128;
+  const int aoff = wr * 64 * 128, boff = wc * 32 * 128;
 
   int cur = rstart(xcd) + (bid >> 3);
   // Free de-phasing: when the last round of the walk is partial, the workgroups that walk one tile fewer would finish a tile early;
@@ -243,7 +231,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
     const int fo1 = (fl & 15) * 128 + ((((F8 ? 2 * (fl >> 4) + 1 : 4 + (fl >> 4))) ^ (fl & 7)) << 4);
     if (wr == 1) VLA_BARRIER();      // stagger: the wr = 1 waves run one segment behind
 
-    f32x4 acc[2][2][2][MH];          // [mh][nh][ni][mi]
+    f32x4 acc[2][2][2][4];           // [mh][nh][ni][mi]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -251,9 +239,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-          for (int e = 0; e < MH; ++e) acc[a][b][c][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int e = 0; e < 4; ++e) acc[a][b][c][e] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    bf16x8 fa[MH][2], fb0[2][2], fb1[2][2];
+    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
     for (int t = 0; t < nt; ++t) {
       const char* kb = smem + d * 4 * HT;
       const int so = d * 4, sn = (d ^ 1) * 4;
@@ -267,7 +255,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
         }
         const char* sa = kb + 1 * HT + aoff;
 #pragma unroll
-        for (int mi = 0; mi < MH; ++mi) {
+        for (int mi = 0; mi < 4; ++mi) {
           fa[mi][0] = *reinterpret_cast<const bf16x8*>(sa + mi * 2048 + fo0);
           fa[mi][1] = *reinterpret_cast<const bf16x8*>(sa + mi * 2048 + fo1);
         }
@@ -296,7 +284,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
       {
         const char* sa = kb + 3 * HT + aoff;
 #pragma unroll
-        for (int mi = 0; mi < MH; ++mi) {
+        for (int mi = 0; mi < 4; ++mi) {
           fa[mi][0] = *reinterpret_cast<const bf16x8*>(sa + mi * 2048 + fo0);
           fa[mi][1] = *reinterpret_cast<const bf16x8*>(sa + mi * 2048 + fo1);
         }
@@ -341,8 +329,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-          for (int mi = 0; mi < MH; ++mi) {
-            const float sav = p.scaleA[min(em0 + wr * 2 * HR + mh * HR + mi * 16 + lr, p.M - 1)];
+          for (int mi = 0; mi < 4; ++mi) {
+            const float sav = p.scaleA[min(em0 + wr * 128 + mh * 64 + mi * 16 + lr, p.M - 1)];
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[mh][t4 >> 1][t4 & 1][mi][j] *= sav * sbv[j];
           }
@@ -375,9 +363,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
     bool skip[2], inside[2], fastm[2];
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh) {
-      const int wm0 = em0 + wr * 2 * HR + mh * HR;
+      const int wm0 = em0 + wr * 128 + mh * 64;
       skip[mh] = wm0 >= p.M || wn0 >= p.N;          // nothing of this half exists (N = 3.5 tiles: half the waves of the last column)
-      inside[mh] = wm0 + HR <= p.M && wn0 + 64 <= p.N;
+      inside[mh] = wm0 + 64 <= p.M && wn0 + 64 <= p.N;
       fastm[mh] = EPI != 2 && (plain_rows || live_rows) && vec_ok && inside[mh] && !skip[mh];
     }
     // Residual segments (plain epilogue): ALWAYS sixteen loads per lane, in two straight-line groups, read on every path - a
@@ -385,7 +373,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
     // compiler a pending register to protect with vmcnt(0) wherever it reuses it.  A half that takes the general path, or a
     // GEMM without residual, reads the head of B instead and ignores it.
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 rv[2][2 * MH];
+    u32x4 rv[2][8];
     int fres0 = 0, fres1 = 0;
     const char* rsrc = nullptr;
     if constexpr (HAS_RES) {
@@ -398,25 +386,24 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
     auto load_res = [&](int mh, int it0, int it1) {
 #pragma unroll
       for (int it = it0; it < it1; ++it) {
-        const long long off = ((long long)(em0 + wr * 2 * HR + mh * HR + it * 8 + (el >> 3)) * p.ldr + wn0 + (el & 7) * 8) * 2;
+        const long long off = ((long long)(em0 + wr * 128 + mh * 64 + it * 8 + (el >> 3)) * p.ldr + wn0 + (el & 7) * 8) * 2;
         rv[mh][it] = *reinterpret_cast<const u32x4*>(rsrc + ((mh == 0 ? fres0 : fres1) ? off : 0));
       }
     };
     auto drop_res = [&](int mh) {          // a path that does not add the residual still reads the registers (see above)
-      if constexpr (MH == 4) asm volatile("" ::"v"(rv[mh][0]), "v"(rv[mh][1]), "v"(rv[mh][2]), "v"(rv[mh][3]), "v"(rv[mh][4]), "v"(rv[mh][5]), "v"(rv[mh][6]),
-                                          "v"(rv[mh][7]));
-      else asm volatile("" ::"v"(rv[mh][0]), "v"(rv[mh][1]), "v"(rv[mh][2]), "v"(rv[mh][3]), "v"(rv[mh][4]), "v"(rv[mh][5]));
+      asm volatile("" ::"v"(rv[mh][0]), "v"(rv[mh][1]), "v"(rv[mh][2]), "v"(rv[mh][3]), "v"(rv[mh][4]), "v"(rv[mh][5]), "v"(rv[mh][6]),
+                   "v"(rv[mh][7]));
     };
     // next tile: its K-tile 0 goes out now
     if (PRE && nxt >= 0) { setup(nxt); stage_k0(d); }
     char* const reg = PRE ? smem + (d ^ 1) * 4 * HT + wid * STG : smem + wid * STG;
-    if constexpr (HAS_RES) load_res(0, 0, MH); // the first segments: in flight under the activation math (16 registers: all 32
+    if constexpr (HAS_RES) load_res(0, 0, 4); // the first segments: in flight under the activation math (16 registers: all 32
                                                // of the half do not fit beside 128 accumulators)
 
     if constexpr (EPI == 2) {
 #pragma unroll
       for (int mh = 0; mh < 2; ++mh) {
-        const int wm0 = em0 + wr * 2 * HR + mh * HR;
+        const int wm0 = em0 + wr * 128 + mh * 64;
         auto A4 = [&](int t4, int mi) -> f32x4& { return acc[mh][t4 >> 1][t4 & 1][mi]; };
         // SwiGLU backward fused into dH = dY . W_down (accumulator = dH of this 64 x 64 patch): read the matching interleaved
           // pre-activations GU[m, 2N], emit dGU in the same layout; dH itself is never stored.
@@ -468,8 +455,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
 
       // ---- phase A: alpha / bias / activation on all 128 values of the lane, rounded and packed.  The fp32 accumulators end
       //      here: what the stores below carry is half the registers, and the residual segments fit beside it.
-      uint2 pk[2][4][MH];         // [mh][t4 = 2 nh + ni][mi]: columns t4*16 + lq*4 .. +3 of row mi*16 + lr
-      uint2 hp[2][2][MH];         // SwiGLU forward: the products h
+      uint2 pk[2][4][4];          // [mh][t4 = 2 nh + ni][mi]: columns t4*16 + lq*4 .. +3 of row mi*16 + lr
+      uint2 hp[2][2][4];          // SwiGLU forward: the products h
       if constexpr (EPI == 1) {
         // columns interleaved in 16s - even n tiles are gate, odd n tiles the matching up columns
         // (Qwen2's gate / up projections carry no bias and alpha is 1: the wave-uniform `plain` spares two FMAs per pair)
@@ -479,7 +466,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
 #pragma unroll
           for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
-            for (int mi = 0; mi < MH; ++mi) {
+            for (int mi = 0; mi < 4; ++mi) {
               f32x4 ga = acc[mh][pr][0][mi], ua = acc[mh][pr][1][mi];
               if (!plain) {
 #pragma unroll
@@ -503,7 +490,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
 #pragma unroll
             for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
-              for (int mi = 0; mi < MH; ++mi) {
+              for (int mi = 0; mi < 4; ++mi) {
                 const f32x4 a = acc[mh][t4 >> 1][t4 & 1][mi];
                 float x[4];
 #pragma unroll
@@ -521,8 +508,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
 #pragma unroll
           for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-            for (int mi = 0; mi < MH; ++mi) {
-              const int pos = min(em0 + wr * 2 * HR + mh * HR + mi * 16 + lr, p.M - 1) % p.rope_T;
+            for (int mi = 0; mi < 4; ++mi) {
+              const int pos = min(em0 + wr * 128 + mh * 64 + mi * 16 + lr, p.M - 1) % p.rope_T;
 #pragma unroll
               for (int ni = 0; ni < 2; ++ni) {
                 const int d = ni * 16 + lq * 4;
@@ -552,8 +539,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
 #pragma unroll
           for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-            for (int mi = 0; mi < MH; ++mi) {
-              const int pos = min(em0 + wr * 2 * HR + mh * HR + mi * 16 + lr, p.M - 1) % p.rope_T;
+            for (int mi = 0; mi < 4; ++mi) {
+              const int pos = min(em0 + wr * 128 + mh * 64 + mi * 16 + lr, p.M - 1) % p.rope_T;
 #pragma unroll
               for (int t4 = 0; t4 < 4; ++t4) {
                 const int d = (wn0 + t4 * 16 + lq * 4) % p.rope_dh;
@@ -589,21 +576,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
       for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4)
-          if constexpr (MH == 4)
-            asm volatile("" : "+v"(pk[mh][t4][0].x), "+v"(pk[mh][t4][0].y), "+v"(pk[mh][t4][1].x), "+v"(pk[mh][t4][1].y),
-                              "+v"(pk[mh][t4][2].x), "+v"(pk[mh][t4][2].y), "+v"(pk[mh][t4][3].x), "+v"(pk[mh][t4][3].y));
-          else
-            asm volatile("" : "+v"(pk[mh][t4][0].x), "+v"(pk[mh][t4][0].y), "+v"(pk[mh][t4][1].x), "+v"(pk[mh][t4][1].y),
-                              "+v"(pk[mh][t4][2].x), "+v"(pk[mh][t4][2].y));
+          asm volatile("" : "+v"(pk[mh][t4][0].x), "+v"(pk[mh][t4][0].y), "+v"(pk[mh][t4][1].x), "+v"(pk[mh][t4][1].y),
+                            "+v"(pk[mh][t4][2].x), "+v"(pk[mh][t4][2].y), "+v"(pk[mh][t4][3].x), "+v"(pk[mh][t4][3].y));
       asm volatile("" : "+v"(el));
       // ---- phase B: per 64 x 64 half, through the wave's staging region, 16-B stores of whole row segments.  The common case
       //      - the half entirely inside C, 16-B aligned rows, plain row addressing - runs without a branch and with all its
       //      residual segments requested up front (in the general path every conditional load is followed by its own
       //      vmcnt(0): 16 serial round trips per tile).
-      if constexpr (HAS_RES) { load_res(0, MH, 2 * MH); load_res(1, 0, 2 * MH); }     // the rest: behind the first stores
+      if constexpr (HAS_RES) { load_res(0, 4, 8); load_res(1, 0, 8); }     // the rest: behind the first stores
 #pragma unroll
       for (int mh = 0; mh < 2; ++mh) {
-        const int wm0 = em0 + wr * 2 * HR + mh * HR;
+        const int wm0 = em0 + wr * 128 + mh * 64;
         if (skip[mh]) {
           if constexpr (HAS_RES) drop_res(mh);
           continue;
@@ -615,15 +598,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
 #pragma unroll
           for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
-            for (int mi = 0; mi < MH; ++mi)
+            for (int mi = 0; mi < 4; ++mi)
               *reinterpret_cast<uint2*>(reg + (mi * 16 + lr) * HSTR + (pr * 16 + lq * 4) * 2) = hp[mh][pr][mi];
           const bool hvec = ((p.ldc2 & 7) == 0) && (((size_t)C2 & 15) == 0);
-          uint4 hv[MH];
+          uint4 hv[4];
 #pragma unroll
-          for (int it = 0; it < MH; ++it) hv[it] = *reinterpret_cast<const uint4*>(reg + (it * 16 + (el >> 2)) * HSTR + (el & 3) * 16);
+          for (int it = 0; it < 4; ++it) hv[it] = *reinterpret_cast<const uint4*>(reg + (it * 16 + (el >> 2)) * HSTR + (el & 3) * 16);
           __builtin_amdgcn_sched_barrier(0);                      // (the four staged segments in flight before the first store)
 #pragma unroll
-          for (int it = 0; it < MH; ++it) {                       // HR rows x 4 chunks of 16 B: 16 rows per pass
+          for (int it = 0; it < 4; ++it) {                        // 64 rows x 4 chunks of 16 B: 16 rows per pass
             const int row = it * 16 + (el >> 2), ch = el & 3;
             const int m = wm0 + row, hc = (wn0 >> 1) + ch * 8;
             const uint4 v = hv[it];
@@ -644,21 +627,21 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
           }
           if (p.C == nullptr) continue;
           // pre-activations kept for a live-row backward only (c_live): a 64-row block without a live row stores nothing
-          if (c_live_mod > 0 && (wm0 % c_live_mod) + HR - 1 < p.c_live_from) continue;
+          if (c_live_mod > 0 && (wm0 % c_live_mod) + 63 < p.c_live_from) continue;
         }
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
-          for (int mi = 0; mi < MH; ++mi) {
+          for (int mi = 0; mi < 4; ++mi) {
             const int row = mi * 16 + lr;
             *reinterpret_cast<uint2*>(reg + row * 128 + (((t4 * 2 + (lq >> 1)) ^ ((row >> 1) & 7)) << 4) + (lq & 1) * 8) = pk[mh][t4][mi];
           }
         if (fastm[mh]) {
           // all eight staged segments are requested before the first store waits for one (one LDS round trip per half instead
           // of eight serial ones: 270 cycles each on the stamped build - the epilogue's stores are not what it waits for)
-          uint4 vv[2 * MH];
+          uint4 vv[8];
 #pragma unroll
-          for (int it = 0; it < 2 * MH; ++it) {                  // HR rows x 8 chunks of 16 B: 8 rows per pass
+          for (int it = 0; it < 8; ++it) {                       // 64 rows x 8 chunks of 16 B: 8 rows per pass
             const int row = it * 8 + (el >> 3), ch = el & 7;
             vv[it] = *reinterpret_cast<const uint4*>(reg + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
           }
@@ -668,7 +651,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
           int lpos = 0;                                          // position of the half's first row in its row group
           if constexpr (LIVE) lpos = __builtin_amdgcn_readfirstlane(wm0 % c_live_mod);
 #pragma unroll
-          for (int it = 0; it < 2 * MH; ++it) {
+          for (int it = 0; it < 8; ++it) {
             const int row = it * 8 + (el >> 3), ch = el & 7;
             if constexpr (LIVE) {                                // (64 rows wrap at most once: c_live_mod >= 64)
               int pos = lpos + row;
@@ -696,7 +679,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
         auto store_rows = [&](auto fast_t) {
           constexpr bool FAST = decltype(fast_t)::value;
 #pragma nounroll
-          for (int it = 0; it < 2 * MH; ++it) {                  // HR rows x 8 chunks of 16 B: 8 rows per pass (rare path: kept rolled)
+          for (int it = 0; it < 8; ++it) {                       // 64 rows x 8 chunks of 16 B: 8 rows per pass (rare path: kept rolled)
             const int row = it * 8 + (el >> 3), ch = el & 7;
             const int m = wm0 + row, n = wn0 + ch * 8;
             uint4 v = *reinterpret_cast<const uint4*>(reg + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
@@ -759,15 +742,15 @@ int num_cus() {
   return n;
 }
 
-template <int EPI, bool F8 = false, bool RES = true, bool R2 = false, int MH = 4>
+template <int EPI, bool F8 = false, bool RES = true, bool R2 = false>
 int launch256(const GemmP& p0, int batch, hipStream_t st) {
   GemmP p = p0;
   p.tiles_n = (p.N + 255) / 256;
-  p.ntiles = ((p.M + 64 * MH - 1) / (64 * MH)) * p.tiles_n;
+  p.ntiles = ((p.M + 255) / 256) * p.tiles_n;
   p.batch = batch;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, F8, RES, R2, MH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, F8, RES, R2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
   // one workgroup per CU walks the tiles (VLA_GEMM256_GRID overrides the workgroup count: 0 = one workgroup per tile)
@@ -787,7 +770,7 @@ int launch256(const GemmP& p0, int batch, hipStream_t st) {
     const long long tile_cycles = (long long)(p.K / BK) * 2128 + 13000;       // K loop + what surrounds it (stamped: DESIGN section 4)
     p.stagger = (int)(tile_cycles * (se != nullptr ? atoi(se) : 50) / 100 / 1024);
   }
-  hipLaunchKernelGGL((gemm256_kernel<EPI, F8, RES, R2, MH>), dim3((unsigned)grid), dim3(512), LDS_BYTES, st, p);
+  hipLaunchKernelGGL((gemm256_kernel<EPI, F8, RES, R2>), dim3((unsigned)grid), dim3(512), LDS_BYTES, st, p);
   return 0;
 }
 
@@ -800,6 +783,5 @@ int vla_gemm256_launch(const GemmP& p, int epi, int batch, hipStream_t st) {
   if (p.rope_mode == 2) return launch256<0, false, false, true>(p, batch, st);     // (host: plain epilogue, no residual)
   if (epi == 1) return launch256<1>(p, batch, st);
   if (epi == 2) return launch256<2>(p, batch, st);
-  if (p.tile_rows == 192) return p.R ? launch256<0, false, true, false, 3>(p, batch, st) : launch256<0, false, false, false, 3>(p, batch, st);
   return p.R ? launch256<0, false, true>(p, batch, st) : launch256<0, false, false>(p, batch, st);
 }

@@ -17,7 +17,6 @@ struct GemmP {
   int bias_post;                            // 1: round alpha * acc to bf16 before adding the bias (torch CPU Linear on a strided input)
   int rope_mode, rope_T, rope_dh, rope_cols; const float* rope_cos; const float* rope_sin;
   const float* scaleA; const float* scaleB;   // fp8 operands (A, B point at OCP e4m3 bytes): per-row dequantisation scales [M], [N]
-  int tile_rows;                            // gemm256.hip: 256, or 192 = the three-m-tile form for sub-round launches (plain epilogues)
   int stagger;                              // gemm256.hip: start delay (units of 1024 cycles) of the workgroups that walk one tile fewer than the others (0 = none)
   const bf16_t* A2; const bf16_t* B2; int K2, lda2, ldb2;   // K extension (gemm.hip EXT): C = epilogue(A . B^T + A2 . B2^T)
 };
