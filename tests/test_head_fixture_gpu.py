@@ -108,6 +108,8 @@ def test_full_head_within_the_reference_bf16_error_budget(case, ref_softmax):
         nfl = (taps[i].float().cpu() != torch.as_tensor(z["xblk_bf16"][j]).float()).float().mean().item()
         print(f"{case} ref_softmax={ref_softmax}: block {i} output native-vs-reference-bf16 {r:.2e} ({100 * nfl:.2f} % of its elements differ)")
         assert r <= 4e-3 * (i + 1)
+        if ref_softmax and case in ("pro_d128_kt64", "orig_d128_kt64"):
+            assert nfl == 0.0, "phase Inference at D = 128: the tapped blocks reproduce the reference's bf16 run bit for bit"
     gap = rel(torch.as_tensor(z["out_bf16"]), z["out_fp32"])
     r_ref, r_truth = rel(pred, z["out_bf16"]), rel(pred, z["out_fp32"])
     print(f"{case} ref_softmax={ref_softmax}: actions  native-vs-ref_bf16 {r_ref:.3e}  native-vs-ref_fp32 {r_truth:.3e}  ref_bf16-vs-ref_fp32 {gap:.3e}")
@@ -116,6 +118,8 @@ def test_full_head_within_the_reference_bf16_error_budget(case, ref_softmax):
     # (hidden states, tests/test_engine_gpu.py) get the 1.25
     assert r_truth <= 1.5 * gap, "further from the fp32 truth than 1.5 x the reference's own bf16 run"
     assert r_ref <= 1.5 * 2 ** 0.5 * gap
+    if ref_softmax:
+        return              # (the backward is the same kernel in either mode: its budget is asserted once, on the default forward)
     se = sr = 0.0
     for k in GG.grad_keys(case) + ["proprio.fc2.bias"]:
         ref16, ref32 = torch.as_tensor(z[f"g_bf16.{k}"]), torch.as_tensor(z[f"g_fp32.{k}"])
