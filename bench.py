@@ -65,7 +65,7 @@ def measure_gemm_roofline(eng, batch, noise, lr, reps=10, record_only=False, ste
     events (so the GPU, not the Python launcher, paces the interval) and weighted by its count per step.
     step_fn: the eager step to record (default: the adapter-only engine step; --mode lora / full pass their trainer's)."""
     from vla_adapter_amd import ops
-    calls = {}
+    calls, fam_of = {}, {}          # fam_of: launch signature -> kernel family (for the per-family traffic split of the PMC passes)
     orig = ops.gemm_nt
 
     def rec(a, b, **kw):
@@ -78,6 +78,7 @@ def measure_gemm_roofline(eng, batch, noise, lr, reps=10, record_only=False, ste
             if kw2.get("out") is None and kw2.get("act", 0) != 4:
                 kw2["out"] = r
             calls[sig] = [0, gemm_flops_of_call(a, b, a.dim() == 3, ext), a, b, kw2, gemm_bytes_of_call(a, b, a.dim() == 3, kw2)]
+            fam_of[sig] = "gemm256_kernel" if (kw.get("fp8") is None and ext is None and orig(a, b, **dict(kw2, query_256=True))) else "gemm_nt_kernel"
         calls[sig][0] += 1
         return r
 
@@ -139,8 +140,15 @@ def measure_gemm_roofline(eng, batch, noise, lr, reps=10, record_only=False, ste
         ops.gemm_nt, ops.gemm_swiglu_bwd, ops.gemm_tn, ops.gemm_tn_grouped = orig, orig_sw, orig_tn, orig_tng
         eng.reducer = reducer
     if record_only:
+        fams = {}
+        for sig, c in calls.items():
+            fam = fam_of.get(sig, "gemm_tn_kernel" if sig[0] in ("tn", "tng") else "gemm_nt_kernel")
+            d_ = fams.setdefault(fam, dict(launches=0, algorithmic_bytes=0.0, flops=0.0))
+            d_["launches"] += c[0]
+            d_["algorithmic_bytes"] += c[0] * c[5]
+            d_["flops"] += c[0] * c[1]
         return dict(launches=sum(c[0] for c in calls.values()), flops=sum(c[0] * c[1] for c in calls.values()),
-                    bytes=sum(c[0] * c[5] for c in calls.values()))
+                    bytes=sum(c[0] * c[5] for c in calls.values()), families=fams)
     total_t = total_f = total_b = total_pk = 0.0
     n = 0
     per = []
@@ -192,11 +200,11 @@ def roofline_block(roof, convention):
 def pmc_traffic():
     """HBM-side bytes per GEMM launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate
     runs of this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if not collected."""
-    for name in ("r03_gemm_traffic_pmc.json", "r02_gemm_traffic_pmc.json", "r01_gemm_traffic_pmc.json"):
+    for name in ("r04_gemm_traffic_pmc.json", "r03_gemm_traffic_pmc.json", "r02_gemm_traffic_pmc.json", "r01_gemm_traffic_pmc.json"):
         f = os.path.join(ROOT, "profiles", name)
         try:
             d = json.load(open(f))
-            return {"bytes_per_launch": round(d["bytes_per_launch"]), "source": "profiles/" + name,
+            return {"bytes_per_launch": round(d["bytes_per_launch"]), "source": "profiles/" + name, "by_kernel_family": d.get("by_kernel_family"),
                     "note": "TCC fetch/write sizes = traffic between the 8 private L2s and the fabric (Infinity Cache + HBM), not HBM alone: "
                             "every XCD streams the weight operand into its own L2 (DESIGN.md 4)"}
         except Exception:
@@ -210,7 +218,7 @@ def in_situ_roofline(gemm_flops_per_step):
     sum us_per_step over the gemm rows).  Kernels of concurrent streams share the CUs, so a launch's in-situ duration includes the
     time it waits for CUs other streams hold: this is a LOWER bound on the kernel's own rate."""
     from vla_adapter_amd import flops
-    for name in ("r03_gemm_in_situ.json", "r02_gemm_in_situ.json"):
+    for name in ("r04_gemm_in_situ.json", "r03_gemm_in_situ.json", "r02_gemm_in_situ.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
@@ -224,6 +232,22 @@ def in_situ_roofline(gemm_flops_per_step):
                 "gemm_us_per_step_in_situ": us, "gemm_launches_per_step": d["gemm_launches_per_step"],
                 "source": f"profiles/{name} (+ {name[:3]}_kernel_summary_steady.csv)"}
     return None
+
+
+def gemm256_counters():
+    """rocprofv3 --pmc counters of the dominant kernel (gemm256_kernel) on the four big step shapes (tools/collect_gemm256_pmc.sh ->
+    profiles/r04_gemm256_pmc.json): MFMA-pipe busy share, clock held, wave wait share, fabric bytes over algorithmic bytes.  Stamped
+    with the source digest of the build they were taken from: another build's counters are reported as stale."""
+    from vla_adapter_amd import flops
+    f = os.path.join(ROOT, "profiles", "r04_gemm256_pmc.json")
+    try:
+        d = json.load(open(f))
+    except Exception:
+        return None
+    keep = ("name", "M", "N", "K", "tiles", "avg_us", "tflops", "mfma_busy_share", "clock_ghz_from_gui_active", "wave_wait_any_share",
+            "wave_issue_stall_share", "lds_bank_conflict_share_of_lds_cycles", "traffic_over_algorithmic")
+    return {"source": "profiles/r04_gemm256_pmc.json", "stale": d.get("source_digest") != flops.source_digest(),
+            "profile_source_digest": d.get("source_digest"), "shapes": [{k: sh.get(k) for k in keep} for sh in d.get("shapes", [])]}
 
 
 def host_cores() -> int:
@@ -374,6 +398,12 @@ def bench_lora(args, cfg, W, eng, batch, noise, lr, rank, local, world, B, P):
         torch.cuda.empty_cache()
         return out
 
+    if args.fp8_only:                    # profiling aid: the trace then holds the fp8 step alone
+        r8 = run(True)
+        if rank == 0:
+            print(json.dumps({"metric": "LoRA step with fp8 base-weight products only (profiling run)", "value": round(B * args.steps / r8["dt"], 2), "unit": "samples/s",
+                              "ms_per_step": round(r8["ms"], 3), "steps": args.steps, "warmup": args.warmup, "dtype": "fp8 base products + bf16", "roofline": r8["roof"]}), flush=True)
+        return
     r16 = run(False)
     r8 = run(True) if args.fp8 else None
     desc = {"config2": "Prismatic SigLIP-224 + Qwen2.5-0.5B", "dinosiglip-0_5b": "DINOv2-L + SigLIP-so400m fused + Qwen2.5-0.5B (the reference's documented recipe)",
@@ -422,6 +452,7 @@ def main():
     ap.add_argument("--lora-rank", type=int, default=64)
     ap.add_argument("--fp8", action="store_true", help="--mode lora: also time the step with the frozen base weights' products on OCP e4m3 operands "
                                                        "(BASELINE configs[4]'s fp8 MFMA weight path), printed beside the bf16 line")
+    ap.add_argument("--fp8-only", action="store_true", help="--mode lora: time ONLY the fp8 variant (profiling runs)")
     ap.add_argument("--ddp-algo", default=os.environ.get("VLA_DDP_ALGO", "allreduce"), choices=["allreduce", "rs_ag"],
                     help="gradient exchange per bucket: one all-reduce, or reduce-scatter + all-gather (all xGMI links of the node at once)")
     ap.add_argument("--objective", default="l1", choices=["l1", "token_ce"],
@@ -546,7 +577,8 @@ def main():
                           "ms_per_step": round(ms, 3), "steps": args.steps, "warmup": args.warmup,
                           "executed_steps": eng.executed_steps, "marker_grid_x": MARKER_BYTES // 16, "gemm_flops_per_step": rec["flops"],
                           "source_digest": flops.source_digest(),
-                          "gemm_launches_per_step": rec["launches"], "gemm_algorithmic_bytes_per_step": rec["bytes"]}), flush=True)
+                          "gemm_launches_per_step": rec["launches"], "gemm_algorithmic_bytes_per_step": rec["bytes"],
+                          "gemm_families": rec["families"]}), flush=True)
     elif rank == 0:
         roof = measure_gemm_roofline(eng, batch, noise, lr)
         fp8_var = None
@@ -600,6 +632,7 @@ def main():
                          "frac": round(roof["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
                          "frac_in_situ": (in_situ_roofline(roof["flops"]) or {}).get("frac_in_situ"), "in_situ": in_situ_roofline(roof["flops"]),
                          "traffic": (pmc_traffic() or {}).get("bytes_per_launch"), "traffic_detail": pmc_traffic(),
+                         "gemm256_counters": gemm256_counters(),
                          "algorithmic_bytes_per_launch": round(roof["bytes"] / roof["launches"]),
                          "avg_launch_us": round(roof["seconds"] / roof["launches"] * 1e6, 1),
                          "timing": "each distinct launch signature of one step replayed back-to-back between two HIP events on its "

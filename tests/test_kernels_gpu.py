@@ -297,7 +297,7 @@ def test_attention_bwd(ops, B, S, Hq, Hkv, dh, causal, masked):
 
 # ------------------------------------------------------------------ action-head attention
 @pytest.mark.parametrize("B,Ka,Kt,D", [(2, 65, 256, 896), (3, 65, 24, 64), (1, 65, 512, 896), (2, 65, 40, 512), (5, 65, 16, 128),
-                                       (3, 65, 16, 256), (2, 65, 100, 1024)])
+                                       (3, 65, 16, 256), (2, 65, 100, 1024), (2, 65, 512, 1536), (1, 65, 40, 1536)])     # D 1536: head dim 192 (Qwen2.5-1.5B, MFMA since round 4)
 def test_head_attention(ops, B, Ka, Kt, D):
     H, T = 8, 8
     dh = D // H

@@ -1,7 +1,7 @@
 # Run ON THE GPU BOX (gpurun): counters for gemm256_kernel - the kernel that dominates the step - on the four big
 # step shapes (tools/pmc_gemm256.py).  One rocprofv3 --pmc pass per counter group with --kernel-trace only (gpurun refuses --pmc
 # together with the sys / hip / hsa trace domains); FETCH_SIZE and WRITE_SIZE in separate passes (TCC slots, MI355X_MICROARCH.md).
-# tools/summarise_gemm256_pmc.py reduces gpurun_out/prof_gemm256_pmc to profiles/r03_gemm256_pmc.json.
+# tools/summarise_gemm256_pmc.py reduces gpurun_out/prof_gemm256_pmc to profiles/r04_gemm256_pmc.json.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_gemm256_pmc
 rm -rf $OUT && mkdir -p $OUT

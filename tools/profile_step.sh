@@ -1,10 +1,10 @@
 # Run ON THE GPU BOX (gpurun): rocprofv3 kernel trace + stats of the DEFAULT step alone (no CPU baseline, no full-backward
 # variant, no GEMM probe replays: every kernel in the trace belongs to a training step), then the two PMC passes (separate runs,
 # as MI355X_MICROARCH.md prescribes) and an un-profiled bench line.  tools/summarise_profiles.py turns gpurun_out/prof_<round> into
-# profiles/<round>_* (round = $VLA_ROUND, default r03).
+# profiles/<round>_* (round = $VLA_ROUND, default r04).
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/prof_${VLA_ROUND:-r03}
+OUT=gpurun_out/prof_${VLA_ROUND:-r04}
 rm -rf $OUT && mkdir -p $OUT
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-full-backward --no-probe > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
 if [ -z "$SKIP_PMC" ]; then

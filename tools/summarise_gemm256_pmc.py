@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/prof_gemm256_pmc (tools/collect_gemm256_pmc.sh) -> profiles/r03_gemm256_pmc.json: per big step shape the raw counters
+"""gpurun_out/prof_gemm256_pmc (tools/collect_gemm256_pmc.sh) -> profiles/r04_gemm256_pmc.json: per big step shape the raw counters
 of gemm256_kernel (mean over its three launches) and the derived numbers north_star asks for - MFMA-busy share, wave wait share,
 LDS bank-conflict share, fabric-side bytes against the algorithmic bytes (FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md
 prescribes).  --stage box reduces the counter CSVs to a small JSON on the GPU box; --stage repo copies it into profiles/."""
@@ -63,7 +63,10 @@ def stage_box():
             # independent of the counters: MFMA pipe occupancy = MFMAs x 16 cycles (16x16x32 bf16: 8 passes) / (1024 SIMDs x cycles at 2.4 GHz)
             d["mfma_pipe_share_at_2p4ghz"] = round(m["mfma_per_launch"] * 16 / (1024 * d["avg_us"] * 2400.0), 4)
         out.append(d)
-    json.dump(dict(kernel="gemm256_kernel", note="rocprofv3 --pmc, one pass per counter group, kernel-trace only; means over three launches per shape; "
+    import sys
+    sys.path.insert(0, ROOT)
+    from vla_adapter_amd import flops
+    json.dump(dict(kernel="gemm256_kernel", source_digest=flops.source_digest(), note="rocprofv3 --pmc, one pass per counter group, kernel-trace only; means over three launches per shape; "
                    "FETCH_SIZE doubled per MI355X_MICROARCH.md; SQ cycle counters in quad-cycles except SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES",
                    shapes=out), open(os.path.join(SRC, "gemm256_pmc.json"), "w"), indent=1)
     for d in out:
@@ -86,6 +89,6 @@ if __name__ == "__main__":
                 sh["mfma_busy_cycles_per_mfma"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / sh["mfma_per_launch"], 2)
                 if sh.get("avg_us"):
                     sh["clock_ghz_from_gui_active"] = round(c["GRBM_GUI_ACTIVE"] / 8.0 / sh["avg_us"] / 1e3, 3)
-        json.dump(d, open(os.path.join(ROOT, "profiles", "r03_gemm256_pmc.json"), "w"), indent=1)
+        json.dump(d, open(os.path.join(ROOT, "profiles", "r04_gemm256_pmc.json"), "w"), indent=1)
         for sh in d["shapes"]:
             print({k: v for k, v in sh.items() if k != "counters_mean_of_3_launches"})

@@ -18,7 +18,7 @@ import shutil
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = os.environ.get("VLA_ROUND", "r03")                       # profiles are named per round
+RND = os.environ.get("VLA_ROUND", "r04")                       # profiles are named per round
 SRC, DST = os.path.join(ROOT, "gpurun_out", "prof_" + RND), os.path.join(ROOT, "profiles")
 GEMM_KERNELS = ("gemm_nt_kernel", "gemm256_kernel", "gemm_tn_kernel", "gemm_tn256_kernel", "gemm_tn_grouped_kernel", "gemm_tn256_grouped_kernel")
 
@@ -74,16 +74,29 @@ def stage_box():
         print(f"no marker pair found (grid {mgrid}): steady summary not written")
 
 
-def pmc_sum(sub, counter):
+def family_of(kernel_name: str) -> str:
+    return "gemm256_kernel" if "gemm256_kernel" in kernel_name else "gemm_tn_kernel" if "gemm_tn" in kernel_name else "gemm_nt_kernel"
+
+
+def pmc_sum(sub, counter, by_family=None):
+    """Sum of `counter` over the GEMM dispatches of the PMC pass `sub` (+ per kernel family into by_family[family] = [sum, launches]).
+    One dispatch may appear on several rows (one per XCD / counter instance): launches are counted by dispatch id."""
     f = glob.glob(os.path.join(SRC, sub, "*", "*_counter_collection.csv"))
     if not f:
         return None, 0
-    tot, n = 0.0, 0
+    tot, seen = 0.0, set()
     for r in csv.DictReader(open(f[0])):
         if any(g in r["Kernel_Name"] for g in GEMM_KERNELS) and r["Counter_Name"] == counter:
-            tot += float(r["Counter_Value"])
-            n += 1
-    return tot, n
+            v = float(r["Counter_Value"])
+            tot += v
+            did = r.get("Dispatch_Id", len(seen))
+            new = did not in seen
+            seen.add(did)
+            if by_family is not None:
+                e = by_family.setdefault(family_of(r["Kernel_Name"]), [0.0, 0])
+                e[0] += v
+                e[1] += int(new)
+    return tot, len(seen)
 
 
 def stage_repo():
@@ -121,11 +134,25 @@ def stage_repo():
         out["frac_in_situ"] = round(out["gemm_tflops_in_situ"] / 2500.0, 4)
     json.dump(out, open(os.path.join(DST, RND + "_gemm_in_situ.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != "instantiations"}, indent=1))
-    fetch, n1 = pmc_sum("pmc_fetch", "FETCH_SIZE")      # KB
-    write, n2 = pmc_sum("pmc_write", "WRITE_SIZE")
+    ff, fw = {}, {}
+    fetch, n1 = pmc_sum("pmc_fetch", "FETCH_SIZE", ff)      # KB
+    write, n2 = pmc_sum("pmc_write", "WRITE_SIZE", fw)
     if fetch is not None and n1 == n2 and n1 > 0:
+        # per kernel family: fabric-side bytes per launch against the algorithmic bytes per launch of the SAME family (bench.py's
+        # recording step tags every GEMM call with the kernel it routes to: bench_under_rocprof.json "gemm_families"); the PMC passes
+        # run `--steps 2 --warmup 1 --eager` + the capture-free recording step = 4 executed steps
+        fams, alg = {}, bench.get("gemm_families") or {}
+        for fam in sorted(set(ff) | set(fw)):
+            fb, nf = ff.get(fam, [0.0, 0])
+            wb, _ = fw.get(fam, [0.0, 0])
+            e = {"launches": nf, "fabric_bytes_per_launch": round((2.0 * fb + wb) * 1024 / max(1, nf))}
+            if fam in alg and alg[fam]["launches"]:
+                e["algorithmic_bytes_per_launch"] = round(alg[fam]["algorithmic_bytes"] / alg[fam]["launches"])
+                e["launches_per_step"] = alg[fam]["launches"]
+                e["traffic_over_algorithmic"] = round(e["fabric_bytes_per_launch"] / e["algorithmic_bytes_per_launch"], 3)
+            fams[fam] = e
         pm = {"kernels": list(GEMM_KERNELS), "launches": n1, "fetch_size_kb_sum": fetch, "write_size_kb_sum": write, "fetch_correction": 2.0,
-              "bytes_per_launch": (2.0 * fetch + write) * 1024 / n1,
+              "bytes_per_launch": (2.0 * fetch + write) * 1024 / n1, "by_kernel_family": fams, "source_digest": bench.get("source_digest"),
               "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools/profile_step.sh) over bench.py --steps 2 "
                       "--warmup 1 --eager; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B)"}
         json.dump(pm, open(os.path.join(DST, RND + "_gemm_traffic_pmc.json"), "w"), indent=1)

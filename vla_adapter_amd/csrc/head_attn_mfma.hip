@@ -862,14 +862,14 @@ void set_attrs() {
 void set_all_attrs() {
   static bool done = false;
   if (done) return;
-  set_attrs<16>(); set_attrs<32>(); set_attrs<64>(); set_attrs<112>(); set_attrs<128>();
+  set_attrs<16>(); set_attrs<32>(); set_attrs<64>(); set_attrs<112>(); set_attrs<128>(); set_attrs<192>();
   done = true;
 }
 
 }  // namespace
 
 bool head_attn_mfma_supported(const HP& p) {
-  return (p.dh == 16 || p.dh == 32 || p.dh == 64 || p.dh == 112 || p.dh == 128) && p.T <= 32 && p.T >= 1 &&
+  return (p.dh == 16 || p.dh == 32 || p.dh == 64 || p.dh == 112 || p.dh == 128 || p.dh == 192) && p.T <= 32 && p.T >= 1 &&
          (long long)p.T * (p.T + p.Ka + p.Kt) >= 2 * p.T;   // probs slab must hold LSE + delta
 }
 
@@ -880,6 +880,7 @@ void head_attn_mfma_fwd(const HP& p, hipStream_t st) {
     case 32: launch_fwd<32>(p, st); break;
     case 64: launch_fwd<64>(p, st); break;
     case 112: launch_fwd<112>(p, st); break;
+    case 192: launch_fwd<192>(p, st); break;      // Qwen2.5-1.5B: d 1536 / 8 heads (BASELINE configs[4])
     default: launch_fwd<128>(p, st); break;
   }
 }
@@ -890,6 +891,7 @@ void head_attn_mfma_bwd(const HP& p, hipStream_t st) {
     case 32: launch_bwd<32>(p, st); break;
     case 64: launch_bwd<64>(p, st); break;
     case 112: launch_bwd<112>(p, st); break;
+    case 192: launch_bwd<192>(p, st); break;
     default: launch_bwd<128>(p, st); break;
   }
 }
