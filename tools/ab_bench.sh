@@ -5,5 +5,4 @@ run VLA_VIS_AFTER=0
 run VLA_VIS_AFTER=2
 run VLA_VIS_AFTER=4
 run VLA_VIS_AFTER=6
-run VLA_NO_NARROW_LONGK=1
 run A=1
