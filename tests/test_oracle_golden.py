@@ -85,6 +85,23 @@ def test_qwen2_tiny_forward_backward():
     close(x.grad, z["dx"])
 
 
+def test_token_ce_matches_the_hf_causal_lm_loss():
+    """SURVEY 8f-4, pinned in round 4: oracle.token_ce on the last hidden state = the loss and the logits installed transformers'
+    Qwen2ForCausalLM returns for the same multimodal labels (tools/make_golden_ce.py; stand-in for the reference's pinned fork, whose
+    LLM computes this loss behind PrismaticVLM.forward, vlms/prismatic.py:469-481): label placement around the patch rows, the shift
+    by one, the mean over the labelled positions, IGNORE_INDEX rows and a padded tail."""
+    z = load("qwen2_tiny_ce.npz")
+    loss, logits = O.token_ce(z["hidden_last"], z["lm_head"], z["labels"].long(), int(z["num_patches"]), emu=False)
+    torch.testing.assert_close(logits, z["logits"], rtol=1e-4, atol=1e-5)
+    assert abs(loss.item() - float(z["loss"])) <= 2e-6 * abs(float(z["loss"])), (loss.item(), float(z["loss"]))
+    # and the arithmetic itself, independent of any fixture: torch's own cross entropy on the shifted logits
+    import torch.nn.functional as F
+    B, Np = z["labels"].shape[0], int(z["num_patches"])
+    mm = torch.cat([z["labels"][:, :1].long(), torch.full((B, Np), -100), z["labels"][:, 1:].long()], 1)
+    ref = F.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), mm[:, 1:].reshape(-1), ignore_index=-100)
+    assert abs(loss.item() - ref.item()) <= 2e-6 * abs(ref.item())
+
+
 @pytest.mark.parametrize("tag,emu", [("f32", False), ("bf16", True)])
 def test_adamw(tag, emu):
     z = load(f"adamw_{tag}.npz")
