@@ -15,8 +15,9 @@ reference's own leaf modules (``prismatic/models/action_heads.py``, ``prismatic/
 Qwen2 (the reference's pinned fork is absent) and writes ``tests/golden/*.npz``; ``tests/test_oracle_golden.py``
 checks this file against them.  Rows a1, a7, a8, a9, a10 are therefore pinned by reference code run here;
 a5 is pinned by installed-transformers Qwen2 (third-party, version differs from the reference's pin);
-a2, a3, a4, a6, a11 (ViT from timm, VLM glue, LoRA from peft: not importable) are **parity unpinned** -
-restated from the reference text and checked only for self-consistency; the fp8 registry restates the NATIVE build's arithmetic
+a3 (ViT; timm absent) is pinned by third-party stand-ins too since round 4: installed transformers' SiglipVisionModel and
+Dinov2WithRegistersModel (tools/make_golden_vit.py).  a2, a4, a6, a11 (VLM glue, LoRA from peft: not importable) are **parity unpinned**
+- restated from the reference text and checked only for self-consistency; the fp8 registry restates the NATIVE build's arithmetic
 (the reference has no fp8 code).  token_ce is pinned like a5: against the loss / logits of installed transformers'
 Qwen2ForCausalLM (tools/make_golden_ce.py -> tests/golden/qwen2_tiny_ce.npz) and torch's cross_entropy.
 

@@ -85,6 +85,23 @@ def test_qwen2_tiny_forward_backward():
     close(x.grad, z["dx"])
 
 
+@pytest.mark.parametrize("name", ["vit_siglip_tiny", "vit_dinov2reg_tiny"])
+def test_vit_restatement_matches_independent_implementations(name):
+    """SURVEY a3, pinned in round 4 by third-party stand-ins: oracle.vit_forward - restated from the reference text because timm is
+    absent - against installed transformers' SiglipVisionModel / Dinov2WithRegistersModel built from local configs
+    (tools/make_golden_vit.py): patch convolution, position embedding on the patch tokens, cls + 4 register tokens in front (DINOv2),
+    pre-norm blocks with biased q/k/v, erf GELU, LayerScale, and the output BEHIND block depth-2 without the prefix tokens and without a
+    final norm (modeling_prismatic.py:141-142, 196-237)."""
+    z = load(name + ".npz")
+    d, depth, heads, mlp, P, npre, ls = z["cfg"].tolist()
+    cfg = dict(d=d, depth=depth, heads=heads, mlp=mlp, patch=P, n_prefix=npre, layerscale=bool(ls), eps=1e-6, gelu_tanh=False)
+    out = O.vit_forward(z["pixels"], sub(z, "w."), cfg, emu=False)
+    torch.testing.assert_close(out, z["out"], rtol=2e-4, atol=2e-5)
+    # the rounding-point emulation stays a small perturbation of the same function
+    emu = O.vit_forward(z["pixels"], sub(z, "w."), cfg, emu=True)
+    assert ((emu - z["out"]).norm() / z["out"].norm()).item() < 2e-2
+
+
 def test_token_ce_matches_the_hf_causal_lm_loss():
     """SURVEY 8f-4, pinned in round 4: oracle.token_ce on the last hidden state = the loss and the logits installed transformers'
     Qwen2ForCausalLM returns for the same multimodal labels (tools/make_golden_ce.py; stand-in for the reference's pinned fork, whose
