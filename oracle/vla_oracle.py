@@ -216,7 +216,8 @@ def im2col(pixels, P: int):
 
 # ----------------------------------------------------------------------------------------------
 # a3  ViT featurizer (timm VisionTransformer semantics; evidence film_vit_wrapper.py:69-75,114-168;
-#     modeling_prismatic.py:120-144, 196-237).  PARITY UNPINNED (timm absent).
+#     modeling_prismatic.py:120-144, 196-237).  Pinned since round 4 by third-party stand-ins (transformers' SiglipVisionModel /
+#     Dinov2WithRegistersModel: tests/golden/vit_*_tiny.npz); timm itself is absent.
 # ----------------------------------------------------------------------------------------------
 def vit_forward(pixels, p: Dict[str, torch.Tensor], cfg: Dict, emu=False) -> torch.Tensor:
     """pixels [B,3,H,W] -> patch features [B, Np, d] = output of block ``depth-2``, prefix tokens dropped,
