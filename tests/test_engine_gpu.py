@@ -644,6 +644,49 @@ def test_full_size_full_finetune_step_config4():
     assert all(l == l and abs(l) < 1e2 for l in ls), ls
 
 
+def test_config4_per_gpu_shape_batch16_captured_steps(monkeypatch):
+    """BASELINE configs[3] at the per-GPU shape it names - full-backbone unfreeze, bf16, batch 16 per GPU - as the captured three-stream
+    step with AdamW range by range under the backward (the form bench.py --mode full times; the eight-GPU exchange itself is rehearsed
+    on gloo in tests/test_ddp_gpu.py and unmeasured on hardware): four steps, finite and falling loss, every parameter group fed, and
+    the batch-16 rows 0-1 of the first step's forward equal to a batch-2 forward of the same two samples bit for bit (split-K off: at
+    M = 704 the long-K products would otherwise meet their K slices in fp32 planes - another summation order)."""
+    monkeypatch.setenv("VLA_NO_SPLITK", "1")
+    from vla_adapter_amd import engine as E, synthetic as S
+    from vla_adapter_amd.full_finetune import FullFinetune
+    cfg = E.config2()
+    W = S.make_weights(cfg, DEV, seed=0)
+    batch = S.make_batch(cfg, 16, DEV, seed=81, P=32)
+    batch["pixel_values"] = batch["pixel_values"].to(BF)
+    two = {k: v[:2].contiguous() for k, v in batch.items()}
+    e2 = E.VLAEngine(cfg, W, DEV)
+    f2 = FullFinetune(e2)
+    p2 = f2.forward(two, None).clone()
+    h2 = e2.llm.HS[cfg.llm.n_layers].clone()
+    del f2, e2
+    eng = E.VLAEngine(cfg, W, DEV)
+    ft = FullFinetune(eng)
+    p16 = ft.forward(batch, None)
+    torch.cuda.synchronize()
+    assert torch.equal(p16[:2], p2) and torch.equal(eng.llm.HS[cfg.llm.n_layers][:2], h2), "batch-16 rows differ from the batch-2 run"
+    p0 = ft.P.data.clone()
+    ft.capture(batch, None)
+    ls = [ft.train_step_graphed(2e-5)[0].item() for _ in range(4)]
+    torch.cuda.synchronize()
+    assert all(l == l and abs(l) < 1e2 for l in ls) and ls[-1] < ls[0], ls
+    g = ft.P.grad.float()
+    assert torch.isfinite(g).all()
+    for name in ("llm.0.wqkv", "llm.23.wd", "vit0.0.wqkv", "vit0.25.w2", "proj.fc1.weight", "llm.embed", "vit0.pos", "llm.11.n2", "vit0.12.b1"):
+        off, shape = ft.P.offsets[name]
+        n = 1
+        for d in shape:
+            n *= d
+        assert g[off:off + n].abs().max().item() > 0, name
+        # matrices must have moved; vectors near 1.0 (norm weights: one bf16 ulp = 7.8e-3) do not see lr = 2e-5 - in the reference's
+        # bf16 optimizer either (DESIGN section 5d); the token table moves on the rows of the batch's ids only
+        if len(shape) >= 2 and name != "llm.embed":
+            assert not torch.equal(ft.P.data[off:off + n], p0[off:off + n]), name
+
+
 def test_qwen25_15b_layer_geometry_forward_backward():
     """Qwen2.5-1.5B's layer geometry (BASELINE configs[4]: d 1536, 12 x 128 heads, 2 KV heads, MLP 8960) at two layers: head
     dim 128 takes the unfused-RoPE projection, the 128-wide attention forward / backward kernels, and the head's first LayerNorm
