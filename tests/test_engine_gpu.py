@@ -644,6 +644,45 @@ def test_full_size_full_finetune_step_config4():
     assert all(l == l and abs(l) < 1e2 for l in ls), ls
 
 
+def test_adapter_step_skips_llm_layers_above_the_heads_last_block():
+    """Qwen2.5-1.5B has 28 layers, the head 24 blocks: hidden_states[25..28] reach neither the loss nor the actions.  The adapter-only
+    step and predict() run the first n_act layers only (round 4; the LoRA / full trainers did since round 3) - every gradient must be
+    BIT-IDENTICAL to the run that computes all layers, the captured step must work, and forward_vlm() - the API twin that returns
+    every hidden state (modeling_prismatic.py:680-686) - still fills them all.  3 layers, 2 blocks."""
+    from vla_adapter_amd import engine as E, synthetic as S
+    cfg = E.tiny_config()
+    cfg.llm = E.LLMCfg(256, 3, 4, 2, 64, 512, 1e-6, 1e6, 1024)
+    cfg.num_blocks = 2
+    W = S.make_weights(cfg, DEV, seed=3, std=0.05)
+    batch = S.make_batch(cfg, 3, DEV, seed=4, P=20, ragged=True)
+    grads, preds = {}, {}
+    for n_act in (2, 3):
+        eng = E.VLAEngine(cfg, W, DEV)
+        assert eng.n_act == 2
+        eng.n_act = n_act
+        pred = eng.forward(batch, None, for_training=True)
+        eng.loss_and_backward(pred, batch["actions"])
+        torch.cuda.synchronize()
+        grads[n_act], preds[n_act] = eng.head.P.grad.clone(), pred.clone()
+    assert torch.equal(preds[2], preds[3]) and torch.equal(grads[2], grads[3]), "dead layers must contribute exactly nothing"
+    assert grads[2].float().abs().max().item() > 0
+    eng = E.VLAEngine(cfg, W, DEV)
+    eng.forward_vlm(batch)                                  # API twin: all n + 1 hidden states
+    torch.cuda.synchronize()
+    out, _ = _oracle_run(cfg, W, batch, None, True, cfg.num_blocks)
+    tru, _ = _oracle_run(cfg, W, batch, None, False, cfg.num_blocks)
+    for i in range(cfg.llm.n_layers + 1):
+        budget(eng.llm.HS[i], out["hidden_states"][i], tru["hidden_states"][i], f"3-layer LLM under a 2-block head: hidden_states[{i}]")
+    a = eng.predict({k: v for k, v in batch.items()})
+    torch.cuda.synchronize()
+    budget(a, out["pred"].detach(), tru["pred"].detach(), "predict() on n_act layers")
+    eng.capture({k: v.clone() for k, v in batch.items()}, None)
+    ls = [eng.train_step_graphed(5e-4)[0].item() for _ in range(4)]
+    eng.flush()
+    torch.cuda.synchronize()
+    assert all(l == l for l in ls) and ls[-1] < ls[0], ls
+
+
 def test_config4_per_gpu_shape_batch16_captured_steps(monkeypatch):
     """BASELINE configs[3] at the per-GPU shape it names - full-backbone unfreeze, bf16, batch 16 per GPU - as the captured three-stream
     step with AdamW range by range under the backward (the form bench.py --mode full times; the eight-GPU exchange itself is rehearsed

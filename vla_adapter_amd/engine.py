@@ -336,12 +336,16 @@ class LLM:
         n = self.cfg.n_layers
         return i + 1 if i < n - 1 else n + 1
 
-    def forward(self, B: int, S: int, kmask_u8: torch.Tensor, keep_from_row: int = 0):
-        """HS[0] must already hold inputs_embeds [B,S,D].  Fills HS[1..n] (HF hidden_states semantics)."""
+    def forward(self, B: int, S: int, kmask_u8: torch.Tensor, keep_from_row: int = 0, n_run: Optional[int] = None):
+        """HS[0] must already hold inputs_embeds [B,S,D].  Fills HS[1..n] (HF hidden_states semantics).  n_run < n_layers: only the
+        first n_run layers (hidden_states[1..n_run]: all the action head reads when it has fewer blocks than the LLM has layers)."""
+        n = self.cfg.n_layers
+        n_run = n if n_run is None else n_run
         self.fwd_begin(B, S, kmask_u8, keep_from_row)
-        for i in range(self.cfg.n_layers):
+        for i in range(n_run):
             self.fwd_layer(i)
-        self.fwd_final()
+        if n_run == n:
+            self.fwd_final()
 
     def fwd_begin(self, B: int, S: int, kmask_u8: torch.Tensor, keep_from_row: int = 0):
         """keep_from_row: the backward of this forward will only visit the rows >= keep_from_row of every sequence
@@ -435,24 +439,30 @@ class LLM:
     # window; every op below works on compact [B * (S - row0), .] gradients and reads the forward's tensors through
     # row-window addressing.  row0 = 0 is the plain full-sequence backward (needed as soon as ViT / projector / LoRA
     # weights train).  The surviving gradients are the same numbers either way (tests/test_engine_gpu.py).
-    def backward(self, dHS: torch.Tensor, B: int, S: int, row0: int = 0) -> torch.Tensor:
+    def backward(self, dHS: torch.Tensor, B: int, S: int, row0: int = 0, n_run: Optional[int] = None) -> torch.Tensor:
         """dHS [n+1, B, S - row0, D]: gradient w.r.t. rows >= row0 of hidden_states[i] (i = 0..n, HF convention; [0]
-        unused).  Returns the gradient w.r.t. rows >= row0 of inputs_embeds, [B, S - row0, D] (frozen weights: no dW)."""
-        self.bwd_begin(dHS, row0)
-        for i in range(self.cfg.n_layers - 1, -1, -1):
+        unused).  Returns the gradient w.r.t. rows >= row0 of inputs_embeds, [B, S - row0, D] (frozen weights: no dW).
+        n_run < n_layers: the layers above n_run never reached the loss (forward(n_run=)): the chain starts at layer n_run - 1."""
+        n_run = self.cfg.n_layers if n_run is None else n_run
+        self.bwd_begin(dHS, row0, n_run)
+        for i in range(n_run - 1, -1, -1):
             self.bwd_layer(i, dHS)
         return self.bwd_result()
 
-    def bwd_begin(self, dHS: torch.Tensor, row0: int = 0):
+    def bwd_begin(self, dHS: torch.Tensor, row0: int = 0, n_run: Optional[int] = None):
         n, S, D = self.cfg.n_layers, self.S, self.cfg.d
+        self._n_run = n if n_run is None else n_run
         assert 0 <= row0 < S and row0 % 32 == 0, "live-row window must start on a multiple of 32"
         assert row0 >= self.gu_row0, "the forward dropped backward-only rows this window needs"
         self.r0, self.Rl = row0, S - row0
         Mr = self.B * self.Rl
         assert tuple(dHS.shape[1:]) == (self.B, self.Rl, D)
         self._win = (self.Rl, S, row0)                        # (rows per sequence, sequence rows, first row)
-        self._d = ops.rmsnorm_bwd(dHS[n].view(Mr, D), self.HS[n + 1].view(-1, D), self.norm, self.RF, out=self.d_a[:Mr],
-                                  x_rows=self._win)
+        if self._n_run == n:
+            self._d = ops.rmsnorm_bwd(dHS[n].view(Mr, D), self.HS[n + 1].view(-1, D), self.norm, self.RF, out=self.d_a[:Mr],
+                                      x_rows=self._win)
+        else:           # hidden_states[n_run] is a raw layer output (no final norm behind it): its gradient is the head's alone
+            self._d = ops.copy2d(dHS[self._n_run].view(Mr, D), self.d_a[:Mr], Mr, D, D, D)
         self._other = self.d_b[:Mr]
 
     def bwd_layer(self, i: int, dHS: torch.Tensor):
@@ -460,7 +470,7 @@ class LLM:
         n, M, D, H, KV, dh, I = c.n_layers, B * S, c.d, c.heads, c.kv_heads, c.dh, c.inter
         Mr = B * R
         L, d, other = self.layers[i], self._d, self._other
-        if i < n - 1:                                   # head contribution to the output of layer i
+        if i < self._n_run - 1:                         # head contribution to the output of layer i (the top layer's came in bwd_begin)
             ops.add_(d, dHS[i + 1].view(Mr, D))
         gu_live = self.GU[i][r0:]                       # first sequence's window; the others by row-group addressing
         d_gu, d_n = self.d_gu[:Mr], self.d_n[:Mr]
@@ -946,6 +956,10 @@ class VLAEngine:
         self.reducer = None        # ddp.FlatGradReducer when world_size > 1
         self.ga, self._micro, self._gacc = 1, 0, None     # gradient accumulation (set_grad_accumulation)
         self.executed_steps = 0    # forward+backward passes enqueued so far (eager, pipelined or replayed): profile bookkeeping
+        # LLM layers above the head's last block (Qwen2.5-1.5B: 28 layers, 24 blocks - action_heads.py:117-118 reads hidden_states[1..24])
+        # never reach the loss or the predicted actions: the training step and predict() run the first n_act layers only, as the
+        # LoRA / full trainers do; forward_vlm() - the API twin that RETURNS every hidden state - runs them all
+        self.n_act = min(cfg.llm.n_layers, cfg.num_blocks)
         self.fp8_frozen = False
         if os.environ.get("VLA_FP8_FROZEN"):
             self.enable_fp8_frozen()
@@ -1022,6 +1036,7 @@ class VLAEngine:
         cfg, llm, head = self.cfg, self.llm, self.head
         n, nb = cfg.llm.n_layers, cfg.num_blocks
         self._vision_begin(batch)                                 # host-side bookkeeping only
+        n_all, n = n, self.n_act                                  # (layers above the head's last block do not reach the actions)
         segs = [(f"V{j}", (lambda j=j: self._vision_backbone(j, batch)), None, ("v", j)) for j in range(len(self.vits))]
         ch = self._chunks(n, [6] * max(0, (n - 6) // 6) + [4, 2]) if n >= 12 else self._chunks(n, [1])   # few launches: the caller blocks on every call
 
@@ -1032,7 +1047,7 @@ class VLAEngine:
                     llm.fwd_begin(self.B, self.S, self._embed(batch), 0)
                 for i in range(lo, hi):
                     llm.fwd_layer(i)
-                if hi == n:
+                if hi == n_all:
                     llm.fwd_final()
             return fn
 
@@ -1058,7 +1073,8 @@ class VLAEngine:
         prismatic/models/vlms/prismatic.py:312-481 (embedding gather + patch splice only; ``labels`` not needed)."""
         self._vision(batch)
         mm = self._embed(batch, action_queries)
-        self.llm.forward(self.B, self.S, mm, self.live_row0() if (for_training and action_queries) else 0)
+        self.llm.forward(self.B, self.S, mm, self.live_row0() if (for_training and action_queries) else 0,
+                         n_run=self.n_act if for_training else None)
 
     def token_ce(self, labels: torch.Tensor):
         """HF shifted token cross-entropy of the last forward_vlm (prismatic/models/vlms/prismatic.py:469-481):
@@ -1197,7 +1213,7 @@ class VLAEngine:
         aq_off = head.P.offsets["action_queries"][0]
         if self.reducer is not None and exchange:       # head/proprio grads are final: exchange them under the LLM backward
             self.reducer.reduce_async(head.P.grad, 0, aq_off)
-        dX0 = llm.backward(dHS, B, S, row0)
+        dX0 = llm.backward(dHS, B, S, row0, n_run=self.n_act)
         dq = ops.action_query_grad(dX0.contiguous(), self.pos0, Np, row0)
         ops.cast_f32_bf16(dq, out=head.P.g("action_queries"))
         if self.reducer is not None and exchange:
@@ -1269,8 +1285,9 @@ class VLAEngine:
     def _segments(self, batch, noise):
         """[(stream 'M'|'H', fn, wait_key|None, signal_key|None)] for everything after the vision stage."""
         cfg, llm, head = self.cfg, self.llm, self.head
-        n, nb = cfg.llm.n_layers, cfg.num_blocks
-        assert nb <= n
+        n_all, nb = cfg.llm.n_layers, cfg.num_blocks
+        assert nb <= n_all
+        n = self.n_act                                  # layers that reach the loss
         # long chunks at the bottom layers, single layers at the top: the head's last forward chunk and first backward
         # chunk (the serial turn-around) stay short; the backward walks the same ranges top-down
         fch = self._chunks(n, [4] * max(0, (n - 4) // 4) + [2, 1, 1]) if n >= 8 else self._chunks(n, [1])
@@ -1289,7 +1306,7 @@ class VLAEngine:
                     m_begin()
                 for i in range(lo, hi):
                     llm.fwd_layer(i)
-                if hi == n:
+                if hi == n_all:
                     llm.fwd_final()
             return fn
 
@@ -1316,7 +1333,7 @@ class VLAEngine:
         def m_bwd(lo, hi, first, last):
             def fn():
                 if first:
-                    llm.bwd_begin(self._dHS, self._row0_used)
+                    llm.bwd_begin(self._dHS, self._row0_used, n)
                 for i in range(hi - 1, lo - 1, -1):
                     llm.bwd_layer(i, self._dHS)
                 if last:

@@ -61,10 +61,15 @@ def step_flops_per_sample(cfg: VLACfg, L: int = 96, row0: int = 0) -> dict:
     vit = sum(vit_fwd(c) for c in cfg.vit) * cfg.n_img
     proj, lin, att, head = proj_fwd(cfg), llm_linear_fwd(cfg, S), llm_attn_fwd(cfg, S), head_fwd(cfg)
     total = vit + proj + 2 * lin + 3 * att + 3 * head
+    # executed: the LLM layers above the head's last block (Qwen2.5-1.5B: 4 of 28) reach neither the loss nor the actions and are not
+    # run by the training step (engine.VLAEngine.n_act); the autograd convention above counts them, as the reference executes them
+    fa = min(cfg.llm.n_layers, cfg.num_blocks) / cfg.llm.n_layers
+    lin_a, att_a = lin * fa, att * fa
     task_dx = cfg.num_blocks * 2 * cfg.n_patches * 2 * cfg.llm.d * cfg.llm.d        # dX of k_task / v_task (dead when row0 > 0)
-    live = vit + proj + lin * (1 + (S - row0) / S) + att + llm_attn_bwd_live(cfg, S, row0) + 3 * head - (task_dx if row0 else 0)
+    live = vit + proj + lin_a * (1 + (S - row0) / S) + att_a + llm_attn_bwd_live(cfg, S, row0) * fa + 3 * head - (task_dx if row0 else 0)
+    full_a = vit + proj + 2 * lin_a + 3 * att_a + 3 * head
     return dict(vit_fwd=vit, proj_fwd=proj, llm_linear_fwd=lin, llm_attn_fwd=att, head_fwd=head, forward=vit + proj + lin + att + head,
-                step=total, step_live=live if row0 else total)
+                step=total, step_live=live if row0 else full_a)
 
 
 def source_digest() -> str:
