@@ -350,16 +350,36 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int
   float* sDelta = sLse + 32;
   lds_zero16(sQ, 2 * TILE * 2, lane, 64);   // pad columns stay zero (wave-private region)
 
-  bf16x8 kf[G::KS], vf[G::KS];
+  // The key tile's K and V rows as MFMA fragments (lane = key, 8 consecutive d).  Head dims up to 72 keep them in registers for the
+  // whole query loop; at 128 that is 64 registers beside 128 accumulator and 64 prefetch registers - the kernel spilled 115 dwords
+  // INSIDE the loop (370 us per layer on the Qwen2.5-1.5B shape, 5 x its MFMA time) - so there the fragments live in LDS, one
+  // [key][d] image per key tile behind the waves' regions (the waves of a key tile are the q heads of ONE kv head: same K, same V),
+  // and are read per k-step like the Q / dO fragments.
+  constexpr bool KV_LDS = D > 72;
+  bf16x8 kf[KV_LDS ? 1 : G::KS], vf[KV_LDS ? 1 : G::KS];
+  bf16_t* sKt = reinterpret_cast<bf16_t*>(smem + grp * KT * WAVE_BYTES) + kt * 2 * TILE;
+  bf16_t* sVt = sKt + TILE;
   {
     const bf16_t* kp = p.k + (long long)b * p.k_sb + (long long)kc * p.k_ss + hkv * D;
     const bf16_t* vp = p.v + (long long)b * p.v_sb + (long long)kc * p.v_ss + hkv * D;
+    if constexpr (KV_LDS) {
+      if (hh == 0) {                       // one wave per key tile stages both images (pad columns: never read, d < DQ = D here)
 #pragma unroll
-    for (int ks = 0; ks < G::KS; ++ks) {
-      const int d = 16 * ks + 8 * h;
-      const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      kf[ks] = (d < D) ? *reinterpret_cast<const bf16x8*>(kp + d) : z;
-      vf[ks] = (d < D) ? *reinterpret_cast<const bf16x8*>(vp + d) : z;
+        for (int ks = 0; ks < G::KS; ++ks) {
+          const int d = 16 * ks + 8 * h;
+          *reinterpret_cast<bf16x8*>(sKt + (lane & 31) * G::LD + d) = *reinterpret_cast<const bf16x8*>(kp + d);
+          *reinterpret_cast<bf16x8*>(sVt + (lane & 31) * G::LD + d) = *reinterpret_cast<const bf16x8*>(vp + d);
+        }
+      }
+      __syncthreads();
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < G::KS; ++ks) {
+        const int d = 16 * ks + 8 * h;
+        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        kf[ks] = (d < D) ? *reinterpret_cast<const bf16x8*>(kp + d) : z;
+        vf[ks] = (d < D) ? *reinterpret_cast<const bf16x8*>(vp + d) : z;
+      }
     }
   }
   const bool kok = ki < p.Sk && (!p.kmask || p.kmask[(long long)b * p.Sk + kc]);
@@ -372,9 +392,14 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int
     const bf16_t* db = p.dout + (long long)b * p.do_sb + hq * D;
     const long long sbase = ((long long)b * p.Hq + hq) * p.Sq, lbase = ((long long)b * p.Hq + hq) * p.lse_hs;
     const int qstart = p.causal ? max(k0 - p.q_off, 0) : 0;   // k0, q_off are multiples of 32
+    // (head dim 128: the next query tile is NOT held in registers across the MFMAs - those 64 registers were the other half of the
+    //  spills; the tile is requested at the top of its own iteration and the workgroup's other waves cover the round trip)
+    constexpr bool PF = !KV_LDS;
     u32x4 rq[TileGeo<D, 64>::NCH], rdo[TileGeo<D, 64>::NCH];
-    tile_prefetch<D, 64>(rq, qb, p.q_ss, qstart, p.Sq, lane);
-    tile_prefetch<D, 64>(rdo, db, p.do_ss, qstart, p.Sq, lane);
+    if constexpr (PF) {
+      tile_prefetch<D, 64>(rq, qb, p.q_ss, qstart, p.Sq, lane);
+      tile_prefetch<D, 64>(rdo, db, p.do_ss, qstart, p.Sq, lane);
+    }
     float lse_n = 0.f, delta_n = 0.f;
     if (lane < 32) {
       const int qq = min(qstart + lane, p.Sq - 1);
@@ -382,6 +407,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int
       delta_n = p.delta[sbase + qq];
     }
     for (int q0 = qstart; q0 < p.Sq; q0 += 32) {
+      if constexpr (!PF) {
+        tile_prefetch<D, 64>(rq, qb, p.q_ss, q0, p.Sq, lane);
+        tile_prefetch<D, 64>(rdo, db, p.do_ss, q0, p.Sq, lane);
+      }
       tile_store<D, 64, G::LD>(rq, sQ, lane);
       tile_store<D, 64, G::LD>(rdo, sdO, lane);
       if (lane < 32) {
@@ -389,8 +418,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int
         sDelta[lane] = delta_n;
       }
       if (q0 + 32 < p.Sq) {
-        tile_prefetch<D, 64>(rq, qb, p.q_ss, q0 + 32, p.Sq, lane);
-        tile_prefetch<D, 64>(rdo, db, p.do_ss, q0 + 32, p.Sq, lane);
+        if constexpr (PF) {
+          tile_prefetch<D, 64>(rq, qb, p.q_ss, q0 + 32, p.Sq, lane);
+          tile_prefetch<D, 64>(rdo, db, p.do_ss, q0 + 32, p.Sq, lane);
+        }
         if (lane < 32) {
           const int qq = min(q0 + 32 + lane, p.Sq - 1);
           lse_n = p.lse[lbase + qq];
@@ -404,8 +435,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int
       for (int ks = 0; ks < G::KS; ++ks) {
         const bf16x8 qf = *reinterpret_cast<const bf16x8*>(sQ + (lane & 31) * G::LD + 16 * ks + 8 * h);
         const bf16x8 df = *reinterpret_cast<const bf16x8*>(sdO + (lane & 31) * G::LD + 16 * ks + 8 * h);
-        S = mfma32(qf, kf[ks], S);     // S[q x key]: A = Q rows, B = K^T
-        dP = mfma32(df, vf[ks], dP);   // dP[q x key] = dO . V^T
+        if constexpr (KV_LDS) {
+          S = mfma32(qf, *reinterpret_cast<const bf16x8*>(sKt + (lane & 31) * G::LD + 16 * ks + 8 * h), S);
+          dP = mfma32(df, *reinterpret_cast<const bf16x8*>(sVt + (lane & 31) * G::LD + 16 * ks + 8 * h), dP);
+        } else {
+          S = mfma32(qf, kf[ks], S);     // S[q x key]: A = Q rows, B = K^T
+          dP = mfma32(df, vf[ks], dP);   // dP[q x key] = dO . V^T
+        }
       }
       f32x16 dS;
 #pragma unroll
@@ -564,7 +600,7 @@ extern "C" int vla_attn_bwd(void* stream, const vla_attn_desc* d) {
     gk = dim3(p.B, p.Hkv, gk.x);
   }
   const int ld = ((p.dh + 31) / 32 * 32 + 8);
-  const size_t lds = (size_t)grp * KT * (2 * 32 * ld * 2 + 256);
+  const size_t lds = (size_t)grp * KT * (2 * 32 * ld * 2 + 256) + (p.dh > 72 ? (size_t)KT * 2 * 32 * ld * 2 : 0);   // (+ the K / V images at dh 128)
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
