@@ -446,9 +446,11 @@ def test_adamw_bit_exact_vs_torch_golden(ops):
 
 
 # ------------------------------------------------------------------ fused rotary embeddings
-def test_gemm_fused_rope_half(ops):
-    """QKV projection with the HF rotate_half RoPE applied in the GEMM epilogue == Linear then apply_rotary_pos_emb."""
-    B, S, H, KV, dh, K = 2, 40, 4, 2, 64, 128
+@pytest.mark.parametrize("dh,H,KV,B,S,K", [(64, 4, 2, 2, 40, 128), (128, 3, 1, 3, 50, 192), (128, 12, 2, 2, 137, 1536)])
+def test_gemm_fused_rope_half(ops, dh, H, KV, B, S, K, monkeypatch):
+    """QKV projection with the HF rotate_half RoPE applied in the GEMM epilogue == Linear then apply_rotary_pos_emb; head dim 64
+    (Qwen2.5-0.5B) and 128 (Qwen2.5-1.5B: one head per 128-column tile, round 4), the latter also bit-identical to the projection
+    followed by the stand-alone vla_rope_half pass it replaces, and routed off the 256-row kernel even when that is forced."""
     N = (H + 2 * KV) * dh
     x, w, bias = gen(B * S, K, seed=90), gen(N, K, seed=91, scale=0.1), gen(N, seed=92)
     cos, sin = ops.rope_half_tables(S, dh, 1e6, DEV)
@@ -457,7 +459,14 @@ def test_gemm_fused_rope_half(ops):
     c, s = O.rope_half_tables(S, dh, 1e6, True)
     q = O.rope_half(y[:, :H * dh].view(B, S, H, dh).transpose(1, 2), c, s, True).transpose(1, 2).reshape(B * S, H * dh)
     k = O.rope_half(y[:, H * dh:(H + KV) * dh].view(B, S, KV, dh).transpose(1, 2), c, s, True).transpose(1, 2).reshape(B * S, KV * dh)
-    check(out, torch.cat([q, k, y[:, (H + KV) * dh:]], 1), name="gemm + rope_half")
+    check(out, torch.cat([q, k, y[:, (H + KV) * dh:]], 1), name=f"gemm + rope_half dh {dh}")
+    if dh == 128:
+        plain = ops.gemm_nt(x.to(DEV), w.to(DEV), bias=bias.to(DEV))
+        ops.rope_half_(plain[:, :H * dh], cos, sin, S, H, dh)
+        ops.rope_half_(plain[:, H * dh:(H + KV) * dh], cos, sin, S, KV, dh)
+        assert torch.equal(out, plain), "fused epilogue vs projection + stand-alone RoPE pass"
+        monkeypatch.setenv("VLA_GEMM_TILE", "6")
+        assert torch.equal(ops.gemm_nt(x.to(DEV), w.to(DEV), bias=bias.to(DEV), rope=(1, cos, sin, S, dh, (H + KV) * dh)), out)
 
 
 @pytest.mark.parametrize("tile", [2, 3])

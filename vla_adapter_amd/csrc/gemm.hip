@@ -168,8 +168,11 @@ void gemm_nt_kernel(GemmP p) {                                   //  workgroups 
   // Tile-local first column of this wave's 16-wide n tile ni.  Plain: WTN consecutive columns.  Fused rotate_half on the
   // 8-wave geometry (32 columns per wave, head dim 64): the wave owns 16 columns of EACH half of one head, so that the
   // rotation partners d <-> d + 32 are n tiles 0 and 1 of the same lane (no exchange between waves).
+  // Head dim 128 (Qwen2.5-1.5B, round 4): the tile's 128 columns are ONE head, the halves are columns [0, 64) and [64, 128): wave wc owns
+  // 16 columns of each (n tile 0: 16 wc .., n tile 1: 64 + 16 wc ..) - the same lane-local rotation, another column map.
   constexpr bool PERM = ROPE == 1 && C::NT == 2;
-  auto cbase = [&](int ni) { return PERM ? (wc >> 1) * 64 + ni * 32 + (wc & 1) * 16 : wc * C::WTN + ni * 16; };
+  const bool wide = PERM && p.rope_dh == 128;          // (wave-uniform)
+  auto cbase = [&](int ni) { return PERM ? (wide ? ni * 64 + wc * 16 : (wc >> 1) * 64 + ni * 32 + (wc & 1) * 16) : wc * C::WTN + ni * 16; };
   const bf16_t* bias = p.bias ? p.bias + (long long)z * p.sBias : nullptr;
   float bv[C::NT][4];
   {
@@ -442,7 +445,7 @@ void gemm_nt_kernel(GemmP p) {                                   //  workgroups 
           }
         } else if (ROPE == 1 && C::NT == 2) {
           // same rotation on the permuted 8-wave layout: n tile 0 holds head columns d = 16 (wc & 1) + 4 lq + j, tile 1 d + 32
-          const int half = p.rope_dh >> 1, d = (wc & 1) * 16 + lq * 4;
+          const int half = p.rope_dh >> 1, d = (wide ? wc * 16 : (wc & 1) * 16) + lq * 4;
           const float4 c = *reinterpret_cast<const float4*>(p.rope_cos + (long long)pos * half + d);
           const float4 sn = *reinterpret_cast<const float4*>(p.rope_sin + (long long)pos * half + d);
           const float cc[4] = {c.x, c.y, c.z, c.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
@@ -689,6 +692,8 @@ static TileChoice route(const vla_gemm_desc* d) {
   if (tc.bm == 256 && tc.bn == 257 && !vla_gemm256_extent_ok(d)) tc = TileChoice{128, 128};   // operands of 4 GiB and more: 64-bit-pointer kernel
   // interleaved RoPE on the 256-row kernel: the plain epilogue without residual (the head's K|V projections) - anything else keeps gemm.hip's
   if (tc.bm == 256 && tc.bn == 257 && d->rope_mode == 2 && (d->R || d->act != VLA_ACT_NONE || d->fp8)) tc = TileChoice{128, 128};
+  // rotate_half at head dim 128: the 128-row kernel's column map (one head per 128-column tile); the 256-row kernel's is built on 64-wide heads
+  if (tc.bm == 256 && tc.bn == 257 && d->rope_mode == 1 && d->rope_dh != 64) tc = TileChoice{128, 128};
   return tc;
 }
 
@@ -771,7 +776,8 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
     VLA_REQUIRE(d->rope_cos && d->rope_sin && d->rope_T > 0 && d->rope_dh > 0 && d->rope_dh % 4 == 0 && d->rope_cols % 64 == 0 &&
                     (((uintptr_t)d->rope_cos | (uintptr_t)d->rope_sin) & 15) == 0 && d->act != VLA_ACT_SWIGLU,
                 "gemm: bad rope arguments");
-    if (d->rope_mode == 1) VLA_REQUIRE(d->rope_dh == 64, "gemm: fused rotate_half RoPE needs head dim 64");
+    if (d->rope_mode == 1) VLA_REQUIRE(d->rope_dh == 64 || (d->rope_dh == 128 && d->N % 128 == 0 && d->rope_cols % 128 == 0),
+                                       "gemm: fused rotate_half RoPE needs head dim 64, or 128 with N and rope_cols multiples of 128");
   }
   const char* e = getenv("VLA_GEMM_TILE");
   const TileChoice tc = route(d);
@@ -794,7 +800,8 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
     // 128-row kernel (two workgroups per CU, one's epilogue under the other's K loop) is as fast or faster (gate/up 162 vs 162 us,
     // down 62 vs 70, ViT fc1 63 vs 87), on big squares the 256-row kernel wins (8192^3: 2503 vs 2108 TF/s) - it takes those.
     const int force = e ? atoi(e) : 0;
-    if ((force == 6 || (force == 0 && d->M >= 4096 && d->N >= 4096 && d->K >= 4096)) && d->c_group == 0 && d->r_group == 0 && fits256)
+    if ((force == 6 || (force == 0 && d->M >= 4096 && d->N >= 4096 && d->K >= 4096)) && d->c_group == 0 && d->r_group == 0 && fits256 &&
+        !(d->rope_mode == 1 && d->rope_dh != 64))
       vla_gemm256_launch(p, d->act == VLA_ACT_SWIGLU ? 1 : 0, 1, st);
     else if (d->rope_mode == 1) launch<128, 128, 2, 1, 4, true>(p, d->M, d->N, 1, st);
     else launch<128, 128, 2, 0, 4, true>(p, d->M, d->N, 1, st);

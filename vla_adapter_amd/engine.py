@@ -372,13 +372,13 @@ class LLM:
             ops.rmsnorm_fwd_q8(x, L["n1"], c.eps, q8, qs, rstd=self.R1[i][r0:r1])
         else:
             self._rms(x, L["n1"], nbuf, self.R1[i][r0:r1])
-        if fp8 and dh == 64:
+        if fp8 and dh in (64, 128):
             ops.gemm_nt(q8, L["wqkv_q"], bias=L["bqkv"], out=qkv, rope=(1, self.cos, self.sin, S, dh, (H + KV) * dh), fp8=(qs, L["wqkv_s"]))
         elif fp8:
             ops.gemm_nt(q8, L["wqkv_q"], bias=L["bqkv"], out=qkv, fp8=(qs, L["wqkv_s"]))
             ops.rope_half_(qkv[:, :H * dh], self.cos, self.sin, S, H, dh)
             ops.rope_half_(qkv[:, H * dh:(H + KV) * dh], self.cos, self.sin, S, KV, dh)
-        elif dh == 64:          # RoPE fused into the projection's epilogue
+        elif dh in (64, 128):   # RoPE fused into the projection's epilogue (head dim 128: the 128-row kernel's column map, round 4)
             ops.gemm_nt(nbuf, L["wqkv"], bias=L["bqkv"], out=qkv, rope=(1, self.cos, self.sin, S, dh, (H + KV) * dh))
         else:
             ops.gemm_nt(nbuf, L["wqkv"], bias=L["bqkv"], out=qkv)

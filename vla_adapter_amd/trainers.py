@@ -300,7 +300,7 @@ class BackboneTrainer:
             x, k = llm.HS[i].view(-1, D), f"llm.{i}."
             self._rms(x, L["n1"], self.N1[i], llm.R1[i])
             qkv = llm.QKV[i]
-            if dh == 64:          # RoPE in the projection's epilogue (the LoRA delta is already inside the accumulator)
+            if dh in (64, 128):   # RoPE in the projection's epilogue (the LoRA delta is already inside the accumulator)
                 self._lin(k + "qkv", self.N1[i], L["wqkv"], L["bqkv"], out=qkv, rope=(1, llm.cos, llm.sin, S, dh, (H + KV) * dh))
             else:
                 self._lin(k + "qkv", self.N1[i], L["wqkv"], L["bqkv"], out=qkv)
