@@ -61,7 +61,7 @@ typedef struct vla_gemm_desc {
   int a_group, c_group;
   long long a_group_stride, c_group_stride;
   /* optional fused rotary embedding on output columns [0, rope_cols) (after bias, before residual): position =
-   * row % rope_T.  rope_mode 1: HF rotate_half, head dim 64, tables f32 [rope_T, 32] (Qwen2 q/k, see vla_rope_half);
+   * row % rope_T.  rope_mode 1: HF rotate_half, head dim 64 or 128, tables f32 [rope_T, rope_dh/2] (Qwen2 q/k, see vla_rope_half);
    * rope_mode 2: action-head interleaved pairs, tables f32 [rope_T, rope_dh] (see vla_rope_interleaved). */
   int rope_mode, rope_T, rope_dh, rope_cols;
   const float* rope_cos; const float* rope_sin;
@@ -191,7 +191,7 @@ typedef struct vla_attn_desc {
   /* backward only */
   const void* dout; void* dq; void* dk; void* dv; float* delta; /* delta f32 [B,Hq,Sq] workspace */
   long long do_sb, dq_sb, dk_sb, dv_sb; int do_ss, dq_ss, dk_ss, dv_ss;
-  /* backward, optional: q/k were produced by rotate_half RoPE (tables f32 [S, 32], dh 64, position = sequence index):
+  /* backward, optional: q/k were produced by rotate_half RoPE (tables f32 [S, dh/2], dh 64 or 128, position = sequence index):
    * dq/dk are returned already mapped through its transpose, i.e. as gradients of the PRE-rotation projections */
   const float* rope_cos; const float* rope_sin;
   /* optional window (all 0 = plain): query i sits at sequence position q_off + i (causal masking and RoPE use that

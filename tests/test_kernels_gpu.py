@@ -483,8 +483,8 @@ def test_gemm_fused_rope_interleaved(ops, tile, monkeypatch):
     check(out, torch.cat([k, y[:, D:]], 1), name="gemm + interleaved rope")
 
 
-def test_attention_bwd_fused_inverse_rope(ops):
-    B, S, Hq, Hkv, dh = 2, 77, 4, 2, 64
+@pytest.mark.parametrize("B,S,Hq,Hkv,dh", [(2, 77, 4, 2, 64), (2, 77, 4, 2, 128), (1, 600, 12, 2, 128)])   # dh 128: Qwen2.5-1.5B geometry (round 4)
+def test_attention_bwd_fused_inverse_rope(ops, B, S, Hq, Hkv, dh):
     qkv, q, k, v = _attn_inputs(B, S, Hq, Hkv, dh, 96)
     dout = gen(B, S, Hq * dh, seed=97)
     d = qkv.to(DEV)
@@ -594,7 +594,8 @@ def test_gemm_fused_swiglu_backward(ops):
 # Row-window forms used by the live-row LLM backward (engine.LLM.backward): each must reproduce, bit for bit, the rows
 # >= row0 of the full-sequence op (same instructions in the same order per row).
 @pytest.mark.parametrize("B,S,Hq,Hkv,dh,row0,masked,rope", [(2, 96, 4, 2, 64, 32, False, True), (2, 352, 14, 2, 64, 288, True, True),
-                                                            (1, 120, 4, 2, 64, 64, True, False), (2, 100, 2, 2, 72, 32, False, False)])
+                                                            (1, 120, 4, 2, 64, 64, True, False), (2, 100, 2, 2, 72, 32, False, False),
+                                                            (2, 352, 12, 2, 128, 288, True, True)])
 def test_attention_bwd_live_rows(ops, B, S, Hq, Hkv, dh, row0, masked, rope):
     qkv, q, k, v = _attn_inputs(B, S, Hq, Hkv, dh, 140)
     dout = gen(B, S, Hq * dh, seed=141).to(DEV)

@@ -291,17 +291,22 @@ __global__ __launch_bounds__(256, (D <= 64 ? 3 : 2)) void attn_bwd_dq_kernel(Att
       for (int t = 0; t < G::DT; ++t) dQ[t] = mfma32(tr_frag(sK, G::LD, s, 32 * t, lane), df, dQ[t]);
     }
   }
-  if (p.rope_cos && G::DT == 2) {      // d/dx of y = x*cos + rotate_half(x)*sin : inverse rotation (D == 64: pairs are tiles 0/1)
+  if constexpr (G::DT % 2 == 0 && D == 32 * G::DT) {   // d/dx of y = x*cos + rotate_half(x)*sin : inverse rotation (column d pairs with d + D/2: tile t with t + DT/2)
+    if (p.rope_cos) {
+      constexpr int HT = G::DT / 2, HALF = D / 2;
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+      for (int t = 0; t < HT; ++t)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int d = 8 * g + 4 * h + j;
-        const float c = p.rope_cos[(long long)(qc + p.q_off) * 32 + d], sn = p.rope_sin[(long long)(qc + p.q_off) * 32 + d];
-        const float a = dQ[0][4 * g + j], bb = dQ[G::DT - 1][4 * g + j];
-        dQ[0][4 * g + j] = a * c + bb * sn;
-        dQ[G::DT - 1][4 * g + j] = bb * c - a * sn;
-      }
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int d = 32 * t + 8 * g + 4 * h + j;
+            const float c = p.rope_cos[(long long)(qc + p.q_off) * HALF + d], sn = p.rope_sin[(long long)(qc + p.q_off) * HALF + d];
+            const float a = dQ[t][4 * g + j], bb = dQ[t + HT][4 * g + j];
+            dQ[t][4 * g + j] = a * c + bb * sn;
+            dQ[t + HT][4 * g + j] = bb * c - a * sn;
+          }
+    }
   }
   {                                     // row-contiguous stores through the wave's LDS region (as attn_fwd_kernel)
     bf16_t* so = sO + w * 32 * G::LD;
@@ -488,12 +493,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int
           const float* src = reinterpret_cast<const float*>(smem) + (kt2 * grp) * (32 * ACC_LD) + key * ACC_LD + d;
           float sum = 0.f;
           for (int g = 0; g < grp; ++g) sum += src[g * (32 * ACC_LD)];
-          if (pass == 0 && p.rope_cos && D == 64) {          // inverse RoPE on dK: partner column d +- 32
-            const float* srp = src + (d < 32 ? 32 : -32);
+          if (pass == 0 && p.rope_cos && (D == 64 || D == 128)) {   // inverse RoPE on dK: partner column d +- D/2
+            constexpr int HALF = D / 2;
+            const float* srp = src + (d < HALF ? HALF : -HALF);
             float other = 0.f;
             for (int g = 0; g < grp; ++g) other += srp[g * (32 * ACC_LD)];
-            const float c = p.rope_cos[(long long)kg * 32 + (d & 31)], sn = p.rope_sin[(long long)kg * 32 + (d & 31)];
-            sum = d < 32 ? sum * c + other * sn : sum * c - other * sn;
+            const float c = p.rope_cos[(long long)kg * HALF + (d & (HALF - 1))], sn = p.rope_sin[(long long)kg * HALF + (d & (HALF - 1))];
+            sum = d < HALF ? sum * c + other * sn : sum * c - other * sn;
           }
           outp[(long long)b * o_sb + (long long)(kg - p.dkv_k0) * o_ss + hkv * D + d] = f2bf(sum);
         }
@@ -501,17 +507,22 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnP p, int grp, int
     }
     return;
   }
-  if (p.rope_cos && G::DT == 2) {
+  if constexpr (G::DT % 2 == 0 && D == 32 * G::DT) {
+    if (p.rope_cos) {
+      constexpr int HT = G::DT / 2, HALF = D / 2;
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+      for (int t = 0; t < HT; ++t)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int d = 8 * g + 4 * h + j;
-        const float c = p.rope_cos[(long long)kc * 32 + d], sn = p.rope_sin[(long long)kc * 32 + d];
-        const float a = dK[0][4 * g + j], bb = dK[G::DT - 1][4 * g + j];
-        dK[0][4 * g + j] = a * c + bb * sn;
-        dK[G::DT - 1][4 * g + j] = bb * c - a * sn;
-      }
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int d = 32 * t + 8 * g + 4 * h + j;
+            const float c = p.rope_cos[(long long)kc * HALF + d], sn = p.rope_sin[(long long)kc * HALF + d];
+            const float a = dK[t][4 * g + j], bb = dK[t + HT][4 * g + j];
+            dK[t][4 * g + j] = a * c + bb * sn;
+            dK[t + HT][4 * g + j] = bb * c - a * sn;
+          }
+    }
   }
   if (hh == 0 && ki < p.Sk) {
     bf16_t* okp = p.dk + (long long)b * p.dk_sb + (long long)(ki - p.dkv_k0) * p.dk_ss + hkv * D;
@@ -559,7 +570,7 @@ int fill(AttnP& p, const vla_attn_desc* d, bool bwd) {
     p.do_sb = d->do_sb; p.dq_sb = d->dq_sb; p.dk_sb = d->dk_sb; p.dv_sb = d->dv_sb;
     p.do_ss = d->do_ss; p.dq_ss = d->dq_ss; p.dk_ss = d->dk_ss; p.dv_ss = d->dv_ss;
     p.rope_cos = d->rope_cos; p.rope_sin = d->rope_sin;
-    if (d->rope_cos) VLA_REQUIRE(d->rope_sin && d->dh == 64 && d->Sq + d->q_off == d->Sk, "attn_bwd: fused inverse RoPE needs dh == 64 (tables f32 [Sk, 32])");
+    if (d->rope_cos) VLA_REQUIRE(d->rope_sin && (d->dh == 64 || d->dh == 128) && d->Sq + d->q_off == d->Sk, "attn_bwd: fused inverse RoPE needs dh 64 or 128 (tables f32 [Sk, dh/2])");
   }
   return VLA_OK;
 }
@@ -588,7 +599,7 @@ extern "C" int vla_attn_bwd(void* stream, const vla_attn_desc* d) {
   int rc = fill(p, d, true);
   if (rc) return rc;
   VLA_REQUIRE(p.dh == 64 || p.dh == 72 || p.dh == 128, "attn_bwd: dh 64, 72 or 128 only");
-  VLA_REQUIRE(p.dh == 64 || !p.rope_cos, "attn_bwd: the fused inverse RoPE needs head dim 64 (apply vla_rope_half with sign -1 otherwise)");
+  VLA_REQUIRE(p.dh == 64 || p.dh == 128 || !p.rope_cos, "attn_bwd: the fused inverse RoPE needs head dim 64 or 128 (apply vla_rope_half with sign -1 otherwise)");
   hipStream_t st = (hipStream_t)stream;
   const int grp = p.Hq / p.Hkv;
   VLA_REQUIRE(grp <= 8, "attn_bwd: at most 8 query heads per kv head");

@@ -488,8 +488,8 @@ class LLM:
         d_qkv = self.d_qkv[:Mr]
         dq, dk, dv = self._attn_views(d_qkv.view(B, R, W))
         ops.attn_bwd(dao.view(B, R, -1), q[:, r0:], k, v, self.AO[i].view(B, S, -1)[:, r0:], self.LSE[i], H, KV, dh, True,
-                     self.kmask, dq=dq, dk=dk, dv=dv, rope=(self.cos, self.sin) if dh == 64 else None, row0=r0)
-        if dh != 64:
+                     self.kmask, dq=dq, dk=dk, dv=dv, rope=(self.cos, self.sin) if dh in (64, 128) else None, row0=r0)
+        if dh not in (64, 128):
             cs, sn = self.cos[r0:], self.sin[r0:]
             ops.rope_half_(d_qkv[:, :H * dh], cs, sn, R, H, dh, sign=-1)
             ops.rope_half_(d_qkv[:, H * dh:(H + KV) * dh], cs, sn, R, KV, dh, sign=-1)

@@ -349,8 +349,8 @@ class BackboneTrainer:
             d_qkv = self.G_qkv[i]
             dq, dk, dv = llm._attn_views(d_qkv.view(B, S, -1))
             ops.attn_bwd(dao.view(B, S, -1), q, kk, v, llm.AO[i].view(B, S, -1), llm.LSE[i], H, KV, dh, True, llm.kmask, dq=dq, dk=dk, dv=dv,
-                         rope=(llm.cos, llm.sin) if dh == 64 else None)
-            if dh != 64:
+                         rope=(llm.cos, llm.sin) if dh in (64, 128) else None)
+            if dh not in (64, 128):
                 ops.rope_half_(d_qkv[:, :H * dh], llm.cos, llm.sin, S, H, dh, sign=-1)
                 ops.rope_half_(d_qkv[:, H * dh:(H + KV) * dh], llm.cos, llm.sin, S, KV, dh, sign=-1)
             d_n = self._lin_bwd(k + "qkv", d_qkv, self.N1[i], L["wqkvT"], out=self.G_n1[i] if tv else llm.d_n[:M])
