@@ -33,8 +33,9 @@ extern "C" {
  *   4  round 3: vla_gemm_desc gained the RMSNorm fields (ssq_out .. rstd_out); new entry point vla_gemm_uses_256.
  *   5  round 4: the RMSNorm fields are gone again (the fold measured slower and left the tree: tools/diag/gemm256_pruned_paths.patch);
  *      fp8 = 1 may be combined with the K extension (and, in that form, with the SwiGLU-backward epilogue).
+ *   6  round 4: new entry point vla_gemm_latency_hint (no layout change).
  * A binder checks vla_version() AND vla_desc_size() against its own struct definitions before the first call. */
-#define VLA_ABI_VERSION 5
+#define VLA_ABI_VERSION 6
 int vla_version(void);
 /* sizeof() of the descriptor structs as this library was compiled: which = 0 vla_gemm_desc, 1 vla_attn_desc, 2 vla_head_attn_desc,
  * 3 vla_gemm_tn_desc; -1 for an unknown index.  A caller whose struct is shorter would make the library read past its end. */
@@ -99,6 +100,13 @@ typedef struct vla_gemm_desc {
  * 32-bit per-lane byte offsets; larger operands are routed to the 128-row kernel, which uses 64-bit pointers).  Host arithmetic. */
 /* 1 when vla_gemm_bf16_nt would run this descriptor on the 256 x 256 kernel (the routing is shape- and device-dependent). */
 int vla_gemm_uses_256(const vla_gemm_desc* desc);
+/* Process-wide hint for vla_gemm_bf16_nt, read when a product is launched (= when a hipGraph is captured): on = 1 says the following
+ * products run on an otherwise idle chip and are bound by the latency of a launch, not by throughput - the batch-1 predict_action of
+ * modeling_prismatic.py:892-972 / openvla_utils.py:737-825 (every product there is at most one workgroup per CU and took 17-22 us
+ * whatever its size: one K-tile in flight per workgroup).  Such launches then use a four-stage operand ring (three K-tiles in flight).
+ * Kernel selection only: results are bit-identical with and without the hint.  on = 0 clears it, on < 0 only queries.  Returns the
+ * previous value. */
+int vla_gemm_latency_hint(int on);
 int vla_gemm256_extent_ok(const vla_gemm_desc* desc /* host */);
 
 /* ---------------------------------------------------------------- TN GEMM (weight gradients) */

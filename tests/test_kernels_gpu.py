@@ -1002,6 +1002,47 @@ def test_gemm256_race_screen(ops, M, N, K, monkeypatch):
     monkeypatch.setenv("VLA_GEMM_TILE", "0")
 
 
+@pytest.mark.parametrize("M,N,K,kind", [(8, 896, 896, "plain"), (8, 2688, 896, "rope2"), (369, 1152, 896, "rope1"), (256, 4304, 1152, "gelu"),
+                                        (369, 896, 4864, "res"), (64, 896, 256, "plain"), (130, 200, 320, "res"), (369, 896, 4864, "split"),
+                                        (256, 1152, 192, "plain"), (369, 9728, 896, "plain"), (1000, 2048, 512, "gelu"), (64, 896, 384, "res"),
+                                        (100, 640, 448, "plain"), (369, 1152, 1152, "rope1")])
+def test_gemm_deep_ring_bit_identical(ops, M, N, K, kind, monkeypatch):
+    """Under vla_gemm_latency_hint launches of at most one workgroup per CU run on deeper operand rings (latency-bound batch-1 products,
+    round 4): 64 x 128 tiles with six stages when those still fit one round, else 128 x 128 tiles with four (369 x 9728, 1000 x 2048) -
+    same K order, same MFMA sequence: equal to the two-stage kernel bit for bit, repeated under memory load (the counted waits of a
+    deeper ring are a synchronisation structure of their own; K = 192 ... 448: the three- to seven-K-tile prologue / tail cases, K = 192
+    stays on two stages)."""
+    a, b, bias, r = gen(M, K, seed=231).to(DEV), gen(N, K, seed=232, scale=0.05).to(DEV), gen(N, seed=233).to(DEV), gen(M, N, seed=234).to(DEV)
+    kw = dict(bias=bias, split_k=0)
+    if kind == "rope1":
+        cos, sin = ops.rope_half_tables(M, 64, 1e6, DEV)
+        kw["rope"] = (1, cos, sin, M, 64, 1024)
+    elif kind == "rope2":
+        T, dh = 8, 112
+        rc, rs_ = ops.rope_inter_tables(T, dh, DEV)
+        kw["rope"] = (2, rc, rs_, T, dh, 1792)
+    elif kind == "gelu":
+        kw["act"] = 1
+    elif kind == "res":
+        kw["residual"] = r
+    elif kind == "split":
+        kw.update(residual=r, split_k=4)
+    assert ops._lib().vla_gemm_latency_hint(-1) == 0
+    ref = ops.gemm_nt(a, b, **kw)
+    junk, side = torch.empty(64 << 20, dtype=torch.uint8, device=DEV), torch.cuda.Stream()
+    outs = []
+    with ops.latency_hint():
+        assert ops._lib().vla_gemm_latency_hint(-1) == 1
+        for i in range(12):
+            with torch.cuda.stream(side):
+                junk.add_(1)
+            outs.append(ops.gemm_nt(a, b, **kw))
+    assert ops._lib().vla_gemm_latency_hint(-1) == 0
+    torch.cuda.synchronize()
+    bad = [i for i, o in enumerate(outs) if not torch.equal(o, ref)]
+    assert not bad, f"deep ring {M}x{N}x{K} {kind}: launches {bad} differ from the two-stage kernel"
+
+
 def test_gemm256_swiglu_forward_and_backward_bit_identical(ops, monkeypatch):
     M, D, I = 1100, 896, 1216
     x, wg, wu = gen(M, D, seed=211), gen(I, D, seed=212, scale=0.05), gen(I, D, seed=213, scale=0.05)

@@ -20,6 +20,8 @@ configs = {
     "siglip224+qwen2.5-0.5b, 1 image (BASELINE configs[1] backbone)": E.config2(),
     "dinov2+siglip fused, 2 images, qwen2.5-0.5b (reference LIBERO default)": E.VLACfg(vit=[E.DINOV2_L_REG4, E.SIGLIP_SO400M], n_img=2),
 }
+if len(sys.argv) > 1:            # optional: index of the one configuration to run (profiling)
+    configs = dict([list(configs.items())[int(sys.argv[1])]])
 P = 48          # LIBERO prompt with the Qwen chat template (~48 ids)
 for name, cfg in configs.items():
     W = S.make_weights(cfg, dev, seed=0)

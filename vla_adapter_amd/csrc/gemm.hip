@@ -22,6 +22,7 @@
 // wave-quantisation model (a 616-tile problem on 512 slots wastes 40 % of the machine with 128x128 tiles).
 //
 // Epilogue rounding points follow the reference under bf16 autocast: bf16(acc+bias) -> act -> bf16 -> (+residual) -> bf16.
+#include <atomic>
 #include "common.h"
 #include "gemm_params.h"
 #include "../../include/vla_native.h"
@@ -199,14 +200,18 @@ void gemm_nt_kernel(GemmP p) {                                   //  workgroups 
     if (s < nt) stage(s, s);
   int buf = 0;
   static_assert(C::NT <= 4, "wave tiles are 64 x 32 or 64 x 64");
+  static_assert(STAGES >= 2 && STAGES <= 6 && 4 * C::PPW < 64, "the counted waits below cover rings of 2 to 6 stages (vmcnt is a 6-bit counter)");
   // One K-tile (written as a macro so that the fp8 product with a bf16 extension can run it as TWO loops - e4m3 tiles, then bf16
   // tiles - each with one MFMA form and one set of fragment offsets: as one loop with a per-tile branch the kernel needed 200
   // registers and lost its second resident workgroup).  All fragment reads of the K-tile (both 32-deep k-steps) are issued up
   // front: the second k-step's LDS latency hides under the first k-step's MFMAs instead of stalling between them.
 #define VLA_KTILE(F8T, FO)                                                                                                           \
   do {                                                                                                                               \
-    /* retire this wave's pieces of tile t; up to STAGES-2 younger tiles stay in flight */                                           \
-    if (STAGES == 3 && t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PPW) : "memory");                                      \
+    /* retire this wave's pieces of tile t; up to STAGES-2 younger tiles stay in flight (in-order return: a counted wait) */       \
+    if (STAGES >= 6 && t + 4 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * C::PPW) : "memory");                                  \
+    else if (STAGES >= 5 && t + 3 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * C::PPW) : "memory");                             \
+    else if (STAGES >= 4 && t + 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * C::PPW) : "memory");                             \
+    else if (STAGES >= 3 && t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::PPW) : "memory");                                 \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                            \
     __builtin_amdgcn_s_barrier(); /* tile t visible to every wave; every wave is done reading tile t-1's buffer */                    \
     asm volatile("" ::: "memory");                                                                                                   \
@@ -684,6 +689,13 @@ extern "C" int vla_gemm256_extent_ok(const vla_gemm_desc* d) {
   return (offA + d->K) * EB < lim && (offB + d->K) * EB < lim;
 }
 
+// Caller's hint (process-wide, read at launch = at graph capture): the following products run on an otherwise idle chip and are bound
+// by latency, not throughput (batch-1 predict_action).  Selects kernels only - results are bit-identical either way.
+static std::atomic<int> g_latency_hint{0};
+extern "C" int vla_gemm_latency_hint(int on) {
+  return on < 0 ? g_latency_hint.load(std::memory_order_relaxed) : g_latency_hint.exchange(on ? 1 : 0, std::memory_order_relaxed);
+}
+
 // The tile choice of vla_gemm_bf16_nt for a descriptor (shared with the predicate below).
 static TileChoice route(const vla_gemm_desc* d) {
   const int split = d->split_k > 1 ? d->split_k : 1;
@@ -814,12 +826,35 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
     //  ~80 isolated and cost 0.1 ms on the step: the other streams already fill the tail round.  tools/diag/gemm256_pruned_paths.patch)
     vla_gemm256_launch(p, epi, d->batch, st);
   } else if (d->act == VLA_ACT_SWIGLU_BWD) launch<128, 128, 2, 3, 4>(p, d->M, d->N, d->batch, st);
-  else if (d->rope_mode == 1) launch<128, 128, 2, 1, 4>(p, d->M, d->N, d->batch, st);   // 8 waves, rotation pairs inside a lane
-  else if (d->rope_mode == 2) {
-    if (tc.bn == 128) launch<128, 128, 2, 2, 4>(p, d->M, d->N, d->batch, st);
-    else launch<128, 64, 2, 2>(p, d->M, d->N, d->batch, st);
-  } else if (tc.bn == 128) launch<128, 128, 2, 0, 4>(p, d->M, d->N, split > 1 ? split : d->batch, st);   // 8 waves (2x4) of 64x32
-  else launch<128, 64, 2, 0>(p, d->M, d->N, split > 1 ? split : d->batch, st);
+  else {
+    // Launches of at most one workgroup per CU (batch-1 inference: every product; the training step: the action head's x-chain) are
+    // bound by the LATENCY of a K-tile, not by bandwidth: with the two-stage ring one K-tile is in flight per workgroup and every tile
+    // costs a full trip to HBM (~1.2 us against 0.2 us of MFMAs: 17-22 us for ANY product of the batch-1 pass, K = 896-1152, whatever its
+    // size).  They run on a four-stage ring (128 KiB of LDS: the CU is theirs anyway), three K-tiles in flight - or, when even 64-row tiles
+    // leave CUs idle, on 64 x 128 tiles with a six-stage ring (144 KiB, five in flight, twice the workgroups: what such a launch can keep
+    // in flight is workgroups x ring bytes) -, the same K order and MFMA sequence: bit-identical (test_gemm_deep_ring_bit_identical).
+    // Only under vla_gemm_latency_hint(1): in the training step the same launches share the chip with two other streams' kernels, and a 128-KiB workgroup waits for a whole CU's LDS where the 64-KiB one
+    // slips in beside another (step 24.13 -> 24.44 ms same box with the deep ring on every sub-round launch).  VLA_NO_DEEP_RING=1: two
+    // stages everywhere (A/B aid).
+    const int nb = split > 1 ? split : d->batch;
+    const long long wgs = (long long)((d->M + 127) / 128) * ((d->N + 127) / 128) * nb, wgs64 = (long long)((d->M + 63) / 64) * ((d->N + 127) / 128) * nb;
+    const bool lat = g_latency_hint.load(std::memory_order_relaxed) > 0 && tc.bn == 128 && p.K / BK >= 4 && !getenv("VLA_NO_DEEP_RING");
+    const bool deep64 = lat && wgs64 <= vla_num_cus();            // 64-row tiles, six stages (144 KiB): twice the workgroups, five K-tiles in flight
+    const bool deep = lat && !deep64 && wgs <= vla_num_cus();     // 128-row tiles, four stages (128 KiB)
+    if (d->rope_mode == 1) {               // 8 waves, rotation pairs inside a lane
+      if (deep64) launch<64, 128, 6, 1, 4>(p, d->M, d->N, nb, st);
+      else if (deep) launch<128, 128, 4, 1, 4>(p, d->M, d->N, nb, st);
+      else launch<128, 128, 2, 1, 4>(p, d->M, d->N, nb, st);
+    } else if (d->rope_mode == 2) {
+      if (deep64) launch<64, 128, 6, 2, 4>(p, d->M, d->N, nb, st);
+      else if (deep) launch<128, 128, 4, 2, 4>(p, d->M, d->N, nb, st);
+      else if (tc.bn == 128) launch<128, 128, 2, 2, 4>(p, d->M, d->N, nb, st);
+      else launch<128, 64, 2, 2>(p, d->M, d->N, nb, st);
+    } else if (deep64) launch<64, 128, 6, 0, 4>(p, d->M, d->N, nb, st);
+    else if (deep) launch<128, 128, 4, 0, 4>(p, d->M, d->N, nb, st);
+    else if (tc.bn == 128) launch<128, 128, 2, 0, 4>(p, d->M, d->N, nb, st);   // 8 waves (2x4) of 64x32
+    else launch<128, 64, 2, 0>(p, d->M, d->N, nb, st);
+  }
   VLA_CHECK_LAUNCH("gemm_bf16_nt");
   if (split > 1) {
     const long long total = (long long)d->M * d->N / 4;

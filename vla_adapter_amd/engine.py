@@ -1021,7 +1021,8 @@ class VLAEngine:
                 self.forward(static, None)
             torch.cuda.synchronize()
             segs = self._predict_segments(static)
-            graphs = self._capture_segments(segs, {})
+            with ops.latency_hint():                 # sub-chip launches on an idle chip: the deep-ring GEMM (bit-identical; baked into the graphs)
+                graphs = self._capture_segments(segs, {})
             torch.cuda.synchronize()
             cache[key] = (graphs, static, segs)
         graphs, static, segs = cache[key]

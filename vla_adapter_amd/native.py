@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = (os.environ.get("VLA_NATIVE_LIB") or None) or os.path.join(_HERE, "libvla_native.so")   # override: same-box A/B of two builds
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_TANH, ACT_SWIGLU, ACT_SWIGLU_BWD = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 5          # include/vla_native.h: VLA_ABI_VERSION
+ABI_VERSION = 6          # include/vla_native.h: VLA_ABI_VERSION
 
 
 class NativeLibraryMissing(ImportError):
@@ -77,6 +77,7 @@ _PROTOS = {
     "vla_desc_size": ([_I], _I),
     "vla_gemm256_extent_ok": ([C.POINTER(GemmDesc)], _I),
     "vla_gemm_uses_256": ([C.POINTER(GemmDesc)], _I),
+    "vla_gemm_latency_hint": ([C.c_int], _I),
     "vla_gemm_bf16_tn": ([_P, C.POINTER(GemmTnDesc)], _I),
     "vla_gemm_bf16_tn_grouped": ([_P, C.POINTER(GemmTnDesc), _I], _I),
     "vla_copy_rows3d": ([_P, _P, _P, _I, _I, _I, _L, _L, _L, _L], _I),

@@ -143,6 +143,19 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_m
     return out
 
 
+class latency_hint:
+    """``with ops.latency_hint():`` - the products launched (or captured into a hipGraph) inside run on an otherwise idle chip and are
+    latency-bound (batch-1 predict_action): vla_gemm_latency_hint(1) for the block.  Kernel selection only, bit-identical results."""
+
+    def __enter__(self):
+        self.prev = _lib().vla_gemm_latency_hint(1)
+        return self
+
+    def __exit__(self, *exc):
+        _lib().vla_gemm_latency_hint(self.prev)
+        return False
+
+
 _SPLITK_WS = {}
 
 
