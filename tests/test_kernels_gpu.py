@@ -1043,6 +1043,34 @@ def test_gemm_deep_ring_bit_identical(ops, M, N, K, kind, monkeypatch):
     assert not bad, f"deep ring {M}x{N}x{K} {kind}: launches {bad} differ from the two-stage kernel"
 
 
+@pytest.mark.parametrize("M,N,K,sk", [(4096, 64, 1152, 0), (5632, 192, 896, 0), (2048, 128, 1024, 0), (1500, 64, 256, 0), (1024, 192, 1792, 0),
+                                      (5632, 128, 1536, 0), (1031, 64, 128, 0), (4096, 192, 1152, 0), (4096, 128, 896, 0),
+                                      (4096, 64, 1920, None), (2048, 192, 2048, None)])
+def test_gemm_skinny(ops, M, N, K, sk, monkeypatch):
+    """gemm_skinny.hip (the LoRA t = 2 x A^T / dt = 2 dy B products, round 4): 32 rows x all N columns per workgroup, the contraction
+    split over its four waves.  Against the oracle's Linear; against the 128-row tiles (another fp32 association: a tolerance); bit for
+    bit against the 128-row tiles with split_k = 4 where their slices coincide (K % 256 == 0: the same four partial sums in the same
+    order).  Ragged M, a strided output; sk = None: ops.gemm_nt's own choice (K = 2048 and more stays on the 128-row tiles with split-K)."""
+    a, b = gen(M, K, seed=241).to(DEV), gen(N, K, seed=242, scale=0.05).to(DEV)
+    big = torch.zeros(M, N + 64, dtype=BF, device=DEV)
+    out = ops.gemm_nt(a, b, alpha=2.0, out=big[:, :N], split_k=sk)
+    assert torch.equal(big[:, N:], torch.zeros_like(big[:, N:])), "wrote outside its columns"
+    check(out, O.rnd(2.0 * (f(a) @ f(b).T), True), name=f"skinny {M}x{N}x{K} vs fp32")
+    monkeypatch.setenv("VLA_NO_SKINNY", "1")
+    ref = ops.gemm_nt(a, b, alpha=2.0, split_k=0)
+    d = (out.float() - ref.float()).abs()
+    assert (d > 0).float().mean().item() < 0.02 and d.max().item() <= 2 ** -7 * ref.float().abs().max().item(), "against the 128-row tiles"
+    if K % 256 == 0 and sk == 0:
+        ref4 = ops.gemm_nt(a, b, alpha=2.0, split_k=4, out=torch.empty(M, N, dtype=BF, device=DEV))
+        assert torch.equal(out, ref4), f"skinny {M}x{N}x{K}: differs from split_k = 4 of the 128-row tiles"
+    monkeypatch.delenv("VLA_NO_SKINNY")
+    # the routing leaves everything with an epilogue alone
+    bias = gen(N, seed=243).to(DEV)
+    y = ops.gemm_nt(a, b, bias=bias, split_k=0)
+    monkeypatch.setenv("VLA_NO_SKINNY", "1")
+    assert torch.equal(y, ops.gemm_nt(a, b, bias=bias, split_k=0))
+
+
 def test_gemm256_swiglu_forward_and_backward_bit_identical(ops, monkeypatch):
     M, D, I = 1100, 896, 1216
     x, wg, wu = gen(M, D, seed=211), gen(I, D, seed=212, scale=0.05), gen(I, D, seed=213, scale=0.05)

@@ -147,6 +147,40 @@ def test_gemm_k_extension_keeps_the_fused_epilogues(ops):
         del os.environ["VLA_GEMM_TILE"]
 
 
+@pytest.mark.parametrize("M,N,K,K2,kind", [(4096, 1152, 1152, 64, "plain"), (5632, 896, 896, 192, "res"), (2100, 1000, 448, 128, "res"), (1024, 768, 64, 64, "gelu"),
+                                           (5632, 1152, 896, 192, "rope"), (2200, 2432, 896, 128, "swiglu"), (4096, 4352, 1152, 64, "gelu")])
+def test_gemm256_k_extension_bit_identical(ops, M, N, K, K2, kind, monkeypatch):
+    """Round 4: the K extension on the 256 x 256 kernel (its EXT instantiations: the K-tiles behind K / 64 staged from A2 / B2) - bit for bit
+    the 128-row kernel's extended product (same K order, same MFMA sequence, same epilogue), every epilogue a LoRA-wrapped Linear uses."""
+    d = lambda t: t.to(DEV)
+    a, b, a2, b2 = d(gen(M, K, seed=31)), d(gen(N, K, seed=32, scale=0.05)), d(gen(M, K2, seed=33)), d(gen(N, K2, seed=34, scale=0.05))
+    kw = dict(ext=(a2, b2))
+    if kind in ("plain", "res", "gelu", "rope"):
+        kw["bias"] = d(gen(N, seed=35))
+    if kind == "res":
+        kw["residual"] = d(gen(M, N, seed=36))
+    if kind == "gelu":
+        kw["act"] = 1
+    if kind == "rope":
+        S = 352
+        cos, sin = ops.rope_half_tables(S, 64, 1e6, DEV)
+        kw["rope"] = (1, cos, sin, S, 64, 1024)
+    if kind == "swiglu":
+        kw["act"] = ops.ACT_SWIGLU
+    monkeypatch.setenv("VLA_GEMM_TILE", "2")
+    ref = ops.gemm_nt(a, b, **kw)
+    monkeypatch.setenv("VLA_GEMM_TILE", "6")
+    assert ops.gemm_nt(a, b, query_256=True, **kw), "the 256-row kernel refused the extended product"
+    out = ops.gemm_nt(a, b, **kw)
+    monkeypatch.delenv("VLA_GEMM_TILE")
+    if kind == "swiglu":
+        assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
+    else:
+        assert torch.equal(out, ref), f"{(out.float() - ref.float()).abs().max().item()}"
+    auto = ops.gemm_nt(a, b, **kw)                                        # whichever kernel the routing picks: the same bits
+    assert torch.equal(auto[1] if kind == "swiglu" else auto, ref[1] if kind == "swiglu" else ref)
+
+
 def _deq(q, s):
     return q.cpu().view(torch.float8_e4m3fn).float() * s.cpu()[:, None]
 

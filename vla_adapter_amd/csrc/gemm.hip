@@ -709,10 +709,42 @@ static TileChoice route(const vla_gemm_desc* d) {
   return tc;
 }
 
+// K extension on the 256 x 256 kernel (round 4; bf16 operands): the routing of the plain product over K + K2, provided the extension's rows
+// are addressable like the main operands' (32-bit per-lane byte offsets, no row groups on A) and the epilogue is one the kernel has
+// (plain / activation / residual / rotate_half at head dim 64 / SwiGLU forward).
+static bool ext_on_256(const vla_gemm_desc* d) {
+  if (d->K2 <= 0 || d->fp8 || d->batch != 1 || d->split_k > 1 || d->act == VLA_ACT_SWIGLU_BWD || d->rope_mode == 2 || d->a_group != 0 ||
+      (d->rope_mode == 1 && d->rope_dh != 64) || !vla_gemm256_extent_ok(d))
+    return false;
+  const unsigned long long ra = (unsigned long long)((d->M + 255) / 256) * 256, rb = (unsigned long long)((d->N + 255) / 256) * 256;
+  if ((ra * d->lda2 + d->K2) * 2 >= (1ull << 32) || (rb * d->ldb2 + d->K2) * 2 >= (1ull << 32)) return false;
+  const char* e = getenv("VLA_GEMM_TILE");
+  const int force = e ? atoi(e) : 0;
+  if (force == 6) return true;
+  if (force != 0) return false;
+  const long long t256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256);
+  static const bool no_rope256 = getenv("VLA_NO_ROPE256") != nullptr;
+  if (d->rope_mode == 1 && (no_rope256 || t256 < 192)) return false;
+  return use_256(d->M, d->N, d->K + d->K2, 1, d->act);
+}
+
 extern "C" int vla_gemm_uses_256(const vla_gemm_desc* d) {
-  if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->K2 > 0 || d->fp8 || d->split_k > 1) return 0;
+  if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->fp8 || d->split_k > 1) return 0;
+  if (d->K2 > 0) return ext_on_256(d) ? 1 : 0;
   const TileChoice tc = route(d);
   return tc.bm == 256 && tc.bn == 257 ? 1 : 0;
+}
+
+// second pass of a split-K product: the `split` fp32 planes of d->ws summed in order, then alpha / bias / activation / residual / rounding
+static int splitk_finalize(const vla_gemm_desc* d, int split, hipStream_t st) {
+  const long long total = (long long)d->M * d->N / 4;
+  const unsigned nblk = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(splitk_finalize_kernel, dim3(nblk), dim3(256), 0, st, (const float*)d->ws, (const bf16_t*)d->bias,
+                     (const bf16_t*)d->R, (bf16_t*)d->C, d->M, d->N, d->ldc, d->ldr, d->act, d->alpha == 0.f ? 1.f : d->alpha, split,
+                     (d->ldc % 4 == 0 && ((uintptr_t)d->C & 7) == 0 && (!d->R || (d->ldr % 4 == 0 && ((uintptr_t)d->R & 7) == 0)) &&
+                      (!d->bias || ((uintptr_t)d->bias & 7) == 0)) ? 1 : 0);
+  VLA_CHECK_LAUNCH("gemm_splitk_finalize");
+  return VLA_OK;
 }
 
 extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
@@ -760,6 +792,15 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   VLA_REQUIRE(d->bias_post_round == 0 || (d->bias_post_round == 1 && d->bias && d->rope_mode != 1 && split == 1 && d->act == VLA_ACT_NONE),
               "gemm: bias_post_round needs a bias and a plain epilogue (no rotate_half rope / split-K / activation)");
   p.ws = nullptr;
+  {   // tall-skinny products (the LoRA t / dt products: N = rank x pairs, M in the thousands, K < 2048): gemm_skinny.hip
+    const char* et = getenv("VLA_GEMM_TILE");
+    const bool plain = !d->bias && !d->R && d->act == VLA_ACT_NONE && d->rope_mode == 0 && d->a_group == 0 && d->c_group == 0 && d->r_group == 0 &&
+                       d->c_live_mod == 0 && !d->bias_post_round && !d->fp8 && d->K2 == 0 && d->C && !(et && atoi(et) != 0);
+    if (vla_gemm_skinny_try(p, d->batch, split, plain, (hipStream_t)stream)) {
+      VLA_CHECK_LAUNCH("gemm_bf16_nt(skinny)");
+      return VLA_OK;
+    }
+  }
   if (split > 1) {
     VLA_REQUIRE(d->ws && d->batch == 1 && d->K % (BK * split) == 0 && d->rope_mode == 0 && d->c_group == 0 && d->r_group == 0 &&
                     d->res_mod == 0 && d->c_live_mod == 0 && d->C &&
@@ -794,13 +835,14 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   const char* e = getenv("VLA_GEMM_TILE");
   const TileChoice tc = route(d);
   const bool fits256 = vla_gemm256_extent_ok(d) != 0;
-  if (d->K2 > 0) {                 // K extension: 128-row kernel (the 256-row kernel's hand-counted DMA schedule has one operand pair)
+  if (d->K2 > 0) {                 // K extension: the 128-row kernel, or - bf16, chip-filling shapes - the 256-row kernel's EXT instantiations
     hipStream_t sx = (hipStream_t)stream;
     if (d->fp8) {                  // e4m3 base operands, bf16 extension: the scales meet the accumulator between the two contractions
       if (d->act == VLA_ACT_SWIGLU_BWD) launch<128, 128, 2, 3, 4, true, true>(p, d->M, d->N, 1, sx);
       else if (d->rope_mode == 1) launch<128, 128, 2, 1, 4, true, true>(p, d->M, d->N, 1, sx);
       else launch<128, 128, 2, 0, 4, true, true>(p, d->M, d->N, 1, sx);
-    } else if (d->act == VLA_ACT_SWIGLU_BWD) launch<128, 128, 2, 3, 4, false, true>(p, d->M, d->N, 1, sx);
+    } else if (ext_on_256(d)) vla_gemm256_launch(p, d->act == VLA_ACT_SWIGLU ? 1 : 0, 1, sx);     // (p.K2 > 0: the EXT instantiations)
+    else if (d->act == VLA_ACT_SWIGLU_BWD) launch<128, 128, 2, 3, 4, false, true>(p, d->M, d->N, 1, sx);
     else if (d->rope_mode == 1) launch<128, 128, 2, 1, 4, false, true>(p, d->M, d->N, 1, sx);
     else launch<128, 128, 2, 0, 4, false, true>(p, d->M, d->N, 1, sx);
     VLA_CHECK_LAUNCH("gemm_bf16_nt(ext)");
@@ -856,14 +898,6 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
     else launch<128, 64, 2, 0>(p, d->M, d->N, nb, st);
   }
   VLA_CHECK_LAUNCH("gemm_bf16_nt");
-  if (split > 1) {
-    const long long total = (long long)d->M * d->N / 4;
-    const unsigned nblk = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(splitk_finalize_kernel, dim3(nblk), dim3(256), 0, st, (const float*)d->ws, (const bf16_t*)d->bias,
-                       (const bf16_t*)d->R, (bf16_t*)d->C, d->M, d->N, d->ldc, d->ldr, d->act, d->alpha == 0.f ? 1.f : d->alpha, split,
-                       (d->ldc % 4 == 0 && ((uintptr_t)d->C & 7) == 0 && (!d->R || (d->ldr % 4 == 0 && ((uintptr_t)d->R & 7) == 0)) &&
-                        (!d->bias || ((uintptr_t)d->bias & 7) == 0)) ? 1 : 0);
-    VLA_CHECK_LAUNCH("gemm_splitk_finalize");
-  }
+  if (split > 1) return splitk_finalize(d, split, st);
   return VLA_OK;
 }

@@ -96,7 +96,10 @@ __device__ __forceinline__ v8i_f8 cat8(bf16x8 lo, bf16x8 hi) {          // two 1
 // F8: OCP e4m3 operands with per-row fp32 scales (gemm.hip's fp8 form, same conventions): a K-tile stays 128 B per row = 128
 // elements = ONE v_mfma_scale_f32_16x16x128_f8f6f4 per 16 x 16 tile instead of two bf16 MFMAs - identical staging, LDS image and
 // barrier structure, half the K-tiles per product.  The scales are applied to the accumulators at the start of the epilogue.
-template <int EPI, bool F8 = false, bool RES = true, bool R2 = false>
+// EXT (round 4): K extension - the contraction continues over a second bf16 operand pair (A2 [M, K2], B2 [N, K2]: gemm.hip's EXT, the
+// LoRA-wrapped Linear as one product); the K-tiles behind K / 64 are staged from (A2, B2) through four more per-lane offsets each, the
+// loop, its counted waits and the epilogues are unchanged.  Separate instantiations: the plain kernels keep their register count.
+template <int EPI, bool F8 = false, bool RES = true, bool R2 = false, bool EXT = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int EB = F8 ? 1 : 2;      // bytes per operand element
@@ -122,6 +125,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
   // sources as wave-uniform bases + 32-bit per-lane byte offsets (half the address registers of eight pointers)
   const char* Ab; const char* Bb;
   unsigned oa[2][2], ob[2][2];
+  unsigned oa2[EXT ? 2 : 1][2], ob2[EXT ? 2 : 1][2];      // EXT: the same rows of A2 / B2 (their own row strides)
   auto setup = [&](int swz) {
     int sl = lane;
     asm volatile("" : "+v"(sl));       // per-tile address arithmetic stays here (hoisted out of the tile loop it costs registers
@@ -152,15 +156,31 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
         oa[h][j] = (unsigned)((gA > 0 ? (long long)(ra / gA) * p.sgA + (long long)(ra % gA) * p.lda : (long long)ra * p.lda) * EB + kc);
         const int rb = min(n0 + (wid >> 1) * 64 + h * 32 + (wid & 1) * 16 + j * 8 + lrow, p.N - 1);
         ob[h][j] = (unsigned)((long long)rb * p.ldb * EB + kc);
+        if constexpr (EXT) {
+          oa2[h][j] = (unsigned)((long long)ra * p.lda2 * 2 + kc);
+          ob2[h][j] = (unsigned)((long long)rb * p.ldb2 * 2 + kc);
+        }
       }
   };
   const unsigned wdst = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem) + wid * 2048;
   // half-tile kinds inside a K-tile buffer: 0 = B0, 1 = A0, 2 = B1, 3 = A1 (the order of first use)
   auto stage_a = [&](int slot, int h, int k0) {
+    if (EXT && k0 >= p.K) {          // (wave-uniform: K-tiles of the extension)
+      const char* b2 = reinterpret_cast<const char*>(p.A2) + (k0 - p.K) * 2;
+      glds16s(b2, oa2[EXT ? h : 0][0], wdst + slot * HT);
+      glds16s(b2, oa2[EXT ? h : 0][1], wdst + slot * HT + 1024);
+      return;
+    }
     glds16s(Ab + k0 * 2, oa[h][0], wdst + slot * HT);
     glds16s(Ab + k0 * 2, oa[h][1], wdst + slot * HT + 1024);
   };
   auto stage_b = [&](int slot, int h, int k0) {
+    if (EXT && k0 >= p.K) {
+      const char* b2 = reinterpret_cast<const char*>(p.B2) + (k0 - p.K) * 2;
+      glds16s(b2, ob2[EXT ? h : 0][0], wdst + slot * HT);
+      glds16s(b2, ob2[EXT ? h : 0][1], wdst + slot * HT + 1024);
+      return;
+    }
     glds16s(Bb + k0 * 2, ob[h][0], wdst + slot * HT);
     glds16s(Bb + k0 * 2, ob[h][1], wdst + slot * HT + 1024);
   };
@@ -192,7 +212,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmP p) {
     }
   };
 
-  const int nt = p.K / (F8 ? 2 * BK : BK);      // K-tiles of 128 B per row
+  const int nt = p.K / (F8 ? 2 * BK : BK) + (EXT ? p.K2 / BK : 0);      // K-tiles of 128 B per row (EXT: those of the extension behind)
 
   const int aoff = wr * 64 * 128, boff = wc * 32 * 128;
 
@@ -742,7 +762,7 @@ int num_cus() {
   return n;
 }
 
-template <int EPI, bool F8 = false, bool RES = true, bool R2 = false>
+template <int EPI, bool F8 = false, bool RES = true, bool R2 = false, bool EXT = false>
 int launch256(const GemmP& p0, int batch, hipStream_t st) {
   GemmP p = p0;
   p.tiles_n = (p.N + 255) / 256;
@@ -750,7 +770,7 @@ int launch256(const GemmP& p0, int batch, hipStream_t st) {
   p.batch = batch;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, F8, RES, R2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm256_kernel<EPI, F8, RES, R2, EXT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
   // one workgroup per CU walks the tiles (VLA_GEMM256_GRID overrides the workgroup count: 0 = one workgroup per tile)
@@ -767,10 +787,10 @@ int launch256(const GemmP& p0, int batch, hipStream_t st) {
   if (grid <= 0 || grid > total) grid = total;
   p.stagger = 0;
   if (total > grid && total % grid != 0) {
-    const long long tile_cycles = (long long)(p.K / BK) * 2128 + 13000;       // K loop + what surrounds it (stamped: DESIGN section 4)
+    const long long tile_cycles = (long long)((p.K + (EXT ? p.K2 : 0)) / BK) * 2128 + 13000;       // K loop + what surrounds it (stamped: DESIGN section 4)
     p.stagger = (int)(tile_cycles * (se != nullptr ? atoi(se) : 50) / 100 / 1024);
   }
-  hipLaunchKernelGGL((gemm256_kernel<EPI, F8, RES, R2>), dim3((unsigned)grid), dim3(512), LDS_BYTES, st, p);
+  hipLaunchKernelGGL((gemm256_kernel<EPI, F8, RES, R2, EXT>), dim3((unsigned)grid), dim3(512), LDS_BYTES, st, p);
   return 0;
 }
 
@@ -779,6 +799,10 @@ int launch256(const GemmP& p0, int batch, hipStream_t st) {
 int vla_num_cus() { return num_cus(); }
 
 int vla_gemm256_launch(const GemmP& p, int epi, int batch, hipStream_t st) {
+  if (p.K2 > 0) {                    // K extension (host: bf16, batch 1, plain / residual / rotate_half or SwiGLU-forward epilogue)
+    if (epi == 1) return launch256<1, false, true, false, true>(p, 1, st);
+    return p.R ? launch256<0, false, true, false, true>(p, 1, st) : launch256<0, false, false, false, true>(p, 1, st);
+  }
   if (p.scaleA != nullptr) return epi == 1 ? launch256<1, true>(p, batch, st) : launch256<0, true>(p, batch, st);     // fp8 operands
   if (p.rope_mode == 2) return launch256<0, false, false, true>(p, batch, st);     // (host: plain epilogue, no residual)
   if (epi == 1) return launch256<1>(p, batch, st);
