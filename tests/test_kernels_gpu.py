@@ -1028,6 +1028,7 @@ def test_gemm_deep_ring_bit_identical(ops, M, N, K, kind, monkeypatch):
     elif kind == "split":
         kw.update(residual=r, split_k=4)
     assert ops._lib().vla_gemm_latency_hint(-1) == 0
+    monkeypatch.setenv("VLA_NO_SMALL_ROWS", "1")      # (the hint's other routing - gemm_skinny.hip for <= 512 rows - has its own test below)
     ref = ops.gemm_nt(a, b, **kw)
     junk, side = torch.empty(64 << 20, dtype=torch.uint8, device=DEV), torch.cuda.Stream()
     outs = []
@@ -1064,11 +1065,46 @@ def test_gemm_skinny(ops, M, N, K, sk, monkeypatch):
         ref4 = ops.gemm_nt(a, b, alpha=2.0, split_k=4, out=torch.empty(M, N, dtype=BF, device=DEV))
         assert torch.equal(out, ref4), f"skinny {M}x{N}x{K}: differs from split_k = 4 of the 128-row tiles"
     monkeypatch.delenv("VLA_NO_SKINNY")
-    # the routing leaves everything with an epilogue alone
-    bias = gen(N, seed=243).to(DEV)
-    y = ops.gemm_nt(a, b, bias=bias, split_k=0)
-    monkeypatch.setenv("VLA_NO_SKINNY", "1")
-    assert torch.equal(y, ops.gemm_nt(a, b, bias=bias, split_k=0))
+
+
+@pytest.mark.parametrize("M,N,K,kind", [(256, 896, 896, "bias_relu"), (256, 2688, 896, "rope2"), (256, 896, 896, "res"), (8, 896, 896, "res"),
+                                        (8, 2688, 896, "rope2"), (369, 896, 896, "res"), (256, 3456, 1152, "bias"), (256, 4352, 1152, "gelu"),
+                                        (100, 1008, 640, "post"), (512, 1024, 1024, "res"), (200, 48, 512, "bias"), (64, 896, 1792, "gelu_res")])
+def test_gemm_small_rows(ops, M, N, K, kind, monkeypatch):
+    """gemm_skinny.hip, shape class (b), under the latency hint: products of at most 512 rows (the batch-1 pass) on
+    16 x 16 ... 64 x 96 output tiles with the contraction split over the workgroup's four waves, gemm.hip's epilogue at gemm.hip's rounding
+    points.  Against the oracle's Linear; against the 128-row tiles (another fp32 association: rare one-ulp differences); bit for bit against
+    the 128-row tiles with split_k = 4 where the four K slices coincide (K % 256 == 0, epilogues the split-K second pass has)."""
+    a, b = gen(M, K, seed=251).to(DEV), gen(N, K, seed=252, scale=0.05).to(DEV)
+    bias, r = gen(N, seed=253).to(DEV), gen(M, N, seed=254).to(DEV)
+    kw = {}
+    if kind in ("bias_relu", "bias", "gelu", "rope2", "post", "res", "gelu_res"):
+        kw["bias"] = bias
+    if kind == "bias_relu":
+        kw["act"] = 2
+    if kind in ("gelu", "gelu_res"):
+        kw["act"] = 1
+    if kind in ("res", "gelu_res"):
+        kw["residual"] = r
+    if kind == "post":
+        kw["bias_post_round"] = True
+    if kind == "rope2":
+        T, dh = 8, 112
+        rc, rs_ = ops.rope_inter_tables(T, dh, DEV)
+        kw["rope"] = (2, rc, rs_, T, dh, 1792)
+    with ops.latency_hint():                       # (class (b) is the batch-1 pass's: only under vla_gemm_latency_hint)
+        out = ops.gemm_nt(a, b, split_k=0, **kw)
+    ref = ops.gemm_nt(a, b, split_k=0, **kw)
+    d = (out.float() - ref.float()).abs()
+    assert (d > 0).float().mean().item() < 0.02 and d.max().item() <= 2 ** -6 * ref.float().abs().max().item(), \
+        f"{kind} {M}x{N}x{K}: {(d > 0).float().mean().item():.4f} of the elements differ, max {d.max().item():.3e}"
+    if K % 256 == 0 and kind not in ("rope2", "post"):
+        ref4 = ops.gemm_nt(a, b, split_k=4, out=torch.empty(M, N, dtype=BF, device=DEV), **kw)
+        assert torch.equal(out, ref4), f"{kind} {M}x{N}x{K}: differs from split_k = 4 of the 128-row tiles"
+    if kind in ("bias", "res", "bias_relu"):
+        y = O.linear(f(a), f(b), f(bias), emu=True)
+        y = torch.relu(y) if kind == "bias_relu" else y
+        check(out, O.rnd(y + f(r), True) if kind == "res" else y, name=f"small rows {kind} vs oracle")
 
 
 def test_gemm256_swiglu_forward_and_backward_bit_identical(ops, monkeypatch):

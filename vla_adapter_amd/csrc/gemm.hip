@@ -792,15 +792,6 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   VLA_REQUIRE(d->bias_post_round == 0 || (d->bias_post_round == 1 && d->bias && d->rope_mode != 1 && split == 1 && d->act == VLA_ACT_NONE),
               "gemm: bias_post_round needs a bias and a plain epilogue (no rotate_half rope / split-K / activation)");
   p.ws = nullptr;
-  {   // tall-skinny products (the LoRA t / dt products: N = rank x pairs, M in the thousands, K < 2048): gemm_skinny.hip
-    const char* et = getenv("VLA_GEMM_TILE");
-    const bool plain = !d->bias && !d->R && d->act == VLA_ACT_NONE && d->rope_mode == 0 && d->a_group == 0 && d->c_group == 0 && d->r_group == 0 &&
-                       d->c_live_mod == 0 && !d->bias_post_round && !d->fp8 && d->K2 == 0 && d->C && !(et && atoi(et) != 0);
-    if (vla_gemm_skinny_try(p, d->batch, split, plain, (hipStream_t)stream)) {
-      VLA_CHECK_LAUNCH("gemm_bf16_nt(skinny)");
-      return VLA_OK;
-    }
-  }
   if (split > 1) {
     VLA_REQUIRE(d->ws && d->batch == 1 && d->K % (BK * split) == 0 && d->rope_mode == 0 && d->c_group == 0 && d->r_group == 0 &&
                     d->res_mod == 0 && d->c_live_mod == 0 && d->C &&
@@ -833,6 +824,14 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
                                        "gemm: fused rotate_half RoPE needs head dim 64, or 128 with N and rope_cols multiples of 128");
   }
   const char* e = getenv("VLA_GEMM_TILE");
+  {   // small-output products (the LoRA t / dt products; the action head's Linears on 8 x B rows; the batch-1 pass): gemm_skinny.hip
+    const bool simple = d->batch == 1 && split == 1 && d->a_group == 0 && d->c_group == 0 && d->r_group == 0 && d->res_mod == 0 && d->c_live_mod == 0 &&
+                        !d->fp8 && d->K2 == 0 && d->C && !(e && atoi(e) != 0);
+    if (vla_gemm_skinny_try(p, simple, g_latency_hint.load(std::memory_order_relaxed) > 0, (hipStream_t)stream)) {
+      VLA_CHECK_LAUNCH("gemm_bf16_nt(skinny)");
+      return VLA_OK;
+    }
+  }
   const TileChoice tc = route(d);
   const bool fits256 = vla_gemm256_extent_ok(d) != 0;
   if (d->K2 > 0) {                 // K extension: the 128-row kernel, or - bf16, chip-filling shapes - the 256-row kernel's EXT instantiations

@@ -23,6 +23,7 @@ struct GemmP {
 
 // gemm256.hip: 256x256x64 tile, 8 waves, staggered 8-phase schedule.  epi: 0 plain, 1 SwiGLU forward, 2 SwiGLU backward.
 int vla_gemm256_launch(const GemmP& p, int epi, int batch, hipStream_t st);
-// gemm_skinny.hip: tall-skinny products (N = 64 / 128 / 192, K < 2048, plain epilogue: alpha only): 1 = launched there, 0 = not its shape.
-int vla_gemm_skinny_try(const GemmP& p, int batch, int split, bool plain_epilogue, hipStream_t st);
+// gemm_skinny.hip: small-output products (tall-skinny N = 64 / 128 / 192, or - under the latency hint - M <= 512; K < 2048; bias / activation / residual /
+// interleaved-RoPE epilogue): 1 = launched there, 0 = not its shape.  `p` must be completely filled.
+int vla_gemm_skinny_try(const GemmP& p, bool simple_addressing, bool latency_hint, hipStream_t st);
 int vla_num_cus();      // compute units of the current device (cached)
