@@ -33,7 +33,7 @@ extern "C" {
  *   4  round 3: vla_gemm_desc gained the RMSNorm fields (ssq_out .. rstd_out); new entry point vla_gemm_uses_256.
  *   5  round 4: the RMSNorm fields are gone again (the fold measured slower and left the tree: tools/diag/gemm256_pruned_paths.patch);
  *      fp8 = 1 may be combined with the K extension (and, in that form, with the SwiGLU-backward epilogue).
- *   6  round 4: new entry point vla_gemm_latency_hint (no layout change).
+ *   6  round 4: new entry points vla_gemm_latency_hint, vla_dropout_bf16, vla_dropout_bwd_add_bf16, vla_inc_i32 (no layout change).
  * A binder checks vla_version() AND vla_desc_size() against its own struct definitions before the first call. */
 #define VLA_ABI_VERSION 6
 int vla_version(void);
@@ -325,6 +325,19 @@ int vla_layerscale_fwd(void* stream, const void* a, const void* ls, const void* 
 int vla_layerscale_bwd(void* stream, const void* dy, const void* a, const void* ls, void* da, float* dls, int rows, int cols);
 /* Zero nbytes at ptr (16-B aligned) with a store kernel on the given stream (gradient accumulators, dHS); graph-capturable. */
 int vla_fill_zero(void* stream, void* ptr, long long nbytes);
+/* Dropout on the input of a LoRA branch - peft's Linear.forward `lora_B(lora_A(lora_dropout(x))) * scaling` with `--lora_dropout > 0`
+ * (vla-scripts/finetune.py:110, 832-840).  y[r, c] = keep(r, c) ? bf16(x[r, c] / (1 - p)) : 0 on bf16 [rows, cols] tensors (row strides
+ * ldx / ldy in elements, cols and strides multiples of 8).  keep() is a counter-based hash of (seed, *step, r * cols + c): `step` points
+ * at a DEVICE int (may be NULL = 0) so that a captured step draws a fresh mask on every replay (vla_inc_i32 bumps it inside the graph);
+ * the backward regenerates the same mask from the same (seed, step): nothing is stored.  torch's Philox stream is not reproduced
+ * (parity with a peft run is statistical; the tests hand the generated mask to the oracle). */
+int vla_dropout_bf16(void* stream, const void* x, void* y, long long rows, int cols, long long ldx, long long ldy, float p,
+                     unsigned long long seed, const int* step);
+/* its backward, accumulated: dx[r, c] = bf16(dx[r, c] + (keep(r, c) ? bf16(u[r, c] / (1 - p)) : 0)) - the LoRA branch's share of a
+ * wrapped Linear's input gradient (u = dt A) added to the base product's. */
+int vla_dropout_bwd_add_bf16(void* stream, const void* u, void* dx, long long rows, int cols, long long ldu, long long lddx, float p,
+                             unsigned long long seed, const int* step);
+int vla_inc_i32(void* stream, int* ptr);      /* *ptr += 1 on the stream (the dropout step counter; graph-capturable) */
 /* Gather / scatter row indices of the 64 action-query hidden states (+ the proprio slot) for engine.Head, and the NaN guard of a
  * frozen live-row window: see the kernel comment in elementwise.hip (finetune.py:396-409 regroup, done by index). */
 int vla_head_index_prep(void* stream, const int* pos1, const int* pos0, const int* cnt0, int* gather, int* scatter,

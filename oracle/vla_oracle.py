@@ -63,15 +63,19 @@ def linear(x, w, b=None, emu=False, strided_input=False):
         y = (rnd(y, emu) if strided_input else y) + b
     y = rnd(y, emu)
     l = LORA.get(id(w))
+    xl = x
+    if l is not None and id(w) in LORA_DROP:       # peft: lora_A(lora_dropout(x)) - the module's own mask over its input (training mode)
+        mask, p = LORA_DROP[id(w)]
+        xl = rnd(x * mask.reshape(x.shape) * (1.0 / (1.0 - p)), emu)
     if l is not None and LORA_FUSED:
         # the native build's form (vla_adapter_amd/trainers.py): the low-rank branch inside the base product's fp32 accumulator -
         # t = bf16(scale x A^T), y = bf16(x W^T + t B^T + b): ONE rounding of y where peft's module-by-module evaluation has three
         A, Bm, scale = l
-        y = base() + rnd(scale * (x @ A.t()), emu) @ Bm.t()
+        y = base() + rnd(scale * (xl @ A.t()), emu) @ Bm.t()
         return rnd(y + b, emu) if b is not None else rnd(y, emu)
     if l is not None:            # peft Linear.forward: result = base(x) + lora_B(lora_A(x)) * scaling, every step a bf16 tensor
         A, Bm, scale = l
-        y = rnd(y + rnd(rnd(rnd(x @ A.t(), emu) @ Bm.t(), emu) * scale, emu), emu)
+        y = rnd(y + rnd(rnd(rnd(xl @ A.t(), emu) @ Bm.t(), emu) * scale, emu), emu)
     return y
 
 
@@ -136,6 +140,9 @@ def fake_quant_e4m3_rows(t):
 # to evaluate the LoRA-wrapped model (vla-scripts/finetune.py:832-844) through the unchanged restated forward.
 LORA: Dict[int, Tuple[torch.Tensor, torch.Tensor, float]] = {}
 LORA_FUSED = False     # True: restate the native build's single-rounding evaluation instead of peft's module-by-module one
+# lora_dropout > 0 (vla-scripts/finetune.py:110): id(base weight tensor) -> (keep mask of the module's input, 0/1 floats, any shape that
+# reshapes to the input's; p).  Tests fill it with the masks the native kernel generated (torch's Philox stream is not reproduced).
+LORA_DROP: Dict[int, Tuple[torch.Tensor, float]] = {}
 
 
 def gelu(x, emu=False, tanh=False):

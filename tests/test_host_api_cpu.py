@@ -91,7 +91,9 @@ def test_unsupported_reference_flags_raise_instead_of_being_ignored():
     F.check_supported(ok, ok._explicit)
     assert F.train_mode(F.parse_args(["--use_lora", "True"])) == "lora" and F.train_mode(F.parse_args(["--use_fz", "True"])) == "adapter"
     assert F.train_mode(F.parse_args([])) == "full"        # the reference's use_lora=False leaves every VLM parameter trainable (:846-849)
-    for argv, exc in ((["--use_proprio", "True", "--use_lora", "True", "--lora_dropout", "0.1"], NotImplementedError),
+    F.check_supported(*(lambda c: (c, c._explicit))(F.parse_args(["--use_proprio", "True", "--use_lora", "True", "--lora_dropout", "0.1"])))   # round 4: built
+    for argv, exc in ((["--use_proprio", "True", "--use_lora", "True", "--lora_dropout", "0.1", "--fp8_base_weights", "True"], NotImplementedError),
+                      (["--use_proprio", "True", "--use_lora", "True", "--lora_dropout", "1.0"], ValueError),
                       (["--use_proprio", "True", "--use_val_set", "True"], NotImplementedError),
                       (["--use_proprio", "True", "--image_aug", "True"], NotImplementedError),       # explicit out-of-path flag
                       (["--use_proprio", "True", "--shuffle_buffer_size", "5"], NotImplementedError),

@@ -354,3 +354,99 @@ def test_lora_one_layer_of_every_kind_at_full_size_dual_backbone():
     ls = [lo.train_step(batch, 1e-4)[0].item() for _ in range(5)]
     torch.cuda.synchronize()
     assert all(v == v for v in ls) and min(ls) < l0, (l0, ls)
+
+
+def test_lora_dropout_one_llm_layer():
+    """lora_dropout > 0 (vla-scripts/finetune.py:110; peft Linear.forward: lora_B(lora_A(dropout(x))) - every wrapped module drops its own
+    copy of the input): one Qwen2.5-0.5B layer of the config-2 backbone at full width, batch 2, p = 0.1 - dX and all fourteen A / B
+    gradients against the oracle evaluating peft's formula with the SAME masks (regenerated from the kernel's (seed, step) keys;
+    torch's Philox stream is not reproduced: parity with a peft run is statistical, this test pins the arithmetic).  Plus the mask's
+    properties: keep rate, independence between q / k / v of one fused projection, a fresh mask on the next step, identity at p = 0."""
+    from vla_adapter_amd import engine as E, synthetic as S, ops
+    from vla_adapter_amd.trainers import LoRAFinetune
+    cfg = E.config2()
+    W = S.make_weights(cfg, DEV, seed=0)
+    batch = S.make_batch(cfg, 2, DEV, seed=90, P=32, ragged=True)
+    batch["pixel_values"] = batch["pixel_values"].to(BF)
+    eng = E.VLAEngine(cfg, W, DEV)
+    p_drop = 0.1
+    lo = LoRAFinetune(eng, rank=64, seed=1, dropout=p_drop)
+    g = torch.Generator(device=DEV).manual_seed(2)
+    for l in lo.L.values():
+        for p_, _ in l.projs:
+            Bv_ = lo.P.view(f"{l.name}.{p_}.lora_B")
+            Bv_[:l.n_real, :l.r] = (torch.randn(min(l.n_real, Bv_.shape[0]), l.r, generator=g, device=DEV) * 0.01).to(BF)
+    lo.refresh()
+    kl = 11
+    lo.taps = {("llm", kl): {}}
+    pred = lo.forward(batch, None)
+    loss3 = lo.backward(pred, batch["actions"])
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss3).all() and torch.isfinite(lo.P.grad.float()).all() and int(lo._drop_step.item()) == 1
+    B, S_, D, I = eng.B, eng.S, cfg.llm.d, cfg.llm.inter
+    M = B * S_
+
+    def mask_of(key, j, K):
+        return (ops.dropout(torch.ones(M, K, dtype=BF, device=DEV), torch.empty(M, K, dtype=BF, device=DEV), p_drop, lo.drop_seed(key, j), lo._drop_step) != 0).float().cpu()
+
+    where = {"self_attn.q_proj": ("qkv", 0, D), "self_attn.k_proj": ("qkv", 1, D), "self_attn.v_proj": ("qkv", 2, D), "self_attn.o_proj": ("o", 0, D),
+             "mlp.gate_proj": ("gu", 0, D), "mlp.up_proj": ("gu", 1, D), "mlp.down_proj": ("down", 0, I)}
+    masks = {n: mask_of(f"llm.{kl}.{k}", j, K) for n, (k, j, K) in where.items()}
+    for n, m in masks.items():
+        assert abs(m.mean().item() - (1 - p_drop)) < 4e-3, (n, m.mean().item())
+    assert not torch.equal(masks["self_attn.q_proj"], masks["self_attn.k_proj"]) and not torch.equal(masks["self_attn.k_proj"], masks["self_attn.v_proj"])
+    agree = (masks["self_attn.q_proj"] == masks["self_attn.k_proj"]).float().mean().item()          # independent draws: p^2 + (1-p)^2
+    assert abs(agree - (p_drop ** 2 + (1 - p_drop) ** 2)) < 5e-3, agree
+    x1 = torch.randn(64, 256, device=DEV).to(BF)
+    assert torch.equal(ops.dropout(x1, torch.empty_like(x1), 0.0, 7, None), x1)
+    kept = ops.dropout(x1, torch.empty_like(x1), 0.5, 7, None)
+    assert torch.equal(kept[kept != 0], (x1.float() * 2).to(BF)[kept != 0])
+
+    sd = {k: v.detach().float().cpu().clone() for k, v in lo.lora_state_dict().items()}
+    gsd = {}
+    for l in lo.L.values():
+        for p_, _ in l.projs:
+            gsd[f"{l.name}.{p_}.lora_A.weight"], gsd[f"{l.name}.{p_}.lora_B.weight"] = lo.P.g(f"{l.name}.{p_}.lora_A")[:l.r, :l.k_real], lo.P.g(f"{l.name}.{p_}.lora_B")[:l.n_real, :l.r]
+    pre = f"base_model.model.language_model.model.layers.{kl}."
+    names = list(where)
+
+    def registrar(store):
+        def reg(p):
+            for n in names:
+                A = sd[f"{pre}{n}.lora_A.weight"].clone().requires_grad_(True)
+                Bm = sd[f"{pre}{n}.lora_B.weight"].clone().requires_grad_(True)
+                store[n] = (A, Bm)
+                key = [k for k in p if k.endswith(n + ".weight")][0]
+                O.LORA[id(p[key])] = (A, Bm, 2.0)
+                O.LORA_DROP[id(p[key])] = (masks[n], p_drop)
+        return reg
+
+    O.LORA_FUSED = True
+    try:
+        t = lo.taps[("llm", kl)]
+        res, stores = {}, {}
+        for emu in (True, False):
+            stores[emu] = {}
+            res[emu] = llm_layer_oracle(W["llm"], kl, eng.llm.HS[kl], eng.llm.kmask.bool().cpu(), t["d_out"].view(B, S_, D), cfg, emu, lora=registrar(stores[emu]))
+        ck = Checker(f"LoRA with dropout {p_drop}: LLM layer {kl}")
+        ck.add("dX", t["d_in"].view(B, S_, D), res[True][0], res[False][0], TOL_DX)
+        for nme in names:
+            for w, idx in (("lora_A", 0), ("lora_B", 1)):
+                ck.add(f"{nme}.{w}", gsd[f"{pre}{nme}.{w}.weight"], stores[True][nme][idx].grad, stores[False][nme][idx].grad, TOL_DW)
+        ck.run()
+        ck.must_catch_a_wrong_scale("mlp.down_proj.lora_A")
+        # the masks matter: against the oracle WITHOUT dropout the A gradients sit several tolerances away (p = 0.1 averaged over ~700 rows: ~3 %)
+        O.LORA_DROP.clear()
+        nod = {}
+        llm_layer_oracle(W["llm"], kl, eng.llm.HS[kl], eng.llm.kmask.bool().cpu(), t["d_out"].view(B, S_, D), cfg, True,
+                         lora=lambda p: [O.LORA.__setitem__(id(p[[k for k in p if k.endswith(n + ".weight")][0]]),
+                                                            nod.setdefault(n, (sd[f"{pre}{n}.lora_A.weight"].clone().requires_grad_(True),
+                                                                               sd[f"{pre}{n}.lora_B.weight"].clone().requires_grad_(True))) + (2.0,)) for n in names])
+        assert rel(gsd[f"{pre}mlp.down_proj.lora_A.weight"], nod["mlp.down_proj"][0].grad) > 3 * TOL_DW
+    finally:
+        O.LORA_FUSED = False
+        O.LORA_DROP.clear()
+        O.LORA.clear()
+    # a second step draws new masks
+    lo.forward(batch, None)
+    assert int(lo._drop_step.item()) == 2 and not torch.equal(mask_of(f"llm.{kl}.o", 0, D), masks["self_attn.o_proj"])

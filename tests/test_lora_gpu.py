@@ -185,3 +185,23 @@ def test_lora_captured_step_matches_eager_steps():
         res.append((losses, lo.P.data.clone(), eng.head.P.data.clone()))
     assert res[0][0] == res[1][0], (res[0][0], res[1][0])
     assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
+def test_finetune_entry_point_lora_dropout(tmp_path):
+    """`vla-scripts/finetune.py --use_lora True --lora_dropout 0.05` (finetune.py:110) on the plumbing-size dual config, captured step:
+    completes, the loss falls, the mask counter advanced once per step (fresh masks on every graph replay), adapter_config.json carries
+    the value; together with the fp8 base products it is refused."""
+    import glob
+    import json
+    from vla_adapter_amd import engine as E, finetune as F, synthetic as S
+    batches = [S.make_batch(E.tiny_fused_config(), 3, "cuda", seed=710 + i, P=24, ragged=True) for i in range(2)]
+    cfg = F.parse_args(["--tiny", "true", "--backbone", "tiny_fused", "--num_images_in_input", "2", "--use_lora", "True", "--lora_rank", "64",
+                        "--lora_dropout", "0.05", "--batch_size", "3", "--max_steps", "10", "--learning_rate", "1e-3", "--wandb_log_freq", "5",
+                        "--save_freq", "10", "--run_root_dir", str(tmp_path), "--phase", "Training", "--use_proprio", "True"])
+    out = F.finetune(cfg, batches=batches)
+    assert out["mode"] == "lora" and out["log"][-1]["loss_value"] < out["log"][0]["loss_value"], out["log"]
+    d = glob.glob(os.path.join(str(tmp_path), "*--10_chkpt"))[0]
+    assert json.load(open(os.path.join(d, "lora_adapter", "adapter_config.json")))["lora_dropout"] == 0.05
+    with pytest.raises(NotImplementedError):
+        F.finetune(F.parse_args(["--tiny", "true", "--use_lora", "True", "--lora_dropout", "0.05", "--fp8_base_weights", "True", "--max_steps", "1",
+                                 "--run_root_dir", str(tmp_path)]))

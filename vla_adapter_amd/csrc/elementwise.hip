@@ -782,6 +782,79 @@ extern "C" int vla_fill_zero(void* stream, void* ptr, long long nbytes) {
   return VLA_OK;
 }
 
+// ---- dropout on the input of a LoRA branch (peft Linear.forward: lora_B(lora_A(lora_dropout(x))), vla-scripts/finetune.py:110, 832-840) ----
+// Counter-based mask: element (r, c) of a [rows, cols] tensor is kept iff a 16-bit uniform drawn from splitmix64(seed', 2 * chunk + half)
+// is >= p * 65536, chunk = (r * cols + c) / 8 (four 16-bit draws per 64-bit hash, eight elements per thread); seed' = seed + step * odd
+// constant with `step` read from DEVICE memory (a captured step draws fresh masks on every replay: vla_inc_i32 bumps it).  Forward and
+// backward regenerate the same mask from (seed, step) - nothing is stored.  Kept values are scaled by 1 / (1 - p) in fp32 and rounded to
+// bf16 once, as torch's dropout kernel does.  (torch's own Philox stream is not reproduced: parity with a peft run is statistical.)
+__device__ __forceinline__ unsigned long long drop_hash(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+template <bool ADD>
+__global__ void dropout_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long long rows, int cols, long long ldx, long long ldy,
+                               unsigned thr, float scale, unsigned long long seed, const int* __restrict__ step) {
+  const int cpr = cols >> 3;
+  const long long total = rows * cpr;
+  const unsigned long long sd = seed + (unsigned long long)(step ? *step : 0) * 0xD1B54A32D192ED03ull;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / cpr;
+    const int c = (int)(i - r * cpr) * 8;
+    const unsigned long long h0 = drop_hash(sd, 2ull * (unsigned long long)i), h1 = drop_hash(sd, 2ull * (unsigned long long)i + 1);
+    const uint4 xv = *reinterpret_cast<const uint4*>(x + r * ldx + c);
+    const unsigned xw[4] = {xv.x, xv.y, xv.z, xv.w};
+    uint4 yv = uint4{0, 0, 0, 0};
+    if (ADD) yv = *reinterpret_cast<const uint4*>(y + r * ldy + c);
+    unsigned yw[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned long long h = k < 2 ? h0 : h1;
+      const bool k0 = ((unsigned)(h >> (32 * (k & 1))) & 0xffffu) >= thr, k1 = ((unsigned)(h >> (32 * (k & 1) + 16)) & 0xffffu) >= thr;
+      const float a = k0 ? rbf(bf2f((bf16_t)(xw[k] & 0xffff)) * scale) : 0.f, b = k1 ? rbf(bf2f((bf16_t)(xw[k] >> 16)) * scale) : 0.f;
+      if (ADD) yw[k] = pack2(bf2f((bf16_t)(yw[k] & 0xffff)) + a, bf2f((bf16_t)(yw[k] >> 16)) + b);
+      else yw[k] = pack2(a, b);
+    }
+    *reinterpret_cast<uint4*>(y + r * ldy + c) = uint4{yw[0], yw[1], yw[2], yw[3]};
+  }
+}
+
+static int dropout_launch(bool add, void* stream, const void* x, void* y, long long rows, int cols, long long ldx, long long ldy, float p,
+                          unsigned long long seed, const int* step) {
+  VLA_REQUIRE(x && y && rows > 0 && cols > 0 && cols % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0,
+              "dropout: null / empty / cols, row strides must be multiples of 8 and the tensors 16-B aligned");
+  VLA_REQUIRE(p >= 0.f && p < 1.f, "dropout: p in [0, 1)");
+  const unsigned thr = (unsigned)(p * 65536.f + 0.5f);
+  const float scale = 1.f / (1.f - p);
+  const long long total = rows * (cols / 8);
+  if (add) hipLaunchKernelGGL(dropout_kernel<true>, GRID1D(total, 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, rows, cols, ldx, ldy, thr, scale, seed, step);
+  else hipLaunchKernelGGL(dropout_kernel<false>, GRID1D(total, 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, rows, cols, ldx, ldy, thr, scale, seed, step);
+  VLA_CHECK_LAUNCH("dropout");
+  return VLA_OK;
+}
+
+extern "C" int vla_dropout_bf16(void* stream, const void* x, void* y, long long rows, int cols, long long ldx, long long ldy, float p,
+                                unsigned long long seed, const int* step) {
+  return dropout_launch(false, stream, x, y, rows, cols, ldx, ldy, p, seed, step);
+}
+
+extern "C" int vla_dropout_bwd_add_bf16(void* stream, const void* u, void* dx, long long rows, int cols, long long ldu, long long lddx, float p,
+                                        unsigned long long seed, const int* step) {
+  return dropout_launch(true, stream, u, dx, rows, cols, ldu, lddx, p, seed, step);
+}
+
+__global__ void inc_i32_kernel(int* p) { if (threadIdx.x == 0 && blockIdx.x == 0) *p += 1; }
+
+extern "C" int vla_inc_i32(void* stream, int* ptr) {
+  VLA_REQUIRE(ptr, "inc_i32: null");
+  hipLaunchKernelGGL(inc_i32_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ptr);
+  VLA_CHECK_LAUNCH("inc_i32");
+  return VLA_OK;
+}
+
 // Index arrays of the action head for one batch (engine.Head): pos1[B,64] = text-coordinate positions of the action-query
 // hidden states (-1: none).  gather[b, k] = b*S + Np + pos1 (k < 64), gather[b, 64] = -2 (proprio slot: leave the row alone);
 // scatter[b, k] = b*(S-row0) + Np + pos1 - row0 or -1 (dead row / none), scatter[b, 64] = -1;

@@ -133,8 +133,10 @@ def check_supported(cfg: FinetuneConfig, explicit=()) -> None:
     """Raise for every reference option this path does not implement (nothing is parsed and silently dropped)."""
     if cfg.grad_accumulation_steps < 1:
         raise ValueError("grad_accumulation_steps must be >= 1")
-    if cfg.use_lora and cfg.lora_dropout != 0.0:
-        raise NotImplementedError("--lora_dropout > 0: the low-rank branch is built without dropout (every shipped script uses 0.0)")
+    if cfg.use_lora and not 0.0 <= cfg.lora_dropout < 1.0:
+        raise ValueError("--lora_dropout must lie in [0, 1)")
+    if cfg.use_lora and cfg.lora_dropout > 0.0 and cfg.fp8_base_weights:
+        raise NotImplementedError("--lora_dropout > 0 together with --fp8_base_weights: the dropped inputs are bf16 (use one or the other)")
     if cfg.fp8_base_weights and not cfg.use_lora:
         raise NotImplementedError("--fp8_base_weights needs --use_lora True (frozen base weights); the adapter-only forward has engine.enable_fp8_frozen()")
     if cfg.ddp_algo not in ("allreduce", "rs_ag"):
@@ -338,7 +340,7 @@ def finetune(cfg: FinetuneConfig, batches=None, explicit=()) -> dict:
     trainer = None
     if mode == "lora":
         from .trainers import LoRAFinetune
-        trainer = LoRAFinetune(eng, rank=cfg.lora_rank, seed=cfg.seed, fp8=cfg.fp8_base_weights)
+        trainer = LoRAFinetune(eng, rank=cfg.lora_rank, seed=cfg.seed, fp8=cfg.fp8_base_weights, dropout=cfg.lora_dropout)
         if lora_sd is not None:
             trainer.load_lora_state_dict(lora_sd)
     elif mode == "full":

@@ -117,6 +117,9 @@ _PROTOS = {
     "vla_token_ce_bwd": ([_P, _P, _L, _P, _I, _I, _P, _F, _P, _L], _I),
     "vla_copy2d": ([_P, _P, _P, _L, _I, _L, _L, _I, _I, _I, _I, _L], _I),
     "vla_fill_zero": ([_P, _P, _L], _I),
+    "vla_dropout_bf16": ([_P, _P, _P, _L, C.c_int, _L, _L, C.c_float, C.c_ulonglong, _P], _I),
+    "vla_dropout_bwd_add_bf16": ([_P, _P, _P, _L, C.c_int, _L, _L, C.c_float, C.c_ulonglong, _P], _I),
+    "vla_inc_i32": ([_P, _P], _I),
     "vla_quant_fp8_rows": ([_P, _P, _P, _P, _I, _I, _I, _I], _I),
     "vla_rmsnorm_fwd_q8": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F], _I),
     "vla_layernorm_fwd_q8": ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F], _I),

@@ -698,6 +698,30 @@ def quant_fp8_rows(x: torch.Tensor, out: Optional[torch.Tensor] = None, scale: O
     return out, scale
 
 
+def dropout(x: torch.Tensor, out: torch.Tensor, p: float, seed: int, step: Optional[torch.Tensor] = None):
+    """out = dropout(x, p) on 2-D bf16 views (last stride 1): vla_dropout_bf16.  step: device int32 [1] (the mask's second key) or None."""
+    _chk_bf16(x, out)
+    assert x.dim() == 2 and x.shape == out.shape and x.stride(1) == 1 and out.stride(1) == 1
+    N.check(_lib().vla_dropout_bf16(_st(), _p(x), _p(out), x.shape[0], x.shape[1], x.stride(0), out.stride(0), float(p), int(seed) & (2 ** 64 - 1),
+                                    _p(step) if step is not None else None), "dropout")
+    return out
+
+
+def dropout_bwd_add_(dx: torch.Tensor, u: torch.Tensor, p: float, seed: int, step: Optional[torch.Tensor] = None):
+    """dx += dropout'(u) with the mask of dropout(., p, seed, step): vla_dropout_bwd_add_bf16."""
+    _chk_bf16(dx, u)
+    assert u.dim() == 2 and u.shape == dx.shape and u.stride(1) == 1 and dx.stride(1) == 1
+    N.check(_lib().vla_dropout_bwd_add_bf16(_st(), _p(u), _p(dx), u.shape[0], u.shape[1], u.stride(0), dx.stride(0), float(p), int(seed) & (2 ** 64 - 1),
+                                            _p(step) if step is not None else None), "dropout_bwd_add")
+    return dx
+
+
+def inc_i32_(t: torch.Tensor):
+    assert t.dtype == torch.int32 and t.numel() >= 1
+    N.check(_lib().vla_inc_i32(_st(), _p(t)), "inc_i32")
+    return t
+
+
 def zero_(t: torch.Tensor):
     assert t.is_contiguous()
     N.check(_lib().vla_fill_zero(_st(), _p(t), t.numel() * t.element_size()), "fill_zero")

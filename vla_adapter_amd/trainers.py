@@ -96,10 +96,15 @@ class LoraLinear:
         ops.transpose(self.A_cat, out=self.A_catT)
         ops.transpose(self.B_blk, out=self.B_blkT)
 
-    def grads(self, dy2d, x2d, t2d, dt2d, emit):
+    def grads(self, dy2d, x2d, t2d, dt2d, emit, dropped: bool = False):
         """dA_cat = dt^T x (one TN product into the flat gradient), dB_j = dy_j^T t_j per pair (the columns of dy that belong to
-        pair j: a range, or 16-column groups every 32 for gate / up).  emit(a, b, out, alpha, a_cols) launches or collects them."""
-        emit(dt2d, x2d, self.gA_cat)
+        pair j: a range, or 16-column groups every 32 for gate / up).  emit(a, b, out, alpha, a_cols) launches or collects them.
+        dropped (lora_dropout > 0): x2d is [pairs, M, K], pair j's own dropped input - one dA product per pair."""
+        if dropped:
+            for j in range(len(self.projs)):
+                emit(dt2d[:, j * self.rp:(j + 1) * self.rp], x2d[j], self.gA_cat[j * self.rp:(j + 1) * self.rp])
+        else:
+            emit(dt2d, x2d, self.gA_cat)
         for j, (p, d) in enumerate(self.projs):
             gB = self.P.g(f"{self.name}.{p}.lora_B")
             tj = t2d[:, j * self.rp:(j + 1) * self.rp]
@@ -520,6 +525,7 @@ class BackboneTrainer:
         def f_front():
             eng._vision_begin(batch)
             self._alloc(eng.B, eng.S)
+            self._begin_forward()
             for j in range(len(self.vits)):
                 self._vit_forward(j, batch["pixel_values"])
             self._proj_forward()
@@ -603,6 +609,7 @@ class BackboneTrainer:
         def f_front():
             eng._vision_begin(batch)
             self._alloc(eng.B, eng.S)
+            self._begin_forward()
             for j in range(len(self.vits)):
                 self._vit_forward(j, batch["pixel_values"])
             self._proj_forward()
@@ -767,6 +774,9 @@ class BackboneTrainer:
 
     def _begin_backward(self):
         pass
+
+    def _begin_forward(self):
+        pass                     # (first launch of a step: LoRA with dropout bumps its mask counter here)
 
     def _end_backward(self):
         pass
@@ -1118,8 +1128,16 @@ class LoRAFinetune(BackboneTrainer):
     mode = "lora"
     trains_vectors = False
 
-    def __init__(self, eng: E.VLAEngine, rank: int = 32, seed: int = 0, fp8: bool = False, fp8_backward: Optional[bool] = None):
-        """fp8: BASELINE configs[4]'s "fp8 MFMA weight path" where it belongs - under LoRA every base weight is frozen, so every base
+    def __init__(self, eng: E.VLAEngine, rank: int = 32, seed: int = 0, fp8: bool = False, fp8_backward: Optional[bool] = None,
+                 dropout: float = 0.0):
+        """dropout: peft's ``lora_dropout`` (vla-scripts/finetune.py:110, 832-840; every shipped script uses 0.0): each wrapped module drops
+        ITS OWN copy of the input before lora_A - q / k / v of one fused projection draw three masks over the same x.  With p > 0 a pair's
+        t_j = 2 dropout_j(x) A_j^T comes from its own dropped input (kept for dA_j = dt_j^T dropout_j(x)), the base product keeps t B^T
+        inside its accumulator, and the input gradient leaves the single accumulator: dx = dy W + sum_j mask_j * (dt_j A_j) / (1 - p)
+        (one K = r product and one masked accumulation per pair; down_proj's SwiGLU backward then runs as its own pass).  Masks are
+        counter-based (vla_dropout_bf16: seed, pair, step) - regenerated in the backward, fresh on every replay of a captured step;
+        torch's Philox stream is not reproduced (statistical parity only; tests hand the generated masks to the oracle).  Not with fp8.
+        fp8: BASELINE configs[4]'s "fp8 MFMA weight path" where it belongs - under LoRA every base weight is frozen, so every base
         product runs on OCP e4m3 operands (weights quantised once, one scale per output channel; activations per row: inside the
         norm that produces them, or by one pass over the producer's output) while the rank-r branch stays bf16 INSIDE the same
         accumulator (the GEMM's K extension on the dequantised base product).  fp8_backward (default: as fp8): the dX products
@@ -1131,6 +1149,11 @@ class LoRAFinetune(BackboneTrainer):
         cfg, self.rank = self.cfg, rank
         self.fp8 = bool(fp8)
         self.fp8_backward = self.fp8 if fp8_backward is None else (bool(fp8_backward) and self.fp8)
+        self.dropout = float(dropout)
+        assert 0.0 <= self.dropout < 1.0 and not (self.dropout > 0 and self.fp8), "lora_dropout in [0, 1); not together with the fp8 base products"
+        self._drop_seed = (int(seed) * 0x9E3779B97F4A7C15 + 0x5851F42D4C957F2D) & (2 ** 64 - 1)
+        self._drop_step = torch.zeros(1, dtype=torch.int32, device=eng.device)      # bumped by the first launch of every step (in the graph)
+        self.Yd, self._ubuf = {}, {}          # dropout: dropped inputs per Linear [pairs, M, K] (kept for dA); u = dt_j A_j scratch per shape
         c = cfg.llm
         H, KV, dh, I, D = c.heads, c.kv_heads, c.dh, c.inter, c.d
         L: Dict[str, LoraLinear] = {}
@@ -1234,8 +1257,16 @@ class LoRAFinetune(BackboneTrainer):
 
     def _alloc(self, B, S):
         if self._key != (B, S):
-            self.T, self.DT = {}, {}
+            self.T, self.DT, self.Yd, self._ubuf = {}, {}, {}, {}
         super()._alloc(B, S)
+
+    def _begin_forward(self):
+        if self.dropout > 0:
+            ops.inc_i32_(self._drop_step)
+
+    def drop_seed(self, key: str, j: int) -> int:
+        """Mask key of pair j of the wrapped Linear `key` (with the step counter: vla_dropout_bf16's (seed, step))."""
+        return (self._drop_seed + (list(self.L).index(key) * 8 + j + 1) * 0xC2B2AE3D27D4EB4F) & (2 ** 64 - 1)
 
     # ---- the Linear of this mode: base product with the low-rank branch inside its accumulator (GEMM K extension)
     def _lin(self, key, x, W, bias=None, **kw):
@@ -1243,7 +1274,15 @@ class LoRAFinetune(BackboneTrainer):
         t = self.T.get(key)
         if t is None or t.shape[0] != x.shape[0]:
             t = self.T[key] = torch.empty(x.shape[0], l.Rr, device=self.dev, dtype=BF16)
-        ops.gemm_nt(x, l.A_cat, alpha=2.0, out=t)                   # t = 2 x A_cat^T   (alpha / r = 2)
+        if self.dropout > 0:                                        # every pair drops its own copy of x (kept: dA_j needs it)
+            Y = self.Yd.get(key)
+            if Y is None or Y.shape[1] != x.shape[0]:
+                Y = self.Yd[key] = torch.empty(len(l.projs), x.shape[0], x.shape[1], device=self.dev, dtype=BF16)
+            for j in range(len(l.projs)):
+                ops.dropout(x, Y[j], self.dropout, self.drop_seed(key, j), self._drop_step)
+                ops.gemm_nt(Y[j], l.A_cat[j * l.rp:(j + 1) * l.rp], alpha=2.0, out=t[:, j * l.rp:(j + 1) * l.rp])
+        else:
+            ops.gemm_nt(x, l.A_cat, alpha=2.0, out=t)               # t = 2 x A_cat^T   (alpha / r = 2)
         wq = self.Q.get(key)
         if wq is not None:                                          # e4m3 base operands, bf16 low-rank branch, one accumulator
             xq, xs = self._quant(x, "f")
@@ -1257,6 +1296,8 @@ class LoRAFinetune(BackboneTrainer):
         if dt is None or dt.shape[0] != M:
             dt = self.DT[key] = torch.empty(M, l.Rr, device=self.dev, dtype=BF16)
         ops.gemm_nt(dy, l.B_blkT, alpha=2.0, out=dt)                # dt = 2 dy B_blk
+        if self.dropout > 0:
+            return self._lin_bwd_dropout(key, l, dy, dt, WT, out, swiglu_gu)
         l.grads(dy, x, self.T[key], dt, self._defer_tn)             # dA_cat, dB_j: gradient-only work
         wq = self.QT.get(key)
         if wq is not None:                                          # dx = Q(dy) Q(W^T)^T + dt A_cat
@@ -1267,6 +1308,31 @@ class LoRAFinetune(BackboneTrainer):
         if swiglu_gu is not None:
             return ops.gemm_swiglu_bwd(dy, WT, swiglu_gu, out=out, ext=(dt, l.A_catT))
         return ops.gemm_nt(dy, WT, out=out, ext=(dt, l.A_catT))     # dx = dy W + dt A_cat
+
+    def _lin_bwd_dropout(self, key, l, dy, dt, WT, out, swiglu_gu):
+        """lora_dropout > 0: dA_j reads pair j's own dropped input; dx = dy W + sum_j mask_j * (dt_j A_j) / (1 - p) - the low-rank share
+        passes back through each pair's mask, so it cannot ride in the base product's accumulator."""
+        M, rp = dy.shape[0], l.rp
+        l.grads(dy, self.Yd[key], self.T[key], dt, self._defer_tn, dropped=True)
+        if swiglu_gu is not None:                                   # down_proj: dH first, its SwiGLU backward as a pass of its own
+            dx = self._uscratch(M, WT.shape[0], "h")
+            ops.gemm_nt(dy, WT, out=dx)
+        else:
+            dx = ops.gemm_nt(dy, WT, out=out)
+        u = self._uscratch(M, WT.shape[0], "u")
+        for j in range(len(l.projs)):
+            ops.gemm_nt(dt[:, j * rp:(j + 1) * rp], l.A_catT[:, j * rp:(j + 1) * rp], out=u)        # u = dt_j A_j   (K = r)
+            ops.dropout_bwd_add_(dx, u, self.dropout, self.drop_seed(key, j), self._drop_step)
+        if swiglu_gu is not None:
+            return ops.swiglu_bwd(dx, swiglu_gu, out=out)
+        return dx
+
+    def _uscratch(self, rows: int, cols: int, slot: str):
+        k = (rows, cols, slot)
+        b = self._ubuf.get(k)
+        if b is None:
+            b = self._ubuf[k] = torch.empty(rows, cols, device=self.dev, dtype=BF16)
+        return b
 
     def _adam_ranges(self):
         na = self.n_active
