@@ -1069,7 +1069,8 @@ def test_gemm_skinny(ops, M, N, K, sk, monkeypatch):
 
 @pytest.mark.parametrize("M,N,K,kind", [(256, 896, 896, "bias_relu"), (256, 2688, 896, "rope2"), (256, 896, 896, "res"), (8, 896, 896, "res"),
                                         (8, 2688, 896, "rope2"), (369, 896, 896, "res"), (256, 3456, 1152, "bias"), (256, 4352, 1152, "gelu"),
-                                        (100, 1008, 640, "post"), (512, 1024, 1024, "res"), (200, 48, 512, "bias"), (64, 896, 1792, "gelu_res")])
+                                        (100, 1008, 640, "post"), (512, 1024, 1024, "res"), (200, 48, 512, "bias"), (64, 896, 1792, "gelu_res"),
+                                        (369, 1152, 896, "rope1"), (48, 1152, 1024, "rope1")])
 def test_gemm_small_rows(ops, M, N, K, kind, monkeypatch):
     """gemm_skinny.hip, shape class (b), under the latency hint: products of at most 512 rows (the batch-1 pass) on
     16 x 16 ... 64 x 96 output tiles with the contraction split over the workgroup's four waves, gemm.hip's epilogue at gemm.hip's rounding
@@ -1078,8 +1079,11 @@ def test_gemm_small_rows(ops, M, N, K, kind, monkeypatch):
     a, b = gen(M, K, seed=251).to(DEV), gen(N, K, seed=252, scale=0.05).to(DEV)
     bias, r = gen(N, seed=253).to(DEV), gen(M, N, seed=254).to(DEV)
     kw = {}
-    if kind in ("bias_relu", "bias", "gelu", "rope2", "post", "res", "gelu_res"):
+    if kind in ("bias_relu", "bias", "gelu", "rope2", "rope1", "post", "res", "gelu_res"):
         kw["bias"] = bias
+    if kind == "rope1":                              # Qwen2 q | k | v projection: rotate_half on the q and k columns (14 + 2 heads of 64), v untouched
+        cos, sin = ops.rope_half_tables(M, 64, 1e6, DEV)
+        kw["rope"] = (1, cos, sin, M, 64, 1024)
     if kind == "bias_relu":
         kw["act"] = 2
     if kind in ("gelu", "gelu_res"):
@@ -1098,7 +1102,7 @@ def test_gemm_small_rows(ops, M, N, K, kind, monkeypatch):
     d = (out.float() - ref.float()).abs()
     assert (d > 0).float().mean().item() < 0.02 and d.max().item() <= 2 ** -6 * ref.float().abs().max().item(), \
         f"{kind} {M}x{N}x{K}: {(d > 0).float().mean().item():.4f} of the elements differ, max {d.max().item():.3e}"
-    if K % 256 == 0 and kind not in ("rope2", "post"):
+    if K % 256 == 0 and kind not in ("rope2", "rope1", "post"):
         ref4 = ops.gemm_nt(a, b, split_k=4, out=torch.empty(M, N, dtype=BF, device=DEV), **kw)
         assert torch.equal(out, ref4), f"{kind} {M}x{N}x{K}: differs from split_k = 4 of the 128-row tiles"
     if kind in ("bias", "res", "bias_relu"):

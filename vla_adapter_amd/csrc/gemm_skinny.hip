@@ -15,7 +15,7 @@
 // The four partial accumulators meet in LDS and are summed in wave order (deterministic); the epilogue runs on 8-column row chunks.
 //
 // Rounding: fp32 accumulation as four K-quarter partial sums added in order 0..3, then gemm.hip's epilogue at gemm.hip's rounding points
-// (alpha, bias, activation on the bf16-rounded value, interleaved RoPE, bf16, + residual, bf16): the arithmetic of vla_gemm_bf16_nt
+// (alpha, bias, activation on the bf16-rounded value, rotate_half or interleaved RoPE, bf16, + residual, bf16): the arithmetic of vla_gemm_bf16_nt
 // with split_k = 4 (bit-identical to it when K % 256 == 0: test_gemm_skinny / test_gemm_small_rows).
 #include "common.h"
 #include "gemm_params.h"
@@ -80,28 +80,49 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmP p) {
     const int row = c / CPR, col = (c - row * CPR) * 8;
     const int m = m0 + row, n = n0 + col;
     if (m >= p.M || n >= p.N) continue;                              // (N % 8 == 0: a chunk is inside or outside)
-    const float* s = part + row * LDP + col;
-    f32x4 a0 = *reinterpret_cast<const f32x4*>(s), a1 = *reinterpret_cast<const f32x4*>(s + 4);
+    // the eight values of chunk (row, cc) after alpha / bias / activation (fp32, not yet rounded)
+    auto chunk = [&](int cc, float* v) {
+      const float* s = part + row * LDP + cc;
+      f32x4 a0 = *reinterpret_cast<const f32x4*>(s), a1 = *reinterpret_cast<const f32x4*>(s + 4);
 #pragma unroll
-    for (int w = 1; w < 4; ++w) {
-      a0 += *reinterpret_cast<const f32x4*>(s + w * TM * LDP);
-      a1 += *reinterpret_cast<const f32x4*>(s + w * TM * LDP + 4);
-    }
-    float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-    float bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
-      const uint4 b4 = *reinterpret_cast<const uint4*>(p.bias + n);
-      const unsigned bw[4] = {b4.x, b4.y, b4.z, b4.w};
+      for (int w = 1; w < 4; ++w) {
+        a0 += *reinterpret_cast<const f32x4*>(s + w * TM * LDP);
+        a1 += *reinterpret_cast<const f32x4*>(s + w * TM * LDP + 4);
+      }
+      const float r[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      float bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
+        const uint4 b4 = *reinterpret_cast<const uint4*>(p.bias + n0 + cc);
+        const unsigned bw[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) bb[2 * k] = bf2f((bf16_t)(bw[k] & 0xffff)), bb[2 * k + 1] = bf2f((bf16_t)(bw[k] >> 16));
-    }
+        for (int k = 0; k < 4; ++k) bb[2 * k] = bf2f((bf16_t)(bw[k] & 0xffff)), bb[2 * k + 1] = bf2f((bf16_t)(bw[k] >> 16));
+      }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      float x = p.bias_post ? rbf(v[k] * p.alpha) + bb[k] : v[k] * p.alpha + bb[k];
-      if (act == VLA_ACT_GELU) x = gelu_erf(rbf(x));
-      else if (act == VLA_ACT_RELU) x = fmaxf(x, 0.f);
-      else if (act == VLA_ACT_GELU_TANH) x = gelu_tanh(rbf(x));
-      v[k] = x;
+      for (int k = 0; k < 8; ++k) {
+        float x = p.bias_post ? rbf(r[k] * p.alpha) + bb[k] : r[k] * p.alpha + bb[k];
+        if (act == VLA_ACT_GELU) x = gelu_erf(rbf(x));
+        else if (act == VLA_ACT_RELU) x = fmaxf(x, 0.f);
+        else if (act == VLA_ACT_GELU_TANH) x = gelu_tanh(rbf(x));
+        v[k] = x;
+      }
+    };
+    float v[8];
+    chunk(col, v);
+    if (p.rope_mode == 1 && n < p.rope_cols) {                       // HF rotate_half, head dim 64: the partner d +- 32 is another chunk of this row (TN == 64)
+      const int d0 = n & 63, lo = d0 < 32;
+      float q[8];
+      chunk(lo ? col + 32 : col - 32, q);
+      const int pos = m % p.rope_T, d = d0 & 31;
+      const float* cp = p.rope_cos + (long long)pos * 32 + d;
+      const float* sp = p.rope_sin + (long long)pos * 32 + d;
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp), c1 = *reinterpret_cast<const f32x4*>(cp + 4);
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+      const float cc[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]}, ss[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float own = rbf(v[k]), oth = rbf(q[k]);                  // first half: a c - b s;  second half: b c + a s  (a = first, b = second half)
+        v[k] = lo ? rbf(own * cc[k]) + rbf(-oth * ss[k]) : rbf(own * cc[k]) + rbf(oth * ss[k]);
+      }
     }
     if (p.rope_mode == 2 && n < p.rope_cols) {                       // action_heads.py:125-146: pairs (2i, 2i+1), tables of cat([f, f])
       const int pos = m % p.rope_T, d = n % p.rope_dh;
@@ -157,7 +178,7 @@ int vla_gemm_skinny_try(const GemmP& p, bool simple_addressing, bool latency_hin
   if (!(p.act == VLA_ACT_NONE || p.act == VLA_ACT_GELU || p.act == VLA_ACT_RELU || p.act == VLA_ACT_GELU_TANH)) return 0;
   if (p.bias && ((uintptr_t)p.bias & 15) != 0) return 0;
   if (p.R && (p.ldr % 8 != 0 || ((uintptr_t)p.R & 15) != 0)) return 0;
-  if (p.rope_mode == 1 || (p.rope_mode == 2 && (p.rope_dh % 8 != 0 || p.rope_cols % 8 != 0 || (((uintptr_t)p.rope_cos | (uintptr_t)p.rope_sin) & 15) != 0))) return 0;
+  if ((p.rope_mode == 1 && (p.rope_dh != 64 || p.rope_cols % 64 != 0 || tall)) || (p.rope_mode == 2 && (p.rope_dh % 8 != 0 || p.rope_cols % 8 != 0 || (((uintptr_t)p.rope_cos | (uintptr_t)p.rope_sin) & 15) != 0))) return 0;
   // Tile: what a CU has to pull through its L1 is (tile rows + tile columns) x K operand rows per workgroup, times the workgroups it gets -
   // minimised over the instantiated tiles (every CU busy, as few rows each as possible; ties: the larger tile)
   static const int TL[7][2] = {{1, 1}, {1, 2}, {2, 2}, {1, 4}, {2, 4}, {4, 4}, {4, 6}};
@@ -167,6 +188,7 @@ int vla_gemm_skinny_try(const GemmP& p, bool simple_addressing, bool latency_hin
   for (int t = 0; t < 7; ++t) {
     const int tm = 16 * TL[t][0], tn = 16 * TL[t][1];
     if (tall && p.N % tn != 0) continue;
+    if (p.rope_mode == 1 && tn != 64) continue;              // rotate_half: both halves of a head inside one tile row
     const long long wgs = (long long)((p.M + tm - 1) / tm) * ((p.N + tn - 1) / tn), cost = (long long)(tm + tn) * ((wgs + ncu - 1) / ncu);
     if (best < 0 || cost < best_cost || (cost == best_cost && t > best)) best = t, best_cost = cost;
   }
