@@ -192,8 +192,11 @@ int vla_gemm_skinny_try(const GemmP& p, bool simple_addressing, bool latency_hin
     const long long wgs = (long long)((p.M + tm - 1) / tm) * ((p.N + tn - 1) / tn), cost = (long long)(tm + tn) * ((wgs + ncu - 1) / ncu);
     if (best < 0 || cost < best_cost || (cost == best_cost && t > best)) best = t, best_cost = cost;
   }
-  // (b) only where it beats ONE round of gemm.hip's 64 x 128 tiles (192 operand rows per CU): e.g. the two-image ViT's M = 512 products do not
-  if (!tall && best_cost >= 192) return 0;
+  // (b) only for tiles up to 32 x 64 (96 operand rows per workgroup): measured in the batch-1 pass (profiles/r04_prof_predict_summary.txt, us under
+  // the profiler, this kernel vs gemm.hip's 64 x 128 six-stage ring): 16 x 16 tiles 5.1 vs 10.6 (the head's 8-row products), 32 x 32 6.6 vs 12,
+  // 32 x 64 8.9-10.4 vs 12.7-12.9 (LLM o, ViT proj) - but 64 x 64 13.3 vs 12.3 (ViT q|k|v) and 64 x 96 17.3 vs 13.4 (ViT fc1): with 128+ operand
+  // rows per workgroup the LDS-DMA ring keeps more bytes in flight than register fragments at one or two waves per SIMD do
+  if (!tall && best_cost > 96) return 0;
   switch (best) {
     case 0: launch_skinny<1, 1, 8>(p, st); break;
     case 1: launch_skinny<1, 2, 6>(p, st); break;
