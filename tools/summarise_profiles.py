@@ -38,11 +38,17 @@ def _write_summary(path, agg, steps):
     return rows
 
 
+def newest(pattern):
+    """The most recent match (gpurun MERGES a call's files into the local gpurun_out/: earlier collections' raw traces stay beside the new ones)."""
+    f = glob.glob(pattern)
+    return max(f, key=os.path.getmtime) if f else None
+
+
 def stage_box():
     """Two summaries: the whole trace (weight init, capture warm-ups, the recording step included: per-step columns divide by
     every executed step) and kernel_summary_steady.csv = ONLY the launches between bench.py's two marker launches, i.e. the K
     timed graph replays - the step's own kernels and nothing else."""
-    f = glob.glob(os.path.join(SRC, "stats", "*", "*_kernel_trace.csv"))[0]
+    f = newest(os.path.join(SRC, "stats", "*", "*_kernel_trace.csv"))
     bench = json.load(open(os.path.join(SRC, "bench_under_rocprof.json")))
     steps, timed, mgrid = bench["executed_steps"], bench["steps"], str(bench.get("marker_grid_x", -1))
     rows = list(csv.DictReader(open(f)))
@@ -81,11 +87,11 @@ def family_of(kernel_name: str) -> str:
 def pmc_sum(sub, counter, by_family=None):
     """Sum of `counter` over the GEMM dispatches of the PMC pass `sub` (+ per kernel family into by_family[family] = [sum, launches]).
     One dispatch may appear on several rows (one per XCD / counter instance): launches are counted by dispatch id."""
-    f = glob.glob(os.path.join(SRC, sub, "*", "*_counter_collection.csv"))
+    f = newest(os.path.join(SRC, sub, "*", "*_counter_collection.csv"))
     if not f:
         return None, 0
     tot, seen = 0.0, set()
-    for r in csv.DictReader(open(f[0])):
+    for r in csv.DictReader(open(f)):
         if any(g in r["Kernel_Name"] for g in GEMM_KERNELS) and r["Counter_Name"] == counter:
             v = float(r["Counter_Value"])
             tot += v
@@ -105,9 +111,9 @@ def stage_repo():
     steady = os.path.join(SRC, "kernel_summary_steady.csv")
     if os.path.exists(steady):
         shutil.copy(steady, os.path.join(DST, RND + "_kernel_summary_steady.csv"))
-    st = glob.glob(os.path.join(SRC, "stats", "*", "*_kernel_stats.csv"))
+    st = newest(os.path.join(SRC, "stats", "*", "*_kernel_stats.csv"))
     if st:
-        shutil.copy(st[0], os.path.join(DST, RND + "_kernel_stats.csv"))
+        shutil.copy(st, os.path.join(DST, RND + "_kernel_stats.csv"))
     for n in ("bench.json", "bench_under_rocprof.json"):
         if os.path.exists(os.path.join(SRC, n)):
             shutil.copy(os.path.join(SRC, n), os.path.join(DST, RND + "_" + n))
