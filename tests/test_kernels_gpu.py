@@ -269,6 +269,41 @@ def test_attention_fwd(ops, B, S, Hq, Hkv, dh, causal, masked):
     check(lse, torch.logsumexp(s.masked_fill(~allow, float("-inf")), -1), rel=1e-4, mx=1e-3, name="lse")
 
 
+@pytest.mark.parametrize("B,S,Hq,Hkv,dh,causal,masked", [(1, 369, 14, 2, 64, True, True), (1, 369, 14, 2, 64, True, False), (1, 256, 16, 16, 72, False, False),
+                                                         (1, 40, 4, 2, 64, True, False), (2, 100, 2, 2, 64, False, True), (1, 33, 2, 1, 72, True, True),
+                                                         (1, 625, 14, 2, 64, True, True)])
+def test_attention_fwd_keys_split_over_the_waves(ops, B, S, Hq, Hkv, dh, causal, masked):
+    """attn_fwd_split_kernel (round 4, the batch-1 pass under the latency hint): 32-query workgroups whose four waves take every fourth key
+    tile, partial (max, sum, O) merged in LDS.  Against the oracle's attention and fp32 log-sum-exp (the criteria of test_attention_fwd),
+    and against the one-wave-per-query-tile kernel: the same masks, scale and P rounding, another association of the partial sums."""
+    qkv, q, k, v = _attn_inputs(B, S, Hq, Hkv, dh, 44)
+    km = torch.ones(B, S, dtype=torch.bool)
+    if masked:
+        km[0, S - 9:] = False
+        km[0, 5] = False
+        if B > 1:
+            km[1, S // 2:] = False
+    d = qkv.to(DEV)
+    a, b = Hq * dh, (Hq + Hkv) * dh
+    kmd = km.to(torch.uint8).to(DEV) if masked else None
+    ref_o, ref_lse = ops.attn_fwd(d[:, :, :a], d[:, :, a:b], d[:, :, b:], Hq, Hkv, dh, causal, kmd, want_lse=True)
+    with ops.latency_hint():
+        o, lse = ops.attn_fwd(d[:, :, :a], d[:, :, a:b], d[:, :, b:], Hq, Hkv, dh, causal, kmd, want_lse=True)
+    hd = lambda t, h: t.float().reshape(B, S, h, dh).transpose(1, 2)
+    ref = O.attention(hd(q, Hq), hd(k, Hkv), hd(v, Hkv), causal, km if masked else None, None, True)
+    valid = torch.ones(B, S, dtype=torch.bool)
+    if causal and masked:            # a query whose every visible key is masked has no defined output
+        for bb in range(B):
+            for i in range(S):
+                valid[bb, i] = bool(km[bb, :i + 1].any())
+    check(o.float().cpu()[valid], ref.transpose(1, 2).reshape(B, S, Hq * dh)[valid], rel=6e-3, mx=3e-2, name=f"split-key attn fwd dh{dh}")
+    dd = (o.float() - ref_o.float()).abs().cpu()[valid]
+    # (about a third of the outputs move by one bf16 ulp: the two kernels round the same fp32 sums taken in another order)
+    assert dd.max().item() <= 2 ** -6 * ref_o.float().abs().max().item() and (dd > 0).float().mean().item() < 0.5, (dd.max().item(), (dd > 0).float().mean().item())
+    vm = valid[:, None, :].expand(B, Hq, S)
+    assert torch.allclose(lse.cpu()[vm], ref_lse.cpu()[vm], rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("B,S,Hq,Hkv,dh,causal,masked", [(2, 96, 2, 2, 64, False, False), (2, 77, 4, 2, 64, True, True),
                                                        (1, 352, 14, 2, 64, True, True), (1, 100, 2, 2, 72, False, False),
                                                        (1, 352, 12, 2, 128, True, True)])     # Qwen2.5-1.5B head geometry

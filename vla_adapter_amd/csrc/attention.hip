@@ -14,6 +14,8 @@
 #include "attn_common.h"
 #include "../../include/vla_native.h"
 
+int vla_num_cus();      // gemm256.hip
+
 namespace {
 
 struct AttnP {
@@ -199,6 +201,145 @@ __global__ __launch_bounds__(256, (D <= 64 ? 4 : D <= 72 ? 3 : 2)) void attn_fwd
   }
   if (qi < p.Sq && p.lse && h == 0)
     p.lse[((long long)b * p.Hq + hq) * p.lse_hs + qi] = l_run > 0.f ? (m_run + log2f(l_run)) * 0.6931471805599453f : -INFINITY;
+}
+
+// ------------------------------------------------------------------------------------------------ forward, keys split over the waves
+// The batch-1 pass (modeling_prismatic.py:892-972; under vla_gemm_latency_hint): with one sample the kernel above is 42 workgroups whose
+// waves each walk up to 12 key tiles one after the other (14.6 us for 369 tokens).  Here a workgroup owns 32 queries and its four waves
+// take every fourth key tile: K fragments straight from global memory (the same [key][d] rows the LDS image holds), the V tile through a
+// wave-private LDS region (the transposed fragment read needs LDS), no workgroup barrier in the loop; the four partial (max, sum, O) meet
+// in LDS and are merged flash-decoding style.  ceil(S / 32) x heads x B workgroups (168 for the LLM at batch 1), <= 3 key tiles per wave.
+// Same masks, same scale, same rounding of P; the partial sums associate differently (fp32), so results agree with the kernel above to
+// rounding, not bit for bit - which is why it is tied to the hint (a product's bits must not depend on the batch size in a training step).
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_split_kernel(AttnP p) {
+  using G = Geo<D>;
+  constexpr int LDO = G::DV + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem_split[];      // sV [4][32][LD] bf16 | sM [4][32] | sL [4][32] | sO [4][32][LDO] f32
+  bf16_t* sV = reinterpret_cast<bf16_t*>(smem_split);
+  float* sM = reinterpret_cast<float*>(smem_split + 4 * 32 * G::LD * 2);
+  float* sL = sM + 4 * 32;
+  float* sO = sL + 4 * 32;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
+  const int hq = blockIdx.y, b = blockIdx.z, hkv = hq / (p.Hq / p.Hkv);
+  const int q0 = blockIdx.x * 32, qi = q0 + (lane & 31);
+  bf16_t* sv = sV + w * 32 * G::LD;
+  if (D != G::DV) lds_zero16(sv, 32 * G::LD * 2, lane, 64);        // pad columns D .. DV-1 of the V image stay zero
+
+  bf16x8 qf[G::KS];
+  {
+    const bf16_t* qp = p.q + (long long)b * p.q_sb + (long long)min(qi, p.Sq - 1) * p.q_ss + hq * D;
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+      const int d = 16 * ks + 8 * h;
+      qf[ks] = (d < D) ? *reinterpret_cast<const bf16x8*>(qp + d) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+  f32x16 O[G::DT];
+#pragma unroll
+  for (int t = 0; t < G::DT; ++t) O[t] = zero16();
+  float m_run = -INFINITY, l_run = 0.f;
+  const int kend = p.causal ? min(p.Sk, q0 + 32 + p.q_off) : p.Sk;
+  const int ntile = (kend + 31) / 32;
+  const bf16_t* kb = p.k + (long long)b * p.k_sb + hkv * D;
+  const bf16_t* vb = p.v + (long long)b * p.v_sb + hkv * D;
+  for (int kt = w; kt < ntile; kt += 4) {
+    const int k0 = kt * 32, kk = k0 + (lane & 31);
+    u32x4 rv[TileGeo<D, 64>::NCH];
+    tile_prefetch<D, 64>(rv, vb, p.v_ss, k0, p.Sk, lane);
+    bf16x8 kf[G::KS];
+    {
+      const bf16_t* kp = kb + (long long)min(kk, p.Sk - 1) * p.k_ss;
+#pragma unroll
+      for (int ks = 0; ks < G::KS; ++ks) {
+        const int d = 16 * ks + 8 * h;
+        kf[ks] = (d < D) ? *reinterpret_cast<const bf16x8*>(kp + d) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    }
+    const bool kok = kk < p.Sk && (!p.kmask || p.kmask[(long long)b * p.Sk + kk]);
+    const unsigned km = (unsigned)__ballot(kok);             // (lanes 32..63 repeat 0..31: the low word is the tile's mask)
+    f32x16 S = zero16();
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) S = mfma32(kf[ks], qf[ks], S);
+    tile_store<D, 64, G::LD>(rv, sv, lane);                  // (LDS is in order per wave: the previous tile's transposed reads are done)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[r] *= p.scale_log2;
+    if (!(km == 0xffffffffu && (!p.causal || k0 + 31 <= q0 + p.q_off))) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kr = acc_row(r, h);
+        const bool ok = ((km >> kr) & 1u) && (!p.causal || k0 + kr <= qi + p.q_off);
+        S[r] = ok ? S[r] : -INFINITY;
+      }
+    }
+    float mt = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mt = fmaxf(mt, S[r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = fexp2(m_run - m_safe);
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      S[r] = fexp2(S[r] - m_safe);
+      rs += S[r];
+    }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int t = 0; t < G::DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[t][r] *= alpha;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bf16x8 pf = pack_acc(S, s);
+#pragma unroll
+      for (int t = 0; t < G::DT; ++t) O[t] = mfma32(tr_frag(sv, G::LD, s, 32 * t, lane), pf, O[t]);
+    }
+  }
+  // partial results: lane = query (both halves hold the same max / sum), accumulator register 4 g + j of tile t = column 32 t + 8 g + 4 h + j
+  if (h == 0) {
+    sM[w * 32 + lane] = m_run;
+    sL[w * 32 + lane] = l_run;
+  }
+  {
+    float* so = sO + (w * 32 + (lane & 31)) * LDO;
+#pragma unroll
+    for (int t = 0; t < G::DT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) so[32 * t + 8 * g + 4 * h + j] = O[t][4 * g + j];
+  }
+  __syncthreads();
+  constexpr int CPR = D / 8;
+  bf16_t* ob = p.o + (long long)b * p.o_sb + hq * D;
+  for (int c = tid; c < 32 * CPR; c += 256) {
+    const int q = c / CPR, ch = c - q * CPR;
+    if (q0 + q >= p.Sq) continue;
+    float mw[4], M = -INFINITY;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) { mw[ww] = sM[ww * 32 + q]; M = fmaxf(M, mw[ww]); }
+    const float Ms = (M == -INFINITY) ? 0.f : M;
+    float L = 0.f, f[4];
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) { f[ww] = fexp2(mw[ww] - Ms); L += sL[ww * 32 + q] * f[ww]; }
+    const float inv = L > 0.f ? 1.f / L : 0.f;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < 4; ++ww) a += sO[(ww * 32 + q) * LDO + ch * 8 + e] * f[ww];
+      o[e] = a * inv;
+    }
+    *reinterpret_cast<u32x4*>(ob + (long long)(q0 + q) * p.o_ss + ch * 8) = u32x4{pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
+    if (ch == 0 && p.lse) p.lse[((long long)b * p.Hq + hq) * p.lse_hs + q0 + q] = L > 0.f ? (M + log2f(L)) * 0.6931471805599453f : -INFINITY;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ dQ
@@ -582,8 +723,24 @@ extern "C" int vla_attn_fwd(void* stream, const vla_attn_desc* d) {
   int rc = fill(p, d, false);
   if (rc) return rc;
   dim3 grid((p.Sq + 127) / 128, p.Hq, p.B);
-  if (p.causal && grid.x > 1 && grid.x <= 65535) { p.lpt = 1; grid = dim3(p.B, p.Hq, grid.x); }     // heavy query blocks first (AttnP::lpt)
   hipStream_t st = (hipStream_t)stream;
+  // the batch-1 pass (caller's latency hint): fewer workgroups than half the CUs -> 32-query workgroups whose waves split the keys
+  if (vla_gemm_latency_hint(-1) > 0 && (p.dh == 64 || p.dh == 72) && (long long)grid.x * grid.y * grid.z * 2 <= vla_num_cus() &&
+      !getenv("VLA_NO_ATTN_SPLIT")) {
+    const dim3 g2((p.Sq + 31) / 32, p.Hq, p.B);
+    const int dv = (p.dh + 31) / 32 * 32;
+    const size_t lds = (size_t)4 * 32 * (dv + 8) * 2 + 2 * 4 * 32 * 4 + (size_t)4 * 32 * (dv + 1) * 4;
+    static bool split_attr = false;
+    if (!split_attr) {
+      (void)hipFuncSetAttribute((const void*)attn_fwd_split_kernel<72>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      split_attr = true;
+    }
+    if (p.dh == 64) hipLaunchKernelGGL(attn_fwd_split_kernel<64>, g2, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL(attn_fwd_split_kernel<72>, g2, dim3(256), lds, st, p);
+    VLA_CHECK_LAUNCH("attn_fwd(split)");
+    return VLA_OK;
+  }
+  if (p.causal && grid.x > 1 && grid.x <= 65535) { p.lpt = 1; grid = dim3(p.B, p.Hq, grid.x); }     // heavy query blocks first (AttnP::lpt)
   switch (p.dh) {
     case 64: hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, st, p); break;
     case 72: hipLaunchKernelGGL(attn_fwd_kernel<72>, grid, dim3(256), 0, st, p); break;
