@@ -103,9 +103,11 @@ int vla_gemm_uses_256(const vla_gemm_desc* desc);
 /* Process-wide hint for vla_gemm_bf16_nt, read when a product is launched (= when a hipGraph is captured): on = 1 says the following
  * products run on an otherwise idle chip and are bound by the latency of a launch, not by throughput - the batch-1 predict_action of
  * modeling_prismatic.py:892-972 / openvla_utils.py:737-825 (every product there is at most one workgroup per CU and took 17-22 us
- * whatever its size: one K-tile in flight per workgroup).  Such launches then use a four-stage operand ring (three K-tiles in flight).
- * Kernel selection only: results are bit-identical with and without the hint.  on = 0 clears it, on < 0 only queries.  Returns the
- * previous value. */
+ * whatever its size: one K-tile in flight per workgroup).  Under the hint: launches of at most one workgroup per CU use a deeper operand
+ * ring (bit-identical results); products of at most 512 rows run on gemm_skinny.hip's small tiles with the contraction split over a
+ * workgroup's four waves, and vla_attn_fwd launches of fewer workgroups than half the CUs split the KEYS over the waves - both the same
+ * arithmetic in another fp32 association (results agree to rounding; in a training step a product's bits must not depend on the batch
+ * size, hence the hint).  on = 0 clears it, on < 0 only queries.  Returns the previous value. */
 int vla_gemm_latency_hint(int on);
 int vla_gemm256_extent_ok(const vla_gemm_desc* desc /* host */);
 
