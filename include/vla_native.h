@@ -75,7 +75,8 @@ typedef struct vla_gemm_desc {
   /* optional split-K (0/1 = off): the K range is cut into split_k slices that run as blockIdx.z, each parking its fp32
    * accumulators in its own plane of `ws` (device, fp32 [split_k, M, N], no initialisation needed); a second small kernel
    * sums the planes and applies bias / activation (none, GELU, ReLU) / residual.  For few-tile long-K problems (batch-1
-   * inference); batch == 1 and N % 4 == 0 only. */
+   * inference); batch == 1 and N % 4 == 0 only.  A slice is ceil(K / 64 / split_k) K-tiles of 64; when that does not divide K / 64 the
+   * last slice is shorter (and fewer than split_k slices may run): any split_k >= 2 is accepted. */
   int split_k; float* ws;
   /* optional: 1 = round the product to bf16 BEFORE the bias is added, C = bf16(bf16(alpha A.B^T) + bias).  This is what
    * torch's CPU nn.Linear computes for a non-contiguous bf16 input (matmul, then add_) - the reference's k_task / v_task

@@ -728,11 +728,15 @@ def test_gemm_split_k_matches_single_pass(ops, M, N, K, act, res, monkeypatch):
     y = O.linear(a.float(), w.float(), bias.float(), emu=True)
     y = {0: y, 1: O.rnd(O.gelu(y), True), 2: torch.relu(y)}[act]
     check(out, O.rnd(y + r.float(), True) if res else y, name="split-K vs oracle")
-    for sk in (2, 4, 8):          # forced factors agree with the automatic choice
-        if K % (64 * sk) == 0:
-            forced = torch.empty(M, N, dtype=BF, device=DEV)
-            ops.gemm_nt(a.to(DEV), w.to(DEV), out=forced, split_k=sk, **kw)
-            check(forced, f(ref), rel=2e-3, name=f"split-K {sk} vs single pass")
+    for sk in (2, 4, 8, 3, 7, 11, 16):          # forced factors agree with the automatic choice; those that do not divide K / 64 run uneven slices (round 4)
+        forced = torch.empty(M, N, dtype=BF, device=DEV)
+        ops.gemm_nt(a.to(DEV), w.to(DEV), out=forced, split_k=sk, **kw)
+        check(forced, f(ref), rel=2e-3, name=f"split-K {sk} vs single pass")
+    if M <= 640:                                 # the batch-1 pass's choice (latency hint): one 64 x 128 workgroup per CU, slices need not divide K
+        with ops.latency_hint():
+            hinted = torch.empty(M, N, dtype=BF, device=DEV)
+            ops.gemm_nt(a.to(DEV), w.to(DEV), out=hinted, **kw)
+        check(hinted, f(ref), rel=2e-3, name="split-K under the latency hint vs single pass")
     off = torch.empty(M, N, dtype=BF, device=DEV)
     monkeypatch.delenv("VLA_NO_SPLITK")
     ops.gemm_nt(a.to(DEV), w.to(DEV), out=off, split_k=0, **kw)

@@ -134,7 +134,8 @@ void gemm_nt_kernel(GemmP p) {                                   //  workgroups 
       else pp2[i] = reinterpret_cast<const char*>(p.B2) + (long long)min(n0 + (pc - BM / 8) * 8 + (lane >> 3), p.N - 1) * p.ldb2 * 2 + kc;
     }
   }
-  const int nt1 = p.K / (F8 ? 2 * BK : BK);        // K-tiles of 128 B per row from (A, B)
+  // (split-K: slice z owns p.K of the contraction - the last slice what is left of p.Ktot when the slices are uneven)
+  const int nt1 = (p.Ktot > 0 ? min(p.K, p.Ktot - z * p.K) : p.K) / (F8 ? 2 * BK : BK);        // K-tiles of 128 B per row from (A, B)
   auto stage = [&](int buf, int t) {               // K-tile t: 128 B further along every row per tile
     char* base = smem + buf * C::STAGE_BYTES + wid * C::PPW * 1024;
     if (EXT && t >= nt1) {
@@ -787,20 +788,24 @@ extern "C" int vla_gemm_bf16_nt(void* stream, const vla_gemm_desc* d) {
   p.gA = d->a_group; p.sgA = d->a_group_stride; p.gC = d->c_group; p.sgC = d->c_group_stride;
   p.gR = d->r_group; p.sgR = d->r_group_stride;
   p.c_live_mod = d->c_live_mod; p.c_live_from = d->c_live_from;
-  const int split = d->split_k > 1 ? d->split_k : 1;
+  int split = d->split_k > 1 ? d->split_k : 1;     // (split-K below may lower it: uneven slices)
   p.bias_post = d->bias_post_round;
   VLA_REQUIRE(d->bias_post_round == 0 || (d->bias_post_round == 1 && d->bias && d->rope_mode != 1 && split == 1 && d->act == VLA_ACT_NONE),
               "gemm: bias_post_round needs a bias and a plain epilogue (no rotate_half rope / split-K / activation)");
-  p.ws = nullptr;
+  p.ws = nullptr; p.Ktot = 0;
   if (split > 1) {
-    VLA_REQUIRE(d->ws && d->batch == 1 && d->K % (BK * split) == 0 && d->rope_mode == 0 && d->c_group == 0 && d->r_group == 0 &&
+    VLA_REQUIRE(d->ws && d->batch == 1 && d->rope_mode == 0 && d->c_group == 0 && d->r_group == 0 &&
                     d->res_mod == 0 && d->c_live_mod == 0 && d->C &&
                     (d->act == VLA_ACT_NONE || d->act == VLA_ACT_GELU || d->act == VLA_ACT_RELU || d->act == VLA_ACT_GELU_TANH),
-                "gemm: split_k needs an fp32 workspace [split_k, M, N], batch 1, K % (64 * split_k) == 0 and a plain epilogue");
+                "gemm: split_k needs an fp32 workspace [split_k, M, N], batch 1 and a plain epilogue");
     VLA_REQUIRE(d->N % 4 == 0 && ((uintptr_t)d->ws & 15) == 0, "gemm: split_k needs N % 4 == 0 and a 16-B aligned workspace");
+    // slices of ceil(K-tiles / split_k) K-tiles; when that does not divide, the last slice is shorter and fewer slices may be needed
+    const int kt = d->K / BK, per = (kt + split - 1) / split;
+    split = (kt + per - 1) / per;
     p.ws = d->ws;
-    p.K = d->K / split;            // every z slice owns K / split_k of the contraction
-    p.sA = p.sB = p.K;             // ... starting K / split_k elements further along the rows of A and B
+    p.K = per * BK;                // every z slice owns `per` K-tiles of the contraction (the last one what is left of Ktot)
+    p.Ktot = d->K;
+    p.sA = p.sB = p.K;             // ... starting that many elements further along the rows of A and B
     p.bias = nullptr; p.R = nullptr;
   }
   VLA_REQUIRE(d->c_live_mod >= 0 && d->c_live_from >= 0 && (d->c_live_mod == 0 || d->c_live_from < d->c_live_mod),

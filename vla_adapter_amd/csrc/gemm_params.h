@@ -14,6 +14,7 @@ struct GemmP {
   int gA, gC, gR; long long sgA, sgC, sgR;  // row-group addressing: row r -> (r / g) * sg + (r % g) * ld
   int c_live_mod, c_live_from;              // C rows with (m % c_live_mod) < c_live_from are not stored
   float* ws;                                // split-K: fp32 [M, N] accumulator (blockIdx.z = K slice), finalised by a second kernel
+  int Ktot;                                 // split-K: the whole contraction length (slice z covers [z K, min((z + 1) K, Ktot)); 0 = no slices
   int bias_post;                            // 1: round alpha * acc to bf16 before adding the bias (torch CPU Linear on a strided input)
   int rope_mode, rope_T, rope_dh, rope_cols; const float* rope_cos; const float* rope_sin;
   const float* scaleA; const float* scaleB;   // fp8 operands (A, B point at OCP e4m3 bytes): per-row dequantisation scales [M], [N]

@@ -126,14 +126,20 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, *, bias=None, residual=None, res_m
     if split_k is None:
         split_k = 0
         tiles = ((M + 127) // 128) * ((Nn + 127) // 128)
-        if plain and K >= 2048 and tiles <= 256 and not os.environ.get("VLA_NO_SPLITK"):
+        t64 = ((M + 63) // 64) * ((Nn + 127) // 128)
+        if (plain and K >= 2048 and t64 * 2 <= 256 and not os.environ.get("VLA_NO_SPLITK") and not os.environ.get("VLA_NO_SPLITK_UNEVEN")
+                and _lib().vla_gemm_latency_hint(-1) > 0):
+            # the batch-1 pass (latency hint): as many K slices as give every CU one 64 x 128 workgroup, >= 4 K-tiles each (the slices need
+            # not divide K: the last one is shorter) - ViT fc2 256 x 1152 x 4352: 7 slices of 10 K-tiles on 252 workgroups instead of 4 on 144
+            split_k = max(2, min(256 // t64, (K // 64) // 4, 16))
+        elif plain and K >= 2048 and tiles <= 256 and not os.environ.get("VLA_NO_SPLITK"):
             cap = 512                                                   # workgroup slots a split may fill (two per CU)
             for sk in (8, 4, 2):
                 if tiles * sk <= cap and K % (64 * sk) == 0 and K // sk >= 512:
                     split_k = sk
                     break
     if split_k > 1:
-        assert plain and K % (64 * split_k) == 0, "split-K needs a plain epilogue and K divisible by 64 * split_k"
+        assert plain, "split-K needs a plain epilogue"
         d.split_k, d.ws = split_k, _splitk_ws(split_k * M * Nn, a.device).data_ptr()
     if query_256:
         return bool(_lib().vla_gemm_uses_256(C.byref(d)))
