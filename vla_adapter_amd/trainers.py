@@ -165,6 +165,7 @@ class BackboneTrainer:
         self.hstream = torch.cuda.Stream() if nstreams > 2 else None
         self.group_tn = not os.environ.get("VLA_NO_GROUPED_TN")          # (A/B knob)
         self._deferred = []
+        self._refreshed, self._rgraphs = set(), {}      # derived operands rebuilt behind a range's AdamW in this step; their graphs (captured step)
 
     # ---- mode hooks ---------------------------------------------------------------------------------------------
     def _lin(self, key, x, W, bias=None, **kw):
@@ -541,6 +542,7 @@ class BackboneTrainer:
             def h_fwd(c=c, lo=lo, hi=hi):
                 if c == 0:
                     head.fwd_begin(llm.HS, eng.pos1, batch["proprio"], eng.Np, noise)
+                    head.refresh_transposes()        # (W^T operands of the head's backward: beside the LLM forward, not on the turn-around)
                 for i in range(lo, min(hi, nb)):
                     head.fwd_layer(i)
                 if c == len(lch) - 1:
@@ -727,12 +729,16 @@ class BackboneTrainer:
                     if ranges and exchange:
                         self._exchange(ranges, after_event=e)
                     if ranges and update is not None:
-                        self._update_ranges(ranges, e, update)
+                        self._update_ranges(ranges, e, update, k if graphs is not None else None)
         for st in (self.hstream, self.gstream):
             if st is not None:
                 main.wait_stream(st)
 
-    def _update_ranges(self, ranges, final_event, update):
+    def _update_ranges(self, ranges, final_event, update, seg_index=None):
+        """AdamW over the ranges a segment has finished, then - round 4 - the derived operands of exactly those parameters (W^T copies of
+        a full fine-tune, A_cat^T / B_blk / B_blk^T of LoRA pairs): the layer's own backward, their only reader in this step, is over
+        when its range is final, so the rebuild (200-350 launches, 0.8-1.5 ms at the end of the step before) hides under the rest of the
+        backward like the update itself.  seg_index: captured step - the range's rebuild is a small graph of its own."""
         lr, beta1, beta2, eps, wd = update
         red = self.eng.reducer
         st = self.gstream or torch.cuda.current_stream()
@@ -746,6 +752,40 @@ class BackboneTrainer:
                 P = self.P if buf is self.P.grad else self.head.P
                 if hi > lo:
                     ops.adamw_(P.data[lo:hi], P.grad[lo:hi], P.m[lo:hi], P.v[lo:hi], self.step_count, lr, beta1, beta2, eps, wd, gscale=gscale)
+            if seg_index is None:
+                for fn in self._refresh_pieces_in(ranges):
+                    fn()
+            elif seg_index in self._rgraphs:
+                self._rgraphs[seg_index].replay()
+
+    # ---- derived operands, piecewise
+    def _refresh_pieces(self):
+        """[(lo, hi, fn)]: fn rebuilds the operands derived from the parameters at flat offsets [lo, hi) of self.P (none: refresh() does all)."""
+        return []
+
+    def _refresh_pieces_in(self, ranges, mark: bool = True):
+        spans = [(lo, hi) for buf, lo, hi in ranges if buf is self.P.grad and hi > lo]
+        out = []
+        for i, (lo, hi, fn) in enumerate(self._refresh_pieces()):
+            if any(a <= lo and hi <= b for a, b in spans):
+                out.append(fn)
+                if mark:
+                    self._refreshed.add(i)
+        return out
+
+    def _refresh_rest(self):
+        """What no finished range covered in this step (eager path): the remaining pieces, or everything when the mode has no pieces."""
+        pieces = self._refresh_pieces()
+        if not pieces:
+            return self.refresh()
+        for i, (_, _, fn) in enumerate(pieces):
+            if i not in self._refreshed:
+                fn()
+        self._refresh_extra()
+        self._refreshed = set()
+
+    def _refresh_extra(self):
+        pass                     # (derived operands that belong to no parameter range: the token-CE objective's W_lm^T)
 
     def _run_inline(self, segs):
         """The same pieces one after the other on the current stream, gradient work in line (forward() / backward())."""
@@ -900,9 +940,33 @@ class BackboneTrainer:
             with torch.cuda.graph(g, pool=pools[kind], stream=caps[kind], capture_error_mode="thread_local"):
                 fn()
             self._graphs.append(g)
-        self._g_r = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_r, pool=pools["M"], stream=caps["M"], capture_error_mode="thread_local"):
-            self.refresh()
+        # derived operands: per finished range a small graph behind that range's AdamW (overlapped update only), the rest at the step's end
+        self._rgraphs, covered, rpool = {}, set(), torch.cuda.graph_pool_handle()
+        if self.ga == 1 and self.overlap_update and self._refresh_pieces():
+            for k, (st, fn, _, _, ranges) in enumerate(self._segs):
+                if not ranges:
+                    continue
+                before = set(self._refreshed)
+                fns = self._refresh_pieces_in(ranges)
+                covered |= self._refreshed - before
+                if fns:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=rpool, stream=caps["G"], capture_error_mode="thread_local"):     # (a pool of their own: they
+                        for f_ in fns:                                                                               #  replay between the G graphs)
+                            f_()
+                    self._rgraphs[k] = g
+            self._refreshed = set()
+        rest = [f_ for i, (_, _, f_) in enumerate(self._refresh_pieces()) if i not in covered]
+        has_extra = type(self)._refresh_extra is not BackboneTrainer._refresh_extra
+        self._g_r = torch.cuda.CUDAGraph() if (not self._rgraphs or rest or has_extra) else None      # (nothing left: LoRA - every pair lies in a range)
+        if self._g_r is not None:
+            with torch.cuda.graph(self._g_r, pool=pools["M"], stream=caps["M"], capture_error_mode="thread_local"):
+                if self._rgraphs:
+                    for f_ in rest:
+                        f_()
+                    self._refresh_extra()
+                else:
+                    self.refresh()
         torch.cuda.synchronize()
 
     def train_step_graphed(self, lr: float):
@@ -910,12 +974,14 @@ class BackboneTrainer:
             self.step_count += 1
             self._run(self._segs, self._graphs, update=(lr, 0.9, 0.999, 1e-8, 0.01))
             self._after_update(refresh=False)
-            self._g_r.replay()
+            if self._g_r is not None:
+                self._g_r.replay()
             return self._loss3
         self._run(self._segs, self._graphs, exchange=self.ga == 1)
         if self._accumulate():
             self.optimizer_step(lr, refresh=False)
-            self._g_r.replay()
+            if self._g_r is not None:
+                self._g_r.replay()
         return self._loss3
 
     def _after_update(self, refresh: bool):
@@ -923,7 +989,7 @@ class BackboneTrainer:
             self.eng.reducer._pending = False        # every collective was joined range by range (_update_ranges)
         self.head.dirty = True
         if refresh:
-            self.refresh()
+            self._refresh_rest()                     # (eager: the ranges' pieces ran behind their AdamW; captured: the caller replays _g_r)
 
     def _adam_ranges(self):
         return [(0, self.P.numel)]
@@ -1032,6 +1098,30 @@ class FullFinetune(BackboneTrainer):
         self._refresh_objective()
 
     refresh_transposes = refresh
+
+    def _refresh_pieces(self):
+        """One piece per weight matrix: its W^T copy (the flat offsets of the matrix in self.P)."""
+        if getattr(self, "_pieces", None) is None:
+            out = []
+
+            def add(name, holder, k):
+                lo, n = self.P.offsets[name][0], holder[k].numel()
+                out.append((lo, lo + n, lambda h=holder, k=k: ops.transpose(h[k], out=h[k + "T"])))
+            for j, v in enumerate(self.vits):
+                for i, b in enumerate(v.blocks):
+                    for k in ("wqkv", "wproj", "w1", "w2"):
+                        add(f"vit{j}.{i}.{k}", b, k)
+            for k, t in self.projT.items():
+                lo = self.P.offsets["proj." + k][0]
+                out.append((lo, lo + t.numel(), lambda k=k, t=t: ops.transpose(self.eng.proj[k], out=t)))
+            for i, L in enumerate(self.llm.layers):
+                for k in ("wqkv", "wo", "wgu", "wd"):
+                    add(f"llm.{i}.{k}", L, k)
+            self._pieces = out
+        return self._pieces
+
+    def _refresh_extra(self):
+        self._refresh_objective()
 
     # ---- the Linear of this mode
     def _lin(self, key, x, W, bias=None, **kw):
@@ -1212,6 +1302,17 @@ class LoRAFinetune(BackboneTrainer):
     def refresh(self):
         for l in self.L.values():
             l.refresh()
+
+    def _refresh_pieces(self):
+        """One piece per wrapped Linear: B_blk, A_cat^T, B_blk^T from its pairs (adjacent in the flat buffer: first A to last B)."""
+        if getattr(self, "_pieces", None) is None:
+            out = []
+            for l in self.L.values():
+                lo = self.P.offsets[f"{l.name}.{l.projs[0][0]}.lora_A"][0]
+                off, shape = self.P.offsets[f"{l.name}.{l.projs[-1][0]}.lora_B"]
+                out.append((lo, off + int(torch.Size(shape).numel()), l.refresh))
+            self._pieces = out
+        return self._pieces
 
     def fp8_keys(self):
         """(forward keys, backward keys) of the Linears that run on e4m3 base operands (tests register the same set with the oracle)."""
