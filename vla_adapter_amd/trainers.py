@@ -508,7 +508,10 @@ class BackboneTrainer:
         # hidden_states[1..24]) never reach the loss: the reference computes them and throws the result away; autograd hands their
         # parameters all-zero gradients, so AdamW moves them by the weight-decay factor 1 - lr wd alone, which a bf16 parameter does
         # not see (it rounds to 1 for lr wd < 2^-9).  Here they are neither computed nor touched (tests/test_full_finetune_gpu.py).
-        lch = E.VLAEngine._chunks(self.n_active, [self.exchange_layers])
+        # LLM layers per segment: `exchange_layers`, but 2, 1, 1 at the top - the forward -> backward turn-around (last head blocks, loss, first
+        # head-backward blocks) is what the LLM backward waits for: with four-layer segments the M stream idled 1.3 ms there (tools/trainer_timeline.py)
+        el, na = self.exchange_layers, self.n_active
+        lch = E.VLAEngine._chunks(na, [el] * max(0, (na - 4) // el) + [2, 1, 1]) if na >= 8 and not os.environ.get("VLA_UNIFORM_CHUNKS") else E.VLAEngine._chunks(na, [el])
         two = self.gstream is not None
         segs = []
 
@@ -716,11 +719,19 @@ class BackboneTrainer:
             with torch.cuda.stream(stream):
                 for w in ([] if wait is None else wait if isinstance(wait, list) else [wait]):
                     stream.wait_event(ev[w])
+                tl = getattr(self, "_timeline", None)           # (tools/trainer_timeline.py: timing events around every segment)
+                if tl is not None and fn is not None:
+                    t0 = torch.cuda.Event(enable_timing=True)
+                    t0.record(stream)
                 if fn is not None:
                     if graphs is None:
                         fn()
                     elif graphs[k] is not None:
                         graphs[k].replay()
+                if tl is not None and fn is not None:
+                    t1 = torch.cuda.Event(enable_timing=True)
+                    t1.record(stream)
+                    tl.append((st, k, t0, t1))
                 if signal is not None or ranges:
                     e = torch.cuda.Event()
                     e.record(stream)
