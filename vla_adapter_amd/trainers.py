@@ -572,8 +572,7 @@ class BackboneTrainer:
         add("M", self._mid_backward, None, ("mid", 0))
         gsig.append(grads(("mid", 0), ("gmid", 0), [(head.P.grad, aq_off, head.P.numel)] + self._ranges("embed") + self._ranges("proj")))
         for j, v in enumerate(self.vits):
-            nbj = len(v.blocks)
-            vch = E.VLAEngine._chunks(nbj, [self.exchange_blocks])
+            vch = self._vit_chunks(j)
             for q, (lo, hi) in enumerate(reversed(vch)):
                 def v_bwd(j=j, lo=lo, hi=hi, first=(q == 0)):
                     if first:
@@ -662,7 +661,7 @@ class BackboneTrainer:
         add("M", f_mid, None, ("mid", 0))
         gsig.append(grads(("mid", 0), ("gmid", 0), self._ranges("proj")))
         for j, v in enumerate(self.vits):
-            vch = E.VLAEngine._chunks(len(v.blocks), [self.exchange_blocks])
+            vch = self._vit_chunks(j)
             for q, (lo, hi) in enumerate(reversed(vch)):
                 def v_bwd(j=j, lo=lo, hi=hi, first=(q == 0)):
                     if first:
@@ -828,6 +827,14 @@ class BackboneTrainer:
 
     def _begin_forward(self):
         pass                     # (first launch of a step: LoRA with dropout bumps its mask counter here)
+
+    def _vit_chunks(self, j: int):
+        """Blocks per backward segment of backbone j: `exchange_blocks`, but 1, 2, 4 at the BOTTOM of the last backbone - the blocks the
+        backward reaches last: the weight gradients, update and operand rebuild of the final segment trail the chain with nothing beside
+        them (1.8 ms behind a seven-block segment in the full fine-tune, tools/trainer_timeline.py)."""
+        nbj = len(self.vits[j].blocks)
+        last = j == len(self.vits) - 1 and nbj >= 14 and not os.environ.get("VLA_UNIFORM_CHUNKS")
+        return E.VLAEngine._chunks(nbj, [1, 2, 4, self.exchange_blocks] if last else [self.exchange_blocks])
 
     def _end_backward(self):
         pass
