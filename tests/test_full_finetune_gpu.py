@@ -213,3 +213,35 @@ def test_overlapped_and_plain_updates_cover_the_same_parameters(monkeypatch):
                 n *= d
             assert torch.equal(tr.P.data[off:off + n], p0[off:off + n]), f"{k} (dead) moved with overlap_update={overlap}"
     assert torch.equal(out[True], out[False]), "the two update paths are the same arithmetic on the same parameters"
+
+
+@pytest.mark.parametrize("mode", ["full", "lora"])
+def test_second_backbone_on_its_own_stream_equals_the_serial_schedule(mode, monkeypatch):
+    """Round 4: with two vision backbones (DINOv2 + SigLIP) the second one's forward and backward run on a stream of their own ("V"
+    segments).  Same kernels on the same data, only the streams differ: after three steps - eager three-stream schedule and captured -
+    every parameter and the losses equal the one-backbone-after-the-other schedule (VLA_SERIAL_BACKBONES=1) bit for bit.  A race between
+    the two chains (a shared scratch buffer, a missing event) would show up here as a difference."""
+    from vla_adapter_amd import engine as E, synthetic as S
+    from vla_adapter_amd.trainers import FullFinetune, LoRAFinetune
+    cfg = E.tiny_fused_config()
+    cfg.n_img = 2
+    batch = S.make_batch(cfg, 3, DEV, seed=14, P=20, ragged=True)
+    res = {}
+    for serial in (False, True):
+        if serial:
+            monkeypatch.setenv("VLA_SERIAL_BACKBONES", "1")
+        else:
+            monkeypatch.delenv("VLA_SERIAL_BACKBONES", raising=False)
+        W = S.make_weights(cfg, DEV, seed=5, std=0.05)
+        eng = E.VLAEngine(cfg, W, DEV)
+        tr = FullFinetune(eng) if mode == "full" else LoRAFinetune(eng, rank=16, seed=2)
+        assert (tr.vstream is None) == serial
+        losses = [tr.train_step(batch, 1e-3)[0].item() for _ in range(3)]
+        tr.capture(batch, None)
+        for _ in range(3):
+            tr.train_step_graphed(1e-3)
+            losses.append(tr._loss3[0].item())
+        torch.cuda.synchronize()
+        res[serial] = (tr.P.data.clone(), tr.head.P.data.clone(), losses)
+    assert res[False][2] == res[True][2], (res[False][2], res[True][2])
+    assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])

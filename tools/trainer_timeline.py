@@ -1,5 +1,5 @@
 """Un-profiled timeline of the captured full / LoRA fine-tune step (trainers.BackboneTrainer._run): HIP timing events around every
-schedule segment on its stream, plus the step's end.  usage: trainer_timeline.py [lora|full] [batch]"""
+schedule segment on its stream, plus the step's end.  usage: trainer_timeline.py [lora|full] [batch] [config2|config5]"""
 import sys
 
 import torch
@@ -12,6 +12,9 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "lora"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 dev = "cuda"
 cfg = E.config2()
+if len(sys.argv) > 3 and sys.argv[3] == "config5":      # BASELINE configs[4]: DINOv2 + SigLIP, two images, Qwen2.5-1.5B
+    cfg = E.NAMED_CONFIGS["config5"]()
+    cfg.n_img = 2
 eng = E.VLAEngine(cfg, S.make_weights(cfg, dev, seed=0), dev)
 batch = S.make_batch(cfg, B, dev, seed=1000, P=32)
 batch["pixel_values"] = batch["pixel_values"].to(torch.bfloat16)

@@ -163,6 +163,10 @@ class BackboneTrainer:
         nstreams = int(os.environ.get("VLA_TRAINER_STREAMS", "3"))
         self.gstream = torch.cuda.Stream() if nstreams > 1 else None
         self.hstream = torch.cuda.Stream() if nstreams > 2 else None
+        # two vision backbones (DINOv2 + SigLIP: the documented recipe, BASELINE configs[4]) are independent of each other in both directions: the
+        # second one's forward and backward run on a stream of their own beside the first's ("V" segments; frozen forwards of 32 images each:
+        # 15.0 ms one after the other, 13.2 ms side by side).  VLA_SERIAL_BACKBONES=1: one after the other on the chain, as before.
+        self.vstream = torch.cuda.Stream() if nstreams > 2 and len(self.vits) == 2 and not os.environ.get("VLA_SERIAL_BACKBONES") else None
         self.group_tn = not os.environ.get("VLA_NO_GROUPED_TN")          # (A/B knob)
         self._deferred = []
         self._refreshed, self._rgraphs = set(), {}      # derived operands rebuilt behind a range's AdamW in this step; their graphs (captured step)
@@ -526,19 +530,31 @@ class BackboneTrainer:
                 add("M", None, None, signal, ranges)
             return signal
 
-        def f_front():
+        side = self.vstream is not None                 # the second backbone on its own stream (forward and backward)
+
+        def f_pre():
             eng._vision_begin(batch)
             self._alloc(eng.B, eng.S)
             self._begin_forward()
-            for j in range(len(self.vits)):
+
+        def f_front():
+            if not side:
+                f_pre()
+            for j in range(1 if side else len(self.vits)):
                 self._vit_forward(j, batch["pixel_values"])
+
+        def f_front2():
             self._proj_forward()
             self._mm = eng._embed(batch)
             self._batch = batch
             llm.fwd_begin(eng.B, eng.S, self._mm, 0)
             self._begin_backward()                  # (fp32 accumulators / sparse embedding gradient: zero before anything adds to them)
             self._dHS = eng._dhs(0)                 # zeroed hidden-state gradients: the head's backward scatters into them
-        add("M", f_front, None, ("front", 0))
+        if side:
+            add("M", f_pre, None, ("pre", 0))
+            add("V", lambda: self._vit_forward(1, batch["pixel_values"]), ("pre", 0), ("vf", 1))
+        add("M", f_front, None, None)
+        add("M", f_front2, ("vf", 1) if side else None, ("front", 0))
         for c, (lo, hi) in enumerate(lch):
             add("M", lambda lo=lo, hi=hi: self._llm_fwd_layers(lo, hi), None, ("f", c))
 
@@ -571,6 +587,7 @@ class BackboneTrainer:
         add("H", head.bwd_end, None, ("hend", 0), [(head.P.grad, 0, aq_off)])
         add("M", self._mid_backward, None, ("mid", 0))
         gsig.append(grads(("mid", 0), ("gmid", 0), [(head.P.grad, aq_off, head.P.numel)] + self._ranges("embed") + self._ranges("proj")))
+        vsegs = []
         for j, v in enumerate(self.vits):
             vch = self._vit_chunks(j)
             for q, (lo, hi) in enumerate(reversed(vch)):
@@ -580,8 +597,14 @@ class BackboneTrainer:
                     self._vit_bwd_blocks(j, lo, hi)
                     if lo == 0 and self.trains_vectors:
                         self._vit_bwd_end(j)
-                add("M", v_bwd, None, ("v", j, q))
-                gsig.append(grads(("v", j, q), ("gv", j, q), self._ranges("vit", lo, hi - 1, j)))
+                vsegs.append((j, q, lo, hi, v_bwd))
+        if side:                                    # the two backbones' segments alternate in the list (each followed by its gradient work): both
+            a, b = [x for x in vsegs if x[0] == 0], [x for x in vsegs if x[0] == 1]     # chains start right behind the projector's backward
+            vsegs = [x for pair in zip(a, b) for x in pair] + a[len(b):] + b[len(a):]
+        for j, q, lo, hi, v_bwd in vsegs:
+            on_side = side and j == 1
+            add("V" if on_side else "M", v_bwd, ("mid", 0) if on_side and q == 0 else None, ("v", j, q))
+            gsig.append(grads(("v", j, q), ("gv", j, q), self._ranges("vit", lo, hi - 1, j)))
         if self.trains_vectors:                     # the tail casts the ONE fp32 buffer every piece's bias / norm sums met in
             add("M", self._end_backward, [sg for sg in gsig if two], ("end", 0), self._ranges("tail"))
         return segs
@@ -699,7 +722,7 @@ class BackboneTrainer:
         self._run_work(work)
 
     def _stream(self, name: str, main):
-        return main if name == "M" else ((self.hstream or main) if name == "H" else (self.gstream or main))
+        return main if name == "M" else ((self.hstream or main) if name == "H" else (self.vstream or main) if name == "V" else (self.gstream or main))
 
     def _run(self, segs, graphs=None, exchange: bool = True, update=None):
         """Enqueue the segments in order (eagerly, or as replays of their captured graphs); events cross the streams; a segment's
@@ -709,7 +732,7 @@ class BackboneTrainer:
         fine-tune hides under the rest of the backward instead of trailing it (torch's optimizer.step() after loss.backward(),
         vla-scripts/finetune.py:1078-1082: same arithmetic, every use of a parameter in the NEXT forward sees the updated value)."""
         main = torch.cuda.current_stream()
-        for st in (self.hstream, self.gstream):
+        for st in (self.hstream, self.gstream, self.vstream):
             if st is not None:
                 st.wait_stream(main)                 # fork: inputs / the previous update are ordered before everything
         ev = {}
@@ -740,7 +763,7 @@ class BackboneTrainer:
                         self._exchange(ranges, after_event=e)
                     if ranges and update is not None:
                         self._update_ranges(ranges, e, update, k if graphs is not None else None)
-        for st in (self.hstream, self.gstream):
+        for st in (self.hstream, self.gstream, self.vstream):
             if st is not None:
                 main.wait_stream(st)
 
@@ -799,13 +822,13 @@ class BackboneTrainer:
 
     def _run_inline(self, segs):
         """The same pieces one after the other on the current stream, gradient work in line (forward() / backward())."""
-        g, h, self.gstream, self.hstream = self.gstream, self.hstream, None, None
+        g, h, v, self.gstream, self.hstream, self.vstream = self.gstream, self.hstream, self.vstream, None, None, None
         try:
             for _, fn, _, _, _ in segs:
                 if fn is not None:
                     fn()
         finally:
-            self.gstream, self.hstream = g, h
+            self.gstream, self.hstream, self.vstream = g, h, v
 
     def forward(self, batch: Dict[str, torch.Tensor], noise: Optional[torch.Tensor] = None):
         """Training forward on the current stream (keeps what backward() needs) -> predicted actions [B, chunk, action_dim]."""
@@ -946,8 +969,8 @@ class BackboneTrainer:
         self._segs = self._segments(batch, noise, 1.0 / self.ga)
         # one memory pool and one capture stream per stream kind: graphs sharing a pool are replayed strictly in capture order on
         # ONE stream, so the allocator's reuse of freed capture-time temporaries stays race-free while the streams overlap
-        pools = {k: torch.cuda.graph_pool_handle() for k in "MHG"}
-        caps = {k: torch.cuda.Stream() for k in "MHG"}
+        pools = {k: torch.cuda.graph_pool_handle() for k in "MHGV"}
+        caps = {k: torch.cuda.Stream() for k in "MHGV"}
         self._graphs = []
         for st, fn, _, _, _ in self._segs:
             if fn is None:
